@@ -1,0 +1,188 @@
+/*
+ * rechub_hip.h — C ABI of librechub_hip.so, the MI355X (gfx950) CTR-training hot path.
+ *
+ * Every entry point replaces an ATen op chain of the reference (datawhalechina/torch-rechub
+ * v0.8.0, 100 % Python on eager PyTorch — there is no FFI in the reference, so the
+ * "interface replaced" is the Python call site cited per function, paths relative to
+ * /root/reference).  Signatures carry plain pointers and sizes only: no torch types.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers unless the name starts with h_;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return value 0 = success, >0 = hipError_t of a failed launch, <0 = RH_E_* argument error
+ *     (rh_last_error() returns a human-readable message for the calling thread);
+ *   - kernels are asynchronous; nothing here synchronises, allocates or frees device memory,
+ *     so every call may be captured into a hipGraph;
+ *   - `err_flag` (device int32, may be NULL) is OR-ed with RH_FLAG_* bits by kernels that
+ *     validate indices; the host reads it at its own sync points.
+ *
+ * Field descriptor tables (device int64 arrays, struct-of-arrays, F = number of fields):
+ *   fdesc[0*F + f] = const float* table base of field f        (vocab_f x D, row-major, fp32)
+ *   fdesc[1*F + f] = float*       dense gradient buffer of that table (same shape) or 0
+ *   fdesc[2*F + f] = int64        vocab_f (rows)
+ *   fdesc[3*F + f] = int64        padding_idx of field f, or -1 (rows whose gradient is dropped,
+ *                                 nn.Embedding(padding_idx=...) semantics, basic/initializers.py:16-21)
+ *   idesc[0*F + f] = const idx_t* index column of field f (one index per sample)
+ *   idesc[1*F + f] = int64        stride between consecutive samples, in elements
+ *   idesc[2*F + f] = int64        output slot of field f: its D values live at columns
+ *                                 [slot*D, slot*D + D) of out / g_out / emb (slot = f unless sequence
+ *                                 features are interleaved with sparse ones, basic/layers.py:80-99)
+ * Two fields may name the same table (SparseFeature.shared_with, basic/layers.py:85,99).
+ */
+#ifndef RECHUB_HIP_H
+#define RECHUB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_ABI_VERSION 1
+
+/* argument errors */
+#define RH_E_BADARG (-1)
+#define RH_E_UNSUPPORTED (-2)
+
+/* err_flag bits */
+#define RH_FLAG_INDEX_OOB 1 /* an index was <0 or >= vocab (reference: IndexError / device assert) */
+
+int rh_abi_version(void);
+const char* rh_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1+K2+K3  fused multi-field gather + FM second order + LR first order (+ dense concat)
+ * replaces: EmbeddingLayer.forward  torch_rechub/basic/layers.py:77-127  (26x nn.Embedding + cat)
+ *           FM.forward              torch_rechub/basic/layers.py:313-319
+ *           LR.forward              torch_rechub/basic/layers.py:185-189 on the flattened embeddings
+ *           as composed by DeepFM.forward torch_rechub/models/ranking/deepfm.py:34-43
+ * out   : (B, out_stride) fp32, rows only 4-byte aligned (e.g. a contiguous (B, 429) tensor); field f
+ *         at columns [slot_f*D, slot_f*D + D), dense values at [dense_col, dense_col + n_dense)
+ *         (sparse block first, dense last: layers.py:120), other columns untouched.
+ * ddesc : device int64 [2*n_dense]: const float* column, sample stride (elements); NULL if n_dense = 0
+ * lr_w  : (F*D,) indexed by FIELD (needs slot_f == f) or NULL; lr_b: (1,) or NULL;
+ *         lr_out (B,) = emb . lr_w + lr_b
+ * fm_out: (B,) or NULL = 0.5 * sum_d[(sum_f v)^2 - sum_f v^2]
+ * s_out : (B, D) or NULL = sum_f v  (saved for the backward)
+ * D must be a multiple of 4 and <= 128 (16-byte lanes); idx_is_i64: 1 = int64 indices, 0 = int32.
+ * field_split: 0 = auto, else 1/2/4/8 lanes-groups per sample (tuning knob).
+ */
+int rh_embed_fwd(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F, int D,
+                 const int64_t* ddesc, int n_dense, int dense_col, float* out, int64_t out_stride,
+                 const float* lr_w, const float* lr_b, float* lr_out, float* fm_out, float* s_out,
+                 int field_split, int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  fused backward of the above
+ * replaces: autograd of the chain above (embedding_dense_backward x F, FM/LR backward),
+ *           driven by loss.backward() at torch_rechub/trainers/ctr_trainer.py:97-98
+ * per lookup (b,f):  g = scale * ( g_out[b, f*D:(f+1)*D] + g_lr[b]*lr_w[f*D:(f+1)*D]
+ *                                  + g_fm[b] * (s_sum[b,:] - emb[b, f*D:(f+1)*D]) )
+ * sink = 0: scatter-add g into the dense gradient buffer fdesc[1*F+f] (skipping padding_idx rows);
+ * sink = 1: write g to rows_out (B, F, D) for the data-parallel exchange.
+ * Any of g_out / g_fm / g_lr may be NULL (term dropped).  emb/s_sum are required when g_fm != NULL,
+ * emb when lr_wgrad != NULL.
+ * lr_wgrad : (nchunks, F*D) partial sums of g_lr[b]*emb[b,:] per sample chunk, nchunks =
+ *            ceil(B / samples_per_block); the caller reduces over dim 0 (deterministic). NULL to skip.
+ * samples_per_block: multiple of 64, 0 = auto (256).
+ */
+int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F, int D,
+                 const float* g_out, int64_t g_stride, const float* emb, int64_t emb_stride,
+                 const float* s_sum, const float* g_fm, const float* g_lr, const float* lr_w,
+                 float* lr_wgrad, float scale, int sink, float* rows_out, int samples_per_block,
+                 int32_t* err_flag, void* stream);
+
+/* number of sample chunks (= rows of lr_wgrad) rh_embed_bwd uses for this B / samples_per_block */
+int rh_embed_bwd_nchunks(int B, int samples_per_block);
+
+/* scatter-add precomputed gradient rows (B, F, D) (e.g. all-gathered from the other ranks)
+ * into the dense gradient buffers.  Same padding_idx and small-vocab LDS aggregation as above. */
+int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F,
+                          int D, const float* rows, float scale, int samples_per_block,
+                          int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FM on an arbitrary (B, F, D) tensor (row stride x_stride floats per sample, fields contiguous)
+ * replaces: FM.forward torch_rechub/basic/layers.py:313-319 and its autograd
+ * reduce_sum = 1 -> out (B,) ; 0 -> out (B, D)
+ */
+int rh_fm_fwd(const float* x, int64_t x_stride, int B, int F, int D, int reduce_sum, float* out,
+              void* stream);
+int rh_fm_bwd(const float* x, int64_t x_stride, int B, int F, int D, int reduce_sum,
+              const float* g_out, float* g_x, int64_t gx_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sequence features: gather + masked pooling
+ * replaces: InputMask.forward basic/layers.py:148-161 + Sum/Average/ConcatPooling :204-251
+ *           as called from EmbeddingLayer.forward basic/layers.py:86-99
+ * idx (B, L) with sample stride idx_stride_b and position stride idx_stride_l (elements)
+ * mode 0 = sum, 1 = mean (divide by count + 1e-16), 2 = concat (no mask, out (B, L, D))
+ * mask_sentinel = padding_idx if set else -1 (positions equal to it are excluded from sum/mean)
+ * out row b at out + b*out_stride (D floats, or L*D floats for concat).
+ */
+int rh_seq_pool_fwd(const float* table, int64_t vocab, const void* idx, int idx_is_i64,
+                    int64_t idx_stride_b, int64_t idx_stride_l, int B, int L, int D, int mode,
+                    int64_t mask_sentinel, float* out, int64_t out_stride, int32_t* err_flag,
+                    void* stream);
+/* backward: scatter-add into grad_table; rows equal to padding_idx (or -1 = none) get no gradient */
+int rh_seq_pool_bwd(float* grad_table, int64_t vocab, const void* idx, int idx_is_i64,
+                    int64_t idx_stride_b, int64_t idx_stride_l, int B, int L, int D, int mode,
+                    int64_t mask_sentinel, int64_t padding_idx, const float* g_out,
+                    int64_t g_stride, float scale, int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  CrossNetwork  x_{l+1} = x0 * (w_l . x_l) + b_l + x_l
+ * replaces: CrossNetwork.forward torch_rechub/basic/layers.py:412-420 and its autograd
+ * x0, x : (B, d) with row strides; w, b : (L, d) contiguous; L <= 4 per call (chain calls for more,
+ * passing the original x0).  One wavefront per sample, d <= 2048.
+ * bwd: g_x0 / g_x may alias-sum: if sum_into_gx != 0 the x0-gradient is added into g_x and g_x0 is
+ * ignored (the x0 == x case of the first segment).
+ * wb_partials: (nblocks, 2, L, d) per-block partial sums of (dW, dB); nblocks is returned by
+ * rh_cross_bwd_nblocks(B); the caller reduces over dim 0.
+ */
+int rh_cross_fwd(const float* x0, int64_t x0_stride, const float* x, int64_t x_stride,
+                 const float* w, const float* b, int B, int d, int L, float* out,
+                 int64_t out_stride, void* stream);
+int rh_cross_bwd_nblocks(int B);
+int rh_cross_max_layers(int d); /* layers one call can take for width d (4 for d <= 512) */
+int rh_cross_bwd(const float* x0, int64_t x0_stride, const float* x, int64_t x_stride,
+                 const float* w, const float* b, int B, int d, int L, const float* g_out,
+                 int64_t g_stride, float* g_x0, float* g_x, int64_t gx_stride, int sum_into_gx,
+                 float* wb_partials, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense Adam with coupled L2, torch.optim.Adam semantics over every row of every table
+ * replaces: optimizer.step() torch_rechub/trainers/ctr_trainer.py:59-61,99 for embedding tables
+ * tdesc (device int64 [5*T]): p, g, m, v pointers and numel per tensor (T <= 128)
+ * h_numel (HOST int64 [T]): the same numel values (multiples of 4), used to size the launch
+ * hyper (device double [16]): inputs  [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay
+ *                             derived [8]=step_size=lr/(1-beta1^t) [9]=sqrt(1-beta2^t)
+ *                                     [10]=1-beta1 [11]=1-beta2 [12]=t
+ * rh_adam_prepare increments *step (device int64) and fills hyper[8..12] on the device in fp64
+ * (as torch does on the host), so prepare + dense can be replayed from a hipGraph.
+ * per element (fp32): g' = g + wd*p; m += (1-b1)*(g'-m); v = v*b2 + (1-b2)*g'^2;
+ *                     p -= step_size * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * zero_grad != 0: g <- 0 where it was non-zero (replaces model.zero_grad(), ctr_trainer.py:97)
+ */
+int rh_adam_prepare(double* hyper, int64_t* step, void* stream);
+int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel, const double* hyper,
+                  int zero_grad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident minibatch assembly (columnar dataset already in HBM)
+ * replaces: TorchDataset.__getitem__ + default_collate  torch_rechub/utils/data.py:14-25,61-83
+ *           and the 39 host->device copies at trainers/ctr_trainer.py:84-85
+ * perm (N,) int64 sample order; *pos (device int64) = first position of this batch;
+ * gathers rows perm[(pos + b) % N], b < B, of sparse (N,F) int64, dense (N,ND) fp32, label (N,) fp32
+ * into the static batch buffers.  rh_batch_advance sets *pos = (*pos + B) % N (separate launch so
+ * that every reader of *pos has finished).
+ */
+int rh_batch_gather(const int64_t* perm, const int64_t* pos, int64_t N, int B, const int64_t* sparse,
+                    int F, const float* dense, int ND, const float* label, int64_t* sparse_out,
+                    float* dense_out, float* label_out, void* stream);
+int rh_batch_advance(int64_t* pos, int64_t B, int64_t N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECHUB_HIP_H */

@@ -1,0 +1,102 @@
+// Internal helpers shared by the gfx950 kernels of librechub_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rechub_hip.h"
+
+#define RH_WAVE 64
+#define RH_BLOCK 256
+
+void rh_set_error(const char* fmt, ...);
+
+#define RH_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      rh_set_error(__VA_ARGS__);     \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+// Returns from the enclosing int function with the hipError_t of the last launch, if any.
+#define RH_LAUNCH_CHECK(name)                                               \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      rh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+      return (int)e_;                                                       \
+    }                                                                       \
+  } while (0)
+
+// Pointers fetched from descriptor tables are generic to the compiler; these helpers pin them to
+// the global address space so the access is a global_load/global_store (vmcnt only), not flat_*.
+#define RH_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+static __device__ __forceinline__ T gload(const void* p) {
+  return *reinterpret_cast<const RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(p));
+}
+template <typename T>
+static __device__ __forceinline__ void gstore(void* p, T v) {
+  *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(p)) = v;
+}
+// 4-byte aligned on purpose: rows of a (B, 429) activation are only dword aligned; the amdhsa target
+// runs in unaligned-access mode, so this is still one global_load_dwordx4 / global_store_dwordx4.
+typedef float rh_v4f __attribute__((ext_vector_type(4), aligned(4)));
+template <>
+__device__ __forceinline__ float4 gload<float4>(const void* p) {
+  const rh_v4f v = *reinterpret_cast<const RH_GLOBAL rh_v4f*>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <>
+__device__ __forceinline__ void gstore<float4>(void* p, float4 v) {
+  rh_v4f x = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<RH_GLOBAL rh_v4f*>(reinterpret_cast<uintptr_t>(p)) = x;
+}
+
+static __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+static __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+static __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+static __device__ __forceinline__ float4 f4_scale(float4 a, float s) {
+  return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+// a + s*b
+static __device__ __forceinline__ float4 f4_fma(float s, float4 b, float4 a) {
+  return make_float4(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z), fmaf(s, b.w, a.w));
+}
+static __device__ __forceinline__ float f4_dot(float4 a, float4 b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+static __device__ __forceinline__ float4 f4_shfl_xor(float4 v, int m) {
+  return make_float4(__shfl_xor(v.x, m, RH_WAVE), __shfl_xor(v.y, m, RH_WAVE),
+                     __shfl_xor(v.z, m, RH_WAVE), __shfl_xor(v.w, m, RH_WAVE));
+}
+// butterfly sum over all 64 lanes of the wavefront; every lane gets the total
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, RH_WAVE);
+  return v;
+}
+// hardware fp32 atomic add on global memory (global_atomic_add_f32, result unused)
+static __device__ __forceinline__ void gatomic_add_f32(float* p, float v) {
+  (void)__builtin_amdgcn_global_atomic_fadd_f32(
+      reinterpret_cast<RH_GLOBAL float*>(reinterpret_cast<uintptr_t>(p)), v);
+}
+static __device__ __forceinline__ void gatomic_add_f4(float* p, float4 v) {
+  gatomic_add_f32(p + 0, v.x);
+  gatomic_add_f32(p + 1, v.y);
+  gatomic_add_f32(p + 2, v.z);
+  gatomic_add_f32(p + 3, v.w);
+}
+// LDS fp32 atomic add (ds_add_f32); p must point into __shared__ memory
+#define RH_LDS_ATOMIC_ADD_F4(base, off, v)   \
+  do {                                       \
+    unsafeAtomicAdd(&(base)[(off) + 0], (v).x); \
+    unsafeAtomicAdd(&(base)[(off) + 1], (v).y); \
+    unsafeAtomicAdd(&(base)[(off) + 2], (v).z); \
+    unsafeAtomicAdd(&(base)[(off) + 3], (v).w); \
+  } while (0)

@@ -1,0 +1,422 @@
+// Fused multi-field embedding gather + FM + LR (forward, backward, row scatter) for gfx950.
+//
+// Reference op chains replaced (paths relative to /root/reference):
+//   EmbeddingLayer.forward  torch_rechub/basic/layers.py:77-127
+//   FM.forward              torch_rechub/basic/layers.py:313-319
+//   LR.forward              torch_rechub/basic/layers.py:185-189
+//   composed by DeepFM.forward torch_rechub/models/ranking/deepfm.py:34-43
+//
+// Roofline: HBM.  A D=16 fp32 row is one 64-byte access, so the forward is a random-gather
+// kernel: lanes are grouped LPR = D/4 per row (one 16-byte load each), FS row-groups per sample,
+// all of a lane's gathers are issued before the first is consumed (index phase -> gather phase ->
+// use phase) and the per-sample FM / LR reductions are wavefront xor-shuffles.  The backward is
+// field-major so that tiny tables (Criteo has vocab 3, 4, 10 ...) are pre-aggregated in LDS:
+// device-scope atomics on one address serialise at ~11 ns each on MI355X, LDS atomics do not.
+#include "common.h"
+
+namespace {
+
+struct EmbedFwdArgs {
+  const int64_t* fdesc;
+  const int64_t* idesc;
+  const int64_t* ddesc;
+  int B, F, D, ND;
+  int dense_col;  // first output column of the dense block
+  float* out;
+  int64_t out_stride;
+  const float* lr_w;
+  const float* lr_b;
+  float* lr_out;
+  float* fm_out;
+  float* s_out;
+  int* err;
+};
+
+// One sample is handled by G = LPR*FS lanes: lane (fs, q) gathers dwords [4q, 4q+4) of the rows
+// of fields f = j*FS + fs, j = 0..ceil(F/FS)-1.  Groups never straddle a wavefront (G | 64).
+template <int LPR, int FS, typename IdxT, bool HAS_LR>
+__global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs a) {
+  constexpr int G = LPR * FS;
+  constexpr int SPB = RH_BLOCK / G;
+  constexpr int U = 8;  // gathers in flight per lane
+  const int tid = threadIdx.x;
+  const int lig = tid % G;
+  const int q = lig % LPR;
+  const int fs = lig / LPR;
+  int64_t b = (int64_t)blockIdx.x * SPB + tid / G;
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;  // keep the wavefront converged for the shuffles; results discarded
+  const int F = a.F, D = a.D;
+  const int nfl = (F + FS - 1) / FS;
+
+  float4 S = f4_zero();
+  float Qs = 0.f, Ls = 0.f;
+  bool oob_any = false;
+  float* orow = a.out + b * a.out_stride + q * 4;
+
+  for (int j0 = 0; j0 < nfl; j0 += U) {
+    int fcl[U];
+    bool ok[U];
+    const IdxT* ip[U];
+    int64_t st[U];
+    const float* tab[U];
+    int64_t voc[U];
+    int col[U];
+    // phase 0: descriptors (L1/L2 resident)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = (j0 + u) * FS + fs;
+      ok[u] = f < F;
+      fcl[u] = ok[u] ? f : F - 1;
+      ip[u] = reinterpret_cast<const IdxT*>(a.idesc[fcl[u]]);
+      st[u] = a.idesc[F + fcl[u]];
+      tab[u] = reinterpret_cast<const float*>(a.fdesc[fcl[u]]);
+      voc[u] = a.fdesc[2 * F + fcl[u]];
+      col[u] = (int)a.idesc[2 * F + fcl[u]] * D;  // output slot of the field -> column
+    }
+    // phase 1: indices
+    int64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) row[u] = (int64_t)gload<IdxT>(ip[u] + b * st[u]);
+    // phase 2: row gathers (16 B per lane), all in flight together
+    float4 v[U];
+    float4 w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool oob = (uint64_t)row[u] >= (uint64_t)voc[u];
+      oob_any |= (oob && ok[u]);
+      const int64_t r = oob ? 0 : row[u];
+      v[u] = gload<float4>(tab[u] + r * D + q * 4);
+      if (HAS_LR) w[u] = gload<float4>(a.lr_w + fcl[u] * D + q * 4);
+    }
+    // phase 3: accumulate (branch-free selects) + emit
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 vm = ok[u] ? v[u] : f4_zero();
+      S = f4_add(S, vm);
+      Qs += f4_dot(vm, vm);
+      if (HAS_LR) Ls += f4_dot(w[u], vm);
+      if (ok[u] && live) gstore<float4>(orow + col[u], v[u]);
+    }
+  }
+
+  // dense values appended after the sparse block (layers.py:120 order)
+  if (a.ND > 0 && live) {
+    for (int j = lig; j < a.ND; j += G) {
+      const float* dp = reinterpret_cast<const float*>(a.ddesc[j]);
+      const int64_t ds = a.ddesc[a.ND + j];
+      a.out[b * a.out_stride + a.dense_col + j] = gload<float>(dp + b * ds);
+    }
+  }
+
+  // S over the FS row-groups of the sample
+#pragma unroll
+  for (int m = LPR; m < G; m <<= 1) S = f4_add(S, f4_shfl_xor(S, m));
+  float t = f4_dot(S, S);
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, RH_WAVE);
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    Qs += __shfl_xor(Qs, m, RH_WAVE);
+    Ls += __shfl_xor(Ls, m, RH_WAVE);
+  }
+  if (live) {
+    if (a.s_out != nullptr && fs == 0) gstore<float4>(a.s_out + b * D + q * 4, S);
+    if (lig == 0) {
+      if (a.fm_out != nullptr) a.fm_out[b] = 0.5f * (t - Qs);
+      if (a.lr_out != nullptr) a.lr_out[b] = Ls + (a.lr_b != nullptr ? a.lr_b[0] : 0.f);
+    }
+  }
+  if (oob_any && a.err != nullptr) atomicOr(a.err, RH_FLAG_INDEX_OOB);
+}
+
+template <int LPR, int FS, typename IdxT>
+int launch_fwd(const EmbedFwdArgs& a, hipStream_t s) {
+  constexpr int SPB = RH_BLOCK / (LPR * FS);
+  const unsigned grid = (unsigned)((a.B + SPB - 1) / SPB);
+  if (a.lr_w != nullptr)
+    hipLaunchKernelGGL((embed_fwd_kernel<LPR, FS, IdxT, true>), dim3(grid), dim3(RH_BLOCK), 0, s, a);
+  else
+    hipLaunchKernelGGL((embed_fwd_kernel<LPR, FS, IdxT, false>), dim3(grid), dim3(RH_BLOCK), 0, s, a);
+  return 0;
+}
+
+template <int LPR, typename IdxT>
+int dispatch_fs(const EmbedFwdArgs& a, int fs, hipStream_t s) {
+  if constexpr (LPR * 8 <= RH_WAVE) {
+    if (fs == 8) return launch_fwd<LPR, 8, IdxT>(a, s);
+  }
+  if constexpr (LPR * 4 <= RH_WAVE) {
+    if (fs >= 4) return launch_fwd<LPR, 4, IdxT>(a, s);
+  }
+  if constexpr (LPR * 2 <= RH_WAVE) {
+    if (fs >= 2) return launch_fwd<LPR, 2, IdxT>(a, s);
+  }
+  return launch_fwd<LPR, 1, IdxT>(a, s);
+}
+
+template <typename IdxT>
+int dispatch_lpr(const EmbedFwdArgs& a, int fs, hipStream_t s) {
+  switch (a.D / 4) {
+    case 1: return dispatch_fs<1, IdxT>(a, fs, s);
+    case 2: return dispatch_fs<2, IdxT>(a, fs, s);
+    case 4: return dispatch_fs<4, IdxT>(a, fs, s);
+    case 8: return dispatch_fs<8, IdxT>(a, fs, s);
+    case 16: return dispatch_fs<16, IdxT>(a, fs, s);
+    case 32: return dispatch_fs<32, IdxT>(a, fs, s);
+    default: return RH_E_UNSUPPORTED;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct EmbedBwdArgs {
+  const int64_t* fdesc;
+  const int64_t* idesc;
+  int B, F, D;
+  const float* g_out;
+  int64_t g_stride;
+  const float* emb;
+  int64_t emb_stride;
+  const float* s_sum;
+  const float* g_fm;
+  const float* g_lr;
+  const float* lr_w;
+  float* lr_wgrad;
+  float scale;
+  float* rows_out;
+  const float* rows_in;
+  int spb;
+  int lds_floats;
+  int* err;
+};
+
+// grid = (sample chunks, fields).  SRC 0: compute the gradient row from the upstream gradients,
+// 1: read it from rows_in.  SINK 0: scatter-add into the table gradient, 1: write to rows_out.
+template <int LPR, typename IdxT, int SRC, int SINK>
+__global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float4 red[RH_BLOCK / RH_WAVE][32];
+  float4* lds4 = reinterpret_cast<float4*>(lds);
+  constexpr int LPP = RH_BLOCK / LPR;  // lookups per pass
+  constexpr int U = 4;
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int q = tid % LPR;
+  const int slot = tid / LPR;
+  const int F = a.F, D = a.D;
+  const IdxT* ip = reinterpret_cast<const IdxT*>(a.idesc[f]);
+  const int64_t st = a.idesc[F + f];
+  float* gtab = reinterpret_cast<float*>(a.fdesc[F + f]);
+  const int64_t vocab = a.fdesc[2 * F + f];
+  const int64_t pad = a.fdesc[3 * F + f];
+  const int col = (int)a.idesc[2 * F + f] * D;  // column of this field in g_out / emb
+  const bool use_lds = (SINK == 0) && (vocab * D <= (int64_t)a.lds_floats);
+  const int n4 = (int)(vocab * D / 4);
+  if (use_lds) {
+    for (int i = tid; i < n4; i += RH_BLOCK) lds4[i] = f4_zero();
+    __syncthreads();
+  }
+  const bool has_gout = (SRC == 0) && a.g_out != nullptr;
+  const bool has_lr = (SRC == 0) && a.g_lr != nullptr && a.lr_w != nullptr;
+  const bool has_fm = (SRC == 0) && a.g_fm != nullptr;
+  const bool want_wgrad = (SRC == 0) && a.lr_wgrad != nullptr && a.g_lr != nullptr;
+  const float4 w4 =
+      has_lr ? gload<float4>(a.lr_w + f * D + q * 4) : f4_zero();
+  float4 wacc = f4_zero();
+  bool oob_any = false;
+  const int64_t b0 = (int64_t)blockIdx.x * a.spb;
+  const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
+
+  for (int64_t bb = b0 + slot; bb < b1; bb += (int64_t)LPP * U) {
+    bool ok[U];
+    int64_t bc[U], row[U];
+    float4 g[U], v[U], s4[U];
+    float gl[U], gf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t b = bb + (int64_t)u * LPP;
+      ok[u] = b < b1;
+      bc[u] = ok[u] ? b : b1 - 1;
+      row[u] = (int64_t)gload<IdxT>(ip + bc[u] * st);
+      if (SRC == 1) {
+        g[u] = gload<float4>(a.rows_in + (bc[u] * F + f) * D + q * 4);
+      } else {
+        g[u] = has_gout ? gload<float4>(a.g_out + bc[u] * a.g_stride + col + q * 4)
+                        : f4_zero();
+        const bool need_v = has_fm || want_wgrad;
+        v[u] = need_v ? gload<float4>(a.emb + bc[u] * a.emb_stride + col + q * 4)
+                      : f4_zero();
+        s4[u] = has_fm ? gload<float4>(a.s_sum + bc[u] * D + q * 4) : f4_zero();
+        gl[u] = (has_lr || want_wgrad) ? a.g_lr[bc[u]] : 0.f;
+        gf[u] = has_fm ? a.g_fm[bc[u]] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 gr = g[u];
+      if (SRC == 0) {
+        gr = f4_fma(gl[u], w4, gr);                   // + g_lr * w   (w4 = 0 when LR absent)
+        gr = f4_fma(gf[u], f4_sub(s4[u], v[u]), gr);  // + g_fm * (S - v)
+        if (want_wgrad && ok[u]) wacc = f4_fma(gl[u], v[u], wacc);
+      }
+      gr = f4_scale(gr, a.scale);
+      if (ok[u]) {
+        if (SINK == 1) {
+          gstore<float4>(a.rows_out + (bc[u] * F + f) * D + q * 4, gr);
+        } else {
+          const bool oob = (uint64_t)row[u] >= (uint64_t)vocab;
+          oob_any |= oob;
+          if (!oob && row[u] != pad) {
+            const int64_t off = row[u] * D + q * 4;
+            if (use_lds) {
+              RH_LDS_ATOMIC_ADD_F4(lds, (int)off, gr);
+            } else {
+              gatomic_add_f4(gtab + off, gr);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (use_lds) {
+    __syncthreads();
+    for (int i = tid; i < n4; i += RH_BLOCK) {
+      const float4 x = lds4[i];
+      if (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f) gatomic_add_f4(gtab + (int64_t)i * 4, x);
+    }
+  }
+  if (want_wgrad) {
+    // sum over the lookups of this block that share q: inside the wavefront, then across the 4
+#pragma unroll
+    for (int m = LPR; m < RH_WAVE; m <<= 1) wacc = f4_add(wacc, f4_shfl_xor(wacc, m));
+    const int lane = tid % RH_WAVE, wave = tid / RH_WAVE;
+    if (lane < LPR) red[wave][lane] = wacc;
+    __syncthreads();
+    if (tid < LPR) {
+      float4 sum = red[0][tid];
+#pragma unroll
+      for (int wv = 1; wv < RH_BLOCK / RH_WAVE; ++wv) sum = f4_add(sum, red[wv][tid]);
+      gstore<float4>(a.lr_wgrad + ((int64_t)blockIdx.x * F + f) * D + tid * 4, sum);
+    }
+  }
+  if (oob_any && a.err != nullptr) atomicOr(a.err, RH_FLAG_INDEX_OOB);
+}
+
+constexpr int kLdsFloats = 8192;  // 32 KiB per block: tables with vocab*D <= 8192 aggregate in LDS
+
+template <int LPR, typename IdxT, int SRC, int SINK>
+int launch_bwd(EmbedBwdArgs a, hipStream_t s) {
+  const unsigned gx = (unsigned)((a.B + a.spb - 1) / a.spb);
+  a.lds_floats = (SINK == 0) ? kLdsFloats : 0;
+  const size_t shmem = (SINK == 0) ? kLdsFloats * sizeof(float) : 0;
+  hipLaunchKernelGGL((embed_bwd_kernel<LPR, IdxT, SRC, SINK>), dim3(gx, (unsigned)a.F), dim3(RH_BLOCK),
+                     shmem, s, a);
+  return 0;
+}
+
+template <typename IdxT, int SRC, int SINK>
+int dispatch_bwd(const EmbedBwdArgs& a, hipStream_t s) {
+  switch (a.D / 4) {
+    case 1: return launch_bwd<1, IdxT, SRC, SINK>(a, s);
+    case 2: return launch_bwd<2, IdxT, SRC, SINK>(a, s);
+    case 4: return launch_bwd<4, IdxT, SRC, SINK>(a, s);
+    case 8: return launch_bwd<8, IdxT, SRC, SINK>(a, s);
+    case 16: return launch_bwd<16, IdxT, SRC, SINK>(a, s);
+    case 32: return launch_bwd<32, IdxT, SRC, SINK>(a, s);
+    default: return RH_E_UNSUPPORTED;
+  }
+}
+
+int check_common(const char* who, const int64_t* fdesc, const int64_t* idesc, int B, int F, int D) {
+  RH_REQUIRE(fdesc != nullptr && idesc != nullptr, RH_E_BADARG, "%s: null descriptor", who);
+  RH_REQUIRE(B >= 0 && F > 0, RH_E_BADARG, "%s: bad shape B=%d F=%d", who, B, F);
+  RH_REQUIRE(D > 0 && D % 4 == 0 && D <= 128 && ((D / 4) & (D / 4 - 1)) == 0, RH_E_UNSUPPORTED,
+             "%s: embed_dim %d unsupported by the fused kernel (need 4,8,16,32,64,128)", who, D);
+  RH_REQUIRE(F <= 65535, RH_E_UNSUPPORTED, "%s: too many fields (%d)", who, F);
+  return 0;
+}
+
+int pick_spb(int spb) {
+  if (spb <= 0) return 256;
+  return ((spb + 63) / 64) * 64;
+}
+
+}  // namespace
+
+extern "C" int rh_embed_fwd(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F,
+                            int D, const int64_t* ddesc, int n_dense, int dense_col, float* out,
+                            int64_t out_stride,
+                            const float* lr_w, const float* lr_b, float* lr_out, float* fm_out,
+                            float* s_out, int field_split, int32_t* err_flag, void* stream) {
+  if (int rc = check_common("rh_embed_fwd", fdesc, idesc, B, F, D)) return rc;
+  RH_REQUIRE(out != nullptr, RH_E_BADARG, "rh_embed_fwd: out is null");
+  RH_REQUIRE(dense_col >= 0 && out_stride >= (int64_t)dense_col + n_dense, RH_E_BADARG,
+             "rh_embed_fwd: out_stride %lld too small for dense block at column %d (+%d)", (long long)out_stride,
+             dense_col, n_dense);
+  RH_REQUIRE(n_dense == 0 || ddesc != nullptr, RH_E_BADARG, "rh_embed_fwd: n_dense > 0 but ddesc is null");
+  RH_REQUIRE(lr_out == nullptr || lr_w != nullptr, RH_E_BADARG, "rh_embed_fwd: lr_out without lr_w");
+  if (B == 0) return 0;
+  EmbedFwdArgs a{fdesc, idesc, ddesc, B, F, D, n_dense, dense_col, out, out_stride, lr_w, lr_b, lr_out, fm_out, s_out, err_flag};
+  if (lr_out == nullptr) a.lr_w = nullptr;
+  int fs = field_split;
+  const int lpr = D / 4;
+  if (fs <= 0) {
+    // smallest split that still gives >= 1024 wavefronts (4 per CU), so every lane keeps
+    // as many gathers in flight as possible without starving the chip at small B
+    fs = 1;
+    while (fs < 8 && lpr * fs * 2 <= RH_WAVE && (int64_t)B * lpr * fs / RH_WAVE < 1024 && fs * 2 <= F) fs *= 2;
+  }
+  while (fs > 1 && lpr * fs > RH_WAVE) fs /= 2;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = idx_is_i64 ? dispatch_lpr<int64_t>(a, fs, s) : dispatch_lpr<int32_t>(a, fs, s);
+  if (rc != 0) return rc;
+  RH_LAUNCH_CHECK("rh_embed_fwd");
+  return 0;
+}
+
+extern "C" int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F,
+                            int D, const float* g_out, int64_t g_stride, const float* emb,
+                            int64_t emb_stride, const float* s_sum, const float* g_fm,
+                            const float* g_lr, const float* lr_w, float* lr_wgrad, float scale, int sink,
+                            float* rows_out, int samples_per_block, int32_t* err_flag, void* stream) {
+  if (int rc = check_common("rh_embed_bwd", fdesc, idesc, B, F, D)) return rc;
+  RH_REQUIRE(sink == 0 || sink == 1, RH_E_BADARG, "rh_embed_bwd: sink must be 0 or 1");
+  RH_REQUIRE(sink == 0 || rows_out != nullptr, RH_E_BADARG, "rh_embed_bwd: sink=1 needs rows_out");
+  RH_REQUIRE(g_fm == nullptr || (emb != nullptr && s_sum != nullptr), RH_E_BADARG,
+             "rh_embed_bwd: g_fm needs emb and s_sum");
+  RH_REQUIRE(lr_wgrad == nullptr || (emb != nullptr && g_lr != nullptr), RH_E_BADARG,
+             "rh_embed_bwd: lr_wgrad needs emb and g_lr");
+  if (B == 0) return 0;
+  EmbedBwdArgs a{fdesc, idesc, B, F, D, g_out, g_stride, emb, emb_stride, s_sum, g_fm, g_lr, lr_w,
+                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, err_flag};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if (sink == 0)
+    rc = idx_is_i64 ? dispatch_bwd<int64_t, 0, 0>(a, s) : dispatch_bwd<int32_t, 0, 0>(a, s);
+  else
+    rc = idx_is_i64 ? dispatch_bwd<int64_t, 0, 1>(a, s) : dispatch_bwd<int32_t, 0, 1>(a, s);
+  if (rc != 0) return rc;
+  RH_LAUNCH_CHECK("rh_embed_bwd");
+  return 0;
+}
+
+extern "C" int rh_embed_bwd_nchunks(int B, int samples_per_block) {
+  const int spb = pick_spb(samples_per_block);
+  return (B + spb - 1) / spb;
+}
+
+extern "C" int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B,
+                                     int F, int D, const float* rows, float scale,
+                                     int samples_per_block, int32_t* err_flag, void* stream) {
+  if (int rc = check_common("rh_embed_scatter_rows", fdesc, idesc, B, F, D)) return rc;
+  RH_REQUIRE(rows != nullptr, RH_E_BADARG, "rh_embed_scatter_rows: rows is null");
+  if (B == 0) return 0;
+  EmbedBwdArgs a{fdesc, idesc, B, F, D, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, err_flag};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = idx_is_i64 ? dispatch_bwd<int64_t, 1, 0>(a, s) : dispatch_bwd<int32_t, 1, 0>(a, s);
+  if (rc != 0) return rc;
+  RH_LAUNCH_CHECK("rh_embed_scatter_rows");
+  return 0;
+}
