@@ -1,0 +1,302 @@
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (datawhalechina/torch-rechub v0.8.0, CPU).
+
+Run in the build container only (needs /root/reference):  ``python oracle/gen_golden.py``
+The fixtures pin (a) the numpy oracle and (b) the HIP path on the GPU box, where the reference is absent.
+
+Files
+  layers.npz          one group of arrays per hot-path layer: inputs, parameters, outputs, input/param gradients
+  model_<cfg>.npz     per model config: feature spec (json), batch, initial state_dict, train/eval predictions,
+                      BCE loss, all parameter gradients, and the state_dict + mean loss after the reference
+                      ``CTRTrainer.train_one_epoch`` ran over three fixed batches (Adam, coupled weight decay)
+Everything is seeded with 2022 (the reference's conventional seed, examples/ranking/run_criteo.py:99).
+Dropout is 0 in the fixtures (masks are RNG-dependent); BatchNorm runs in train mode for the gradient cases.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.ref_import import import_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+SEED = 2022
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def spec_of(fea):
+    kind = type(fea).__name__
+    d = {"kind": kind, "name": fea.name, "embed_dim": fea.embed_dim}
+    if kind != "DenseFeature":
+        d.update(vocab_size=fea.vocab_size, shared_with=fea.shared_with, padding_idx=fea.padding_idx)
+    if kind == "SequenceFeature":
+        d["pooling"] = fea.pooling
+    return d
+
+
+def gen_layers(rh):
+    from torch_rechub.basic.activation import Dice
+    from torch_rechub.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    from torch_rechub.basic.layers import (FM, LR, MLP, CrossNetMix, CrossNetV2, CrossNetwork, EmbeddingLayer)
+    from torch_rechub.models.ranking.din import ActivationUnit
+    torch.manual_seed(SEED)
+    g = torch.Generator().manual_seed(SEED)
+    out = {}
+    B, F, D, ND = 37, 6, 16, 3
+
+    # --- EmbeddingLayer: sparse (+shared table, +padding_idx) + dense, both layouts -------------------------
+    vocabs = [3, 11, 50, 7, 200, 11]
+    feas = [SparseFeature(f"s{i}", vocab_size=v, embed_dim=D) for i, v in enumerate(vocabs[:5])]
+    feas[3] = SparseFeature("s3", vocab_size=7, embed_dim=D, padding_idx=0)
+    feas.append(SparseFeature("s5", vocab_size=11, embed_dim=D, shared_with="s1"))
+    dense = [DenseFeature(f"d{i}") for i in range(ND)]
+    layer = EmbeddingLayer(dense + feas)
+    for k, m in layer.embed_dict.items():
+        torch.nn.init.normal_(m.weight, 0, 0.5, generator=g)
+        if m.padding_idx is not None:
+            with torch.no_grad():
+                m.weight[m.padding_idx].zero_()
+    x = {f.name: torch.randint(0, v, (B,), generator=g) for f, v in zip(feas, vocabs)}
+    x.update({f.name: torch.rand(B, generator=g) for f in dense})
+    sq = layer(x, dense + feas, squeeze_dim=True)
+    ns = layer(x, feas, squeeze_dim=False)
+    gsq = torch.randn(sq.shape, generator=g)
+    sq.backward(gsq)
+    out["emb.idx"] = np.stack([npy(x[f.name]) for f in feas], 1)
+    out["emb.dense"] = np.stack([npy(x[f.name]) for f in dense], 1)
+    out["emb.vocabs"] = np.array(vocabs)
+    for k, m in layer.embed_dict.items():
+        out[f"emb.table.{k}"] = npy(m.weight)
+        out[f"emb.grad.{k}"] = npy(m.weight.grad)
+    out["emb.out_squeeze"] = npy(sq)
+    out["emb.out_3d"] = npy(ns)
+    out["emb.g_squeeze"] = npy(gsq)
+
+    # --- sequence features: sum / mean / concat, padding_idx set and unset ------------------------------------
+    L = 9
+    for tag, pad in (("pad0", 0), ("nopad", None)):
+        for pooling in ("sum", "mean", "concat"):
+            fea = SequenceFeature(f"h_{pooling}_{tag}", vocab_size=40, embed_dim=D, pooling=pooling, padding_idx=pad)
+            lay = EmbeddingLayer([fea])
+            torch.nn.init.normal_(lay.embed_dict[fea.name].weight, 0, 0.5, generator=g)
+            if pad is not None:
+                with torch.no_grad():
+                    lay.embed_dict[fea.name].weight[pad].zero_()
+            idx = torch.randint(1, 40, (B, L), generator=g)
+            lens = torch.randint(1, L + 1, (B,), generator=g)
+            idx[torch.arange(L)[None, :] >= lens[:, None]] = 0  # post-padding with 0 (utils/data.py:176)
+            y = lay({fea.name: idx}, [fea], squeeze_dim=False)
+            gy = torch.randn(y.shape, generator=g)
+            y.backward(gy)
+            key = f"seq.{pooling}.{tag}"
+            out[key + ".idx"] = npy(idx)
+            out[key + ".table"] = npy(lay.embed_dict[fea.name].weight)
+            out[key + ".out"] = npy(y)
+            out[key + ".g"] = npy(gy)
+            out[key + ".grad"] = npy(lay.embed_dict[fea.name].weight.grad)
+
+    # --- FM / LR ---------------------------------------------------------------------------------------------
+    xf = torch.randn(B, F, D, generator=g, requires_grad=True)
+    for rs in (True, False):
+        y = FM(reduce_sum=rs)(xf)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, xf, gy)
+        out[f"fm.{int(rs)}.out"], out[f"fm.{int(rs)}.g"], out[f"fm.{int(rs)}.gx"] = npy(y), npy(gy), npy(gx)
+    out["fm.x"] = npy(xf)
+    lr = LR(F * D)
+    y = lr(xf.flatten(1))
+    out["lr.w"], out["lr.b"], out["lr.out"] = npy(lr.fc.weight), npy(lr.fc.bias), npy(y)
+
+    # --- cross networks ---------------------------------------------------------------------------------------
+    d = 45
+    xc = torch.randn(B, d, generator=g, requires_grad=True)
+    for nl in (1, 3, 6):
+        cn = CrossNetwork(d, nl)
+        for w in cn.w:
+            torch.nn.init.normal_(w.weight, 0, 0.3, generator=g)
+        for b in cn.b:
+            torch.nn.init.normal_(b, 0, 0.3, generator=g)
+        y = cn(xc)
+        gy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad(y, [xc] + [w.weight for w in cn.w] + list(cn.b), gy)
+        k = f"cross.{nl}"
+        out[k + ".W"] = np.concatenate([npy(w.weight) for w in cn.w], 0)
+        out[k + ".B"] = np.stack([npy(b) for b in cn.b], 0)
+        out[k + ".out"], out[k + ".g"], out[k + ".gx"] = npy(y), npy(gy), npy(grads[0])
+        out[k + ".gW"] = np.concatenate([npy(t) for t in grads[1:1 + nl]], 0)
+        out[k + ".gB"] = np.stack([npy(t) for t in grads[1 + nl:]], 0)
+    out["cross.x"] = npy(xc)
+    v2 = CrossNetV2(d, 2)
+    for b in v2.b:
+        torch.nn.init.normal_(b, 0, 0.3, generator=g)
+    out["crossv2.W"] = np.stack([npy(w.weight) for w in v2.w], 0)
+    out["crossv2.B"] = np.stack([npy(b) for b in v2.b], 0)
+    out["crossv2.out"] = npy(v2(xc))
+    mix = CrossNetMix(d, num_layers=2, low_rank=8, num_experts=3)
+    for b in mix.bias:
+        torch.nn.init.normal_(b, 0, 0.3, generator=g)
+    out["crossmix.U"] = np.stack([npy(t) for t in mix.u_list], 0)
+    out["crossmix.V"] = np.stack([npy(t) for t in mix.v_list], 0)
+    out["crossmix.C"] = np.stack([npy(t) for t in mix.c_list], 0)
+    out["crossmix.Wg"] = np.concatenate([npy(t.weight) for t in mix.gating], 0)
+    out["crossmix.bias"] = np.stack([npy(t).reshape(-1) for t in mix.bias], 0)
+    out["crossmix.out"] = npy(mix(xc))
+
+    # --- Dice / ActivationUnit -----------------------------------------------------------------------------------
+    xd = torch.randn(B, 20, generator=g)
+    dice = Dice()
+    out["dice.x"], out["dice.alpha"], out["dice.out"] = npy(xd), npy(dice.alpha), npy(dice(xd))
+    for sm in (False, True):
+        au = ActivationUnit(D, dims=[12, 6], activation="dice", use_softmax=sm)
+        au.eval()  # BatchNorm with running stats (0/1): isolates the attention arithmetic
+        hist = torch.randn(B, L, D, generator=g)
+        tgt = torch.randn(B, D, generator=g)
+        k = f"au.{int(sm)}"
+        out[k + ".hist"], out[k + ".tgt"], out[k + ".out"] = npy(hist), npy(tgt), npy(au(hist, tgt))
+        for n, t in au.state_dict().items():
+            out[k + ".sd." + n] = npy(t)
+
+    # --- torch.optim.Adam trajectory on a small tensor (wd coupled) ------------------------------------------------
+    p = torch.nn.Parameter(torch.randn(5, 8, generator=g))
+    out["adam.p0"] = npy(p)
+    opt = torch.optim.Adam([p], lr=1e-2, weight_decay=1e-3)
+    gs = []
+    for t in range(4):
+        gr = torch.randn(5, 8, generator=g)
+        if t == 2:
+            gr.zero_()  # a step with no data gradient still moves p (Q9)
+        gs.append(npy(gr))
+        p.grad = gr
+        opt.step()
+        out[f"adam.p{t + 1}"] = npy(p)
+    out["adam.g"] = np.stack(gs, 0)
+    out["adam.m"] = npy(opt.state[p]["exp_avg"])
+    out["adam.v"] = npy(opt.state[p]["exp_avg_sq"])
+    np.savez_compressed(os.path.join(OUT, "layers.npz"), **out)
+    print("layers.npz", len(out), "arrays")
+
+
+def build_model(rh, cfg):
+    from torch_rechub.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    from torch_rechub.models.ranking import DCN, DIN, DCNv2, DeepFM, WideDeep
+    D = 16
+    mlp = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
+    if cfg.startswith("din"):
+        feats = [SparseFeature("user_id", vocab_size=30, embed_dim=D)]
+        hist = [SequenceFeature("hist_item", vocab_size=50, embed_dim=D, pooling="concat", shared_with="target_item",
+                                padding_idx=0),
+                SequenceFeature("hist_cate", vocab_size=12, embed_dim=D, pooling="concat", shared_with="target_cate",
+                                padding_idx=0)]
+        tgt = [SparseFeature("target_item", vocab_size=50, embed_dim=D, padding_idx=0),
+               SparseFeature("target_cate", vocab_size=12, embed_dim=D, padding_idx=0)]
+        model = DIN(feats, hist, tgt, mlp_params={"dims": [32, 16], "dropout": 0.0},
+                    attention_mlp_params={"dims": [16, 8], "use_softmax": cfg.endswith("softmax")})
+        return model, {"features": feats, "history_features": hist, "target_features": tgt}
+    dense = [DenseFeature(f"I{i + 1}") for i in range(13)]
+    vocabs = [3, 4, 10, 27, 105, 305, 583, 40, 1460, 24, 18, 15, 633] * 2
+    if cfg == "dcnv2_full_stacked":
+        vocabs = vocabs[:6]  # keeps the (d, d) cross weights of the fixture small
+    sparse = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=D) for i, v in enumerate(vocabs)]
+    if cfg == "deepfm_tutorial":  # tutorials/00: deep = dense + sparse, fm = sparse
+        return DeepFM(dense + sparse, sparse, mlp), {"deep_features": dense + sparse, "fm_features": sparse}
+    if cfg == "deepfm_criteo":  # examples/ranking/run_criteo.py:66: deep = dense only
+        return DeepFM(dense, sparse, mlp), {"deep_features": dense, "fm_features": sparse}
+    if cfg == "widedeep":
+        return WideDeep(dense, sparse, mlp), {"wide_features": dense, "deep_features": sparse}
+    if cfg == "dcn":
+        return DCN(dense + sparse, 3, {"dims": [32, 16]}), {"features": dense + sparse}
+    if cfg == "dcnv2_mix":
+        return DCNv2(dense + sparse, 3, mlp, low_rank=8, num_experts=3), {"features": dense + sparse}
+    if cfg == "dcnv2_full_stacked":
+        return DCNv2(dense + sparse, 2, mlp, model_structure="stacked", use_low_rank_mixture=False), \
+            {"features": dense + sparse}
+    raise ValueError(cfg)
+
+
+def make_batch(groups, B, g, L=7):
+    x = {}
+    seen = set()
+    for feas in groups.values():
+        for f in feas:
+            if f.name in seen:
+                continue
+            seen.add(f.name)
+            kind = type(f).__name__
+            if kind == "DenseFeature":
+                x[f.name] = torch.rand(B, generator=g)
+            elif kind == "SparseFeature":
+                lo = 1 if f.padding_idx == 0 else 0
+                x[f.name] = torch.randint(lo, f.vocab_size, (B,), generator=g)
+            else:
+                idx = torch.randint(1, f.vocab_size, (B, L), generator=g)
+                lens = torch.randint(1, L + 1, (B,), generator=g)
+                idx[torch.arange(L)[None, :] >= lens[:, None]] = 0
+                x[f.name] = idx
+    y = (torch.rand(B, generator=g) < 0.25).long()
+    return x, y
+
+
+def gen_model(rh, cfg):
+    from torch_rechub.trainers import CTRTrainer
+    torch.manual_seed(SEED)
+    g = torch.Generator().manual_seed(SEED + 1)
+    model, groups = build_model(rh, cfg)
+    # larger-than-default table init so that FM / attention terms are numerically visible
+    for m in model.modules():
+        if isinstance(m, torch.nn.Embedding):
+            torch.nn.init.normal_(m.weight, 0, 0.1, generator=g)
+            if m.padding_idx is not None:
+                with torch.no_grad():
+                    m.weight[m.padding_idx].zero_()
+    B = 48
+    batches = [make_batch(groups, B, g) for _ in range(3)]
+    out = {"spec": np.array(json.dumps({k: [spec_of(f) for f in v] for k, v in groups.items()})),
+           "cfg": np.array(cfg)}
+    for n, t in model.state_dict().items():
+        out["sd0." + n] = npy(t)
+    x, y = batches[0]
+    for bi, (bx, by) in enumerate(batches):
+        for k, v in bx.items():
+            out[f"x{bi}.{k}"] = npy(v)
+        out[f"y{bi}"] = npy(by)
+    model.eval()
+    with torch.no_grad():
+        out["pred_eval"] = npy(model(x))
+    model.train()
+    sd_backup = {k: v.clone() for k, v in model.state_dict().items()}
+    pred = model(x)
+    loss = torch.nn.BCELoss()(pred, y.float())
+    model.zero_grad()
+    loss.backward()
+    out["pred_train"] = npy(pred)
+    out["loss"] = np.array(loss.item())
+    for n, p in model.named_parameters():
+        out["grad." + n] = npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    model.load_state_dict(sd_backup)  # undo the BatchNorm running-stat update of the probe forward
+    model.zero_grad()
+    # the reference training loop itself: trainers/ctr_trainer.py:77-108 over three fixed batches
+    wd = 1e-3
+    trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": wd}, n_epoch=1, device="cpu")
+    mean_loss = trainer.train_one_epoch(batches)
+    out["train.lr"], out["train.wd"], out["train.mean_loss"] = np.array(1e-2), np.array(wd), np.array(mean_loss)
+    for n, t in model.state_dict().items():
+        out["sd3." + n] = npy(t)
+    np.savez_compressed(os.path.join(OUT, f"model_{cfg}.npz"), **out)
+    print(f"model_{cfg}.npz", len(out), "arrays, loss", loss.item(), "mean train loss", mean_loss)
+
+
+CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
+           "din_softmax"]
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    rh = import_reference()
+    gen_layers(rh)
+    for cfg in CONFIGS:
+        gen_model(rh, cfg)

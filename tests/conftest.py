@@ -1,0 +1,87 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def layers_golden():
+    return load_golden("layers.npz")
+
+
+MODEL_CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
+                 "din_softmax"]
+
+
+def features_from_spec(spec_json):
+    """Rebuild feature objects (torch_rechub_amd classes) from the json spec stored in a model fixture.
+
+    Feature objects are shared between groups by name, as in the generator (Q2 semantics)."""
+    from torch_rechub_amd.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    spec = json.loads(str(spec_json))
+    made = {}
+    groups = {}
+    for gname, feas in spec.items():
+        lst = []
+        for d in feas:
+            key = (d["kind"], d["name"])
+            if key not in made:
+                if d["kind"] == "DenseFeature":
+                    made[key] = DenseFeature(d["name"], d["embed_dim"])
+                elif d["kind"] == "SparseFeature":
+                    made[key] = SparseFeature(d["name"], d["vocab_size"], d["embed_dim"], shared_with=d["shared_with"],
+                                              padding_idx=d["padding_idx"])
+                else:
+                    made[key] = SequenceFeature(d["name"], d["vocab_size"], d["embed_dim"], pooling=d["pooling"],
+                                                shared_with=d["shared_with"], padding_idx=d["padding_idx"])
+            lst.append(made[key])
+        groups[gname] = lst
+    return groups
+
+
+def build_amd_model(cfg, groups):
+    """Same constructor calls as oracle/gen_golden.py::build_model, on the torch_rechub_amd classes."""
+    from torch_rechub_amd.models.ranking import DCN, DIN, DCNv2, DeepFM, WideDeep
+    mlp = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
+    if cfg.startswith("din"):
+        return DIN(groups["features"], groups["history_features"], groups["target_features"],
+                   mlp_params={"dims": [32, 16], "dropout": 0.0},
+                   attention_mlp_params={"dims": [16, 8], "use_softmax": cfg.endswith("softmax")})
+    if cfg.startswith("deepfm"):
+        return DeepFM(groups["deep_features"], groups["fm_features"], mlp)
+    if cfg == "widedeep":
+        return WideDeep(groups["wide_features"], groups["deep_features"], mlp)
+    if cfg == "dcn":
+        return DCN(groups["features"], 3, {"dims": [32, 16]})
+    if cfg == "dcnv2_mix":
+        return DCNv2(groups["features"], 3, mlp, low_rank=8, num_experts=3)
+    if cfg == "dcnv2_full_stacked":
+        return DCNv2(groups["features"], 2, mlp, model_structure="stacked", use_low_rank_mixture=False)
+    raise ValueError(cfg)
+
+
+def golden_batch(gold, bi):
+    import torch
+    x = {k[len(f"x{bi}."):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(f"x{bi}.")}
+    y = torch.from_numpy(gold[f"y{bi}"])
+    return x, y
+
+
+def golden_state(gold, prefix):
+    import torch
+    return {k[len(prefix):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(prefix)}

@@ -1,0 +1,174 @@
+"""Host-side logic that needs no GPU: API surface, checkpoint keys, feature sharing, loud failure on CPU
+tensors, loaders, regularisation arithmetic (values from the reference's tests/test_regularization.py)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from conftest import MODEL_CONFIGS, build_amd_model, features_from_spec, golden_batch, golden_state, load_golden
+
+
+@pytest.mark.parametrize("cfg", MODEL_CONFIGS)
+def test_state_dict_keys_and_shapes_match_reference(cfg):
+    gold = load_golden(f"model_{cfg}.npz")
+    model = build_amd_model(cfg, features_from_spec(gold["spec"]))
+    ref = golden_state(gold, "sd0.")
+    mine = model.state_dict()
+    assert list(mine.keys()) == list(ref.keys())  # same names, same order: model.pth round-trips
+    for k in ref:
+        assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+    model.load_state_dict(ref)  # strict
+
+
+def test_tables_stay_nn_embedding_and_are_shared_across_models():
+    from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
+    from torch_rechub_amd.models.ranking import DCN, DeepFM
+    dense = [DenseFeature("d0")]
+    sparse = [SparseFeature("a", 10, 16), SparseFeature("b", 7, 16, shared_with="a")]
+    m1 = DeepFM(dense + sparse, sparse, {"dims": [8]})
+    m2 = DCN(dense + sparse, 2, {"dims": [8]})
+    assert isinstance(m1.embedding.embed_dict["a"], nn.Embedding)
+    assert "b" not in m1.embedding.embed_dict  # shared_with features own no table (layers.py:69-72)
+    assert m1.embedding.embed_dict["a"] is m2.embedding.embed_dict["a"]  # cached on the Feature object (Q2)
+    assert m1.embedding.n_dense == 1
+
+
+def test_initializers_zero_padding_row_and_default_std():
+    from torch_rechub_amd.basic.features import SparseFeature
+    from torch_rechub_amd.basic.initializers import RandomUniform, XavierNormal
+    torch.manual_seed(0)
+    t = SparseFeature("x", 5000, 16, padding_idx=3).get_embedding_layer()
+    assert torch.all(t.weight[3] == 0) and t.padding_idx == 3
+    assert 0.5e-4 < t.weight.std().item() < 2e-4  # RandomNormal(0, 1e-4) default (features.py:54)
+    u = RandomUniform(-1, 1)(50, 8, padding_idx=0)
+    assert torch.all(u.weight[0] == 0) and u.weight.abs().max() <= 1
+    assert XavierNormal()(50, 8).weight.shape == (50, 8)
+
+
+def test_auto_embedding_dim_rule():
+    from torch_rechub_amd.basic.features import SparseFeature, get_auto_embedding_dim
+    assert get_auto_embedding_dim(10000) == 60
+    assert SparseFeature("x", 16).embed_dim == 12
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    gold = load_golden("model_deepfm_tutorial.npz")
+    model = build_amd_model("deepfm_tutorial", features_from_spec(gold["spec"]))
+    x, _ = golden_batch(gold, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(x)
+    from torch_rechub_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.fm(torch.zeros(2, 3, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cross_network(torch.zeros(2, 8), torch.zeros(1, 8), torch.zeros(1, 8))
+
+
+def test_trainer_refuses_cpu_device():
+    from torch_rechub_amd.trainers import CTRTrainer
+    gold = load_golden("model_dcn.npz")
+    model = build_amd_model("dcn", features_from_spec(gold["spec"]))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        CTRTrainer(model, device="cpu")
+
+
+def test_embedding_layer_error_messages_match_reference():
+    from torch_rechub_amd.basic.features import DenseFeature, SequenceFeature
+    from torch_rechub_amd.basic.layers import EmbeddingLayer, InputMask
+    lay = EmbeddingLayer([DenseFeature("d")])
+    with pytest.raises(ValueError, match="expected SparseFeatures"):
+        lay({"d": torch.zeros(3)}, [DenseFeature("d")], squeeze_dim=False)
+    assert lay({"d": torch.arange(3)}, [DenseFeature("d")], squeeze_dim=True).shape == (3, 1)  # dense-only path
+    bad = SequenceFeature("h", 10, 16, pooling="max")
+    lay2 = EmbeddingLayer([bad])
+    with pytest.raises(ValueError, match="Sequence pooling method supports only"):
+        lay2({"h": torch.zeros(2, 3, dtype=torch.long)}, [bad])
+    with pytest.raises(ValueError, match="Only SparseFeature or SequenceFeature"):
+        InputMask()({"d": torch.zeros(3)}, DenseFeature("d"))
+
+
+def test_input_mask_and_pooling_shims():
+    from torch_rechub_amd.basic.features import SequenceFeature
+    from torch_rechub_amd.basic.layers import AveragePooling, InputMask, SumPooling
+    idx = torch.tensor([[3, 4, 0, 0], [1, 0, 0, 0]])
+    x = {"h": idx}
+    m0 = InputMask()(x, SequenceFeature("h", 10, 4, padding_idx=0))
+    assert m0.shape == (2, 1, 4) and m0.sum().item() == 3
+    m1 = InputMask()(x, SequenceFeature("h", 10, 4))  # sentinel -1: nothing masked
+    assert m1.sum().item() == 8
+    e = torch.arange(2 * 4 * 3, dtype=torch.float32).view(2, 4, 3)
+    np.testing.assert_allclose(SumPooling()(e, m0).numpy(), torch.bmm(m0, e).squeeze(1).numpy())
+    np.testing.assert_allclose(AveragePooling()(e, m0).numpy(),
+                               (torch.bmm(m0, e).squeeze(1) / (m0.sum(-1) + 1e-16)).numpy())
+
+
+def test_regularization_loss_values():
+    """Known answers of the reference's tests/test_regularization.py style: exact sums by hand."""
+    from torch_rechub_amd.basic.loss_func import RegularizationLoss
+
+    class M(nn.Module):
+
+        def __init__(self):
+            super().__init__()
+            self.emb = nn.Embedding(3, 2)
+            self.fc = nn.Linear(2, 1)
+            self.bn = nn.BatchNorm1d(1)
+            with torch.no_grad():
+                self.emb.weight.copy_(torch.tensor([[1., -2.], [3., 0.], [0.5, 0.5]]))
+                self.fc.weight.copy_(torch.tensor([[2., -1.]]))
+                self.fc.bias.fill_(0.5)
+
+    m = M()
+    assert RegularizationLoss()(m) == 0.0  # python float when disabled (ctr_trainer.py adds it to the loss)
+    l = RegularizationLoss(embedding_l1=0.1, embedding_l2=0.01, dense_l1=0.2, dense_l2=0.02)(m)
+    emb_l1, emb_l2 = 1 + 2 + 3 + 0.5 + 0.5, 1 + 4 + 9 + 0.25 + 0.25
+    den_l1, den_l2 = 2 + 1 + 0.5, 4 + 1 + 0.25  # BatchNorm params skipped
+    assert abs(l.item() - (0.1 * emb_l1 + 0.01 * emb_l2 + 0.2 * den_l1 + 0.02 * den_l2)) < 1e-6
+    l.backward()
+    assert m.emb.weight.grad is not None and m.bn.weight.grad is None
+
+
+def test_data_generator_split_and_batches():
+    from torch_rechub_amd.utils.data import DataGenerator
+    n = 100
+    x = {"a": np.arange(n), "b": np.random.rand(n).astype(np.float32)}
+    y = (np.arange(n) % 2)
+    tr, va, te = DataGenerator(x, y).generate_dataloader(split_ratio=[0.7, 0.1], batch_size=16)
+    assert len(tr.dataset) == 70 and len(va.dataset) == 10 and len(te.dataset) == 20
+    xb, yb = next(iter(tr))
+    assert set(xb) == {"a", "b"} and xb["a"].shape == (16,) and yb.dtype == torch.int64
+    seen = sorted(int(v) for loader in (tr, va, te) for xb, _ in loader for v in xb["a"])
+    assert seen == list(range(n))  # every row exactly once across the three splits
+
+
+def test_pack_indices_zero_copy_and_fallback():
+    from torch_rechub_amd.distributed import pack_indices
+    base = torch.arange(24).view(6, 4)
+    cols = [base[:, j] for j in range(4)]
+    packed = pack_indices(cols)
+    assert packed.data_ptr() == base.data_ptr() and torch.equal(packed, base)
+    loose = [torch.arange(6), torch.arange(6) + 10]
+    assert torch.equal(pack_indices(loose), torch.stack(loose, 1))
+
+
+def test_dense_grad_reducer_flat_views_cpu():
+    from torch_rechub_amd.distributed import DenseGradReducer
+    lin = nn.Sequential(nn.Linear(3, 2), nn.Linear(2, 1))
+    red = DenseGradReducer(list(lin.parameters()))
+    assert red.flat.numel() == 6 + 2 + 2 + 1
+    lin(torch.ones(4, 3)).sum().backward()
+    assert all(red.ready)  # post-accumulate hooks fired
+    for i, p in enumerate(lin.parameters()):
+        assert p.grad.data_ptr() == red.flat[red.offsets[i]:].data_ptr()  # accumulated in place into the bucket
+    assert red.flat.abs().sum() > 0
+    red.zero()
+    assert red.flat.abs().sum() == 0 and not any(red.ready)
+
+
+def test_table_parameters_detection():
+    from torch_rechub_amd.distributed import table_parameters
+    gold = load_golden("model_din.npz")
+    model = build_amd_model("din", features_from_spec(gold["spec"]))
+    names = {n for n, p in model.named_parameters() if any(p is q for q in table_parameters(model))}
+    assert names == {"embedding.embed_dict.user_id.weight", "embedding.embed_dict.target_item.weight",
+                     "embedding.embed_dict.target_cate.weight"}

@@ -1,0 +1,88 @@
+"""ctypes binding of ``csrc/librechub_hip.so`` (the C ABI declared in ``include/rechub_hip.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing or a symbol cannot be
+resolved the import of any op fails loudly (``RuntimeError``), and every op refuses tensors that
+are not on a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librechub_hip.so")
+
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+
+# name -> argtypes; every function returns int (0 ok) unless listed in _RESTYPES
+SIGNATURES = {
+    "rh_abi_version": [],
+    "rh_last_error": [],
+    "rh_embed_fwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
+                     c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
+    "rh_embed_bwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                     c_ptr, c_ptr, c_f32, c_int, c_ptr, c_int, c_ptr, c_ptr],
+    "rh_embed_bwd_nchunks": [c_int, c_int],
+    "rh_embed_scatter_rows": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_f32, c_int, c_ptr, c_ptr],
+    "rh_fm_fwd": [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_fm_bwd": [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr],
+    "rh_seq_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_ptr, c_i64,
+                        c_ptr, c_ptr],
+    "rh_seq_pool_bwd": [c_ptr, c_i64, c_ptr, c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_ptr,
+                        c_i64, c_f32, c_ptr, c_ptr],
+    "rh_cross_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr],
+    "rh_cross_bwd_nblocks": [c_int],
+    "rh_cross_max_layers": [c_int],
+    "rh_cross_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
+                     c_i64, c_int, c_ptr, c_ptr],
+    "rh_adam_prepare": [c_ptr, c_ptr, c_ptr],
+    "rh_adam_dense": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
+    "rh_batch_gather": [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],
+}
+_RESTYPES = {"rh_last_error": ctypes.c_char_p}
+# functions whose int return value is a result, not a status
+_VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers"}
+
+ABI_VERSION = 1
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise RuntimeError (never fall back) when it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"librechub_hip.so not found at {LIB_PATH}. Build it with "
+                           f"`python -c 'import __graft_entry__ as g; g.build()'` or `{_HERE}/csrc/build.sh` "
+                           "(there is no CPU fallback for the HIP hot path).")
+    # torch must be imported first so that the HIP runtime already mapped by torch (same SONAME
+    # libamdhip64.so.7) is the one this library binds to: one runtime, shared streams.
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"librechub_hip.so does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    got = lib.rh_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"librechub_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _VALUE_RETURNING:
+        return rc
+    if rc != 0:
+        msg = lib.rh_last_error()
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
+    return 0

@@ -1,0 +1,1 @@
+from . import activation, callback, features, initializers, layers, loss_func  # noqa: F401

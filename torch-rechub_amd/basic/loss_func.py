@@ -1,0 +1,44 @@
+"""RegularizationLoss (API mirror of torch_rechub/basic/loss_func.py:6-68).
+
+Same classification rules: parameters of normalisation layers are skipped, parameters of
+``nn.Embedding`` / ``nn.EmbeddingBag`` modules use the embedding coefficients, everything else the
+dense ones.  Returns the python float 0.0 when nothing applies (the trainer adds it to the loss).
+"""
+import torch
+from torch import nn
+
+_NORMS = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.LayerNorm, nn.GroupNorm, nn.InstanceNorm1d,
+          nn.InstanceNorm2d, nn.InstanceNorm3d)
+
+
+class RegularizationLoss(nn.Module):
+
+    def __init__(self, embedding_l1=0.0, embedding_l2=0.0, dense_l1=0.0, dense_l2=0.0):
+        super().__init__()
+        self.embedding_l1 = embedding_l1
+        self.embedding_l2 = embedding_l2
+        self.dense_l1 = dense_l1
+        self.dense_l2 = dense_l2
+
+    def active(self):
+        return max(self.embedding_l1, self.embedding_l2, self.dense_l1, self.dense_l2) > 0
+
+    def forward(self, model):
+        total = 0.0
+        if not self.active():
+            return total
+        skip, tables = set(), set()
+        for m in model.modules():
+            if isinstance(m, _NORMS):
+                skip.update(id(p) for p in m.parameters())
+            elif isinstance(m, (nn.Embedding, nn.EmbeddingBag)):
+                tables.update(id(p) for p in m.parameters())
+        for p in model.parameters():
+            if not p.requires_grad or id(p) in skip:
+                continue
+            l1, l2 = (self.embedding_l1, self.embedding_l2) if id(p) in tables else (self.dense_l1, self.dense_l2)
+            if l1 > 0:
+                total = total + l1 * p.abs().sum()
+            if l2 > 0:
+                total = total + l2 * (p * p).sum()
+        return total

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
   const int64_t vocab = a.fdesc[2 * F + f];
   const int64_t pad = a.fdesc[3 * F + f];
   const int col = (int)a.idesc[2 * F + f] * D;  // column of this field in g_out / emb
-  const bool use_lds = (SINK == 0) && (vocab * D <= (int64_t)a.lds_floats);
+  const bool has_tab = gtab != nullptr;  // frozen tables (requires_grad = False) carry no gradient buffer
+  const bool use_lds = (SINK == 0) && has_tab && (vocab * D <= (int64_t)a.lds_floats);
   const int n4 = (int)(vocab * D / 4);
   if (use_lds) {
     for (int i = tid; i < n4; i += RH_BLOCK) lds4[i] = f4_zero();
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
         } else {
           const bool oob = (uint64_t)row[u] >= (uint64_t)vocab;
           oob_any |= oob;
-          if (!oob && row[u] != pad) {
+          if (has_tab && !oob && row[u] != pad) {
             const int64_t off = row[u] * D + q * 4;
             if (use_lds) {
               RH_LDS_ATOMIC_ADD_F4(lds, (int)off, gr);

@@ -1,0 +1,8 @@
+"""Ranking models on the hot path (reference torch_rechub/models/ranking/__init__.py)."""
+from .dcn import DCN
+from .dcn_v2 import DCNv2
+from .deepfm import DeepFM
+from .din import DIN, ActivationUnit
+from .widedeep import WideDeep
+
+__all__ = ["WideDeep", "DeepFM", "DCN", "DCNv2", "DIN"]

@@ -1,0 +1,54 @@
+"""DeepFM (API mirror of torch_rechub/models/ranking/deepfm.py:14-43).
+
+Reference forward: two full gathers of the same tables (deep + fm feature lists), LR on the flattened
+fm embeddings, FM, MLP, sigmoid.  Here, when the fm features are plain sparse features of one width,
+ONE kernel launch gathers every table once and emits the MLP input (sparse block + dense values),
+the FM scalar and the LR scalar (ops.fused_embedding); its backward is one launch too.
+Attribute / parameter names are the reference's (``linear.fc``, ``embedding.embed_dict``, ``mlp.mlp``).
+"""
+import torch
+
+from ... import ops
+from ...basic.features import SparseFeature
+from ...basic.layers import FM, LR, MLP, EmbeddingLayer
+
+
+class DeepFM(torch.nn.Module):
+
+    def __init__(self, deep_features, fm_features, mlp_params):
+        super().__init__()
+        self.deep_features = deep_features
+        self.fm_features = fm_features
+        self.deep_dims = sum(fea.embed_dim for fea in deep_features)
+        self.fm_dims = sum(fea.embed_dim for fea in fm_features)
+        self.linear = LR(self.fm_dims)
+        self.fm = FM(reduce_sum=True)
+        self.embedding = EmbeddingLayer(deep_features + fm_features)
+        self.mlp = MLP(self.deep_dims, **mlp_params)
+
+    def _deep_shares_fm_gather(self, x):
+        deep_sparse = [f for f in self.deep_features if isinstance(f, SparseFeature)]
+        if len(deep_sparse) != len(self.fm_features) or any(a is not b for a, b in zip(deep_sparse, self.fm_features)):
+            return False
+        return self.embedding.can_fuse(x, self.deep_features)
+
+    def forward(self, x):
+        emb = self.embedding
+        if emb.can_fuse(x, self.fm_features):
+            w, b = self.linear.fc.weight, self.linear.fc.bias
+            if self._deep_shares_fm_gather(x):
+                dense = [f for f in self.deep_features if not isinstance(f, SparseFeature)]
+                call = emb.make_call(x, self.fm_features, dense, want_fm=True, want_lr=True)
+                input_deep, y_fm, y_linear = ops.fused_embedding(call, w, b)
+            else:
+                call = emb.make_call(x, self.fm_features, (), want_fm=True, want_lr=True)
+                _, y_fm, y_linear = ops.fused_embedding(call, w, b)
+                input_deep = emb(x, self.deep_features, squeeze_dim=True)
+        else:
+            input_deep = emb(x, self.deep_features, squeeze_dim=True)
+            input_fm = emb(x, self.fm_features, squeeze_dim=False)
+            y_linear = self.linear(input_fm.flatten(start_dim=1))
+            y_fm = self.fm(input_fm)
+        y_deep = self.mlp(input_deep)
+        y = y_linear + y_fm + y_deep
+        return torch.sigmoid(y.squeeze(1))

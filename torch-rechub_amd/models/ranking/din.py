@@ -1,0 +1,62 @@
+"""Deep Interest Network (API mirror of torch_rechub/models/ranking/din.py:16-93).
+
+Quirks kept on purpose: the attention applies NO padding mask, padded positions go through the
+BatchNorm statistics of the attention MLP (B*L rows) and receive a weight; history feature i pairs with
+target feature i by position.
+"""
+import torch
+from torch import nn
+
+from ...basic.layers import MLP, EmbeddingLayer
+
+
+class DIN(nn.Module):
+
+    def __init__(self, features, history_features, target_features, mlp_params, attention_mlp_params):
+        super().__init__()
+        self.features = features
+        self.history_features = history_features
+        self.target_features = target_features
+        self.num_history_features = len(history_features)
+        self.all_dims = sum(fea.embed_dim for fea in features + history_features + target_features)
+        self.embedding = EmbeddingLayer(features + history_features + target_features)
+        self.attention_layers = nn.ModuleList(
+            [ActivationUnit(fea.embed_dim, **attention_mlp_params) for fea in self.history_features])
+        self.mlp = MLP(self.all_dims, activation="dice", **mlp_params)
+
+    def forward(self, x):
+        embed_x_features = self.embedding(x, self.features)  # (B, n_feat, D)
+        embed_x_history = self.embedding(x, self.history_features)  # (B, n_hist, L, D)
+        embed_x_target = self.embedding(x, self.target_features)  # (B, n_tgt, D)
+        pooled = [
+            self.attention_layers[i](embed_x_history[:, i, :, :], embed_x_target[:, i, :]).unsqueeze(1)
+            for i in range(self.num_history_features)
+        ]
+        attention_pooling = torch.cat(pooled, dim=1)
+        mlp_in = torch.cat([
+            attention_pooling.flatten(start_dim=1),
+            embed_x_target.flatten(start_dim=1),
+            embed_x_features.flatten(start_dim=1)
+        ], dim=1)
+        return torch.sigmoid(self.mlp(mlp_in).squeeze(1))
+
+
+class ActivationUnit(nn.Module):
+    """DIN local activation unit: weight_l = MLP([t, h_l, t-h_l, t*h_l]); out = sum_l weight_l * h_l."""
+
+    def __init__(self, emb_dim, dims=None, activation="dice", use_softmax=False):
+        super().__init__()
+        if dims is None:
+            dims = [36]
+        self.emb_dim = emb_dim
+        self.use_softmax = use_softmax
+        self.attention = MLP(4 * self.emb_dim, dims=dims, activation=activation)
+
+    def forward(self, history, target):
+        B, L, D = history.shape
+        t = target.unsqueeze(1).expand(-1, L, -1)
+        att_input = torch.cat([t, history, t - history, t * history], dim=-1)
+        att_weight = self.attention(att_input.reshape(-1, 4 * D)).view(-1, L)
+        if self.use_softmax:
+            att_weight = att_weight.softmax(dim=-1)
+        return (att_weight.unsqueeze(-1) * history).sum(dim=1)

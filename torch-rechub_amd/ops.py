@@ -1,0 +1,449 @@
+"""Autograd bindings of the gfx950 kernels (C ABI in ``include/rechub_hip.h``).
+
+Each op hands raw device pointers + the current HIP stream to ``librechub_hip.so`` through ctypes.
+PyTorch is only the allocator / stream / autograd plumbing here.  There is no CPU path: tensors that
+are not on a HIP device raise ``RuntimeError``.
+
+Gradient convention for embedding tables (replaces ``embedding_dense_backward`` + ``model.zero_grad``,
+reference trainers/ctr_trainer.py:97-98): every table owns ONE persistent dense gradient buffer
+(``grad_buffer(weight)``), zero outside the rows touched since the last optimizer step.  The fused
+backward scatter-adds into it and publishes it as ``weight.grad``; ``FusedDenseAdam`` re-zeroes the
+touched rows inside its own pass.  A stock ``torch.optim`` optimizer sees an ordinary dense ``.grad``.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+_NULL = ctypes.c_void_p(0)
+
+
+def _p(t):
+    return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_hip(*tensors):
+    """Fail loudly for anything that is not a HIP tensor (there is no CPU fallback)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("torch_rechub_amd: this op runs only on a HIP device (MI355X); got a "
+                               f"{t.device} tensor. There is no CPU fallback by design.")
+    _lib.load()
+
+
+# --------------------------------------------------------------------------------------------
+# persistent per-table state
+# --------------------------------------------------------------------------------------------
+def grad_buffer(weight):
+    """The persistent dense gradient buffer of a table (allocated zeroed on first use)."""
+    buf = getattr(weight, "_rh_grad", None)
+    if buf is None or buf.device != weight.device or buf.shape != weight.shape:
+        buf = torch.zeros_like(weight, memory_format=torch.contiguous_format)
+        weight._rh_grad = buf
+        weight._rh_dirty = False
+    return buf
+
+
+def _publish_grad(weight):
+    """Make ``weight.grad`` the persistent buffer (folding in a foreign dense grad if one exists)."""
+    buf = weight._rh_grad
+    g = weight.grad
+    if g is None:
+        weight.grad = buf
+    elif g.data_ptr() != buf.data_ptr():
+        buf.add_(g)
+        weight.grad = buf
+    weight._rh_dirty = True
+
+
+def _prepare_grad(weight):
+    """Called before a scatter: drop stale contents if the user reset ``.grad`` since the last backward."""
+    buf = grad_buffer(weight)
+    if weight._rh_dirty:
+        g = weight.grad
+        if g is None or g.data_ptr() != buf.data_ptr():
+            buf.zero_()  # zero_grad(set_to_none=True) happened: the buffer holds last step's rows
+            weight._rh_dirty = False
+    return buf
+
+
+_err_flags = {}
+
+
+def err_flag(device):
+    """Per-device int32 word the kernels OR error bits into (index out of range ...)."""
+    f = _err_flags.get(device)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=device)
+        _err_flags[device] = f
+    return f
+
+
+def check_errors(device=None):
+    """Synchronising check of the kernel error word; raises IndexError like the reference's CPU path."""
+    for dev, f in list(_err_flags.items()):
+        if device is not None and dev != device:
+            continue
+        v = int(f.item())
+        if v:
+            f.zero_()
+            if v & 1:
+                raise IndexError("torch_rechub_amd: an embedding index was out of range (index < 0 or >= vocab_size)")
+            raise RuntimeError(f"torch_rechub_amd: kernel error flag {v}")
+
+
+class _DescCache(object):
+    """Tiny LRU of host tuples -> device int64 descriptor tensors (no upload when pointers repeat)."""
+
+    def __init__(self, cap=8):
+        self.cap = cap
+        self.d = OrderedDict()
+
+    def get(self, key, device):
+        k = (key, device)
+        t = self.d.get(k)
+        if t is None:
+            t = torch.tensor(key, dtype=torch.int64).to(device)
+            self.d[k] = t
+            if len(self.d) > self.cap:
+                self.d.popitem(last=False)
+        else:
+            self.d.move_to_end(k)
+        return t
+
+
+class EmbedCall(object):
+    """Everything one fused gather needs besides the autograd inputs: descriptors + shapes.
+
+    weights : table weights per field (a weight may repeat: shared tables)
+    pads    : padding_idx per field (-1 = none)
+    idx     : index tensors per field, shape (B,), int64 or int32, on the device
+    dense   : dense value tensors (B,), float32, appended after the sparse block
+    """
+    _fcache = _DescCache(16)
+    _icache = _DescCache(16)
+    _dcache = _DescCache(16)
+
+    def __init__(self, weights, pads, idx, dense=(), want_fm=False, want_lr=False, slots=None, width=None,
+                 field_split=0, samples_per_block=0):
+        self.weights = list(weights)
+        self.idx = list(idx)
+        self.dense = list(dense)
+        F = len(self.weights)
+        if F == 0 or len(self.idx) != F or len(pads) != F:
+            raise ValueError("EmbedCall: need one weight, padding_idx and index tensor per field")
+        require_hip(*self.weights, *self.idx, *self.dense)
+        self.F = F
+        self.D = int(self.weights[0].shape[1])
+        for w in self.weights:
+            if w.dim() != 2 or w.shape[1] != self.D or w.dtype != torch.float32 or not w.is_contiguous():
+                raise ValueError("EmbedCall: tables must be contiguous float32 (vocab, D) with one common D")
+        self.B = int(self.idx[0].shape[0])
+        idt = self.idx[0].dtype
+        if idt not in (torch.int64, torch.int32):
+            raise ValueError(f"EmbedCall: index dtype {idt} unsupported (int64 / int32)")
+        for t in self.idx:
+            if t.dim() != 1 or t.shape[0] != self.B or t.dtype != idt:
+                raise ValueError("EmbedCall: every index tensor must be (B,) with one common integer dtype")
+        for t in self.dense:
+            if t.dim() != 1 or t.shape[0] != self.B or t.dtype != torch.float32:
+                raise ValueError("EmbedCall: dense values must be float32 (B,)")
+        self.idx_is_i64 = 1 if idt == torch.int64 else 0
+        self.pads = [(-1 if p is None else int(p)) for p in pads]
+        self.slots = list(range(F)) if slots is None else list(slots)
+        self.dense_col = (max(self.slots) + 1) * self.D
+        self.width = self.dense_col + len(self.dense) if width is None else int(width)
+        self.want_fm = bool(want_fm)
+        self.want_lr = bool(want_lr)
+        if self.want_lr and self.slots != list(range(F)):
+            raise ValueError("EmbedCall: fused LR needs slot f == field f")
+        self.field_split = field_split
+        self.samples_per_block = samples_per_block
+        self.device = self.weights[0].device
+
+    # descriptor tables ------------------------------------------------------------------
+    def fdesc(self, with_grads):
+        ptrs = [w.data_ptr() for w in self.weights]
+        if with_grads:
+            gp = [(_prepare_grad(w).data_ptr() if w.requires_grad else 0) for w in self.weights]
+        else:
+            gp = [0] * self.F
+        key = tuple(ptrs + gp + [int(w.shape[0]) for w in self.weights] + self.pads)
+        return EmbedCall._fcache.get(key, self.device)
+
+    def idesc(self):
+        key = tuple([t.data_ptr() for t in self.idx] + [t.stride(0) for t in self.idx] + self.slots)
+        return EmbedCall._icache.get(key, self.device)
+
+    def ddesc(self):
+        if not self.dense:
+            return None
+        key = tuple([t.data_ptr() for t in self.dense] + [t.stride(0) for t in self.dense])
+        return EmbedCall._dcache.get(key, self.device)
+
+
+# data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
+_sparse_exchange = None
+
+
+def set_sparse_exchange(fn):
+    """fn(call, rows_local (B,F,D)) -> (idx_all (W*B,F) int, rows_all (W*B,F,D)) or None to disable."""
+    global _sparse_exchange
+    _sparse_exchange = fn
+
+
+_pre_backward_hooks = []
+
+
+def add_pre_embed_backward_hook(fn):
+    """fn() runs at the start of every fused-embedding backward (used to kick the dense all-reduce early)."""
+    _pre_backward_hooks.append(fn)
+    return fn
+
+
+def remove_pre_embed_backward_hook(fn):
+    if fn in _pre_backward_hooks:
+        _pre_backward_hooks.remove(fn)
+
+
+class _EmbedFused(torch.autograd.Function):
+    """out (B,width), fm (B,1)|None, lr (B,1)|None = fused_embedding(call, lr_w, lr_b, *table weights)."""
+
+    @staticmethod
+    def forward(ctx, call, lr_w, lr_b, *weights):
+        B, F, D = call.B, call.F, call.D
+        dev = call.device
+        out = torch.empty((B, call.width), dtype=torch.float32, device=dev)
+        fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if call.want_fm else None
+        lr = torch.empty((B, 1), dtype=torch.float32, device=dev) if call.want_lr else None
+        s_sum = torch.empty((B, D), dtype=torch.float32, device=dev) if call.want_fm else None
+        if call.want_lr:
+            if lr_w is None or lr_w.numel() != F * D or not lr_w.is_contiguous() or lr_w.dtype != torch.float32:
+                raise ValueError("fused LR weight must be contiguous float32 with F*D elements")
+            require_hip(lr_w, lr_b)
+        ddesc = call.ddesc()
+        _lib.call("rh_embed_fwd", _p(call.fdesc(False)), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(ddesc),
+                  len(call.dense), call.dense_col, _p(out), out.stride(0), _p(lr_w if call.want_lr else None),
+                  _p(lr_b if call.want_lr else None), _p(lr), _p(fm), _p(s_sum), call.field_split,
+                  _p(err_flag(dev)), _stream())
+        ctx.call = call
+        ctx.has_lr_b = lr_b is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(out, s_sum, lr_w if call.want_lr else None)
+        outs = [out]
+        nd = []
+        outs.append(fm)
+        outs.append(lr)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_out, g_fm, g_lr):
+        call = ctx.call
+        out, s_sum, lr_w = ctx.saved_tensors
+        B, F, D = call.B, call.F, call.D
+        dev = call.device
+        for hook in list(_pre_backward_hooks):
+            hook()
+        if g_out is not None and (g_out.stride(1) != 1 or g_out.stride(0) < call.width):
+            g_out = g_out.contiguous()
+        g_fm = None if g_fm is None else g_fm.reshape(-1).contiguous()
+        g_lr = None if g_lr is None else g_lr.reshape(-1).contiguous()
+        any_table = any(w.requires_grad for w in call.weights)
+        want_wgrad = g_lr is not None and lr_w is not None and ctx.needs_input_grad[1]
+        nchunks = _lib.call("rh_embed_bwd_nchunks", B, call.samples_per_block)
+        partial = torch.empty((nchunks, F * D), dtype=torch.float32, device=dev) if want_wgrad else None
+        exchange = _sparse_exchange if any_table else None
+        if any_table or want_wgrad:
+            if exchange is None:
+                fdesc = call.fdesc(True)
+                rows = None
+                sink = 0
+            else:
+                fdesc = call.fdesc(False)
+                rows = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+                sink = 1
+            _lib.call("rh_embed_bwd", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
+                      0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
+                      _p(lr_w), _p(partial), 1.0, sink, _p(rows), call.samples_per_block, _p(err_flag(dev)),
+                      _stream())
+            if exchange is not None:
+                idx_all, rows_all = exchange(call, rows)
+                scatter_rows(call, idx_all, rows_all)
+            if any_table:
+                for w in {id(w): w for w in call.weights if w.requires_grad}.values():
+                    _publish_grad(w)
+        g_w = partial.sum(0).view_as(lr_w) if want_wgrad else None
+        g_b = g_lr.sum().reshape(1) if (g_lr is not None and ctx.has_lr_b and ctx.needs_input_grad[2]) else None
+        return (None, g_w, g_b) + (None,) * len(call.weights)
+
+
+def fused_embedding(call, lr_w=None, lr_b=None):
+    """Run the fused gather (+FM, +LR); returns (out, fm, lr) with fm / lr None when not requested."""
+    return _EmbedFused.apply(call, lr_w, lr_b, *call.weights)
+
+
+def scatter_rows(call, idx_all, rows_all):
+    """Scatter-add gradient rows (N,F,D) for packed indices idx_all (N,F) into the tables' grad buffers."""
+    require_hip(idx_all, rows_all)
+    N = int(idx_all.shape[0])
+    F, D = call.F, call.D
+    ptrs = [idx_all.data_ptr() + f * idx_all.element_size() for f in range(F)]
+    key = tuple(ptrs + [idx_all.stride(0)] * F + list(range(F)))
+    idesc = EmbedCall._icache.get(key, call.device)
+    _lib.call("rh_embed_scatter_rows", _p(call.fdesc(True)), _p(idesc), 1 if idx_all.dtype == torch.int64 else 0,
+              N, F, D, _p(rows_all), 1.0, call.samples_per_block, _p(err_flag(call.device)), _stream())
+
+
+# --------------------------------------------------------------------------------------------
+class _FMFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, reduce_sum):
+        require_hip(x)
+        if x.dim() != 3 or x.dtype != torch.float32:
+            raise ValueError("FM expects a float32 (B, num_features, embed_dim) tensor")
+        if x.stride(2) != 1 or x.stride(1) != x.shape[2]:
+            x = x.contiguous()
+        B, F, D = x.shape
+        out = torch.empty((B, 1) if reduce_sum else (B, D), dtype=torch.float32, device=x.device)
+        _lib.call("rh_fm_fwd", _p(x), x.stride(0), B, F, D, 1 if reduce_sum else 0, _p(out), _stream())
+        ctx.reduce_sum = reduce_sum
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, F, D = x.shape
+        g = g.contiguous()
+        gx = torch.empty((B, F, D), dtype=torch.float32, device=x.device)
+        _lib.call("rh_fm_bwd", _p(x), x.stride(0), B, F, D, 1 if ctx.reduce_sum else 0, _p(g), _p(gx), gx.stride(0),
+                  _stream())
+        return gx, None
+
+
+def fm(x, reduce_sum=True):
+    return _FMFn.apply(x, reduce_sum)
+
+
+# --------------------------------------------------------------------------------------------
+_POOL_MODES = {"sum": 0, "mean": 1, "concat": 2}
+
+
+class _SeqPoolFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, weight, idx, mode, sentinel, padding_idx):
+        require_hip(weight, idx)
+        if idx.dim() != 2 or idx.dtype not in (torch.int64, torch.int32):
+            raise ValueError("sequence feature values must be an integer (B, L) tensor")
+        B, L = idx.shape
+        V, D = weight.shape
+        out = torch.empty((B, L, D) if mode == 2 else (B, D), dtype=torch.float32, device=weight.device)
+        _lib.call("rh_seq_pool_fwd", _p(weight), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
+                  idx.stride(1), B, L, D, mode, sentinel, _p(out), out.stride(0), _p(err_flag(weight.device)),
+                  _stream())
+        ctx.meta = (mode, sentinel, -1 if padding_idx is None else int(padding_idx))
+        ctx.weight = weight
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        weight = ctx.weight
+        mode, sentinel, pad = ctx.meta
+        if weight.requires_grad:
+            B, L = idx.shape
+            V, D = weight.shape
+            g = g.contiguous()
+            buf = _prepare_grad(weight)
+            _lib.call("rh_seq_pool_bwd", _p(buf), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
+                      idx.stride(1), B, L, D, mode, sentinel, pad, _p(g), g.stride(0), 1.0,
+                      _p(err_flag(weight.device)), _stream())
+            _publish_grad(weight)
+        return None, None, None, None, None
+
+
+def seq_pool(weight, idx, pooling, padding_idx):
+    """Gather + masked pooling of one sequence feature (mask sentinel = padding_idx, or -1 when unset)."""
+    if pooling not in _POOL_MODES:
+        raise ValueError("Sequence pooling method supports only pooling in %s, got %s." % (["sum", "mean"], pooling))
+    sentinel = -1 if padding_idx is None else int(padding_idx)
+    return _SeqPoolFn.apply(weight, idx, _POOL_MODES[pooling], sentinel, padding_idx)
+
+
+# --------------------------------------------------------------------------------------------
+class _CrossFn(torch.autograd.Function):
+    """CrossNetwork: x_{l+1} = x0 * (w_l . x_l) + b_l + x_l, W and Bv stacked (L, d)."""
+
+    @staticmethod
+    def forward(ctx, x, W, Bv):
+        require_hip(x, W, Bv)
+        if x.dim() != 2 or x.dtype != torch.float32:
+            raise ValueError("CrossNetwork expects a float32 (B, d) tensor")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        W = W.contiguous()
+        Bv = Bv.contiguous()
+        B, d = x.shape
+        L = W.shape[0]
+        seg = _lib.call("rh_cross_max_layers", d)
+        if seg <= 0:
+            raise ValueError(f"CrossNetwork width {d} unsupported by the HIP kernel (1..2048)")
+        xs = [x]
+        cur = x
+        for l0 in range(0, L, seg):
+            n = min(seg, L - l0)
+            out = torch.empty((B, d), dtype=torch.float32, device=x.device)
+            _lib.call("rh_cross_fwd", _p(x), x.stride(0), _p(cur), cur.stride(0), _p(W[l0:l0 + n]), _p(Bv[l0:l0 + n]),
+                      B, d, n, _p(out), out.stride(0), _stream())
+            cur = out
+            xs.append(cur)
+        ctx.seg = seg
+        ctx.save_for_backward(W, Bv, *xs[:-1])
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        W, Bv, *xs = ctx.saved_tensors
+        x = xs[0]
+        B, d = x.shape
+        L = W.shape[0]
+        seg = ctx.seg
+        g = g.contiguous()
+        gW = torch.empty_like(W)
+        gB = torch.empty_like(Bv)
+        nblocks = _lib.call("rh_cross_bwd_nblocks", B)
+        starts = list(range(0, L, seg))
+        gx0_total = None
+        for si in reversed(range(len(starts))):
+            l0 = starts[si]
+            n = min(seg, L - l0)
+            cur = xs[si]
+            first = si == 0
+            partial = torch.empty((nblocks, 2, n, d), dtype=torch.float32, device=x.device)
+            gx = torch.empty((B, d), dtype=torch.float32, device=x.device)
+            gx0 = None if first else torch.empty((B, d), dtype=torch.float32, device=x.device)
+            _lib.call("rh_cross_bwd", _p(x), x.stride(0), _p(cur), cur.stride(0), _p(W[l0:l0 + n]), _p(Bv[l0:l0 + n]),
+                      B, d, n, _p(g), g.stride(0), _p(gx0), _p(gx), gx.stride(0), 1 if first else 0, _p(partial),
+                      _stream())
+            red = partial.sum(0)
+            gW[l0:l0 + n] = red[0]
+            gB[l0:l0 + n] = red[1]
+            if not first:
+                gx0_total = gx0 if gx0_total is None else gx0_total + gx0
+            g = gx
+        if gx0_total is not None:
+            g = g + gx0_total
+        return g, gW, gB
+
+
+def cross_network(x, W, Bv):
+    return _CrossFn.apply(x, W, Bv)

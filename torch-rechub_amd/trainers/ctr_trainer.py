@@ -1,0 +1,252 @@
+"""CTRTrainer with the reference's constructor and methods (torch_rechub/trainers/ctr_trainer.py:11-187).
+
+What changes relative to the reference loop (train_one_epoch, :77-108):
+* ``optimizer_fn=torch.optim.Adam`` (the default) becomes ``optim.TableAdam``: identical arithmetic, but all
+  embedding tables are stepped by one streaming HIP kernel that also re-zeroes their gradient rows;
+* ``model.zero_grad()`` is one memset of the flat dense-gradient bucket (tables are re-zeroed by the step);
+* the loss is accumulated on the device and read back every ``log_interval`` batches, not twice per step;
+* multi-GPU = one process per GPU (torchrun) over RCCL instead of ``nn.DataParallel`` (``gpus`` is accepted for
+  signature compatibility; with an initialised process group of world size > 1 the replica on this rank is
+  synchronised by ``distributed.DataParallelContext``);
+* with a ``DeviceDataLoader`` and ``use_graph=True`` a full batch step (batch assembly, forward, backward,
+  optimizer) is captured once into a hipGraph and replayed.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import tqdm
+
+from .. import ops
+from ..basic.callback import EarlyStopper
+from ..basic.loss_func import RegularizationLoss
+from ..distributed import DataParallelContext, DenseGradReducer, table_parameters
+from ..optim import TableAdam
+from ..utils.data import DeviceDataLoader
+
+
+class CTRTrainer(object):
+
+    def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
+                 scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
+                 loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True):
+        self.model = model
+        self.gpus = [] if gpus is None else gpus
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("torch_rechub_amd.CTRTrainer drives the HIP hot path: device must be a HIP device "
+                               f"('cuda:N'), got {device!r}. Use the reference trainer for CPU runs.")
+        self.model.to(self.device)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.dp = DataParallelContext(self.model) if self.world > 1 else None
+        if optimizer_params is None:
+            optimizer_params = {"lr": 1e-3, "weight_decay": 1e-5}
+        tables = table_parameters(self.model)
+        if optimizer_fn is torch.optim.Adam and not optimizer_params.get("amsgrad", False):
+            self.optimizer = TableAdam(self.model.parameters(), table_params=tables, **optimizer_params)
+        else:
+            self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
+        table_ids = {id(p) for p in tables}
+        if self.dp is not None:
+            self.reducer = self.dp.reducer
+        else:
+            self.reducer = DenseGradReducer([p for p in self.model.parameters() if id(p) not in table_ids])
+        if regularization_params is None:
+            regularization_params = {"embedding_l1": 0.0, "embedding_l2": 0.0, "dense_l1": 0.0, "dense_l2": 0.0}
+        self.scheduler = None
+        if scheduler_fn is not None:
+            self.scheduler = scheduler_fn(self.optimizer, **scheduler_params)
+        self.loss_mode = loss_mode
+        self.criterion = torch.nn.BCELoss()
+        from sklearn.metrics import roc_auc_score
+        self.evaluate_fn = roc_auc_score
+        self.n_epoch = n_epoch
+        self.early_stopper = EarlyStopper(patience=earlystop_patience)
+        self.model_path = model_path
+        self.reg_loss_fn = RegularizationLoss(**regularization_params)
+        self.model_logger = model_logger
+        if use_graph is None:
+            use_graph = os.environ.get("RECHUB_HIPGRAPH", "0") == "1"
+        self.use_graph = bool(use_graph) and self.world == 1
+        self.show_progress = show_progress and self.rank == 0
+        self._graph = None
+        self._graph_loss = None
+
+    # -- one optimisation step ----------------------------------------------------------------
+    def _zero_grad(self):
+        self.reducer.zero()
+        if not isinstance(self.optimizer, TableAdam):
+            for p in table_parameters(self.model):
+                if getattr(p, "_rh_dirty", False):
+                    ops.grad_buffer(p).zero_()
+                    p._rh_dirty = False
+
+    def train_step(self, x_dict, y):
+        """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
+        if self.loss_mode:
+            y_pred = self.model(x_dict)
+            loss = self.criterion(y_pred, y)
+        else:
+            y_pred, other_loss = self.model(x_dict)
+            loss = self.criterion(y_pred, y) + other_loss
+        loss = loss + self.reg_loss_fn(self.model)
+        report = loss.detach()
+        if self.world > 1:
+            loss = loss / self.world  # gradients are SUMMED over ranks: global-batch mean, as DataParallel
+        self._zero_grad()
+        loss.backward()
+        if self.world > 1:
+            self.reducer.finish()
+        self.optimizer.step()
+        return report
+
+    GRAPH_WARMUP = 3
+
+    def _graphed_step(self, loader):
+        """Replay the captured (batch assembly + train_step); the first call warms up eagerly and captures.
+
+        Returns (sum of losses, number of batches consumed).  Warm-up steps are real optimisation steps.
+        """
+        if self._graph is None:
+            if isinstance(self.optimizer, TableAdam):
+                self.optimizer.sync_hyper()
+            total = torch.zeros((), dtype=torch.float32, device=self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.GRAPH_WARMUP):  # allocator, descriptor caches, lazily created optimizer state
+                    x, y = loader.load_next()
+                    total += self.train_step(x, y)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                x, y = loader.load_next()
+                self._graph_loss = self.train_step(x, y)
+            return total, self.GRAPH_WARMUP
+        self._graph.replay()
+        return self._graph_loss, 1
+
+    def train_one_epoch(self, data_loader, log_interval=10):
+        self.model.train()
+        device_loader = isinstance(data_loader, DeviceDataLoader)
+        if isinstance(self.optimizer, TableAdam):
+            self.optimizer.sync_hyper()
+        run = torch.zeros((), dtype=torch.float32, device=self.device)
+        epoch = torch.zeros((), dtype=torch.float32, device=self.device)
+        batch_count = 0
+        full = data_loader.N // data_loader.batch_size if device_loader else 0
+        if device_loader and self.use_graph and (self._graph is not None or full > self.GRAPH_WARMUP):
+            data_loader.reshuffle()
+            rem = data_loader.N - full * data_loader.batch_size
+            it = tqdm.tqdm(total=full, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
+            since_log = 0
+            while batch_count < full:
+                if self._graph is None and full - batch_count <= self.GRAPH_WARMUP:
+                    x, y = data_loader.load_next()
+                    loss, n = self.train_step(x, y), 1
+                else:
+                    loss, n = self._graphed_step(data_loader)
+                run += loss
+                epoch += loss
+                batch_count += n
+                since_log += n
+                it.update(n)
+                if since_log >= log_interval:
+                    it.set_postfix(loss=run.item() / since_log)
+                    run.zero_()
+                    since_log = 0
+            it.close()
+            if rem and not data_loader.drop_last:
+                x, y = data_loader.load_next(rem)
+                epoch += self.train_step(x, y)
+                batch_count += 1
+        else:
+            it = tqdm.tqdm(data_loader, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
+            for i, (x_dict, y) in enumerate(it):
+                if not device_loader:
+                    x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
+                    y = y.to(self.device, non_blocking=True)
+                loss = self.train_step(x_dict, y.float())
+                run += loss
+                epoch += loss
+                batch_count += 1
+                if (i + 1) % log_interval == 0:
+                    it.set_postfix(loss=run.item() / log_interval)
+                    run.zero_()
+        ops.check_errors(self.device)
+        return epoch.item() / batch_count if batch_count > 0 else 0
+
+    # -- epochs -------------------------------------------------------------------------------
+    def fit(self, train_dataloader, val_dataloader=None):
+        for logger in self._iter_loggers():
+            logger.log_hyperparams({"n_epoch": self.n_epoch, "learning_rate": self.optimizer.param_groups[0]["lr"],
+                                    "loss_mode": self.loss_mode})
+        for epoch_i in range(self.n_epoch):
+            if self.rank == 0:
+                print("epoch:", epoch_i)
+            train_loss = self.train_one_epoch(train_dataloader)
+            for logger in self._iter_loggers():
+                logger.log_metrics({"train/loss": train_loss, "learning_rate": self.optimizer.param_groups[0]["lr"]},
+                                   step=epoch_i)
+            if self.scheduler is not None:
+                if epoch_i % self.scheduler.step_size == 0 and self.rank == 0:
+                    print("Current lr : {}".format(self.optimizer.state_dict()["param_groups"][0]["lr"]))
+                self.scheduler.step()
+            if val_dataloader:
+                auc = self.evaluate(self.model, val_dataloader)
+                if self.rank == 0:
+                    print("epoch:", epoch_i, "validation: auc:", auc)
+                for logger in self._iter_loggers():
+                    logger.log_metrics({"val/auc": auc}, step=epoch_i)
+                if self.early_stopper.stop_training(auc, self.model.state_dict()):
+                    if self.rank == 0:
+                        print(f"validation: best auc: {self.early_stopper.best_auc}")
+                    self.model.load_state_dict(self.early_stopper.best_weights)
+                    break
+        if self.rank == 0:
+            torch.save(self.model.state_dict(), os.path.join(self.model_path, "model.pth"))
+        for logger in self._iter_loggers():
+            logger.finish()
+
+    def _iter_loggers(self):
+        if self.model_logger is None or self.rank != 0:
+            return []
+        if isinstance(self.model_logger, (list, tuple)):
+            return list(self.model_logger)
+        return [self.model_logger]
+
+    def _to_device(self, x_dict):
+        return {k: (v if v.is_cuda else v.to(self.device, non_blocking=True)) for k, v in x_dict.items()}
+
+    def evaluate(self, model, data_loader):
+        model.eval()
+        targets, predicts = [], []
+        with torch.no_grad():
+            it = tqdm.tqdm(data_loader, desc="validation", smoothing=0, mininterval=1.0,
+                           disable=not self.show_progress)
+            for x_dict, y in it:
+                y_pred = model(self._to_device(x_dict)) if self.loss_mode else model(self._to_device(x_dict))[0]
+                targets.append(y.detach().float().reshape(-1).cpu())
+                predicts.append(y_pred.detach().float().reshape(-1).cpu())
+        ops.check_errors(self.device)
+        return self.evaluate_fn(torch.cat(targets).numpy(), torch.cat(predicts).numpy())
+
+    def predict(self, model, data_loader):
+        model.eval()
+        predicts = []
+        with torch.no_grad():
+            it = tqdm.tqdm(data_loader, desc="predict", smoothing=0, mininterval=1.0, disable=not self.show_progress)
+            for x_dict, y in it:
+                y_pred = model(self._to_device(x_dict)) if self.loss_mode else model(self._to_device(x_dict))[0]
+                predicts.extend(y_pred.tolist())
+        ops.check_errors(self.device)
+        return predicts
+
+    def export_onnx(self, *args, **kwargs):
+        raise NotImplementedError("ONNX export is outside the HIP hot path; export with the reference "
+                                  "torch_rechub.trainers.CTRTrainer after loading this model's state_dict "
+                                  "(the checkpoint keys are identical).")
+
+    def visualization(self, *args, **kwargs):
+        raise NotImplementedError("model visualisation is outside the HIP hot path; use the reference trainer.")
