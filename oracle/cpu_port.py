@@ -1,0 +1,144 @@
+"""CPU port (plain eager PyTorch, fp32) of the reference's DeepFM / DCN training step — the ``cpu_baseline`` that
+``bench.py`` times on the GPU box's host cores, where /root/reference does not exist.
+
+TEST / BASELINE INFRASTRUCTURE ONLY: never imported by ``torch-rechub_amd``.
+
+It restates the reference's op chain one-for-one, so that its cost profile is the reference's:
+  * one ``nn.Embedding`` per sparse feature, looked up per feature and concatenated
+    (EmbeddingLayer.forward, torch_rechub/basic/layers.py:77-127) — and DeepFM gathers TWICE
+    (models/ranking/deepfm.py:35,37);
+  * FM = 2 sums + pow + sub + sum + mul (layers.py:313-319); LR = nn.Linear (layers.py:183-189);
+  * MLP = [Linear, BatchNorm1d, ReLU, Dropout] x k + Linear (layers.py:276-292);
+  * CrossNetwork loop (layers.py:412-420);
+  * step = BCELoss on probabilities, model.zero_grad(), backward (dense embedding gradients), torch.optim.Adam over
+    every parameter incl. all table rows (trainers/ctr_trainer.py:59-61, 87-99), loss.item() twice per step.
+Pinned by tests/test_oracle_golden.py::test_cpu_port_* against the reference's golden vectors.
+"""
+import time
+
+import torch
+from torch import nn
+
+
+class PortMLP(nn.Module):
+
+    def __init__(self, input_dim, dims, dropout=0.0, output_layer=True):
+        super().__init__()
+        layers = []
+        for w in dims:
+            layers += [nn.Linear(input_dim, w), nn.BatchNorm1d(w), nn.ReLU(inplace=True), nn.Dropout(p=dropout)]
+            input_dim = w
+        if output_layer:
+            layers.append(nn.Linear(input_dim, 1))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class PortEmbedding(nn.Module):
+    """Per-feature tables in a ModuleDict; forward(x, names, dense_names, squeeze) as layers.py:77-127."""
+
+    def __init__(self, vocabs, embed_dim, init_std=1e-4):
+        super().__init__()
+        self.embed_dict = nn.ModuleDict()
+        for name, v in vocabs.items():
+            e = nn.Embedding(v, embed_dim)
+            nn.init.normal_(e.weight, 0.0, init_std)  # RandomNormal(0, 1e-4), features.py:54
+            self.embed_dict[name] = e
+
+    def forward(self, x, sparse_names, dense_names=(), squeeze_dim=False):
+        sparse_emb = [self.embed_dict[n](x[n].long()).unsqueeze(1) for n in sparse_names]
+        dense_values = [x[n].float().unsqueeze(1) for n in dense_names]
+        emb = torch.cat(sparse_emb, dim=1) if sparse_emb else None
+        if not squeeze_dim:
+            return emb
+        if emb is None:
+            return torch.cat(dense_values, dim=1)
+        if dense_values:
+            return torch.cat((emb.flatten(start_dim=1), torch.cat(dense_values, dim=1)), dim=1)
+        return emb.flatten(start_dim=1)
+
+
+def fm_port(x):
+    square_of_sum = torch.sum(x, dim=1)**2
+    sum_of_square = torch.sum(x**2, dim=1)
+    return 0.5 * torch.sum(square_of_sum - sum_of_square, dim=1, keepdim=True)
+
+
+class PortDeepFM(nn.Module):
+    """tutorials/00 wiring: deep = dense + sparse, fm = sparse (parameter names as the reference's state_dict)."""
+
+    def __init__(self, vocabs, dense_names, embed_dim=16, dims=(256, 128), dropout=0.2, deep_uses_sparse=True,
+                 init_std=1e-4):
+        super().__init__()
+        self.sparse_names = list(vocabs)
+        self.dense_names = list(dense_names)
+        self.deep_uses_sparse = deep_uses_sparse
+        fm_dims = len(self.sparse_names) * embed_dim
+        deep_dims = len(self.dense_names) + (fm_dims if deep_uses_sparse else 0)
+
+        class _LR(nn.Module):
+
+            def __init__(self, n):
+                super().__init__()
+                self.fc = nn.Linear(n, 1, bias=True)
+
+            def forward(self, x):
+                return self.fc(x)
+
+        self.linear = _LR(fm_dims)
+        self.embedding = PortEmbedding(vocabs, embed_dim, init_std)
+        self.mlp = PortMLP(deep_dims, list(dims), dropout)
+
+    def forward(self, x):
+        deep_sparse = self.sparse_names if self.deep_uses_sparse else []
+        input_deep = self.embedding(x, deep_sparse, self.dense_names, squeeze_dim=True)  # gather #1
+        input_fm = self.embedding(x, self.sparse_names, (), squeeze_dim=False)  # gather #2 (deepfm.py:37)
+        y = self.linear(input_fm.flatten(start_dim=1)) + fm_port(input_fm) + self.mlp(input_deep)
+        return torch.sigmoid(y.squeeze(1))
+
+
+def train_step(model, optimizer, criterion, x, y):
+    """Body of CTRTrainer.train_one_epoch (ctr_trainer.py:84-101), regularisation off (python 0.0)."""
+    y_pred = model(x)
+    loss = criterion(y_pred, y.float())
+    model.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.item() + 0.0 * loss.item()  # the reference syncs twice per step (:100-101)
+
+
+def time_cpu_baseline(vocabs, n_dense, batch_size, budget_s=20.0, min_steps=3, max_steps=50, seed=2022, threads=None):
+    """Times model-step-only training (pre-collated batches) of the DeepFM port at the given shape.
+
+    Returns dict(samples_per_s, steps, ms_per_step, cores, build_s).  Roughly ``budget_s`` seconds of steps.
+    """
+    if threads:
+        torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    t0 = time.perf_counter()
+    names = {f"C{i + 1}": int(v) for i, v in enumerate(vocabs)}
+    dense_names = [f"I{i + 1}" for i in range(n_dense)]
+    model = PortDeepFM(names, dense_names)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)  # trainer default, ctr_trainer.py:60
+    crit = nn.BCELoss()
+    build_s = time.perf_counter() - t0
+
+    def batch():
+        x = {n: torch.randint(0, v, (batch_size,), generator=g) for n, v in names.items()}
+        x.update({n: torch.rand(batch_size, generator=g) for n in dense_names})
+        return x, (torch.rand(batch_size, generator=g) < 0.25).long()
+
+    batches = [batch() for _ in range(4)]
+    train_step(model, opt, crit, *batches[0])  # warm-up: allocates the dense gradients and Adam state
+    steps, t_start = 0, time.perf_counter()
+    while steps < max_steps:
+        train_step(model, opt, crit, *batches[steps % len(batches)])
+        steps += 1
+        if steps >= min_steps and time.perf_counter() - t_start > budget_s:
+            break
+    dt = time.perf_counter() - t_start
+    return dict(samples_per_s=steps * batch_size / dt, steps=steps, ms_per_step=1e3 * dt / steps,
+                cores=torch.get_num_threads(), build_s=build_s)

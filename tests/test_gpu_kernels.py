@@ -1,0 +1,468 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel (through the C ABI, via torch_rechub_amd.ops) against
+the numpy oracle (oracle/ctr_oracle.py, float64) on identical seeded inputs, plus the reference golden vectors.
+
+Tolerances (fp32 path vs float64 oracle; reduction order differs, nothing else):
+  gathers / copies: bit-exact;   FM / LR / cross / pooling outputs and gradients: rtol 1e-5 (+ atol scaled to the
+  magnitude of the compared array);   Adam: rtol 2e-6 per step.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+
+pytestmark = pytest.mark.gpu
+F64 = np.float64
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol=1e-5, atol_scale=1e-6, what=""):
+    a = a.detach().cpu().numpy().astype(F64) if torch.is_tensor(a) else np.asarray(a, F64)
+    b = np.asarray(b, F64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    atol = atol_scale * max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def make_case(B, vocabs, D, ND, seed, idx_dtype=torch.int64, packed=True, shared=None, pads=None, std=0.5):
+    g = torch.Generator().manual_seed(seed)
+    tables = [torch.randn(v, D, generator=g) * std for v in vocabs]
+    if shared:
+        for f, src in shared.items():
+            tables[f] = tables[src]
+    pads = pads or [None] * len(vocabs)
+    for t, p in zip(tables, pads):
+        if p is not None:
+            t[p].zero_()
+    idx = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], 1).to(idx_dtype)
+    dense = torch.rand(B, ND, generator=g)
+    d = dev()
+    dev_tables = {}
+    wts = []
+    for t in tables:
+        if id(t) not in dev_tables:
+            dev_tables[id(t)] = torch.nn.Parameter(t.to(d))
+        wts.append(dev_tables[id(t)])
+    if packed:
+        idx_d = idx.to(d)
+        idx_cols = [idx_d[:, f] for f in range(len(vocabs))]
+        dense_d = dense.to(d)
+        dense_cols = [dense_d[:, j] for j in range(ND)]
+    else:
+        idx_cols = [idx[:, f].contiguous().to(d) for f in range(len(vocabs))]
+        dense_cols = [dense[:, j].contiguous().to(d) for j in range(ND)]
+    np_by_id = {}
+    for t in tables:  # shared tables stay ONE numpy array so that the oracle accumulates their gradient jointly
+        np_by_id.setdefault(id(t), t.numpy().astype(F64))
+    np_tables = [np_by_id[id(t)] for t in tables]
+    return dict(tables=tables, np_tables=np_tables, wts=wts, pads=pads, idx=idx, idx_cols=idx_cols, dense=dense,
+                dense_cols=dense_cols, B=B, F=len(vocabs), D=D, ND=ND, g=g)
+
+
+CRITEO_LIKE = [3, 4, 10, 27, 105, 305, 583, 40, 1460, 24, 18, 15, 633, 5000, 20000, 3, 12517, 2173, 4, 93145, 10, 5652,
+               7, 14992, 286181, 142572]
+
+
+@pytest.mark.parametrize("B,vocabs,D,ND,idt,packed,fs", [
+    (4096, CRITEO_LIKE, 16, 13, torch.int64, True, 0),
+    (4096, CRITEO_LIKE, 16, 13, torch.int64, False, 1),
+    (1000, CRITEO_LIKE, 16, 13, torch.int32, True, 2),
+    (257, CRITEO_LIKE[:7], 16, 0, torch.int64, True, 8),
+    (1, [5, 9], 16, 1, torch.int64, True, 0),
+    (63, [11], 16, 2, torch.int64, False, 0),
+    (300, [50] * 39, 16, 0, torch.int64, True, 4),
+    (129, [7, 300, 41], 4, 3, torch.int64, True, 0),
+    (129, [7, 300, 41], 8, 0, torch.int32, False, 0),
+    (200, [7, 300, 41, 9], 32, 5, torch.int64, True, 0),
+    (77, [7, 300, 41], 64, 1, torch.int64, True, 0),
+    (33, [7, 300], 128, 2, torch.int64, True, 0),
+])
+def test_embed_fwd(B, vocabs, D, ND, idt, packed, fs):
+    from torch_rechub_amd import ops
+    c = make_case(B, vocabs, D, ND, seed=B + D, idx_dtype=idt, packed=packed)
+    g = c["g"]
+    F = c["F"]
+    lr_w = torch.randn(1, F * D, generator=g).to(dev())
+    lr_b = torch.randn(1, generator=g).to(dev())
+    call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"], c["dense_cols"], want_fm=True, want_lr=True,
+                         field_split=fs)
+    out, fm, lr = ops.fused_embedding(call, lr_w, lr_b)
+    torch.cuda.synchronize()
+    ops.check_errors()
+    deep, y_fm, y_lr = O.deepfm_sparse_part(c["np_tables"], c["idx"].numpy(), lr_w.cpu().numpy().astype(F64),
+                                            lr_b.cpu().numpy().astype(F64), c["dense"].numpy().astype(F64))
+    assert out.shape == (B, F * D + ND)
+    # gather + dense concat are pure copies: bit-exact against the fp32 tables
+    exact = O.embedding_layer_squeeze([t.numpy() for t in c["tables"]], c["idx"].numpy(), c["dense"].numpy())
+    assert np.array_equal(out.cpu().numpy(), exact)
+    close(fm, y_fm, what="fm")
+    close(lr, y_lr, what="lr")
+
+
+def test_embed_fwd_plain_gather_no_fm_no_lr_and_3d_view():
+    from torch_rechub_amd import ops
+    c = make_case(500, [9, 1000, 3], 16, 0, seed=3)
+    call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"])
+    out, fm, lr = ops.fused_embedding(call)
+    assert fm is None and lr is None
+    assert np.array_equal(out.view(500, 3, 16).cpu().numpy(),
+                          O.embedding_gather([t.numpy() for t in c["tables"]], c["idx"].numpy()))
+
+
+def test_embed_index_out_of_range_raises_index_error():
+    from torch_rechub_amd import ops
+    c = make_case(64, [5, 6], 16, 0, seed=5)
+    c["idx_cols"][1][7] = 6  # == vocab
+    call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"])
+    ops.fused_embedding(call)
+    with pytest.raises(IndexError):
+        ops.check_errors()
+    c["idx_cols"][1][7] = -1
+    ops.fused_embedding(ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"]))
+    with pytest.raises(IndexError):
+        ops.check_errors()
+    ops.check_errors()  # flag was cleared
+
+
+@pytest.mark.parametrize("B,vocabs,D,shared,pads,spb", [
+    (4096, CRITEO_LIKE, 16, None, None, 0),
+    (1000, [3, 50, 700, 3, 9000], 16, {3: 0}, [None, 0, None, None, 5], 0),
+    (130, [4, 600], 16, None, None, 64),
+    (515, [4, 600, 31], 32, None, [1, None, None], 128),
+    (99, [4, 600, 31], 8, {2: 0}, None, 0),
+    (64, [40], 64, None, None, 0),
+    (1, [40, 3], 16, None, None, 0),
+])
+def test_embed_bwd(B, vocabs, D, shared, pads, spb):
+    from torch_rechub_amd import ops
+    ND = 2
+    c = make_case(B, vocabs, D, ND, seed=B + 7 * D, shared=shared, pads=pads)
+    g = c["g"]
+    F = c["F"]
+    lr_w = torch.nn.Parameter(torch.randn(1, F * D, generator=g).to(dev()))
+    lr_b = torch.nn.Parameter(torch.randn(1, generator=g).to(dev()))
+    call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"], c["dense_cols"], want_fm=True, want_lr=True,
+                         samples_per_block=spb)
+    out, fm, lr = ops.fused_embedding(call, lr_w, lr_b)
+    g_deep = torch.randn(B, F * D + ND, generator=g)
+    g_fm = torch.randn(B, 1, generator=g)
+    g_lr = torch.randn(B, 1, generator=g)
+    torch.autograd.backward([out, fm, lr], [g_deep.to(dev()), g_fm.to(dev()), g_lr.to(dev())])
+    torch.cuda.synchronize()
+    ops.check_errors()
+    grads, gw, gb, rows = O.deepfm_sparse_part_backward(c["np_tables"], c["idx"].numpy(),
+                                                        lr_w.detach().cpu().numpy().astype(F64),
+                                                        g_deep.numpy().astype(F64), g_fm.numpy().astype(F64),
+                                                        g_lr.numpy().astype(F64), padding_idx=c["pads"])
+    for f, w in enumerate(c["wts"]):
+        assert w.grad is not None and w.grad.data_ptr() == ops.grad_buffer(w).data_ptr()
+        close(w.grad, grads[f], rtol=2e-5, atol_scale=2e-6, what=f"table grad field {f}")
+        if c["pads"][f] is not None:
+            assert torch.all(w.grad[c["pads"][f]] == 0)
+    close(lr_w.grad, gw, rtol=2e-5, atol_scale=2e-6, what="lr_w grad")
+    close(lr_b.grad, gb, rtol=2e-5, atol_scale=2e-6, what="lr_b grad")
+
+
+def test_embed_bwd_rows_sink_and_scatter_rows_equal_fused_scatter():
+    """sink=1 (rows for the data-parallel exchange) followed by rh_embed_scatter_rows == sink=0."""
+    from torch_rechub_amd import _lib, ops
+    B, D = 700, 16
+    vocabs = [3, 50, 7000, 12]
+    c = make_case(B, vocabs, D, 0, seed=11, pads=[None, 1, None, None])
+    F = c["F"]
+    g = c["g"]
+    call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"], want_fm=True)
+    out, fm, _ = ops.fused_embedding(call)
+    g_out = torch.randn(B, F * D, generator=g).to(dev())
+    g_fm = torch.randn(B, generator=g).to(dev())
+    s_sum = out.detach().view(B, F, D).sum(1).contiguous()
+    rows = torch.empty(B, F, D, device=dev())
+    _lib.call("rh_embed_bwd", ops._p(call.fdesc(False)), ops._p(call.idesc()), 1, B, F, D, ops._p(g_out),
+              g_out.stride(0), ops._p(out), out.stride(0), ops._p(s_sum), ops._p(g_fm), ops._p(None), ops._p(None),
+              ops._p(None), 1.0, 1, ops._p(rows), 0, ops._p(ops.err_flag(dev())), ops._stream())
+    _, _, _, rows_ref = O.deepfm_sparse_part_backward(c["np_tables"], c["idx"].numpy(), np.zeros((1, F * D)),
+                                                      g_out.cpu().numpy().astype(F64), g_fm.cpu().numpy().astype(F64),
+                                                      None, padding_idx=c["pads"])
+    close(rows, rows_ref, what="rows sink")
+    idx_all = torch.stack(c["idx_cols"], 1).contiguous()
+    ops.scatter_rows(call, idx_all, rows)
+    torch.cuda.synchronize()
+    want = O.embedding_backward([t.shape for t in c["np_tables"]], c["idx"].numpy(), rows_ref, c["pads"])
+    for f, w in enumerate(c["wts"]):
+        close(ops.grad_buffer(w), want[f], rtol=2e-5, atol_scale=2e-6, what=f"scatter field {f}")
+
+
+def test_embedding_golden_vectors(layers_golden):
+    """The reference's own EmbeddingLayer output / gradients (shared table + padding_idx + dense) on the HIP path."""
+    from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
+    from torch_rechub_amd.basic.layers import EmbeddingLayer
+    g = layers_golden
+    D = 16
+    vocabs = [int(v) for v in g["emb.vocabs"]]
+    feas = [SparseFeature(f"s{i}", vocabs[i], D) for i in range(5)]
+    feas[3] = SparseFeature("s3", 7, D, padding_idx=0)
+    feas.append(SparseFeature("s5", 11, D, shared_with="s1"))
+    dense = [DenseFeature(f"d{i}") for i in range(3)]
+    layer = EmbeddingLayer(dense + feas).to(dev())
+    with torch.no_grad():
+        for k, m in layer.embed_dict.items():
+            m.weight.copy_(torch.from_numpy(g[f"emb.table.{k}"]))
+    x = {f.name: torch.from_numpy(g["emb.idx"][:, i]).to(dev()) for i, f in enumerate(feas)}
+    x.update({f.name: torch.from_numpy(g["emb.dense"][:, i]).to(dev()) for i, f in enumerate(dense)})
+    sq = layer(x, dense + feas, squeeze_dim=True)
+    assert np.array_equal(sq.detach().cpu().numpy(), g["emb.out_squeeze"])
+    assert np.array_equal(layer(x, feas, squeeze_dim=False).detach().cpu().numpy(), g["emb.out_3d"])
+    sq.backward(torch.from_numpy(g["emb.g_squeeze"]).to(dev()))
+    for k, m in layer.embed_dict.items():
+        close(m.weight.grad, g[f"emb.grad.{k}"], rtol=2e-5, atol_scale=2e-6, what=k)
+
+
+@pytest.mark.parametrize("B,F,D", [(37, 6, 16), (1000, 26, 16), (65, 3, 7), (9, 5, 40), (3, 2, 100)])
+@pytest.mark.parametrize("rs", [True, False])
+def test_fm_standalone(B, F, D, rs):
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + F + D)
+    x = torch.randn(B, F, D, generator=g)
+    xd = x.to(dev()).requires_grad_(True)
+    y = ops.fm(xd, rs)
+    close(y, O.fm_forward(x.numpy().astype(F64), rs), what="fm out")
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(dev()))
+    close(xd.grad, O.fm_backward(x.numpy().astype(F64), gy.numpy().astype(F64), rs), what="fm gx")
+
+
+def test_fm_golden(layers_golden):
+    from torch_rechub_amd.basic.layers import FM
+    g = layers_golden
+    x = torch.from_numpy(g["fm.x"]).to(dev()).requires_grad_(True)
+    for rs in (1, 0):
+        y = FM(reduce_sum=bool(rs))(x)
+        close(y, g[f"fm.{rs}.out"], what="fm golden out")
+        (gx,) = torch.autograd.grad(y, x, torch.from_numpy(g[f"fm.{rs}.g"]).to(dev()))
+        close(gx, g[f"fm.{rs}.gx"], what="fm golden gx")
+
+
+@pytest.mark.parametrize("pooling", ["sum", "mean", "concat"])
+@pytest.mark.parametrize("tag,pad", [("pad0", 0), ("nopad", None)])
+def test_seq_pool_golden(layers_golden, pooling, tag, pad):
+    from torch_rechub_amd import ops
+    g = layers_golden
+    k = f"seq.{pooling}.{tag}"
+    w = torch.nn.Parameter(torch.from_numpy(g[k + ".table"]).to(dev()))
+    idx = torch.from_numpy(g[k + ".idx"]).to(dev())
+    y = ops.seq_pool(w, idx, pooling, pad)
+    ref = g[k + ".out"][:, 0]
+    if pooling == "concat":
+        assert np.array_equal(y.detach().cpu().numpy(), ref)
+    else:
+        close(y, ref, what=k)
+    y.backward(torch.from_numpy(g[k + ".g"][:, 0]).to(dev()))
+    close(w.grad, g[k + ".grad"], rtol=2e-5, atol_scale=2e-6, what=k + " grad")
+
+
+@pytest.mark.parametrize("B,L,V,D,pooling,pad,idt", [
+    (300, 100, 5000, 16, "concat", 0, torch.int64),
+    (300, 100, 5000, 16, "mean", 0, torch.int64),
+    (257, 50, 800, 16, "sum", None, torch.int32),
+    (64, 7, 30, 64, "mean", 0, torch.int64),
+    (5, 1, 30, 8, "sum", 0, torch.int64),
+    (40, 33, 100, 32, "concat", None, torch.int64),
+])
+def test_seq_pool_vs_oracle(B, L, V, D, pooling, pad, idt):
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + L)
+    table = torch.randn(V, D, generator=g) * 0.5
+    if pad is not None:
+        table[pad].zero_()
+    idx = torch.randint(1, V, (B, L), generator=g)
+    lens = torch.randint(0, L + 1, (B,), generator=g)  # includes fully padded rows (count 0 -> mean 0)
+    idx[torch.arange(L)[None, :] >= lens[:, None]] = 0
+    w = torch.nn.Parameter(table.to(dev()))
+    y = ops.seq_pool(w, idx.to(idt).to(dev()), pooling, pad)
+    ref = O.seq_pool(table.numpy().astype(F64), idx.numpy(), pooling, pad)
+    close(y, ref, what="seq out")
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(dev()))
+    close(w.grad, O.seq_pool_backward(table.shape, idx.numpy(), pooling, gy.numpy().astype(F64), pad), rtol=2e-5,
+          atol_scale=2e-6, what="seq grad")
+
+
+@pytest.mark.parametrize("nl", [1, 3, 6])
+def test_cross_network_golden(layers_golden, nl):
+    from torch_rechub_amd.basic.layers import CrossNetwork
+    g = layers_golden
+    d = g["cross.x"].shape[1]
+    cn = CrossNetwork(d, nl).to(dev())
+    with torch.no_grad():
+        for l in range(nl):
+            cn.w[l].weight.copy_(torch.from_numpy(g[f"cross.{nl}.W"][l:l + 1]))
+            cn.b[l].copy_(torch.from_numpy(g[f"cross.{nl}.B"][l]))
+    x = torch.from_numpy(g["cross.x"]).to(dev()).requires_grad_(True)
+    y = cn(x)
+    close(y, g[f"cross.{nl}.out"], rtol=2e-5, atol_scale=2e-6, what="cross out")
+    y.backward(torch.from_numpy(g[f"cross.{nl}.g"]).to(dev()))
+    close(x.grad, g[f"cross.{nl}.gx"], rtol=1e-4, atol_scale=1e-5, what="cross gx")
+    gW = torch.cat([w.weight.grad for w in cn.w], 0)
+    gB = torch.stack([b.grad for b in cn.b], 0)
+    close(gW, g[f"cross.{nl}.gW"], rtol=1e-4, atol_scale=1e-5, what="cross gW")
+    close(gB, g[f"cross.{nl}.gB"], rtol=1e-4, atol_scale=1e-5, what="cross gB")
+
+
+@pytest.mark.parametrize("B,d,L", [(4096, 429, 3), (1000, 429, 4), (333, 64, 2), (50, 1, 1), (129, 65, 3), (70, 600, 2),
+                                   (33, 1100, 1), (17, 2048, 1), (64, 429, 7), (5, 600, 5)])
+def test_cross_network_vs_oracle(B, d, L):
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + d + L)
+    x = torch.randn(B, d, generator=g)
+    W = torch.randn(L, d, generator=g) / np.sqrt(d)
+    Bv = torch.randn(L, d, generator=g) * 0.1
+    xd, Wd, Bd = (t.to(dev()).requires_grad_(True) for t in (x, W, Bv))
+    y = ops.cross_network(xd, Wd, Bd)
+    close(y, O.cross_network_forward(x.numpy().astype(F64), W.numpy().astype(F64), Bv.numpy().astype(F64)), rtol=2e-5,
+          atol_scale=2e-6, what="cross out")
+    gy = torch.randn(B, d, generator=g)
+    y.backward(gy.to(dev()))
+    gx, gW, gB = O.cross_network_backward(x.numpy().astype(F64), W.numpy().astype(F64), Bv.numpy().astype(F64),
+                                          gy.numpy().astype(F64))
+    close(xd.grad, gx, rtol=1e-4, atol_scale=1e-5, what="cross gx")
+    close(Wd.grad, gW, rtol=1e-4, atol_scale=1e-5, what="cross gW")
+    close(Bd.grad, gB, rtol=1e-4, atol_scale=1e-5, what="cross gB")
+
+
+def test_cross_v2_and_mix_golden(layers_golden):
+    from torch_rechub_amd.basic.layers import CrossNetMix, CrossNetV2
+    g = layers_golden
+    x = torch.from_numpy(g["cross.x"]).to(dev())
+    d = x.shape[1]
+    v2 = CrossNetV2(d, 2).to(dev())
+    with torch.no_grad():
+        for l in range(2):
+            v2.w[l].weight.copy_(torch.from_numpy(g["crossv2.W"][l]))
+            v2.b[l].copy_(torch.from_numpy(g["crossv2.B"][l]))
+    close(v2(x), g["crossv2.out"], rtol=1e-4, atol_scale=1e-5, what="crossv2")
+    mix = CrossNetMix(d, num_layers=2, low_rank=8, num_experts=3).to(dev())
+    with torch.no_grad():
+        for l in range(2):
+            mix.u_list[l].copy_(torch.from_numpy(g["crossmix.U"][l]))
+            mix.v_list[l].copy_(torch.from_numpy(g["crossmix.V"][l]))
+            mix.c_list[l].copy_(torch.from_numpy(g["crossmix.C"][l]))
+            mix.bias[l].copy_(torch.from_numpy(g["crossmix.bias"][l]).view(-1, 1))
+        for e in range(3):
+            mix.gating[e].weight.copy_(torch.from_numpy(g["crossmix.Wg"][e:e + 1]))
+    close(mix(x), g["crossmix.out"], rtol=1e-4, atol_scale=1e-5, what="crossmix")
+
+
+def test_dice_golden(layers_golden):
+    from torch_rechub_amd.basic.activation import Dice
+    g = layers_golden
+    dice = Dice().to(dev())
+    with torch.no_grad():
+        dice.alpha.copy_(torch.from_numpy(g["dice.alpha"]))
+    close(dice(torch.from_numpy(g["dice.x"]).to(dev())), g["dice.out"], what="dice")
+
+
+@pytest.mark.parametrize("sm", [0, 1])
+def test_activation_unit_golden(layers_golden, sm):
+    from torch_rechub_amd.models.ranking.din import ActivationUnit
+    g = layers_golden
+    k = f"au.{sm}"
+    au = ActivationUnit(16, dims=[12, 6], activation="dice", use_softmax=bool(sm))
+    au.load_state_dict({n[len(k + ".sd."):]: torch.from_numpy(g[n]) for n in g.files if n.startswith(k + ".sd.")})
+    au.to(dev()).eval()
+    out = au(torch.from_numpy(g[k + ".hist"]).to(dev()), torch.from_numpy(g[k + ".tgt"]).to(dev()))
+    close(out, g[k + ".out"], rtol=1e-4, atol_scale=1e-5, what="activation unit")
+
+
+# ----------------------------------------------------------------------------------------------------------
+def run_table_adam(shapes, steps, lr, wd, seed, grad_prob=0.5):
+    """TableAdam on bare 'tables' with random sparse-ish gradients; returns (params, oracle params)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.optim import TableAdam
+    g = torch.Generator().manual_seed(seed)
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).to(dev())) for s in shapes]
+    opt = TableAdam(ps, table_params=ps, lr=lr, weight_decay=wd)
+    ref = [p.detach().cpu().numpy().astype(F64) for p in ps]
+    ms = [np.zeros_like(r) for r in ref]
+    vs = [np.zeros_like(r) for r in ref]
+    for t in range(1, steps + 1):
+        for i, p in enumerate(ps):
+            gr = torch.randn(shapes[i], generator=g)
+            rows = (torch.rand(shapes[i][0], generator=g) < grad_prob).float().unsqueeze(1)
+            gr = gr * rows  # untouched rows have exactly zero data gradient
+            buf = ops.grad_buffer(p)
+            assert torch.all(buf == 0)  # re-zeroed by the previous step
+            buf.copy_(gr.to(dev()))
+            p._rh_dirty = True
+            ref[i], ms[i], vs[i] = O.adam_step(ref[i], gr.numpy().astype(F64), ms[i], vs[i], t, lr=lr, weight_decay=wd)
+        opt.step()
+    torch.cuda.synchronize()
+    return ps, ref, opt, ms, vs
+
+
+@pytest.mark.parametrize("shapes,steps,lr,wd", [
+    ([(3, 16), (1000, 16), (257, 16), (4, 16)], 5, 1e-2, 1e-3),
+    ([(70000, 16)], 3, 1e-3, 1e-5),
+    ([(5, 4), (1, 8), (1025, 32)], 4, 1e-3, 0.0),
+])
+def test_adam_dense_vs_oracle(shapes, steps, lr, wd):
+    ps, ref, opt, ms, vs = run_table_adam(shapes, steps, lr, wd, seed=len(shapes) + steps)
+    for p, r in zip(ps, ref):
+        close(p, r, rtol=1e-5, atol_scale=1e-6, what="adam param")
+    for i, p in enumerate(ps):
+        close(opt.state[p]["exp_avg"], ms[i], rtol=1e-5, atol_scale=1e-7, what="adam m")
+        close(opt.state[p]["exp_avg_sq"], vs[i], rtol=1e-5, atol_scale=1e-9, what="adam v")
+    assert int(opt._t_step.item()) == steps
+    assert abs(opt.state_dict()["state"][0]["step"].item() - steps) < 1e-6
+
+
+def test_adam_dense_matches_torch_adam_on_device():
+    """Same trajectory as stock torch.optim.Adam fed the same dense gradients (rows without data gradient move too)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.optim import TableAdam
+    g = torch.Generator().manual_seed(9)
+    w0 = torch.randn(5000, 16, generator=g) * 0.05
+    a = torch.nn.Parameter(w0.clone().to(dev()))
+    b = torch.nn.Parameter(w0.clone().to(dev()))
+    oa = TableAdam([a], table_params=[a], lr=1e-3, weight_decay=1e-5)
+    ob = torch.optim.Adam([b], lr=1e-3, weight_decay=1e-5)
+    for t in range(6):
+        gr = torch.zeros(5000, 16)
+        rows = torch.randint(0, 5000, (300,), generator=g)
+        gr[rows] = torch.randn(300, 16, generator=g)
+        ops.grad_buffer(a).copy_(gr.to(dev()))
+        a._rh_dirty = True
+        b.grad = gr.to(dev())
+        oa.step()
+        ob.step()
+    close(a, b.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="vs torch.optim.Adam")
+    assert not torch.equal(a.detach().cpu(), w0)
+
+
+def test_batch_gather_vs_oracle():
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    g = torch.Generator().manual_seed(4)
+    N, F, ND, B = 1003, 26, 13, 128
+    sparse = torch.randint(0, 1 << 40, (N, F), generator=g)
+    dense = torch.rand(N, ND, generator=g)
+    label = (torch.rand(N, generator=g) < 0.25).float()
+    names = [f"C{i}" for i in range(F)]
+    dn = [f"I{i}" for i in range(ND)]
+    dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dn, label.to(dev()), B, shuffle=True)
+    seen = []
+    nb = 0
+    for x, y in dl:
+        nb += 1
+        perm = dl.perm.cpu().numpy()
+        b = y.shape[0]
+        s_ref, d_ref, l_ref = O.batch_gather(perm, (nb - 1) * B, b, sparse.numpy(), dense.numpy(), label.numpy())
+        assert np.array_equal(x.sparse.cpu().numpy(), s_ref)
+        assert np.array_equal(x.dense.cpu().numpy(), d_ref)
+        assert np.array_equal(y.cpu().numpy(), l_ref)
+        assert np.array_equal(x["C3"].cpu().numpy(), s_ref[:, 3]) and np.array_equal(x["I12"].cpu().numpy(), d_ref[:, 12])
+        seen.append(perm[(nb - 1) * B:(nb - 1) * B + b])
+    assert nb == len(dl) == 8
+    assert sorted(np.concatenate(seen).tolist()) == list(range(N))  # every row exactly once per epoch
+    assert int(dl.pos.item()) == 0  # wrapped
