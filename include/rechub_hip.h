@@ -50,6 +50,10 @@ extern "C" {
 int rh_abi_version(void);
 const char* rh_last_error(void);
 
+/* tuning knobs (process-wide; defaults are the measured winners) */
+#define RH_TUNE_WIDE_ATOMICS 1 /* 1: table-gradient atomics carry whole rows per request (default), 0: 16 B pieces */
+int rh_set_tuning(int key, int value);
+
 /* ---------------------------------------------------------------------------------------------
  * K1+K2+K3  fused multi-field gather + FM second order + LR first order (+ dense concat)
  * replaces: EmbeddingLayer.forward  torch_rechub/basic/layers.py:77-127  (26x nn.Embedding + cat)
@@ -164,9 +168,30 @@ int rh_cross_bwd(const float* x0, int64_t x0_stride, const float* x, int64_t x_s
  *                     p -= step_size * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * zero_grad != 0: g <- 0 where it was non-zero (replaces model.zero_grad(), ctr_trainer.py:97)
  */
-int rh_adam_prepare(double* hyper, int64_t* step, void* stream);
+int rh_adam_prepare(double* hyper, int64_t* step, float* ring, int ring_size, void* stream);
 int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel, const double* hyper,
                   int zero_grad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)
+ * replaces: the same optimizer.step() (trainers/ctr_trainer.py:99).  Adam is element-wise and a row that is not in
+ * the batch has the known gradient wd*p, so rows are brought up to date lazily by replaying the skipped steps in
+ * registers; every row is refreshed at least every K steps (sweep window) and immediately when the batch touches it.
+ * ring  (device float [2*ring_size], ring_size a power of two > K): per-step (A_t, E_t) written by rh_adam_prepare
+ *       (hyper[13] = A_t = step_size*sqrt(1-b2^t), hyper[14] = E_t = eps*sqrt(1-b2^t))
+ * ldesc (device int64 [8*T]): p, g, m, v, last (int32 per row: step the row is up to date with) pointers,
+ *       rows, K_t (1 = dense table, stepped with its gradient by the sweep), window rows w_t = ceil(rows/K_t)
+ * rh_adam_lazy_touched: for every lookup of the batch (index columns in idesc, as rh_embed_bwd) claim the row,
+ *       replay it to step t-1, apply step t with its gradient row, re-zero the gradient row.
+ *       field_table (device int64 [2*F]): table index of field f (-1 = skip), padding_idx (-1 = none)
+ * rh_adam_lazy_sweep: bring window (t-1) mod K_t of every table up to date (flush != 0: all rows).
+ * Call order per step: rh_adam_prepare, rh_adam_lazy_touched (once per index batch), rh_adam_lazy_sweep.
+ */
+int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
+                         int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
+                         int ring_size, int samples_per_block, int32_t* err_flag, void* stream);
+int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                       const double* hyper, const float* ring, int ring_size, int flush, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident minibatch assembly (columnar dataset already in HBM)

@@ -29,10 +29,12 @@ def close(a, b, rtol=1e-5, atol_scale=1e-6, what=""):
 
 def make_case(B, vocabs, D, ND, seed, idx_dtype=torch.int64, packed=True, shared=None, pads=None, std=0.5):
     g = torch.Generator().manual_seed(seed)
+    vocabs = list(vocabs)
     tables = [torch.randn(v, D, generator=g) * std for v in vocabs]
     if shared:
         for f, src in shared.items():
             tables[f] = tables[src]
+            vocabs[f] = vocabs[src]  # a shared_with field indexes the owner's table
     pads = pads or [None] * len(vocabs)
     for t, p in zip(tables, pads):
         if p is not None:
@@ -97,7 +99,7 @@ def test_embed_fwd(B, vocabs, D, ND, idt, packed, fs):
     assert out.shape == (B, F * D + ND)
     # gather + dense concat are pure copies: bit-exact against the fp32 tables
     exact = O.embedding_layer_squeeze([t.numpy() for t in c["tables"]], c["idx"].numpy(), c["dense"].numpy())
-    assert np.array_equal(out.cpu().numpy(), exact)
+    assert np.array_equal(out.detach().cpu().numpy(), exact)
     close(fm, y_fm, what="fm")
     close(lr, y_lr, what="lr")
 
@@ -108,7 +110,7 @@ def test_embed_fwd_plain_gather_no_fm_no_lr_and_3d_view():
     call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"])
     out, fm, lr = ops.fused_embedding(call)
     assert fm is None and lr is None
-    assert np.array_equal(out.view(500, 3, 16).cpu().numpy(),
+    assert np.array_equal(out.detach().view(500, 3, 16).cpu().numpy(),
                           O.embedding_gather([t.numpy() for t in c["tables"]], c["idx"].numpy()))
 
 
@@ -466,3 +468,71 @@ def test_batch_gather_vs_oracle():
     assert nb == len(dl) == 8
     assert sorted(np.concatenate(seen).tolist()) == list(range(N))  # every row exactly once per epoch
     assert int(dl.pos.item()) == 0  # wrapped
+
+
+def _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed, flush_every=None):
+    """Drive a dense TableAdam and a lazy one with identical lookup-style gradients; returns both after a flush."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.optim import TableAdam
+    g = torch.Generator().manual_seed(seed)
+    init = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    A = [torch.nn.Parameter(t.clone().to(dev())) for t in init]
+    Bp = [torch.nn.Parameter(t.clone().to(dev())) for t in init]
+    dense = TableAdam(A, table_params=A, lr=1e-2, weight_decay=1e-3)
+    lazy = TableAdam(Bp, table_params=Bp, lr=1e-2, weight_decay=1e-3, lazy_k=lazy_k, lazy_small_rows=small_rows)
+    nb = 97
+    for t in range(steps):
+        del ops.touch_log[:]
+        idx_cols = []
+        for i, s in enumerate(shapes):
+            idx = torch.randint(0, s[0], (nb,), generator=g)
+            if t % 5 == 3:
+                idx[:] = idx[0]  # a step where the whole batch hits one row (duplicates -> one claim)
+            rows_g = torch.randn(nb, s[1], generator=g)
+            dense_g = torch.zeros(s)
+            dense_g.index_add_(0, idx, rows_g)
+            for P in (A[i], Bp[i]):
+                ops.grad_buffer(P).copy_(dense_g.to(dev()))
+                P._rh_dirty = True
+            idx_cols.append(idx.to(dev()))
+        key = tuple([c.data_ptr() for c in idx_cols] + [1] * len(shapes) + list(range(len(shapes))))
+        idesc = ops.EmbedCall._icache.get(key, dev())
+        ops.touch_logging = True
+        # one field per table, all of one embed_dim
+        ops._log_touch(Bp, [None] * len(shapes), idesc, 1, nb, len(shapes), shapes[0][1], idx_cols)
+        lazy.step()  # consumes (and clears) the lookup log
+        dense.step()
+        if flush_every and (t + 1) % flush_every == 0:
+            lazy.flush()
+    lazy.flush()
+    torch.cuda.synchronize()
+    ops.check_errors()
+    return A, Bp, dense, lazy
+
+
+@pytest.mark.parametrize("lazy_k,small_rows,steps,flush_every", [(4, 16, 23, None), (16, 64, 40, 7), (2, 0, 5, None),
+                                                                 (64, 16, 70, None)])
+def test_adam_lazy_is_bit_identical_to_dense(lazy_k, small_rows, steps, flush_every):
+    shapes = [(5, 16), (300, 16), (50, 16), (4099, 16)]
+    A, Bp, dense, lazy = _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed=lazy_k + steps, flush_every=flush_every)
+    for i, (a, b) in enumerate(zip(A, Bp)):
+        assert torch.equal(a.detach(), b.detach()), f"table {i}: params differ"
+        assert torch.equal(dense.state[a]["exp_avg"], lazy.state[b]["exp_avg"]), f"table {i}: exp_avg differs"
+        assert torch.equal(dense.state[a]["exp_avg_sq"], lazy.state[b]["exp_avg_sq"]), f"table {i}: exp_avg_sq differs"
+        from torch_rechub_amd import ops
+        assert torch.all(ops.grad_buffer(b) == 0)  # every touched gradient row was re-zeroed
+    for last in lazy._t_last:
+        assert torch.all(last == steps)  # flush brought every row to the current step
+    assert int(lazy._t_step.item()) == steps
+
+
+def test_adam_lazy_rows_lag_at_most_k_steps():
+    from torch_rechub_amd import ops
+    A, Bp, dense, lazy = _lazy_vs_dense(8, 16, 30, [(3000, 16)], seed=1)
+    # after the flush everything is current; run 5 more steps WITHOUT flush and check the lag bound
+    del ops.touch_log[:]
+    for _ in range(5):
+        lazy.step()
+    torch.cuda.synchronize()
+    lag = int(lazy._t_step.item()) - lazy._t_last[0]
+    assert int(lag.min()) >= 0 and int(lag.max()) < 8

@@ -19,6 +19,7 @@ for s in $STAGES; do
              timeout 600 python bench.py --steps ${BENCH_STEPS:-50} --warmup 10 --graph 1 --no-cpu-baseline > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err"; echo "rc=$?"; cat "$OUT/bench_graph.json"; tail -5 "$OUT/bench_graph.err";;
     prof)    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 20 --warmup 5 --graph 0 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "rc=$?"
              find "$OUT/prof" -name '*kernel_stats*' | head -3; f=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -25 "$f";;
+    kbench)  timeout 600 python tools/kbench.py ${KBENCH_ARGS:-} > "$OUT/kbench.log" 2>&1; echo "rc=$?"; cat "$OUT/kbench.log";;
     *) echo "unknown stage $s";;
   esac
 done

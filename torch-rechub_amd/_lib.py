@@ -19,6 +19,7 @@ c_ptr = ctypes.c_void_p
 SIGNATURES = {
     "rh_abi_version": [],
     "rh_last_error": [],
+    "rh_set_tuning": [c_int, c_int],
     "rh_embed_fwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
     "rh_embed_bwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
@@ -36,7 +37,10 @@ SIGNATURES = {
     "rh_cross_max_layers": [c_int],
     "rh_cross_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_i64, c_int, c_ptr, c_ptr],
-    "rh_adam_prepare": [c_ptr, c_ptr, c_ptr],
+    "rh_adam_prepare": [c_ptr, c_ptr, c_ptr, c_int, c_ptr],
+    "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr,
+                             c_ptr],
+    "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr],
     "rh_adam_dense": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     "rh_batch_gather": [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],

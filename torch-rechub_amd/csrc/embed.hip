@@ -12,6 +12,8 @@
 // use phase) and the per-sample FM / LR reductions are wavefront xor-shuffles.  The backward is
 // field-major so that tiny tables (Criteo has vocab 3, 4, 10 ...) are pre-aggregated in LDS:
 // device-scope atomics on one address serialise at ~11 ns each on MI355X, LDS atomics do not.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -187,6 +189,7 @@ struct EmbedBwdArgs {
   const float* rows_in;
   int spb;
   int lds_floats;
+  int wide_atomics;
   int* err;
 };
 
@@ -228,7 +231,9 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
   const int64_t b0 = (int64_t)blockIdx.x * a.spb;
   const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
 
-  for (int64_t bb = b0 + slot; bb < b1; bb += (int64_t)LPP * U) {
+  // trip count is uniform over the block: the full-line atomic path below shuffles across the wavefront
+  for (int64_t base = b0; base < b1; base += (int64_t)LPP * U) {
+    const int64_t bb = base + slot;
     bool ok[U];
     int64_t bc[U], row[U];
     float4 g[U], v[U], s4[U];
@@ -261,20 +266,42 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
         if (want_wgrad && ok[u]) wacc = f4_fma(gl[u], v[u], wacc);
       }
       gr = f4_scale(gr, a.scale);
-      if (ok[u]) {
-        if (SINK == 1) {
-          gstore<float4>(a.rows_out + (bc[u] * F + f) * D + q * 4, gr);
-        } else {
-          const bool oob = (uint64_t)row[u] >= (uint64_t)vocab;
-          oob_any |= oob;
-          if (has_tab && !oob && row[u] != pad) {
-            const int64_t off = row[u] * D + q * 4;
-            if (use_lds) {
-              RH_LDS_ATOMIC_ADD_F4(lds, (int)off, gr);
-            } else {
-              gatomic_add_f4(gtab + off, gr);
-            }
+      if (SINK == 1) {
+        if (ok[u]) gstore<float4>(a.rows_out + (bc[u] * F + f) * D + q * 4, gr);
+      } else {
+        const bool oob = (uint64_t)row[u] >= (uint64_t)vocab;
+        oob_any |= (oob && ok[u]);
+        const bool live = ok[u] && has_tab && !oob && row[u] != pad;
+        if (use_lds) {
+          if (live) {
+            const int off = (int)(row[u] * D) + q * 4;
+            RH_LDS_ATOMIC_ADD_F4(lds, off, gr);
           }
+        } else if (a.wide_atomics) {
+          // Re-lay the wavefront's 256 gradient floats (64/LPR rows x 4*LPR dwords) so that one atomic
+          // instruction carries WHOLE rows: 4 requests of 64 contiguous dwords instead of 4 requests that each
+          // touch a quarter of every row.  Device-scope float atomics are memory-side RMWs on MI355X: their cost
+          // is per request per line, so a full 64-byte row per request is 4x fewer line operations.
+          constexpr int DD = 4 * LPR;
+          const int lane = tid % RH_WAVE;
+          const int row_lo = (int)(row[u] & 0xffffffff), row_hi = (int)(row[u] >> 32);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = j * RH_WAVE + lane;
+            const int rsl = e / DD;
+            const int dw = e % DD;
+            const int src = rsl * LPR + dw / 4;
+            const float vx = __shfl(gr.x, src, RH_WAVE), vy = __shfl(gr.y, src, RH_WAVE);
+            const float vz = __shfl(gr.z, src, RH_WAVE), vw = __shfl(gr.w, src, RH_WAVE);
+            const int c = dw & 3;
+            const float val = c == 0 ? vx : (c == 1 ? vy : (c == 2 ? vz : vw));
+            const int head = rsl * LPR;
+            const int64_t r = ((int64_t)__shfl(row_hi, head, RH_WAVE) << 32) | (uint32_t)__shfl(row_lo, head, RH_WAVE);
+            const int flag = __shfl((int)live, head, RH_WAVE);
+            if (flag) gatomic_add_f32(gtab + r * DD + dw, val);
+          }
+        } else if (live) {
+          gatomic_add_f4(gtab + row[u] * D + q * 4, gr);
         }
       }
     }
@@ -306,10 +333,21 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
 
 constexpr int kLdsFloats = 8192;  // 32 KiB per block: tables with vocab*D <= 8192 aggregate in LDS
 
+int g_wide_atomics = -1;  // tuning knob RH_TUNE_WIDE_ATOMICS (env RECHUB_WIDE_ATOMICS), default on
+
+int wide_atomics_default() {
+  if (g_wide_atomics < 0) {
+    const char* e = getenv("RECHUB_WIDE_ATOMICS");
+    g_wide_atomics = (e != nullptr) ? (atoi(e) != 0) : 1;
+  }
+  return g_wide_atomics;
+}
+
 template <int LPR, typename IdxT, int SRC, int SINK>
 int launch_bwd(EmbedBwdArgs a, hipStream_t s) {
   const unsigned gx = (unsigned)((a.B + a.spb - 1) / a.spb);
   a.lds_floats = (SINK == 0) ? kLdsFloats : 0;
+  a.wide_atomics = wide_atomics_default();
   const size_t shmem = (SINK == 0) ? kLdsFloats * sizeof(float) : 0;
   hipLaunchKernelGGL((embed_bwd_kernel<LPR, IdxT, SRC, SINK>), dim3(gx, (unsigned)a.F), dim3(RH_BLOCK),
                      shmem, s, a);
@@ -390,7 +428,7 @@ extern "C" int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_
              "rh_embed_bwd: lr_wgrad needs emb and g_lr");
   if (B == 0) return 0;
   EmbedBwdArgs a{fdesc, idesc, B, F, D, g_out, g_stride, emb, emb_stride, s_sum, g_fm, g_lr, lr_w,
-                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, err_flag};
+                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, 0, err_flag};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (sink == 0)
@@ -400,6 +438,15 @@ extern "C" int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_
   if (rc != 0) return rc;
   RH_LAUNCH_CHECK("rh_embed_bwd");
   return 0;
+}
+
+extern "C" int rh_set_tuning(int key, int value) {
+  if (key == RH_TUNE_WIDE_ATOMICS) {
+    g_wide_atomics = value != 0;
+    return 0;
+  }
+  rh_set_error("rh_set_tuning: unknown key %d", key);
+  return RH_E_BADARG;
 }
 
 extern "C" int rh_embed_bwd_nchunks(int B, int samples_per_block) {
@@ -414,7 +461,7 @@ extern "C" int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc,
   RH_REQUIRE(rows != nullptr, RH_E_BADARG, "rh_embed_scatter_rows: rows is null");
   if (B == 0) return 0;
   EmbedBwdArgs a{fdesc, idesc, B, F, D, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, err_flag};
+                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, 0, err_flag};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = idx_is_i64 ? dispatch_bwd<int64_t, 1, 0>(a, s) : dispatch_bwd<int32_t, 1, 0>(a, s);
   if (rc != 0) return rc;

@@ -25,7 +25,7 @@ struct AdamArgs {
   int64_t vb_prefix[kMaxTensors + 1];  // virtual-block prefix sum per tensor
 };
 
-__global__ void adam_prepare_kernel(double* hyper, int64_t* step) {
+__global__ void adam_prepare_kernel(double* hyper, int64_t* step, float* ring, int64_t ring_mask) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int64_t t = *step + 1;
     *step = t;
@@ -37,33 +37,54 @@ __global__ void adam_prepare_kernel(double* hyper, int64_t* step) {
     hyper[10] = 1.0 - b1;     // lerp weight
     hyper[11] = 1.0 - b2;
     hyper[12] = (double)t;
+    // folded form used by every kernel here:  p -= A * m / (sqrt(v) + E)
+    //   = step_size * m / (sqrt(v)/sqrt(bc2) + eps)   with A = step_size*sqrt(bc2), E = eps*sqrt(bc2)
+    const double A = hyper[8] * hyper[9], E = hyper[3] * hyper[9];
+    hyper[13] = A;
+    hyper[14] = E;
+    if (ring != nullptr) {
+      ring[2 * (t & ring_mask) + 0] = (float)A;
+      ring[2 * (t & ring_mask) + 1] = (float)E;
+    }
   }
 }
 
 struct AdamScalars {
-  float b2, eps, wd, step_size, bc2_sqrt, one_m_b1, one_m_b2;
+  float b2, wd, one_m_b1, one_m_b2;
+  float A, E;  // per-step: A = lr/(1-b1^t)*sqrt(1-b2^t), E = eps*sqrt(1-b2^t)
 };
 
 // One element of torch.optim.Adam (_single_tensor_adam, amsgrad=False, maximize=False):
 //   g += wd*p; m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2);
-//   denom = v.sqrt()/bc2_sqrt + eps; p.addcdiv_(m, denom, -step_size)
-static __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamScalars& h) {
+//   denom = v.sqrt()/bc2_sqrt + eps; p.addcdiv_(m, denom, -step_size)      [ == p -= A*m/(sqrt(v)+E) ]
+// The dense and the lazy kernels share THIS function, so their results are bit-identical.
+static __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamScalars& h, float A,
+                                                 float E) {
   g = fmaf(h.wd, p, g);
   m = fmaf(h.one_m_b1, g - m, m);
   v = fmaf(h.one_m_b2, g * g, v * h.b2);
-  const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
-  p = fmaf(-h.step_size, m / denom, p);
+  p = fmaf(-A, m / (sqrtf(v) + E), p);
+}
+static __device__ __forceinline__ void adam_f4(float4& P, const float4 G, float4& M, float4& V, const AdamScalars& h,
+                                               float A, float E) {
+  adam_elem(P.x, G.x, M.x, V.x, h, A, E);
+  adam_elem(P.y, G.y, M.y, V.y, h, A, E);
+  adam_elem(P.z, G.z, M.z, V.z, h, A, E);
+  adam_elem(P.w, G.w, M.w, V.w, h, A, E);
+}
+static __device__ __forceinline__ AdamScalars load_scalars(const double* hyper) {
+  AdamScalars h;
+  h.b2 = (float)hyper[2];
+  h.wd = (float)hyper[4];
+  h.one_m_b1 = (float)hyper[10];
+  h.one_m_b2 = (float)hyper[11];
+  h.A = (float)hyper[13];
+  h.E = (float)hyper[14];
+  return h;
 }
 
 __global__ __launch_bounds__(RH_BLOCK) void adam_dense_kernel(const AdamArgs a) {
-  AdamScalars h;
-  h.b2 = (float)a.hyper[2];
-  h.eps = (float)a.hyper[3];
-  h.wd = (float)a.hyper[4];
-  h.step_size = (float)a.hyper[8];
-  h.bc2_sqrt = (float)a.hyper[9];
-  h.one_m_b1 = (float)a.hyper[10];
-  h.one_m_b2 = (float)a.hyper[11];
+  const AdamScalars h = load_scalars(a.hyper);
   const int T = a.T;
   for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += gridDim.x) {
     // binary search: last t with vb_prefix[t] <= vb  (wave-uniform, scalar loads from kernarg)
@@ -96,10 +117,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_dense_kernel(const AdamArgs a) 
       if (!ok[k]) continue;
       const int64_t i4 = base4 + (int64_t)k * RH_BLOCK + threadIdx.x;
       const bool gnz = Gv[k].x != 0.f || Gv[k].y != 0.f || Gv[k].z != 0.f || Gv[k].w != 0.f;
-      adam_elem(P[k].x, Gv[k].x, M[k].x, V[k].x, h);
-      adam_elem(P[k].y, Gv[k].y, M[k].y, V[k].y, h);
-      adam_elem(P[k].z, Gv[k].z, M[k].z, V[k].z, h);
-      adam_elem(P[k].w, Gv[k].w, M[k].w, V[k].w, h);
+      adam_f4(P[k], Gv[k], M[k], V[k], h, h.A, h.E);
       gstore<float4>(p + i4 * 4, P[k]);
       gstore<float4>(m + i4 * 4, M[k]);
       gstore<float4>(v + i4 * 4, V[k]);
@@ -108,12 +126,169 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_dense_kernel(const AdamArgs a) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Blocked-lazy EXACT Adam.  Adam is element-wise: a row's (p, m, v) depend only on that row's own gradient history,
+// and a row that is not in the batch has the KNOWN gradient wd*p.  So a row can be brought up to date later by
+// replaying the skipped steps in registers ("replay": g = wd*p with that step's bias corrections from a ring buffer)
+// with NO memory traffic — the result is bit-identical to stepping it densely every step (same adam_elem).
+//   * touched pass: every row the batch looked up is claimed once (atomicMax on its last-step word), replayed up to
+//     step t-1 and then stepped with its data gradient; its gradient row is re-zeroed.
+//   * sweep pass: each step a 1/K window of every table is brought up to date, so no row ever lags more than K steps
+//     (bounds the replay length and the ring); tables with <= small_rows rows use K = 1 (dense, no atomics).
+//   * flush = sweep over all rows (before the weights are read by anything else: eval, state_dict, checkpoint).
+// HBM traffic per step falls from 28 B x all elements to ~1/K of that; the arithmetic (one adam_elem per element per
+// step) is unchanged and becomes the bound.
+// ldesc (device int64 [8*T]): p, g, m, v, last(int32*) pointers, rows, K_t, window rows w_t
+struct LazySweepArgs {
+  const int64_t* ldesc;
+  const double* hyper;
+  const float* ring;
+  int ring_mask;
+  int T;
+  int flush;  // 1: window = whole table
+  int64_t total_vblocks;
+  int64_t vb_prefix[kMaxTensors + 1];
+};
+
+template <int LPR>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySweepArgs a) {
+  constexpr int RPB = RH_BLOCK / LPR;  // rows per block
+  constexpr int D = 4 * LPR;
+  const AdamScalars h = load_scalars(a.hyper);
+  const int t = (int)a.hyper[12];
+  const int T = a.T;
+  const int q = threadIdx.x % LPR;
+  const int slot = threadIdx.x / LPR;
+  for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += gridDim.x) {
+    int lo = 0, hi = T;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.vb_prefix[mid] <= vb) lo = mid; else hi = mid;
+    }
+    const int ti = lo;
+    float* p = reinterpret_cast<float*>(a.ldesc[0 * T + ti]);
+    float* g = reinterpret_cast<float*>(a.ldesc[1 * T + ti]);
+    float* m = reinterpret_cast<float*>(a.ldesc[2 * T + ti]);
+    float* v = reinterpret_cast<float*>(a.ldesc[3 * T + ti]);
+    int* last = reinterpret_cast<int*>(a.ldesc[4 * T + ti]);
+    const int64_t rows = a.ldesc[5 * T + ti];
+    const int64_t K = a.ldesc[6 * T + ti];
+    const int64_t w = a.flush ? rows : a.ldesc[7 * T + ti];
+    const int64_t wstart = a.flush ? 0 : ((int64_t)(t - 1) % K) * w;
+    const int64_t local = (vb - a.vb_prefix[ti]) * RPB + slot;
+    const int64_t r = wstart + local;
+    if (local >= w || r >= rows) continue;
+    const int old = gload<int>(last + r);
+    if (old >= t) continue;  // already stepped by the touched pass
+    const bool with_g = (K == 1);  // dense tables receive their gradient here; others had it applied when touched
+    float4 P = gload<float4>(p + r * D + q * 4);
+    float4 M = gload<float4>(m + r * D + q * 4);
+    float4 V = gload<float4>(v + r * D + q * 4);
+    float4 G = with_g ? gload<float4>(g + r * D + q * 4) : f4_zero();
+    for (int j = old + 1; j < t; ++j) {
+      const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
+      adam_f4(P, f4_zero(), M, V, h, A, E);
+    }
+    adam_f4(P, G, M, V, h, h.A, h.E);
+    gstore<float4>(p + r * D + q * 4, P);
+    gstore<float4>(m + r * D + q * 4, M);
+    gstore<float4>(v + r * D + q * 4, V);
+    if (with_g && (G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)) gstore<float4>(g + r * D + q * 4, f4_zero());
+    if (q == 0) last[r] = t;
+  }
+}
+
+struct LazyTouchedArgs {
+  const int64_t* ldesc;        // [8*T] as above
+  const int64_t* field_table;  // [2*F]: table index of the field (-1: skip), padding_idx (-1: none)
+  const int64_t* idesc;        // [>=2*F] index column pointer + stride per field
+  const double* hyper;
+  const float* ring;
+  int ring_mask;
+  int T, B, F, spb;
+  int* err;
+};
+
+template <int LPR, typename IdxT>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
+  constexpr int LPP = RH_BLOCK / LPR;
+  constexpr int D = 4 * LPR;
+  const int f = blockIdx.y;
+  const int T = a.T, F = a.F;
+  const int64_t ti = a.field_table[f];
+  if (ti < 0) return;
+  const int64_t K = a.ldesc[6 * T + ti];
+  if (K == 1) return;  // dense table: stepped (with its gradient) by the sweep pass
+  const int64_t pad = a.field_table[F + f];
+  float* p = reinterpret_cast<float*>(a.ldesc[0 * T + ti]);
+  float* g = reinterpret_cast<float*>(a.ldesc[1 * T + ti]);
+  float* m = reinterpret_cast<float*>(a.ldesc[2 * T + ti]);
+  float* v = reinterpret_cast<float*>(a.ldesc[3 * T + ti]);
+  int* last = reinterpret_cast<int*>(a.ldesc[4 * T + ti]);
+  const int64_t rows = a.ldesc[5 * T + ti];
+  const IdxT* ip = reinterpret_cast<const IdxT*>(a.idesc[f]);
+  const int64_t st = a.idesc[F + f];
+  const AdamScalars h = load_scalars(a.hyper);
+  const int t = (int)a.hyper[12];
+  const int q = threadIdx.x % LPR;
+  const int slot = threadIdx.x / LPR;
+  const int lane = threadIdx.x % RH_WAVE;
+  const int64_t b0 = (int64_t)blockIdx.x * a.spb;
+  const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
+  for (int64_t base = b0; base < b1; base += LPP) {  // uniform trip count: the claim is broadcast by shuffle
+    const int64_t b = base + slot;
+    const bool ok = b < b1;
+    const int64_t r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
+    const bool valid = ok && (uint64_t)r < (uint64_t)rows && r != pad;
+    int old = t;
+    if (valid && q == 0) {
+      old = gload<int>(last + r);
+      if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
+    }
+    old = __shfl(old, lane - q, RH_WAVE);
+    if (!valid || old >= t) continue;
+    float4 P = gload<float4>(p + r * D + q * 4);
+    float4 M = gload<float4>(m + r * D + q * 4);
+    float4 V = gload<float4>(v + r * D + q * 4);
+    const float4 G = gload<float4>(g + r * D + q * 4);
+    for (int j = old + 1; j < t; ++j) {
+      const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
+      adam_f4(P, f4_zero(), M, V, h, A, E);
+    }
+    adam_f4(P, G, M, V, h, h.A, h.E);
+    gstore<float4>(p + r * D + q * 4, P);
+    gstore<float4>(m + r * D + q * 4, M);
+    gstore<float4>(v + r * D + q * 4, V);
+    gstore<float4>(g + r * D + q * 4, f4_zero());
+  }
+}
+
+template <int LPR>
+int launch_sweep(LazySweepArgs& a, const int64_t* h_rows, const int64_t* h_window, hipStream_t s) {
+  constexpr int RPB = RH_BLOCK / LPR;
+  a.vb_prefix[0] = 0;
+  for (int t = 0; t < a.T; ++t) {
+    const int64_t w = a.flush ? h_rows[t] : (h_window[t] < h_rows[t] ? h_window[t] : h_rows[t]);
+    a.vb_prefix[t + 1] = a.vb_prefix[t] + (w + RPB - 1) / RPB;
+  }
+  for (int t = a.T + 1; t <= kMaxTensors; ++t) a.vb_prefix[t] = a.vb_prefix[a.T];
+  a.total_vblocks = a.vb_prefix[a.T];
+  if (a.total_vblocks == 0) return 0;
+  int64_t grid = a.total_vblocks;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR>), dim3((unsigned)grid), dim3(RH_BLOCK), 0, s, a);
+  return 0;
+}
+
 }  // namespace
 
-extern "C" int rh_adam_prepare(double* hyper, int64_t* step, void* stream) {
+extern "C" int rh_adam_prepare(double* hyper, int64_t* step, float* ring, int ring_size, void* stream) {
   RH_REQUIRE(hyper != nullptr && step != nullptr, RH_E_BADARG, "rh_adam_prepare: null pointer");
+  RH_REQUIRE(ring == nullptr || (ring_size > 0 && (ring_size & (ring_size - 1)) == 0), RH_E_BADARG,
+             "rh_adam_prepare: ring_size must be a power of two");
   hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), hyper,
-                     step);
+                     step, ring, (int64_t)(ring_size - 1));
   RH_LAUNCH_CHECK("rh_adam_prepare");
   return 0;
 }
@@ -144,5 +319,63 @@ extern "C" int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   RH_LAUNCH_CHECK("rh_adam_dense");
+  return 0;
+}
+
+extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                  const double* hyper, const float* ring, int ring_size, int flush, void* stream) {
+  RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring, RH_E_BADARG, "rh_adam_lazy_sweep: null pointer");
+  RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0, RH_E_BADARG, "rh_adam_lazy_sweep: ring_size");
+  LazySweepArgs a;
+  a.ldesc = ldesc;
+  a.hyper = hyper;
+  a.ring = ring;
+  a.ring_mask = ring_size - 1;
+  a.T = T;
+  a.flush = flush;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = RH_E_UNSUPPORTED;
+  switch (D / 4) {
+    case 1: rc = launch_sweep<1>(a, h_rows, h_window, s); break;
+    case 2: rc = launch_sweep<2>(a, h_rows, h_window, s); break;
+    case 4: rc = launch_sweep<4>(a, h_rows, h_window, s); break;
+    case 8: rc = launch_sweep<8>(a, h_rows, h_window, s); break;
+    case 16: rc = launch_sweep<16>(a, h_rows, h_window, s); break;
+    case 32: rc = launch_sweep<32>(a, h_rows, h_window, s); break;
+    default: break;
+  }
+  RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: embed_dim %d unsupported", D);
+  RH_LAUNCH_CHECK("rh_adam_lazy_sweep");
+  return 0;
+}
+
+extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
+                                    int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
+                                    int ring_size, int samples_per_block, int32_t* err_flag, void* stream) {
+  RH_REQUIRE(ldesc && field_table && idesc && hyper && ring, RH_E_BADARG, "rh_adam_lazy_touched: null pointer");
+  RH_REQUIRE(T >= 1 && F >= 1 && F <= 65535 && B >= 0, RH_E_BADARG, "rh_adam_lazy_touched: bad shape");
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0, RH_E_BADARG, "rh_adam_lazy_touched: ring_size");
+  if (B == 0) return 0;
+  int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
+  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
+  const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)F);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define RH_LT(LPR)                                                                                             \
+  if (idx_is_i64)                                                                                              \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t>), grid, dim3(RH_BLOCK), 0, s, a);              \
+  else                                                                                                         \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t>), grid, dim3(RH_BLOCK), 0, s, a);
+  switch (D / 4) {
+    case 1: RH_LT(1) break;
+    case 2: RH_LT(2) break;
+    case 4: RH_LT(4) break;
+    case 8: RH_LT(8) break;
+    case 16: RH_LT(16) break;
+    case 32: RH_LT(32) break;
+    default: rh_set_error("rh_adam_lazy_touched: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
+  }
+#undef RH_LT
+  RH_LAUNCH_CHECK("rh_adam_lazy_touched");
   return 0;
 }

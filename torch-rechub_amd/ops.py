@@ -188,6 +188,18 @@ class EmbedCall(object):
         return EmbedCall._dcache.get(key, self.device)
 
 
+# Lookup log for the lazy optimizer: which (table, index column) pairs received gradient since the last step.
+# Enabled by optim.TableAdam(lazy_k > 1); each record keeps the index tensors alive until the step consumed it.
+touch_log = []
+touch_logging = False
+
+
+def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep):
+    if touch_logging:
+        touch_log.append(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
+                              keep=keep))
+
+
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
 _sparse_exchange = None
 
@@ -275,6 +287,8 @@ class _EmbedFused(torch.autograd.Function):
             if exchange is not None:
                 idx_all, rows_all = exchange(call, rows)
                 scatter_rows(call, idx_all, rows_all)
+            elif any_table:
+                _log_touch(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, call.idx)
             if any_table:
                 for w in {id(w): w for w in call.weights if w.requires_grad}.values():
                     _publish_grad(w)
@@ -298,6 +312,7 @@ def scatter_rows(call, idx_all, rows_all):
     idesc = EmbedCall._icache.get(key, call.device)
     _lib.call("rh_embed_scatter_rows", _p(call.fdesc(True)), _p(idesc), 1 if idx_all.dtype == torch.int64 else 0,
               N, F, D, _p(rows_all), 1.0, call.samples_per_block, _p(err_flag(call.device)), _stream())
+    _log_touch(call.weights, call.pads, idesc, 1 if idx_all.dtype == torch.int64 else 0, N, F, D, [idx_all])
 
 
 # --------------------------------------------------------------------------------------------
@@ -368,6 +383,10 @@ class _SeqPoolFn(torch.autograd.Function):
                       idx.stride(1), B, L, D, mode, sentinel, pad, _p(g), g.stride(0), 1.0,
                       _p(err_flag(weight.device)), _stream())
             _publish_grad(weight)
+            if touch_logging:  # the (B, L) positions are B*L lookups of one field
+                flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
+                idesc = EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device)
+                _log_touch([weight], [pad], idesc, 1 if idx.dtype == torch.int64 else 0, B * L, 1, D, [flat])
         return None, None, None, None, None
 
 

@@ -21,7 +21,15 @@ from . import _lib, ops
 
 class TableAdam(torch.optim.Adam):
 
-    def __init__(self, params, table_params=(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
+    RING = 1024  # per-step (A, E) history for the lazy replay; lazy_k must be < RING
+
+    def __init__(self, params, table_params=(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_k=0,
+                 lazy_small_rows=4096, **kw):
+        """lazy_k <= 1: dense pass over every table row each step (rh_adam_dense).
+        lazy_k  > 1: blocked-lazy EXACT mode — rows are refreshed when the batch touches them and at least every
+        lazy_k steps (rh_adam_lazy_*); bit-identical to the dense pass after ``flush()``.  Valid only while the table
+        gradients come from embedding lookups (fused gather / sequence pooling), not from dense terms such as an
+        embedding L2 regulariser; ``flush()`` must run before anything else reads the tables."""
         params = list(params)
         table_ids = {id(p) for p in table_params}
         if params and isinstance(params[0], dict):
@@ -40,10 +48,22 @@ class TableAdam(torch.optim.Adam):
             raise ValueError("TableAdam: amsgrad / maximize are not supported on the fused table path")
         if others and others[0].is_cuda:
             kw.setdefault("capturable", True)  # device-side step counter: the step is hipGraph-capturable
-            kw.setdefault("foreach", True)
-        super().__init__(groups, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+            if "foreach" not in kw and "fused" not in kw:
+                kw["fused"] = True  # one multi-tensor kernel for the ~15 small dense tensors
+        try:
+            super().__init__(groups, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+        except RuntimeError:
+            if not kw.pop("fused", False):
+                raise
+            kw["foreach"] = True
+            super().__init__(groups, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
         self._tables = tables
         self._t_hyper_host = None
+        self.lazy_k = int(lazy_k) if tables else 0
+        if self.lazy_k >= self.RING:
+            raise ValueError(f"lazy_k must be < {self.RING}")
+        self.lazy_small_rows = int(lazy_small_rows)
+        self._lazy_dirty = False
         if tables:
             dev = tables[0].device
             self._t_m = [torch.zeros_like(p) for p in tables]
@@ -56,6 +76,12 @@ class TableAdam(torch.optim.Adam):
             for p, m, v in zip(tables, self._t_m, self._t_v):
                 # same keys as torch.optim.Adam so state_dict() round-trips; 'step' is synced lazily
                 self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m, "exp_avg_sq": v}
+            self._t_ring = torch.zeros(2 * self.RING, dtype=torch.float32, device=dev)
+            if self.lazy_k > 1:
+                self._t_last = [torch.zeros(p.shape[0], dtype=torch.int32, device=dev) for p in tables]
+                self._lazy_groups = None
+                self._ft_cache = {}
+                ops.touch_logging = True
 
     # ------------------------------------------------------------------------------------
     def _table_group(self):
@@ -73,6 +99,8 @@ class TableAdam(torch.optim.Adam):
         lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
         host = (lr, float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
         if host != self._t_hyper_host:
+            if self._t_hyper_host is not None and host[1:] != self._t_hyper_host[1:]:
+                self.flush()  # betas / eps / weight_decay are assumed constant inside a replay window
             self._t_hyper[:5].copy_(torch.tensor(host, dtype=torch.float64))
             self._t_hyper_host = host
 
@@ -87,17 +115,84 @@ class TableAdam(torch.optim.Adam):
             self._t_desc_key = key
         return self._t_desc
 
+    # -- blocked-lazy exact mode ---------------------------------------------------------
+    def _lazy_setup(self):
+        """Group the tables by embed_dim (one launch each) and build their device descriptors."""
+        grads = [ops.grad_buffer(p) for p in self._tables]
+        key = tuple([p.data_ptr() for p in self._tables] + [g.data_ptr() for g in grads])
+        if self._lazy_groups is not None and self._lazy_key == key:
+            return self._lazy_groups
+        groups = {}
+        for i, p in enumerate(self._tables):
+            groups.setdefault(int(p.shape[1]), []).append(i)
+        out = {}
+        for D, members in groups.items():
+            rows = [int(self._tables[i].shape[0]) for i in members]
+            ks = [1 if r <= self.lazy_small_rows else self.lazy_k for r in rows]
+            win = [-(-r // k) for r, k in zip(rows, ks)]
+            desc = ([self._tables[i].data_ptr() for i in members] + [grads[i].data_ptr() for i in members] +
+                    [self._t_m[i].data_ptr() for i in members] + [self._t_v[i].data_ptr() for i in members] +
+                    [self._t_last[i].data_ptr() for i in members] + rows + ks + win)
+            out[D] = dict(members=members, local={id(self._tables[i]): j for j, i in enumerate(members)},
+                          ldesc=torch.tensor(desc, dtype=torch.int64).to(self._tables[0].device),
+                          h_rows=(ctypes.c_int64 * len(rows))(*rows), h_win=(ctypes.c_int64 * len(rows))(*win))
+        self._lazy_groups, self._lazy_key = out, key
+        self._ft_cache = {}
+        return out
+
+    def _field_table(self, rec, grp):
+        ids = tuple(id(w) for w in rec["weights"]) + tuple(rec["pads"])
+        ft = self._ft_cache.get(ids)
+        if ft is None:
+            tab = [grp["local"].get(id(w), -1) for w in rec["weights"]]
+            pads = [(-1 if q is None else int(q)) for q in rec["pads"]]
+            ft = torch.tensor(tab + pads, dtype=torch.int64).to(self._tables[0].device)
+            self._ft_cache[ids] = ft
+        return ft
+
+    def _lazy_step(self, stream):
+        groups = self._lazy_setup()
+        for rec in ops.touch_log:
+            grp = groups.get(rec["D"])
+            if grp is None:
+                continue
+            _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
+                      ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
+                      ops._p(self._t_ring), self.RING, 0, ops._p(ops.err_flag(self._tables[0].device)), stream)
+        del ops.touch_log[:]
+        for D, grp in groups.items():
+            _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
+                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
+                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 0, stream)
+        self._lazy_dirty = True
+
+    def flush(self):
+        """Bring every table row up to the current step (no-op in dense mode).  Must run before the weights are read
+        by anything but the training step: evaluation, state_dict, checkpointing."""
+        if self.lazy_k > 1 and self._lazy_dirty and self._tables:
+            stream = ops._stream()
+            for D, grp in self._lazy_setup().items():
+                _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
+                          ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
+                          ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 1, stream)
+            self._lazy_dirty = False
+
     def step_tables(self):
-        """One dense Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
+        """One Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
         if not self._tables:
             return
         stream = ops._stream()
-        desc = self._desc()
-        _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), stream)
-        _lib.call("rh_adam_dense", ops._p(desc), len(self._tables), ctypes.cast(self._t_numel, ctypes.c_void_p),
-                  ops._p(self._t_hyper), 1, stream)
+        _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
+                  stream)
+        if self.lazy_k > 1:
+            self._lazy_step(stream)
+        else:
+            desc = self._desc()
+            _lib.call("rh_adam_dense", ops._p(desc), len(self._tables), ctypes.cast(self._t_numel, ctypes.c_void_p),
+                      ops._p(self._t_hyper), 1, stream)
+            del ops.touch_log[:]
         for p in self._tables:
-            p._rh_dirty = False  # the kernel zeroed every non-zero gradient row
+            p._rh_dirty = False  # the kernels zeroed every non-zero gradient row
             if p.grad is None:
                 p.grad = p._rh_grad
 
@@ -136,6 +231,7 @@ class TableAdam(torch.optim.Adam):
                 p._rh_dirty = False
 
     def state_dict(self):
+        self.flush()
         if self._tables:
             t = float(self._t_step.item())
             for p in self._tables:
