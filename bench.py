@@ -190,7 +190,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    trainer.flush()  # lazy mode: every table row is brought to step K INSIDE the timed region (weights are final)
+    trainer.flush()  # lazy mode: every table row is brought to the last step INSIDE the timed region (weights final)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:

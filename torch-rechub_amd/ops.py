@@ -200,6 +200,16 @@ def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep):
                               keep=keep))
 
 
+# Pre-gather hook of the lazy optimizer: rows about to be READ must first be brought up to date (a row that was
+# not in recent batches lags behind the dense semantics until someone looks at it).  fn(record) or None.
+pre_gather_hook = None
+
+
+def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D):
+    if pre_gather_hook is not None:
+        pre_gather_hook(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D))
+
+
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
 _sparse_exchange = None
 
@@ -240,6 +250,7 @@ class _EmbedFused(torch.autograd.Function):
                 raise ValueError("fused LR weight must be contiguous float32 with F*D elements")
             require_hip(lr_w, lr_b)
         ddesc = call.ddesc()
+        _pre_gather(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D)
         _lib.call("rh_embed_fwd", _p(call.fdesc(False)), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(ddesc),
                   len(call.dense), call.dense_col, _p(out), out.stride(0), _p(lr_w if call.want_lr else None),
                   _p(lr_b if call.want_lr else None), _p(lr), _p(fm), _p(s_sum), call.field_split,
@@ -361,6 +372,10 @@ class _SeqPoolFn(torch.autograd.Function):
         B, L = idx.shape
         V, D = weight.shape
         out = torch.empty((B, L, D) if mode == 2 else (B, D), dtype=torch.float32, device=weight.device)
+        if pre_gather_hook is not None:
+            flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
+            _pre_gather([weight], [None], EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device),
+                        1 if idx.dtype == torch.int64 else 0, B * L, 1, D)
         _lib.call("rh_seq_pool_fwd", _p(weight), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
                   idx.stride(1), B, L, D, mode, sentinel, _p(out), out.stride(0), _p(err_flag(weight.device)),
                   _stream())

@@ -82,6 +82,7 @@ class TableAdam(torch.optim.Adam):
                 self._lazy_groups = None
                 self._ft_cache = {}
                 ops.touch_logging = True
+                ops.pre_gather_hook = self._refresh  # rows are brought up to date right before they are read
 
     # ------------------------------------------------------------------------------------
     def _table_group(self):
@@ -150,15 +151,24 @@ class TableAdam(torch.optim.Adam):
             self._ft_cache[ids] = ft
         return ft
 
-    def _lazy_step(self, stream):
-        groups = self._lazy_setup()
-        for rec in ops.touch_log:
-            grp = groups.get(rec["D"])
-            if grp is None:
-                continue
+    def _touch(self, rec, groups, stream):
+        grp = groups.get(rec["D"])
+        if grp is not None:
             _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
-                      ops._p(self._t_ring), self.RING, 0, ops._p(ops.err_flag(self._tables[0].device)), stream)
+                      ops._p(self._t_ring), self.RING, 64, ops._p(ops.err_flag(self._tables[0].device)), stream)
+
+    def _refresh(self, rec):
+        """Pre-gather hook: replay the rows of this index batch up to the last completed step (their gradient rows are
+        zero at this point, so this is the pure wd*p replay); the forward then reads exactly what a dense optimizer
+        would have left in the table."""
+        if self._tables:  # unconditional, so that a captured hipGraph always contains the refresh launch
+            self._touch(rec, self._lazy_setup(), ops._stream())
+
+    def _lazy_step(self, stream):
+        groups = self._lazy_setup()
+        for rec in ops.touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
+            self._touch(rec, groups, stream)
         del ops.touch_log[:]
         for D, grp in groups.items():
             _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
