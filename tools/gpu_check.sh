@@ -17,8 +17,14 @@ for s in $STAGES; do
     props)   timeout 900 python -m pytest tests/test_gpu_properties.py -q -m gpu --timeout 600 > "$OUT/props.log" 2>&1; echo "rc=$?" >> "$OUT/props.log"; tail -30 "$OUT/props.log";;
     bench)   timeout 900 python bench.py --steps ${BENCH_STEPS:-50} --warmup 10 --graph 0 > "$OUT/bench_eager.json" 2> "$OUT/bench_eager.err"; echo "rc=$?"; cat "$OUT/bench_eager.json"; tail -5 "$OUT/bench_eager.err"
              timeout 600 python bench.py --steps ${BENCH_STEPS:-50} --warmup 10 --graph 1 --no-cpu-baseline > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err"; echo "rc=$?"; cat "$OUT/bench_graph.json"; tail -5 "$OUT/bench_graph.err";;
-    prof)    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 20 --warmup 5 --graph 0 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "rc=$?"
-             find "$OUT/prof" -name '*kernel_stats*' | head -3; f=$(find "$OUT/prof" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -25 "$f";;
+    prof)    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps ${PROF_STEPS:-50} --warmup 10 --no-cpu-baseline ${PROF_BENCH_ARGS:-} > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "rc=$?"
+             python tools/prof_summary.py "$OUT/prof" > "$OUT/prof_summary.txt" 2>&1; head -45 "$OUT/prof_summary.txt"
+             find "$OUT/prof" -name '*kernel_trace.csv' -size +20M -delete;;
+    pmc)     for c in FETCH_SIZE WRITE_SIZE; do
+               (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_$c" -o bench -- python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --graph 0 ${PROF_BENCH_ARGS:-} > "$OLDPWD/$OUT/pmc_$c.json" 2> "$OLDPWD/$OUT/pmc_$c.err"); echo "pmc $c rc=$?"
+               python tools/prof_summary.py "$OUT/pmc_$c" --pmc $c > "$OUT/pmc_${c}_summary.txt" 2>&1; head -30 "$OUT/pmc_${c}_summary.txt"
+               find "$OUT/pmc_$c" -name '*.csv' -size +20M -delete
+             done;;
     kbench)  timeout 600 python tools/kbench.py ${KBENCH_ARGS:-} > "$OUT/kbench.log" 2>&1; echo "rc=$?"; cat "$OUT/kbench.log";;
     *) echo "unknown stage $s";;
   esac

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 output directory (csv format): per-kernel count / avg / min / total from the kernel trace,
+or per-kernel mean counter value with --pmc NAME.  Only our rh_* kernels and the top ATen / hipBLASLt ones are listed."""
+import argparse
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for key in ("embed_fwd_kernel", "embed_bwd_kernel", "adam_dense_kernel", "adam_lazy_sweep_kernel",
+                "adam_lazy_touched_kernel", "adam_prepare_kernel", "batch_gather_kernel", "batch_advance_kernel",
+                "cross_fwd_kernel", "cross_bwd_kernel", "seq_pool_kernel", "fm_fwd_kernel", "fm_bwd_kernel"):
+        if key in name:
+            return "rechub::" + key
+    return name[:100]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--pmc", default=None)
+    a = ap.parse_args()
+    if a.pmc:
+        files = glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            sys.exit("no counter_collection.csv under " + a.dir)
+        acc = defaultdict(lambda: [0, 0.0])
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") != a.pmc:
+                    continue
+                k = short(row["Kernel_Name"])
+                acc[k][0] += 1
+                acc[k][1] += float(row["Counter_Value"])
+        print(f"# rocprofv3 --pmc {a.pmc}: mean counter value per dispatch (raw counter units)")
+        print(f"{'kernel':60s} {'dispatches':>10s} {'mean':>16s}")
+        for k, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:25]:
+            print(f"{k:60s} {n:10d} {tot / n:16.1f}")
+        return
+    files = glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True)
+    if not files:
+        sys.exit("no kernel_trace.csv under " + a.dir)
+    acc = defaultdict(list)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            acc[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    total = sum(sum(v) for v in acc.values())
+    print("# rocprofv3 --kernel-trace --stats summary (durations in us)")
+    print(f"{'kernel':100s} {'calls':>7s} {'avg_us':>10s} {'min_us':>10s} {'total_ms':>10s} {'pct':>6s}")
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:45]:
+        print(f"{k:100s} {len(v):7d} {sum(v) / len(v) / 1e3:10.2f} {min(v) / 1e3:10.2f} {sum(v) / 1e6:10.3f} "
+              f"{100.0 * sum(v) / total:6.2f}")
+
+
+if __name__ == "__main__":
+    main()
