@@ -172,6 +172,13 @@ int rh_adam_prepare(double* hyper, int64_t* step, float* ring, int ring_size, vo
 int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel, const double* hyper,
                   int zero_grad, void* stream);
 
+/* Adam for the small dense parameters (MLP / LR / cross weights) in one launch; gradients are read from the packed
+ * flat bucket (the buffer the RCCL all-reduce runs on).  Any numel, 4-byte alignment.  Uses hyper[] of rh_adam_prepare.
+ * sdesc (device int64 [5*T]): p, m, v pointers, numel, offset of the parameter's gradient inside flat_g (T <= 128).
+ * replaces: optimizer.step() for the non-embedding parameters, trainers/ctr_trainer.py:99 */
+int rh_adam_small(const int64_t* sdesc, int T, const int64_t* h_numel, const float* flat_g, const double* hyper,
+                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)
  * replaces: the same optimizer.step() (trainers/ctr_trainer.py:99).  Adam is element-wise and a row that is not in

@@ -48,15 +48,17 @@ def _worker(rank, world, port, out):
         ctx = DataParallelContext(net)
         g = torch.Generator().manual_seed(100 + rank)
         x = torch.randn(6, 5, generator=g)
-        ctx.reducer.zero()
+        ctx.bucket.zero()
         loss = net(x).mean() / world
-        # first layer's gradient is "late": flush() part-way must only reduce what is ready
         loss.backward()
-        assert all(ctx.reducer.ready)
-        ctx.reducer.ready[0] = False  # pretend the first weight is not produced yet
-        ctx.reducer.flush()
-        assert ctx.reducer.reduced[1] and not ctx.reducer.reduced[0]
-        ctx.reducer.finish()
+        assert ctx.bucket.all_present()
+        # the first layer's weight gradient is "late": flush() part-way must only pack / reduce what exists
+        late = net[0].weight.grad
+        net[0].weight.grad = None
+        ctx.bucket.flush()
+        assert ctx.bucket.packed[1] and not ctx.bucket.packed[0]
+        net[0].weight.grad = late
+        ctx.bucket.finish(assign_views=True)
         dense = [p.grad.clone() for p in net.parameters()]
         # sparse exchange: per-rank index columns + gradient rows
         B, F, D = 6, 3, 4

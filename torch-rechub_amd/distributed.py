@@ -4,11 +4,11 @@ Reference: CTRTrainer wraps the model in single-process ``torch.nn.DataParallel`
 (trainers/ctr_trainer.py:53-55): every forward broadcasts ALL parameters (2 GiB of tables) and every
 backward reduces DENSE full-table gradients onto gpus[0].  Here each rank owns a replica and exchanges:
 
-* dense (non-embedding) gradients: ONE flat buffer — every dense ``p.grad`` is a view into it, so there
-  is no pack/unpack — all-reduced (SUM; the trainer scales the loss by 1/world) on a side HIP stream.
-  The reduction of everything already produced is launched when the embedding backward starts
-  (``ops.add_pre_embed_backward_hook``), so it overlaps the scatter kernels; the few late gradients
-  (e.g. the fused LR weight) go in ``finish()``.
+* dense (non-embedding) gradients: packed by one ``torch.cat`` into ONE flat buffer, all-reduced (SUM; the
+  trainer scales the loss by 1/world) on a side HIP stream.  The pack + reduction of everything already
+  produced is launched when the embedding backward starts (``ops.add_pre_embed_backward_hook``), so it
+  overlaps the scatter kernels and the sparse exchange; the few late gradients (e.g. the fused LR weight)
+  go in ``finish()``.  The optimizer reads the flat buffer directly (``rh_adam_small``).
 * embedding gradients: all-gather of (index matrix (B,F), gradient rows (B,F,D)) followed by a local
   scatter-add (``rh_embed_scatter_rows``) — the same sum ``DataParallel`` computes, without moving
   vocab-sized tensors (68-72 B per lookup instead of 2 GiB per step).
@@ -55,11 +55,20 @@ def all_gather_cat(t, group=None):
     return out
 
 
-class DenseGradReducer(object):
-    """Flat-bucket gradient all-reduce for the dense parameters, overlappable with the backward."""
+class DenseGradBucket(object):
+    """The dense (non-embedding) gradients of one step, packed into ONE flat buffer.
+
+    ``zero()`` replaces ``model.zero_grad()`` for these parameters (grads -> None, so autograd hands over its freshly
+    produced gradient tensors instead of launching one accumulate kernel per parameter); ``flush()`` packs every gradient
+    that exists and is not packed yet (one ``torch.cat`` per contiguous run, normally one) and, with world > 1, starts its
+    all-reduce (SUM) on a side HIP stream; ``finish()`` packs / reduces the rest and joins.  The optimizer then reads the
+    flat buffer (``rh_adam_small``).  ``flush()`` is called from a pre-hook of the embedding backward, so the all-reduce
+    of everything the MLP produced overlaps the embedding scatter kernels and the sparse row exchange.
+    """
 
     def __init__(self, params, group=None):
         self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
         self.offsets = [0]
@@ -68,42 +77,28 @@ class DenseGradReducer(object):
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(self.offsets[-1], dtype=torch.float32, device=dev)
         self.use_cuda = dev.type == "cuda"
-        self.side = torch.cuda.Stream(device=dev) if self.use_cuda else None
-        self.ready = [False] * len(self.params)
-        self.reduced = [False] * len(self.params)
+        self.side = torch.cuda.Stream(device=dev) if (self.use_cuda and self.world > 1) else None
+        self.packed = [False] * len(self.params)
         self.pending = []
-        self._handles = []
-        for i, p in enumerate(self.params):
-            p.grad = self.flat[self.offsets[i]:self.offsets[i + 1]].view_as(p)
-            self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
-    def _make_hook(self, i):
-
-        def hook(_p):
-            self.ready[i] = True
-
-        return hook
-
-    def attach(self):
-        """Re-point every dense ``p.grad`` at its view of the flat buffer (after a zero_grad(set_to_none))."""
-        for i, p in enumerate(self.params):
-            view = self.flat[self.offsets[i]:self.offsets[i + 1]].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                p.grad = view
+    def view(self, i):
+        return self.flat[self.offsets[i]:self.offsets[i + 1]].view_as(self.params[i])
 
     def zero(self):
-        """Replaces model.zero_grad() for the dense parameters: one memset, views stay attached."""
-        self.flat.zero_()
-        self.attach()
-        self.ready = [False] * len(self.params)
-        self.reduced = [False] * len(self.params)
+        for p in self.params:
+            p.grad = None
+        self.packed = [False] * len(self.params)
 
-    def _runs(self):
+    def all_present(self):
+        return all(p.grad is not None for p in self.params)
+
+    def _runs(self, want_missing):
         runs, i, n = [], 0, len(self.params)
         while i < n:
-            if self.ready[i] and not self.reduced[i]:
+            ok = (not self.packed[i]) and ((self.params[i].grad is None) == want_missing)
+            if ok:
                 j = i
-                while j < n and self.ready[j] and not self.reduced[j]:
+                while j < n and (not self.packed[j]) and ((self.params[j].grad is None) == want_missing):
                     j += 1
                 runs.append((i, j))
                 i = j
@@ -111,39 +106,49 @@ class DenseGradReducer(object):
                 i += 1
         return runs
 
-    def flush(self):
-        """All-reduce (async, side stream) every gradient that is ready and not yet reduced."""
-        runs = self._runs()
-        if not runs:
+    def _reduce(self, runs):
+        if self.world == 1 or not runs:
             return
-        if self.use_cuda:
+        if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
         for i, j in runs:
             chunk = self.flat[self.offsets[i]:self.offsets[j]]
-            if self.use_cuda:
+            if self.side is not None:
                 with torch.cuda.stream(self.side):
-                    work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             else:
-                work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append(work)
-            for k in range(i, j):
-                self.reduced[k] = True
+                self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
-        """Reduce whatever is left (late gradients, unused parameters stay zero) and join the side stream."""
-        for k in range(len(self.params)):
-            self.ready[k] = True  # parameters that received no gradient contribute zeros, like DDP
+    def flush(self):
+        """Pack (+ start reducing) every gradient that exists and has not been packed yet."""
+        runs = self._runs(want_missing=False)
+        for i, j in runs:
+            torch.cat([self.params[k].grad.reshape(-1) for k in range(i, j)],
+                      out=self.flat[self.offsets[i]:self.offsets[j]])
+            for k in range(i, j):
+                self.packed[k] = True
+        self._reduce(runs)
+
+    def finish(self, assign_views=False):
+        """Pack / reduce what is left (parameters without a gradient contribute zeros, like DDP) and join."""
         self.flush()
+        missing = self._runs(want_missing=True)
+        for i, j in missing:
+            self.flat[self.offsets[i]:self.offsets[j]].zero_()
+            for k in range(i, j):
+                self.packed[k] = True
+        self._reduce(missing)
         for w in self.pending:
             w.wait()
         self.pending = []
-        if self.use_cuda:
+        if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        if assign_views:  # a stock torch optimizer reads p.grad: point it at the (reduced) bucket
+            for i, p in enumerate(self.params):
+                p.grad = self.view(i)
 
     def close(self):
-        for h in self._handles:
-            h.remove()
-        self._handles = []
+        self.pending = []
 
 
 class DataParallelContext(object):
@@ -162,8 +167,8 @@ class DataParallelContext(object):
                     dist.broadcast(t, src=0, group=group)
         tables = {id(p) for p in table_parameters(model)}
         dense = [p for p in model.parameters() if id(p) not in tables]
-        self.reducer = DenseGradReducer(dense, group)
-        self._hook = ops.add_pre_embed_backward_hook(self.reducer.flush)
+        self.bucket = DenseGradBucket(dense, group)
+        self._hook = ops.add_pre_embed_backward_hook(self.bucket.flush)
         ops.set_sparse_exchange(self.sparse_exchange)
 
     def sparse_exchange(self, call, rows):
@@ -175,4 +180,4 @@ class DataParallelContext(object):
     def close(self):
         ops.remove_pre_embed_backward_hook(self._hook)
         ops.set_sparse_exchange(None)
-        self.reducer.close()
+        self.bucket.close()

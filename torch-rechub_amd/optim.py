@@ -58,14 +58,16 @@ class TableAdam(torch.optim.Adam):
             kw["foreach"] = True
             super().__init__(groups, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
         self._tables = tables
+        self._others = others
+        self._bucket = None  # distributed.DenseGradBucket: when attached, dense params step through rh_adam_small
         self._t_hyper_host = None
         self.lazy_k = int(lazy_k) if tables else 0
         if self.lazy_k >= self.RING:
             raise ValueError(f"lazy_k must be < {self.RING}")
         self.lazy_small_rows = int(lazy_small_rows)
         self._lazy_dirty = False
-        if tables:
-            dev = tables[0].device
+        if tables or (others and others[0].is_cuda):
+            dev = (tables or others)[0].device
             self._t_m = [torch.zeros_like(p) for p in tables]
             self._t_v = [torch.zeros_like(p) for p in tables]
             self._t_step = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -91,9 +93,31 @@ class TableAdam(torch.optim.Adam):
                 return g
         return None
 
+    def attach_bucket(self, bucket):
+        """Step the dense parameters with ONE rh_adam_small launch reading the packed gradient bucket."""
+        if [id(p) for p in bucket.params] != [id(p) for p in self._others if p.requires_grad]:
+            raise ValueError("TableAdam.attach_bucket: the bucket must hold exactly the non-table parameters, in order")
+        if not bucket.params or len(bucket.params) > 128:
+            return
+        self._bucket = bucket
+        dev = bucket.flat.device
+        self._s_m = [torch.zeros_like(p) for p in bucket.params]
+        self._s_v = [torch.zeros_like(p) for p in bucket.params]
+        rows = ([p.data_ptr() for p in bucket.params] + [m.data_ptr() for m in self._s_m] +
+                [v.data_ptr() for v in self._s_v] + [p.numel() for p in bucket.params] + list(bucket.offsets[:-1]))
+        self._s_desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self._s_numel = (ctypes.c_int64 * len(bucket.params))(*[p.numel() for p in bucket.params])
+        for p, m, v in zip(bucket.params, self._s_m, self._s_v):
+            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m, "exp_avg_sq": v}
+
+    def _groups_agree(self):
+        keys = ("lr", "betas", "eps", "weight_decay")
+        first = self.param_groups[0]
+        return all(all(g[k] == first[k] for k in keys) for g in self.param_groups[1:])
+
     def sync_hyper(self):
         """Upload lr/betas/eps/weight_decay of the table group if they changed (call outside graph capture)."""
-        g = self._table_group()
+        g = self._table_group() or (self.param_groups[0] if self._bucket is not None else None)
         if g is None:
             return
         lr = g["lr"]
@@ -189,11 +213,19 @@ class TableAdam(torch.optim.Adam):
 
     def step_tables(self):
         """One Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
-        if not self._tables:
+        if not self._tables and self._bucket is None:
             return
         stream = ops._stream()
         _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
                   stream)
+        if self._bucket is not None:
+            b = self._bucket
+            if not all(b.packed):
+                raise RuntimeError("TableAdam: the dense gradient bucket was not packed (call bucket.finish() first)")
+            _lib.call("rh_adam_small", ops._p(self._s_desc), len(b.params), ctypes.cast(self._s_numel, ctypes.c_void_p),
+                      ops._p(b.flat), ops._p(self._t_hyper), stream)
+        if not self._tables:
+            return
         if self.lazy_k > 1:
             self._lazy_step(stream)
         else:
@@ -212,11 +244,13 @@ class TableAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if self._tables:
+        if self._bucket is not None and not self._groups_agree():
+            raise RuntimeError("TableAdam: per-group hyper-parameters differ; detach the bucket to use them")
+        if self._tables or self._bucket is not None:
             if not torch.cuda.is_current_stream_capturing():
                 self.sync_hyper()
             self.step_tables()
-        dense_groups = [g for g in self.param_groups if not g.get("rh_tables")]
+        dense_groups = [] if self._bucket is not None else [g for g in self.param_groups if not g.get("rh_tables")]
         if dense_groups:
             all_groups = self.param_groups
             self.param_groups = dense_groups
@@ -242,9 +276,9 @@ class TableAdam(torch.optim.Adam):
 
     def state_dict(self):
         self.flush()
-        if self._tables:
+        if self._tables or self._bucket is not None:
             t = float(self._t_step.item())
-            for p in self._tables:
+            for p in self._tables + (self._bucket.params if self._bucket is not None else []):
                 self.state[p]["step"] = torch.tensor(t)
         return super().state_dict()
 
@@ -257,4 +291,12 @@ class TableAdam(torch.optim.Adam):
                 self._t_v[i].copy_(st["exp_avg_sq"])
                 st["exp_avg"], st["exp_avg_sq"] = self._t_m[i], self._t_v[i]
             self._t_step.fill_(int(float(self.state[self._tables[0]]["step"])))
+            self._t_hyper_host = None
+        if self._bucket is not None:
+            for i, p in enumerate(self._bucket.params):
+                st = self.state[p]
+                self._s_m[i].copy_(st["exp_avg"])
+                self._s_v[i].copy_(st["exp_avg_sq"])
+                st["exp_avg"], st["exp_avg_sq"] = self._s_m[i], self._s_v[i]
+            self._t_step.fill_(int(float(self.state[self._bucket.params[0]]["step"])))
             self._t_hyper_host = None

@@ -20,7 +20,7 @@ import tqdm
 from .. import ops
 from ..basic.callback import EarlyStopper
 from ..basic.loss_func import RegularizationLoss
-from ..distributed import DataParallelContext, DenseGradReducer, table_parameters
+from ..distributed import DataParallelContext, DenseGradBucket, table_parameters
 from ..optim import TableAdam
 from ..utils.data import DeviceDataLoader
 
@@ -62,9 +62,10 @@ class CTRTrainer(object):
             self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         table_ids = {id(p) for p in tables}
         if self.dp is not None:
-            self.reducer = self.dp.reducer
+            self.bucket = self.dp.bucket
         else:
-            self.reducer = DenseGradReducer([p for p in self.model.parameters() if id(p) not in table_ids])
+            self.bucket = DenseGradBucket([p for p in self.model.parameters() if id(p) not in table_ids])
+        self._bucket_attached = False
         self.scheduler = None
         if scheduler_fn is not None:
             self.scheduler = scheduler_fn(self.optimizer, **scheduler_params)
@@ -86,7 +87,7 @@ class CTRTrainer(object):
 
     # -- one optimisation step ----------------------------------------------------------------
     def _zero_grad(self):
-        self.reducer.zero()
+        self.bucket.zero()
         if not isinstance(self.optimizer, TableAdam):
             for p in table_parameters(self.model):
                 if getattr(p, "_rh_dirty", False):
@@ -107,8 +108,18 @@ class CTRTrainer(object):
             loss = loss / self.world  # gradients are SUMMED over ranks: global-batch mean, as DataParallel
         self._zero_grad()
         loss.backward()
-        if self.world > 1:
-            self.reducer.finish()
+        fast = isinstance(self.optimizer, TableAdam)
+        if fast and not self._bucket_attached:
+            # first step: every dense parameter must receive a gradient for the packed one-launch optimizer path
+            # (torch.optim.Adam skips parameters without a gradient; the packed path cannot)
+            self._bucket_attached = True
+            if self.bucket.all_present() and self.bucket.params:
+                self.optimizer.attach_bucket(self.bucket)
+        packed = fast and self.optimizer._bucket is not None
+        if packed and not self.bucket.all_present():
+            raise RuntimeError("a dense parameter stopped receiving gradients; rebuild the trainer")
+        if packed or self.world > 1:
+            self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
         return report
 
