@@ -55,7 +55,9 @@ def parse():
     ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink every table")
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
-    ap.add_argument("--lazy-k", type=int, default=16)
+    ap.add_argument("--lazy-k", type=int, default=32)
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel machinery (RCCL collectives, split graphs) even on one GPU")
     return ap.parse_args()
 
 
@@ -123,9 +125,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if args.force_dp:
+        os.environ["RECHUB_FORCE_DP"] = "1"
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     device = torch.device(f"cuda:{local}")
@@ -142,7 +149,7 @@ def main():
     sparse_feas = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=EMBED_DIM) for i, v in enumerate(vocabs)]
     with torch.device(device):  # tables are created directly in HBM (2 GiB; never staged through the host)
         model = DeepFM(dense_feas + sparse_feas, sparse_feas, {"dims": [256, 128], "dropout": 0.2, "activation": "relu"})
-    use_graph = (args.graph == "1") or (args.graph == "auto" and world == 1)
+    use_graph = args.graph in ("1", "auto")  # N > 1: two graphs per step with the RCCL exchange between them
     trainer = CTRTrainer(model, device=str(device), show_progress=False, use_graph=use_graph,
                          table_update=args.table_adam, lazy_k=args.lazy_k)
     sparse, dense, label = build_dataset(args.rows, vocabs, device, seed=2022 + rank, dist_kind=args.dist)
@@ -173,7 +180,7 @@ def main():
 
     def step():
         if graph_ok:
-            trainer._graph.replay()
+            trainer._graphed_step(loader)
         else:
             eager_step()
 
@@ -275,7 +282,7 @@ def main():
                 "optimizer": "Adam lr=1e-3 weight_decay=1e-5, dense-exact semantics (every table row moves every step, as "
                              "torch.optim.Adam); execution: " + (f"blocked-lazy exact replay, K={args.lazy_k}, flushed "
                              "inside the timed region" if args.table_adam == "lazy" else "dense pass per step"),
-                "parallelism": f"dp{world}" if world > 1 else "single", "hipgraph": graph_ok,
+                "parallelism": f"dp{world}" if (world > 1 or args.force_dp) else "single", "hipgraph": graph_ok,
                 "vocab_scale": args.vocab_scale,
             },
             "roofline": roofline,
@@ -283,7 +290,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

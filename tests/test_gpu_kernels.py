@@ -482,7 +482,6 @@ def _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed, flush_every=None):
     lazy = TableAdam(Bp, table_params=Bp, lr=1e-2, weight_decay=1e-3, lazy_k=lazy_k, lazy_small_rows=small_rows)
     nb = 97
     for t in range(steps):
-        del ops.touch_log[:]
         idx_cols = []
         for i, s in enumerate(shapes):
             idx = torch.randint(0, s[0], (nb,), generator=g)
@@ -497,10 +496,9 @@ def _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed, flush_every=None):
             idx_cols.append(idx.to(dev()))
         key = tuple([c.data_ptr() for c in idx_cols] + [1] * len(shapes) + list(range(len(shapes))))
         idesc = ops.EmbedCall._icache.get(key, dev())
-        ops.touch_logging = True
         # one field per table, all of one embed_dim
         ops._log_touch(Bp, [None] * len(shapes), idesc, 1, nb, len(shapes), shapes[0][1], idx_cols)
-        lazy.step()  # consumes (and clears) the lookup log
+        lazy.step()  # consumes (and clears) its lookup log
         dense.step()
         if flush_every and (t + 1) % flush_every == 0:
             lazy.flush()
@@ -530,7 +528,6 @@ def test_adam_lazy_rows_lag_at_most_k_steps():
     from torch_rechub_amd import ops
     A, Bp, dense, lazy = _lazy_vs_dense(8, 16, 30, [(3000, 16)], seed=1)
     # after the flush everything is current; run 5 more steps WITHOUT flush and check the lag bound
-    del ops.touch_log[:]
     for _ in range(5):
         lazy.step()
     torch.cuda.synchronize()

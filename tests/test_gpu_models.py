@@ -214,3 +214,60 @@ def test_stock_optimizer_sees_dense_table_gradients():
     touched = torch.unique(torch.cat([b[0]["C5"] for b in batches])).to(dev())
     moved = (w.detach() != before).any(dim=1)
     assert moved[touched].all() and int(moved.sum()) == touched.numel()  # SGD without decay: only touched rows move
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    """A one-rank RCCL process group: lets the full data-parallel code path (collectives included) run on one GPU."""
+    import socket
+
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, monkeypatch, use_graph):
+    """RECHUB_FORCE_DP: dense all-reduce on the side stream + all-gather of (indices, gradient rows) + row scatter
+    (+ the two-graph split step) on a world of one must reproduce the single-GPU fused path."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    N, B = 64 * 12, 64
+    vocabs, sparse, dense, label = _synthetic(N, seed=5)
+    vocabs = [v * 40 for v in vocabs]  # some tables above lazy_small_rows: claims + replay + sweep are exercised
+    sparse = sparse * 40
+    ma, dfe, sfe = _deepfm(vocabs, 3)
+    mb, _, _ = _deepfm(vocabs, 3)
+    mb.load_state_dict(ma.state_dict())
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    params = {"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64}
+    monkeypatch.setenv("RECHUB_FORCE_DP", "0")
+    ta = CTRTrainer(ma, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4)
+    assert ta.dp is None
+    mk = lambda: DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+    la = ta.train_one_epoch(mk())
+    monkeypatch.setenv("RECHUB_FORCE_DP", "1")
+    tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
+                    use_graph=use_graph)
+    assert tb.dp is not None and ops._sparse_exchange is not None
+    try:
+        lb = tb.train_one_epoch(mk())
+        if use_graph:
+            assert tb._graph is not None and tb._graph_b is not None
+    finally:
+        tb.dp.close()
+    assert abs(la - lb) < 1e-5
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        if k.endswith("num_batches_tracked"):
+            assert int(a) == int(b)
+            continue
+        if k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias") or k.endswith("running_mean"):
+            continue
+        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-5, rtol=1e-4)

@@ -42,11 +42,12 @@ def pack_indices(idx_list):
     return torch.stack(idx_list, dim=1)
 
 
-def all_gather_cat(t, group=None):
-    """Concatenate ``t`` from every rank along dim 0 (rank order)."""
+def all_gather_cat(t, group=None, out=None):
+    """Concatenate ``t`` from every rank along dim 0 (rank order), optionally into a preallocated ``out``."""
     world = dist.get_world_size(group)
     t = t.contiguous()
-    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if out is None:
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     try:
         dist.all_gather_into_tensor(out, t, group=group)
     except (RuntimeError, NotImplementedError):
@@ -77,9 +78,12 @@ class DenseGradBucket(object):
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(self.offsets[-1], dtype=torch.float32, device=dev)
         self.use_cuda = dev.type == "cuda"
-        self.side = torch.cuda.Stream(device=dev) if (self.use_cuda and self.world > 1) else None
+        self.side = torch.cuda.Stream(device=dev) if (self.use_cuda and dist.is_available() and dist.is_initialized()) \
+            else None
         self.packed = [False] * len(self.params)
         self.pending = []
+        self.defer = False  # True: flush() only packs; reduce_deferred() starts the all-reduces (split-graph step)
+        self._deferred_runs = []
 
     def view(self, i):
         return self.flat[self.offsets[i]:self.offsets[i + 1]].view_as(self.params[i])
@@ -107,7 +111,31 @@ class DenseGradBucket(object):
         return runs
 
     def _reduce(self, runs):
-        if self.world == 1 or not runs:
+        if self.group_size() == 1 or not runs:
+            return
+        if self.defer:
+            self._deferred_runs += runs
+            return
+        self._launch(runs)
+
+    def group_size(self):
+        return self.world if not self.force else max(self.world, 2)
+
+    force = False  # DataParallelContext(force=True): exercise the collectives even at world size 1 (1-GPU validation)
+
+    def reduce_deferred(self):
+        runs, self._deferred_runs = self._deferred_runs, []
+        self._launch(runs)
+
+    def join(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def _launch(self, runs):
+        if not runs:
             return
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
@@ -138,11 +166,8 @@ class DenseGradBucket(object):
             for k in range(i, j):
                 self.packed[k] = True
         self._reduce(missing)
-        for w in self.pending:
-            w.wait()
-        self.pending = []
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+        if not self.defer:
+            self.join()
         if assign_views:  # a stock torch optimizer reads p.grad: point it at the (reduced) bucket
             for i, p in enumerate(self.params):
                 p.grad = self.view(i)
@@ -154,9 +179,12 @@ class DenseGradBucket(object):
 class DataParallelContext(object):
     """Replica synchronisation for one model on this rank."""
 
-    def __init__(self, model, group=None, broadcast=True):
+    def __init__(self, model, group=None, broadcast=True, force=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (launch with torchrun)")
+        self.deferred_mode = False  # True: the backward only records (call, rows); exchange_deferred() runs later
+        self.deferred = []
+        self._gather_bufs = {}
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -168,14 +196,35 @@ class DataParallelContext(object):
         tables = {id(p) for p in table_parameters(model)}
         dense = [p for p in model.parameters() if id(p) not in tables]
         self.bucket = DenseGradBucket(dense, group)
+        self.bucket.force = force
         self._hook = ops.add_pre_embed_backward_hook(self.bucket.flush)
         ops.set_sparse_exchange(self.sparse_exchange)
 
     def sparse_exchange(self, call, rows):
         """all-gather (indices, gradient rows) of the local batch from every rank."""
+        if self.deferred_mode:
+            self.deferred.append((call, rows))
+            return None
         idx_all = all_gather_cat(pack_indices(call.idx), self.group)
         rows_all = all_gather_cat(rows, self.group)
         return idx_all, rows_all
+
+    def exchange_deferred(self, deferred):
+        """Run the recorded exchanges into STATIC gather buffers (addresses must not change between graph replays)."""
+        out = []
+        for i, (call, rows) in enumerate(deferred):
+            packed = pack_indices(call.idx)
+            bufs = self._gather_bufs.get(i)
+            if bufs is None or bufs[1].shape[1:] != rows.shape[1:] or bufs[1].shape[0] != self.world * rows.shape[0]:
+                bufs = (torch.empty((self.world * packed.shape[0], packed.shape[1]), dtype=packed.dtype,
+                                    device=packed.device),
+                        torch.empty((self.world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype,
+                                    device=rows.device))
+                self._gather_bufs[i] = bufs
+            all_gather_cat(packed, self.group, out=bufs[0])
+            all_gather_cat(rows, self.group, out=bufs[1])
+            out.append((call, bufs[0], bufs[1]))
+        return out
 
     def close(self):
         ops.remove_pre_embed_backward_hook(self._hook)

@@ -188,26 +188,35 @@ class EmbedCall(object):
         return EmbedCall._dcache.get(key, self.device)
 
 
-# Lookup log for the lazy optimizer: which (table, index column) pairs received gradient since the last step.
-# Enabled by optim.TableAdam(lazy_k > 1); each record keeps the index tensors alive until the step consumed it.
-touch_log = []
-touch_logging = False
+# Lazy optimizers (optim.TableAdam(lazy_k > 1)) listen to two events, through weak references:
+#   on_gather(record): rows are about to be READ -> bring them up to date first (a row that was not in recent batches
+#                      lags behind the dense semantics until someone looks at it);
+#   on_touch(record):  (table, index column) pairs received gradient -> the next step must claim those rows.
+# A record keeps the index tensors alive until the listener consumed it.
+_lazy_listeners = []
+
+
+def add_lazy_listener(obj):
+    import weakref
+    _lazy_listeners.append(weakref.ref(obj))
+
+
+def _listeners():
+    live = [r for r in _lazy_listeners if r() is not None]
+    if len(live) != len(_lazy_listeners):
+        _lazy_listeners[:] = live
+    return [r() for r in live]
 
 
 def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep):
-    if touch_logging:
-        touch_log.append(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
-                              keep=keep))
-
-
-# Pre-gather hook of the lazy optimizer: rows about to be READ must first be brought up to date (a row that was
-# not in recent batches lags behind the dense semantics until someone looks at it).  fn(record) or None.
-pre_gather_hook = None
+    for lst in _listeners():
+        lst.on_touch(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
+                          keep=keep))
 
 
 def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D):
-    if pre_gather_hook is not None:
-        pre_gather_hook(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D))
+    for lst in _listeners():
+        lst.on_gather(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D))
 
 
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
@@ -215,7 +224,8 @@ _sparse_exchange = None
 
 
 def set_sparse_exchange(fn):
-    """fn(call, rows_local (B,F,D)) -> (idx_all (W*B,F) int, rows_all (W*B,F,D)) or None to disable."""
+    """fn(call, rows_local (B,F,D)) -> (idx_all (W*B,F) int, rows_all (W*B,F,D)), or None when fn keeps the rows and
+    runs the exchange + scatter itself after the backward.  set_sparse_exchange(None) disables the exchange."""
     global _sparse_exchange
     _sparse_exchange = fn
 
@@ -296,8 +306,9 @@ class _EmbedFused(torch.autograd.Function):
                       _p(lr_w), _p(partial), 1.0, sink, _p(rows), call.samples_per_block, _p(err_flag(dev)),
                       _stream())
             if exchange is not None:
-                idx_all, rows_all = exchange(call, rows)
-                scatter_rows(call, idx_all, rows_all)
+                gathered = exchange(call, rows)
+                if gathered is not None:  # None: the exchange is deferred to after the backward (split-graph step)
+                    scatter_rows(call, gathered[0], gathered[1])
             elif any_table:
                 _log_touch(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, call.idx)
             if any_table:
@@ -372,7 +383,7 @@ class _SeqPoolFn(torch.autograd.Function):
         B, L = idx.shape
         V, D = weight.shape
         out = torch.empty((B, L, D) if mode == 2 else (B, D), dtype=torch.float32, device=weight.device)
-        if pre_gather_hook is not None:
+        if _lazy_listeners:
             flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
             _pre_gather([weight], [None], EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device),
                         1 if idx.dtype == torch.int64 else 0, B * L, 1, D)
@@ -398,7 +409,7 @@ class _SeqPoolFn(torch.autograd.Function):
                       idx.stride(1), B, L, D, mode, sentinel, pad, _p(g), g.stride(0), 1.0,
                       _p(err_flag(weight.device)), _stream())
             _publish_grad(weight)
-            if touch_logging:  # the (B, L) positions are B*L lookups of one field
+            if _lazy_listeners:  # the (B, L) positions are B*L lookups of one field
                 flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
                 idesc = EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device)
                 _log_touch([weight], [pad], idesc, 1 if idx.dtype == torch.int64 else 0, B * L, 1, D, [flat])

@@ -83,8 +83,9 @@ class TableAdam(torch.optim.Adam):
                 self._t_last = [torch.zeros(p.shape[0], dtype=torch.int32, device=dev) for p in tables]
                 self._lazy_groups = None
                 self._ft_cache = {}
-                ops.touch_logging = True
-                ops.pre_gather_hook = self._refresh  # rows are brought up to date right before they are read
+                self._touch_log = []
+                self._table_ids = {id(p) for p in tables}
+                ops.add_lazy_listener(self)  # on_gather: refresh rows before they are read; on_touch: log lookups
 
     # ------------------------------------------------------------------------------------
     def _table_group(self):
@@ -182,18 +183,22 @@ class TableAdam(torch.optim.Adam):
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
                       ops._p(self._t_ring), self.RING, 64, ops._p(ops.err_flag(self._tables[0].device)), stream)
 
-    def _refresh(self, rec):
-        """Pre-gather hook: replay the rows of this index batch up to the last completed step (their gradient rows are
+    def on_gather(self, rec):
+        """Pre-gather event: replay the rows of this index batch up to the last completed step (their gradient rows are
         zero at this point, so this is the pure wd*p replay); the forward then reads exactly what a dense optimizer
-        would have left in the table."""
-        if self._tables:  # unconditional, so that a captured hipGraph always contains the refresh launch
+        would have left in the table.  Unconditional, so that a captured hipGraph always contains the launch."""
+        if any(id(w) in self._table_ids for w in rec["weights"]):
             self._touch(rec, self._lazy_setup(), ops._stream())
+
+    def on_touch(self, rec):
+        if any(id(w) in self._table_ids for w in rec["weights"]):
+            self._touch_log.append(rec)
 
     def _lazy_step(self, stream):
         groups = self._lazy_setup()
-        for rec in ops.touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
+        for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
             self._touch(rec, groups, stream)
-        del ops.touch_log[:]
+        del self._touch_log[:]
         for D, grp in groups.items():
             _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
                       ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
@@ -232,7 +237,6 @@ class TableAdam(torch.optim.Adam):
             desc = self._desc()
             _lib.call("rh_adam_dense", ops._p(desc), len(self._tables), ctypes.cast(self._t_numel, ctypes.c_void_p),
                       ops._p(self._t_hyper), 1, stream)
-            del ops.touch_log[:]
         for p in self._tables:
             p._rh_dirty = False  # the kernels zeroed every non-zero gradient row
             if p.grad is None:

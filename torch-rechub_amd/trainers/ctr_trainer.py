@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=16):
+                 table_update=None, lazy_k=32):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
@@ -40,7 +40,9 @@ class CTRTrainer(object):
         self.model.to(self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
-        self.dp = DataParallelContext(self.model) if self.world > 1 else None
+        # RECHUB_FORCE_DP=1 runs the full data-parallel machinery (RCCL calls included) on a world of one
+        force_dp = os.environ.get("RECHUB_FORCE_DP", "0") == "1" and dist.is_available() and dist.is_initialized()
+        self.dp = DataParallelContext(self.model, force=force_dp) if (self.world > 1 or force_dp) else None
         if optimizer_params is None:
             optimizer_params = {"lr": 1e-3, "weight_decay": 1e-5}
         tables = table_parameters(self.model)
@@ -80,10 +82,12 @@ class CTRTrainer(object):
         self.model_logger = model_logger
         if use_graph is None:
             use_graph = os.environ.get("RECHUB_HIPGRAPH", "0") == "1"
-        self.use_graph = bool(use_graph) and self.world == 1
+        self.use_graph = bool(use_graph)
         self.show_progress = show_progress and self.rank == 0
         self._graph = None
+        self._graph_b = None
         self._graph_loss = None
+        self._deferred_static = None
 
     # -- one optimisation step ----------------------------------------------------------------
     def _zero_grad(self):
@@ -118,9 +122,54 @@ class CTRTrainer(object):
         packed = fast and self.optimizer._bucket is not None
         if packed and not self.bucket.all_present():
             raise RuntimeError("a dense parameter stopped receiving gradients; rebuild the trainer")
-        if packed or self.world > 1:
+        if packed or self.dp is not None:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
+        return report
+
+    # -- split step for hipGraph + RCCL: [graph A: batch, forward, backward, pack] -> eager collectives ->
+    #    [graph B: scatter gathered rows, optimizer].  Collectives stay outside the graphs. ------------------------
+    def _phase_a(self, x_dict, y):
+        self.dp.deferred_mode, self.dp.deferred = True, []
+        self.bucket.defer = True
+        if self.loss_mode:
+            loss = self.criterion(self.model(x_dict), y)
+        else:
+            y_pred, other_loss = self.model(x_dict)
+            loss = self.criterion(y_pred, y) + other_loss
+        loss = loss + self.reg_loss_fn(self.model)
+        report = loss.detach()
+        if self.world > 1:
+            loss = loss / self.world
+        self._zero_grad()
+        loss.backward()
+        if not self._bucket_attached:
+            self._bucket_attached = True
+            if self.bucket.all_present() and self.bucket.params:
+                self.optimizer.attach_bucket(self.bucket)
+        if self.optimizer._bucket is None or not self.bucket.all_present():
+            raise RuntimeError("split-graph data parallel step needs every dense parameter to receive a gradient")
+        self.bucket.flush()  # pack only (defer = True)
+        self.dp.deferred_mode = False
+        return report, list(self.dp.deferred)
+
+    def _phase_x(self, deferred):
+        self.bucket.reduce_deferred()  # dense all-reduce on the side stream ...
+        gathered = self.dp.exchange_deferred(deferred)  # ... overlapping the sparse all-gathers
+        self.bucket.join()
+        return gathered
+
+    def _phase_b(self, gathered):
+        for call, idx_all, rows_all in gathered:
+            ops.scatter_rows(call, idx_all, rows_all)
+            for w in {id(w): w for w in call.weights if w.requires_grad}.values():
+                ops._publish_grad(w)
+        self.bucket.defer = False
+        self.optimizer.step()
+
+    def _split_step(self, x_dict, y):
+        report, deferred = self._phase_a(x_dict, y)
+        self._phase_b(self._phase_x(deferred))
         return report
 
     GRAPH_WARMUP = 3
@@ -130,6 +179,9 @@ class CTRTrainer(object):
 
         Returns (sum of losses, number of batches consumed).  Warm-up steps are real optimisation steps.
         """
+        split = self.dp is not None
+        if split and not isinstance(self.optimizer, TableAdam):
+            raise RuntimeError("hipGraph + data parallel needs the default Adam optimizer (TableAdam)")
         if self._graph is None:
             if isinstance(self.optimizer, TableAdam):
                 self.optimizer.sync_hyper()
@@ -139,14 +191,29 @@ class CTRTrainer(object):
             with torch.cuda.stream(side):
                 for _ in range(self.GRAPH_WARMUP):  # allocator, descriptor caches, lazily created optimizer state
                     x, y = loader.load_next()
-                    total += self.train_step(x, y)
+                    total += self._split_step(x, y) if split else self.train_step(x, y)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = torch.cuda.CUDAGraph()
+            if not split:
+                with torch.cuda.graph(self._graph):
+                    x, y = loader.load_next()
+                    self._graph_loss = self.train_step(x, y)
+                return total, self.GRAPH_WARMUP
             with torch.cuda.graph(self._graph):
                 x, y = loader.load_next()
-                self._graph_loss = self.train_step(x, y)
-            return total, self.GRAPH_WARMUP
+                self._graph_loss, self._deferred_static = self._phase_a(x, y)
+            self._graph.replay()  # capture does not execute: run A for real, exchange, then capture + run B
+            gathered = self._phase_x(self._deferred_static)
+            self._graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
+                self._phase_b(gathered)
+            self._graph_b.replay()
+            return total + self._graph_loss, self.GRAPH_WARMUP + 1
         self._graph.replay()
+        if split:
+            self.bucket._deferred_runs = [(0, len(self.bucket.params))]
+            self._phase_x(self._deferred_static)
+            self._graph_b.replay()
         return self._graph_loss, 1
 
     def train_one_epoch(self, data_loader, log_interval=10):
