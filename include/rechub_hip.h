@@ -155,6 +155,24 @@ int rh_cross_bwd(const float* x0, int64_t x0_stride, const float* x, int64_t x_s
                  float* wb_partials, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * MLP hidden-layer epilogue: BatchNorm1d + ReLU + Dropout fused (the Linear in front stays a library GEMM)
+ * replaces: nn.BatchNorm1d -> ReLU -> nn.Dropout of MLP, torch_rechub/basic/layers.py:281-287, and their autograd
+ * h (B,C) pre-BN activations; training: batch statistics (biased variance), running stats updated with `momentum`
+ * (unbiased variance), num_batches_tracked += 1; eval: running statistics, no dropout.
+ * rng (device int64 [2]): seed, call counter (bumped by the forward); saved_ctr (device int64 [1]): the counter this call
+ * used — the backward recomputes the same dropout mask from it (nothing is stored).
+ * partial: (rh_bn_act_nchunks(B), 2, C) floats; stat: (4, C) floats (mean, rstd kept for the backward).
+ */
+int rh_bn_act_nchunks(int B);
+int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
+                           int training, int64_t* rng, int64_t* saved_ctr, float* partial, float* stat, float* out,
+                           void* stream);
+int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta,
+                           float p_drop, const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat,
+                           float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense Adam with coupled L2, torch.optim.Adam semantics over every row of every table
  * replaces: optimizer.step() torch_rechub/trainers/ctr_trainer.py:59-61,99 for embedding tables
  * tdesc (device int64 [5*T]): p, g, m, v pointers and numel per tensor (T <= 128)

@@ -533,3 +533,56 @@ def test_adam_lazy_rows_lag_at_most_k_steps():
     torch.cuda.synchronize()
     lag = int(lazy._t_step.item()) - lazy._t_last[0]
     assert int(lag.min()) >= 0 and int(lag.max()) < 8
+
+
+@pytest.mark.parametrize("B,C,p", [(4096, 256, 0.0), (4096, 128, 0.0), (37, 32, 0.0), (1000, 200, 0.0), (513, 16, 0.0)])
+def test_bn_relu_dropout_vs_torch_modules(B, C, p):
+    """Fused epilogue == nn.BatchNorm1d -> ReLU -> Dropout(p=0) (outputs, running stats, all gradients) and eval mode."""
+    from torch_rechub_amd import ops
+    torch.manual_seed(B + C)
+    h0 = (torch.randn(B, C) * 2 + torch.randn(C) * 3).to(dev())
+    bn_ref = torch.nn.BatchNorm1d(C).to(dev())
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5)
+        bn_ref.bias.normal_(0, 0.5)
+    bn_mine = torch.nn.BatchNorm1d(C).to(dev())
+    bn_mine.load_state_dict(bn_ref.state_dict())
+    gy = torch.randn(B, C, device=dev())
+    ha = h0.clone().requires_grad_(True)
+    ya = torch.relu(bn_ref(ha))
+    ya.backward(gy)
+    hb = h0.clone().requires_grad_(True)
+    yb = ops.bn_relu_dropout(hb, bn_mine, p)
+    yb.backward(gy)
+    close(yb, ya.detach().cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="bn out")
+    close(hb.grad, ha.grad.cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="bn dx")
+    close(bn_mine.weight.grad, bn_ref.weight.grad.cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dgamma")
+    close(bn_mine.bias.grad, bn_ref.bias.grad.cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dbeta")
+    close(bn_mine.running_mean, bn_ref.running_mean.cpu().numpy(), what="running_mean")
+    close(bn_mine.running_var, bn_ref.running_var.cpu().numpy(), rtol=2e-5, what="running_var")
+    assert int(bn_mine.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 1
+    bn_ref.eval()
+    bn_mine.eval()
+    with torch.no_grad():
+        close(ops.bn_relu_dropout(h0, bn_mine, 0.3), torch.relu(bn_ref(h0)).cpu().numpy(), rtol=2e-5, atol_scale=2e-6,
+              what="eval")
+
+
+def test_fused_dropout_statistics_and_backward_mask():
+    from torch_rechub_amd import ops
+    B, C, p = 4096, 256, 0.2
+    bn = torch.nn.BatchNorm1d(C).to(dev())
+    h = (torch.randn(B, C, device=dev()) + 1.0).requires_grad_(True)
+    y = ops.bn_relu_dropout(h, bn, p)
+    y2 = ops.bn_relu_dropout(h.detach(), bn, p)
+    pos = torch.relu(bn(h.detach())) > 0  # (running stats moved, batch stats are the same) positions alive after relu
+    kept = (y.detach() != 0) & pos
+    frac = kept.sum().item() / pos.sum().item()
+    assert abs(frac - (1 - p)) < 0.01  # keep probability
+    assert (kept != ((y2 != 0) & pos)).any()  # a new mask per call (device-side counter)
+    ref = torch.relu(bn(h.detach())) / (1 - p)
+    np.testing.assert_allclose(y.detach()[kept].cpu().numpy(), ref[kept].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    y.backward(torch.ones_like(y))
+    # gradient flows only through kept positions: dropped & relu-dead columns contribute nothing to dbeta
+    dbeta = (kept.float() / (1 - p)).sum(0)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), dbeta.cpu().numpy(), rtol=1e-4, atol=1e-3)

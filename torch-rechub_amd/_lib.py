@@ -37,6 +37,11 @@ SIGNATURES = {
     "rh_cross_max_layers": [c_int],
     "rh_cross_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_i64, c_int, c_ptr, c_ptr],
+    "rh_bn_act_nchunks": [c_int],
+    "rh_bn_relu_dropout_fwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_int, c_ptr,
+                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_relu_dropout_bwd": [c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                               c_ptr, c_ptr],
     "rh_adam_prepare": [c_ptr, c_ptr, c_ptr, c_int, c_ptr],
     "rh_adam_small": [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr,
@@ -48,7 +53,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"rh_last_error": ctypes.c_char_p}
 # functions whose int return value is a result, not a status
-_VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers"}
+_VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
+                    "rh_bn_act_nchunks"}
 
 ABI_VERSION = 1
 _lib = None

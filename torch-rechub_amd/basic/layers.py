@@ -220,8 +220,28 @@ class MLP(nn.Module):
             layers.append(nn.Linear(input_dim, 1))
         self.mlp = nn.Sequential(*layers)
 
+    @staticmethod
+    def _fusable(bn, act, drop, x):
+        return (isinstance(bn, nn.BatchNorm1d) and isinstance(act, nn.ReLU) and isinstance(drop, nn.Dropout) and
+                bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda and x.dim() == 2 and
+                x.dtype == torch.float32 and (x.shape[0] > 1 or not bn.training) and
+                not (torch.is_grad_enabled() and not bn.training and x.requires_grad))
+
     def forward(self, x):
-        return self.mlp(x)
+        # [Linear, BatchNorm1d, ReLU, Dropout] blocks: library GEMM + ONE fused epilogue (csrc/mlp.hip);
+        # any other activation (dice, prelu, sigmoid ...) runs the modules as they are.
+        mods = list(self.mlp)
+        i = 0
+        while i < len(mods):
+            if i + 3 < len(mods) + 0 and isinstance(mods[i], nn.Linear) and self._fusable(mods[i + 1], mods[i + 2],
+                                                                                            mods[i + 3], x):
+                h = mods[i](x)
+                x = ops.bn_relu_dropout(h, mods[i + 1], mods[i + 3].p if mods[i + 3].training else 0.0)
+                i += 4
+            else:
+                x = mods[i](x)
+                i += 1
+        return x
 
 
 class FM(nn.Module):

@@ -492,3 +492,67 @@ class _CrossFn(torch.autograd.Function):
 
 def cross_network(x, W, Bv):
     return _CrossFn.apply(x, W, Bv)
+
+
+# --------------------------------------------------------------------------------------------
+_rng_state = {}
+
+
+def _dropout_rng(device):
+    """Device-resident (seed, call counter) of the fused dropout; seeded from torch's generator on first use."""
+    st = _rng_state.get(device)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(device)
+        _rng_state[device] = st
+    return st
+
+
+class _BnReluDropoutFn(torch.autograd.Function):
+    """y = dropout(relu(batch_norm(h))) for one MLP hidden layer (training mode); see csrc/mlp.hip."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop):
+        require_hip(h, gamma, beta)
+        h = h.contiguous()
+        B, C = h.shape
+        dev = h.device
+        out = torch.empty_like(h)
+        nch = _lib.call("rh_bn_act_nchunks", B)
+        partial = torch.empty((nch, 2, C), dtype=torch.float32, device=dev)
+        stat = torch.empty((4, C), dtype=torch.float32, device=dev)
+        saved_ctr = torch.empty(1, dtype=torch.int64, device=dev)
+        rng = _dropout_rng(dev)
+        _lib.call("rh_bn_relu_dropout_fwd", _p(h), B, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                  _p(num_batches_tracked), float(momentum), float(eps), float(p_drop), 1, _p(rng), _p(saved_ctr),
+                  _p(partial), _p(stat), _p(out), _stream())
+        ctx.p_drop = float(p_drop)
+        ctx.save_for_backward(h, gamma, beta, stat, saved_ctr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, gamma, beta, stat, saved_ctr = ctx.saved_tensors
+        B, C = h.shape
+        dev = h.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(h)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
+        _lib.call("rh_bn_relu_dropout_bwd", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop, _p(_dropout_rng(dev)),
+                  _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_relu_dropout(h, bn, p_drop):
+    """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``."""
+    if bn.training:
+        return _BnReluDropoutFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                      bn.momentum, bn.eps, p_drop)
+    require_hip(h)
+    h = h.contiguous()
+    out = torch.empty_like(h)
+    _lib.call("rh_bn_relu_dropout_fwd", _p(h), h.shape[0], h.shape[1], _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+              _p(bn.running_var), _p(None), 0.0, float(bn.eps), 0.0, 0, _p(None), _p(None), _p(None), _p(None), _p(out),
+              _stream())
+    return out
