@@ -580,7 +580,7 @@ def test_fused_dropout_statistics_and_backward_mask():
     frac = kept.sum().item() / pos.sum().item()
     assert abs(frac - (1 - p)) < 0.01  # keep probability
     assert (kept != ((y2 != 0) & pos)).any()  # a new mask per call (device-side counter)
-    ref = torch.relu(bn(h.detach())) / (1 - p)
+    ref = (torch.relu(bn(h.detach())) / (1 - p)).detach()
     np.testing.assert_allclose(y.detach()[kept].cpu().numpy(), ref[kept].cpu().numpy(), rtol=1e-4, atol=1e-5)
     y.backward(torch.ones_like(y))
     # gradient flows only through kept positions: dropped & relu-dead columns contribute nothing to dbeta

@@ -17,7 +17,8 @@
 
 namespace {
 
-constexpr int kRowsPerChunk = 32;
+constexpr int kRowsPerChunk = 16;   // 256 row chunks at B = 4096: enough workgroups to fill the chip
+constexpr int kFinCols = 32;        // finalize: 32 columns x 8 chunk groups per block
 
 struct BnArgs {
   const float* h;      // (B, C) pre-BN activations
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
   if (c < a.C) {
     if (MODE == 0) {
       const float shift = a.h[c];
+#pragma unroll 8
       for (int r = r0 + rsub; r < r1; r += RS) {
         const float x = a.h[(int64_t)r * a.C + c] - shift;
         s1 += x;
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
       const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
       const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
       const uint64_t seed = (uint64_t)a.rng[0], ctr = (uint64_t)a.saved_ctr[0];
+#pragma unroll 4
       for (int r = r0 + rsub; r < r1; r += RS) {
         const int64_t i = (int64_t)r * a.C + c;
         const float xhat = (a.h[i] - mean) * rstd;
@@ -98,17 +101,41 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
 
 template <int MODE>
 __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
-  const int c = blockIdx.x * RH_BLOCK + threadIdx.x;
+  __shared__ float red[2][RH_BLOCK];
+  constexpr int GROUPS = RH_BLOCK / kFinCols;
+  const int c = blockIdx.x * kFinCols + threadIdx.x % kFinCols;
+  const int grp = threadIdx.x / kFinCols;
   if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     a.saved_ctr[0] = a.rng[1];  // dropout stream of this call
     a.rng[1] += 1;
     if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
   }
-  if (c >= a.C) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int k = 0; k < a.nchunks; ++k) {
-    s1 += a.partial[((int64_t)k * 2 + 0) * a.C + c];
-    s2 += a.partial[((int64_t)k * 2 + 1) * a.C + c];
+  if (c < a.C) {
+    // chunk partials are summed in a fixed order (group-strided, then across groups): deterministic
+    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = grp;
+    for (; k + 3 * GROUPS < a.nchunks; k += 4 * GROUPS) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        t1[u] += a.partial[((int64_t)(k + u * GROUPS) * 2 + 0) * a.C + c];
+        t2[u] += a.partial[((int64_t)(k + u * GROUPS) * 2 + 1) * a.C + c];
+      }
+    }
+    for (; k < a.nchunks; k += GROUPS) {
+      t1[0] += a.partial[((int64_t)k * 2 + 0) * a.C + c];
+      t2[0] += a.partial[((int64_t)k * 2 + 1) * a.C + c];
+    }
+    s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+    s2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (grp != 0 || c >= a.C) return;
+  for (int g2 = 1; g2 < GROUPS; ++g2) {
+    s1 += red[0][g2 * kFinCols + threadIdx.x];
+    s2 += red[1][g2 * kFinCols + threadIdx.x];
   }
   if (MODE == 0) {
     const float n = (float)a.B;
@@ -210,7 +237,7 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
   const int CW = col_width(C);
   const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
   hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, a, CW);
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK), 0, s, a);
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
   hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(apply_grid((int64_t)B * C)), dim3(RH_BLOCK), 0, s, a);
   RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd");
   return 0;
@@ -231,7 +258,7 @@ extern "C" int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, in
   const int CW = col_width(C);
   const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
   hipLaunchKernelGGL((bn_partial_kernel<1>), pg, dim3(RH_BLOCK), 0, s, a, CW);
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK), 0, s, a);
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
   hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(apply_grid((int64_t)B * C)), dim3(RH_BLOCK), 0, s, a);
   RH_LAUNCH_CHECK("rh_bn_relu_dropout_bwd");
   return 0;
