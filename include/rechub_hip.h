@@ -155,6 +155,30 @@ int rh_cross_bwd(const float* x0, int64_t x0_stride, const float* x, int64_t x_s
                  float* wb_partials, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DIN: Dice activation and the memory-bound ends of the ActivationUnit
+ * rh_dice_fwd/bwd replaces: Dice.forward torch_rechub/basic/activation.py:15-25 (row-wise statistics over the neurons)
+ *   x (N, C) contiguous, alpha (1,), eps; bwd writes gx (N, C) and per-block partial sums of d/d alpha into
+ *   alpha_partial (rh_dice_nblocks(N),) which the caller sums.
+ * rh_din_att_input_fwd/bwd replaces: cat[t, h, t-h, t*h] of ActivationUnit.forward, models/ranking/din.py:80-81
+ *   hist (B, L, D) with batch stride hist_stride (positions contiguous), tgt (B, D) with batch stride tgt_stride,
+ *   out (B*L, 4D);  bwd: g (B*L, 4D) -> g_hist (B, L, D) contiguous, g_tgt (B, D)
+ * rh_din_pool_fwd/bwd replaces: (att_weight.unsqueeze(-1) * history).sum(dim=1), models/ranking/din.py:92
+ *   w (B, L) contiguous -> out (B, D);  bwd: g (B, D) -> g_hist (B, L, D), g_w (B, L)
+ */
+int rh_dice_nblocks(int64_t N);
+int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_t N, int C, float* out, void* stream);
+int rh_dice_bwd(const float* x, const float* g, const float* alpha, float eps, int64_t N, int C, float* gx,
+                float* alpha_partial, void* stream);
+int rh_din_att_input_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, int B, int L,
+                         int D, float* out, void* stream);
+int rh_din_att_input_bwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* g,
+                         int B, int L, int D, float* g_hist, float* g_tgt, void* stream);
+int rh_din_pool_fwd(const float* hist, int64_t hist_stride, const float* w, int B, int L, int D, float* out,
+                    void* stream);
+int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, const float* g, int B, int L, int D,
+                    float* g_hist, float* g_w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * MLP hidden-layer epilogue: BatchNorm1d + ReLU + Dropout fused (the Linear in front stays a library GEMM)
  * replaces: nn.BatchNorm1d -> ReLU -> nn.Dropout of MLP, torch_rechub/basic/layers.py:281-287, and their autograd
  * h (B,C) pre-BN activations; training: batch statistics (biased variance), running stats updated with `momentum`

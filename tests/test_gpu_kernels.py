@@ -586,3 +586,67 @@ def test_fused_dropout_statistics_and_backward_mask():
     # gradient flows only through kept positions: dropped & relu-dead columns contribute nothing to dbeta
     dbeta = (kept.float() / (1 - p)).sum(0)
     np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), dbeta.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+def _dice_ref(x, alpha, eps=1e-3):
+    """basic/activation.py:15-25 in float64 torch (autograd gives the reference gradients)."""
+    avg = x.mean(dim=1, keepdim=True)
+    var = (torch.pow(x - avg, 2) + eps).sum(dim=1, keepdim=True)
+    ps = torch.sigmoid((x - avg) / torch.sqrt(var))
+    return ps * x + (1 - ps) * alpha * x
+
+
+@pytest.mark.parametrize("N,C", [(409600 // 16, 256), (1000, 128), (77, 36), (5, 1), (300, 200), (64, 1100), (3, 2048)])
+def test_dice_kernel_vs_reference_formula(N, C):
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(N, C, generator=g) * 1.5 + 0.3
+    alpha = torch.randn(1, generator=g)
+    gy = torch.randn(N, C, generator=g)
+    xr = x.double().requires_grad_(True)
+    ar = alpha.double().requires_grad_(True)
+    yr = _dice_ref(xr, ar)
+    yr.backward(gy.double())
+    close(O.dice_forward(x.numpy().astype(F64), float(alpha)), yr.detach().numpy(), rtol=1e-12, what="oracle==formula")
+    xd = x.to(dev()).requires_grad_(True)
+    ad = alpha.to(dev()).requires_grad_(True)
+    y = ops.dice(xd, ad, 1e-3)
+    y.backward(gy.to(dev()))
+    close(y, yr.detach().numpy(), rtol=2e-5, atol_scale=2e-6, what="dice out")
+    close(xd.grad, xr.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what="dice gx")
+    close(ad.grad, ar.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what="dice galpha")
+
+
+@pytest.mark.parametrize("B,L,D,strided", [(300, 100, 16, True), (4096, 50, 16, False), (33, 7, 64, True), (5, 1, 8, False),
+                                           (64, 9, 4, True), (10, 33, 128, False)])
+def test_din_attention_ends_vs_reference_formula(B, L, D, strided):
+    """cat[t, h, t-h, t*h] and sum_l w_l h_l (models/ranking/din.py:80-81, 92), forward and backward."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + L + D)
+    hist_all = torch.randn(B, 2, L, D, generator=g)
+    tgt_all = torch.randn(B, 2, D, generator=g)
+    hist, tgt = (hist_all[:, 1], tgt_all[:, 1]) if strided else (hist_all[:, 0].contiguous(), tgt_all[:, 0].contiguous())
+    w = torch.randn(B, L, generator=g)
+    # reference (float64, autograd)
+    hr, tr, wr = hist.double().requires_grad_(True), tgt.double().requires_grad_(True), w.double().requires_grad_(True)
+    te = tr.unsqueeze(1).expand(-1, L, -1)
+    att_in = torch.cat([te, hr, te - hr, te * hr], dim=-1).view(-1, 4 * D)
+    pooled = (wr.unsqueeze(-1) * hr).sum(dim=1)
+    g1 = torch.randn(B * L, 4 * D, generator=g)
+    g2 = torch.randn(B, D, generator=g)
+    torch.autograd.backward([att_in, pooled], [g1.double(), g2.double()])
+    # HIP
+    ha = hist_all.to(dev())
+    ta = tgt_all.to(dev())
+    hd = (ha[:, 1] if strided else ha[:, 0].contiguous()).detach().requires_grad_(True)
+    td = (ta[:, 1] if strided else ta[:, 0].contiguous()).detach().requires_grad_(True)
+    wd = w.to(dev()).requires_grad_(True)
+    a = ops.din_att_input(hd, td)
+    p = ops.din_att_pool(wd, hd)
+    assert np.array_equal(a.detach().cpu().numpy()[:, :2 * D], att_in.detach().float().numpy()[:, :2 * D])  # copies
+    close(a, att_in.detach().numpy(), rtol=1e-6, what="att_input")
+    close(p, pooled.detach().numpy(), rtol=2e-5, atol_scale=2e-6, what="pooled")
+    torch.autograd.backward([a, p], [g1.to(dev()), g2.to(dev())])
+    close(hd.grad, hr.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="g_hist")
+    close(td.grad, tr.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="g_tgt")
+    close(wd.grad, wr.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="g_w")

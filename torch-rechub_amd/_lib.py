@@ -37,6 +37,13 @@ SIGNATURES = {
     "rh_cross_max_layers": [c_int],
     "rh_cross_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_i64, c_int, c_ptr, c_ptr],
+    "rh_dice_nblocks": [c_i64],
+    "rh_dice_fwd": [c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr],
+    "rh_dice_bwd": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_din_att_input_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_din_att_input_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_din_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_din_pool_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "rh_bn_act_nchunks": [c_int],
     "rh_bn_relu_dropout_fwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_int, c_ptr,
                                c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -54,7 +61,7 @@ SIGNATURES = {
 _RESTYPES = {"rh_last_error": ctypes.c_char_p}
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
-                    "rh_bn_act_nchunks"}
+                    "rh_bn_act_nchunks", "rh_dice_nblocks"}
 
 ABI_VERSION = 1
 _lib = None

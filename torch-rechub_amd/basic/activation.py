@@ -6,6 +6,8 @@ NEURONS per row (dim=1) and the "variance" is the SUM of (x-mean)^2 + eps over t
 import torch
 from torch import nn
 
+from .. import ops
+
 
 class Dice(nn.Module):
     """p = sigmoid((x - mean_row) / sqrt(sum_row((x-mean_row)^2 + eps)));  out = p*x + (1-p)*alpha*x."""
@@ -16,6 +18,9 @@ class Dice(nn.Module):
         self.alpha = nn.Parameter(torch.randn(1))
 
     def forward(self, x):
+        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] <= 2048:
+            return ops.dice(x, self.alpha, self.epsilon)  # one pass instead of ten elementwise kernels
+        ops.require_hip(x)
         mu = x.mean(dim=1, keepdim=True)
         c = x - mu
         var = (c * c + self.epsilon).sum(dim=1, keepdim=True)

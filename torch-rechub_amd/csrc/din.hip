@@ -1,0 +1,307 @@
+// DIN hot spots: Dice activation and the two memory-bound ends of the ActivationUnit.
+//
+// Reference:
+//   Dice.forward            torch_rechub/basic/activation.py:15-25   (10 elementwise kernels per call; on the (B*L, 256)
+//                           attention tensors these are 31 % + 10 % + 7 % of the reference's DIN step)
+//       avg = x.mean(1); var = sum_1((x-avg)^2 + eps); ps = sigmoid((x-avg)/sqrt(var)); out = ps*x + (1-ps)*alpha*x
+//       (statistics ACROSS NEURONS per row and a SUM, not the paper's batch statistic: SURVEY Q5)
+//   ActivationUnit.forward  torch_rechub/models/ranking/din.py:77-92
+//       att_input = cat[t, h, t-h, t*h] over (B, L, 4D)   and   output = (att_weight.unsqueeze(-1) * history).sum(1)
+// Roofline: HBM; one pass over the data per kernel (Dice: read x, write out; backward: read x, g, write gx).
+#include "common.h"
+
+namespace {
+
+constexpr int kWaves = RH_BLOCK / RH_WAVE;
+
+// One wavefront per row; lane owns elements lane + 64*k (coalesced).  EPL = ceil(C / 64) <= 32.
+template <int EPL, bool BWD>
+__global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ alpha_p, float eps, int64_t N, int C,
+                                                        float* __restrict__ out, float* __restrict__ alpha_partial) {
+  __shared__ float red[kWaves];
+  const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
+  const int64_t nw = (int64_t)gridDim.x * kWaves;
+  const float alpha = alpha_p[0];
+  const float invC = 1.f / (float)C;
+  float acc_alpha = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * kWaves + wave; r < N; r += nw) {
+    float v[EPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const int e = lane + RH_WAVE * k;
+      v[k] = e < C ? x[r * C + e] : 0.f;
+      s += v[k];
+    }
+    const float avg = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const int e = lane + RH_WAVE * k;
+      const float c = e < C ? v[k] - avg : 0.f;
+      q = fmaf(c, c, q);
+    }
+    const float var = wave_sum(q) + eps * (float)C;
+    const float rs = rsqrtf(var);
+    if (!BWD) {
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        const int e = lane + RH_WAVE * k;
+        if (e < C) {
+          const float ps = 1.f / (1.f + expf(-(v[k] - avg) * rs));
+          out[r * C + e] = ps * v[k] + (1.f - ps) * alpha * v[k];
+        }
+      }
+    } else {
+      // out = x * (alpha + (1-alpha) ps),  ps = sigmoid(z),  z = c * rs
+      float gk[EPL], tk[EPL], psk[EPL];
+      float st = 0.f, stc = 0.f;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        const int e = lane + RH_WAVE * k;
+        gk[k] = e < C ? g[r * C + e] : 0.f;
+        const float c = v[k] - avg;
+        psk[k] = 1.f / (1.f + expf(-c * rs));
+        tk[k] = e < C ? gk[k] * v[k] * (1.f - alpha) * psk[k] * (1.f - psk[k]) : 0.f;  // dL/dz
+        st += tk[k];
+        stc = fmaf(tk[k], c, stc);
+        acc_alpha += e < C ? gk[k] * v[k] * (1.f - psk[k]) : 0.f;
+      }
+      st = wave_sum(st);
+      stc = wave_sum(stc);
+      const float rs3 = rs * rs * rs;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        const int e = lane + RH_WAVE * k;
+        if (e < C) {
+          const float c = v[k] - avg;
+          out[r * C + e] = gk[k] * (alpha + (1.f - alpha) * psk[k]) + rs * tk[k] - rs * invC * st - rs3 * c * stc;
+        }
+      }
+    }
+  }
+  if (BWD) {
+    acc_alpha = wave_sum(acc_alpha);
+    if (lane == 0) red[wave] = acc_alpha;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < kWaves; ++w) t += red[w];
+      alpha_partial[blockIdx.x] = t;
+    }
+  }
+}
+
+int dice_epl(int C) {
+  int e = 1;
+  while (e * RH_WAVE < C) e *= 2;
+  return e;
+}
+
+unsigned dice_grid(int64_t N) {
+  int64_t g = (N + kWaves - 1) / kWaves;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <bool BWD>
+int dice_dispatch(const float* x, const float* g, const float* alpha, float eps, int64_t N, int C, float* out,
+                  float* partial, hipStream_t s) {
+  const unsigned grid = dice_grid(N);
+#define RH_DICE(E) hipLaunchKernelGGL((dice_kernel<E, BWD>), dim3(grid), dim3(RH_BLOCK), 0, s, x, g, alpha, eps, N, C, out, partial)
+  switch (dice_epl(C)) {
+    case 1: RH_DICE(1); break;
+    case 2: RH_DICE(2); break;
+    case 4: RH_DICE(4); break;
+    case 8: RH_DICE(8); break;
+    case 16: RH_DICE(16); break;
+    case 32: RH_DICE(32); break;
+    default: return RH_E_UNSUPPORTED;
+  }
+#undef RH_DICE
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention input / weighted pooling: one sample per group of G = LPR*LS lanes (LPR = D/4 lanes per row of 16 bytes,
+// LS position groups), positions l = j*LS + ls.
+struct AttArgs {
+  const float* hist;  // (B, L, D), batch stride hs
+  int64_t hs;
+  const float* tgt;   // (B, D), batch stride ts
+  int64_t ts;
+  const float* w;     // (B, L) attention weights (pool)
+  const float* g;     // upstream gradient
+  float* o1;          // fwd: att_input (B*L, 4D) | pooled (B, D);  bwd: g_hist (B, L, D)
+  float* o2;          // bwd: g_tgt (B, D) | g_w (B, L)
+  int B, L, D;
+};
+
+// MODE 0: att_input fwd, 1: att_input bwd, 2: weighted pooling fwd, 3: weighted pooling bwd
+template <int LPR, int LS, int MODE>
+__global__ __launch_bounds__(RH_BLOCK) void att_kernel(const AttArgs a) {
+  constexpr int G = LPR * LS;
+  const int lig = threadIdx.x % G;
+  const int q = lig % LPR, ls = lig / LPR;
+  int64_t b = (int64_t)blockIdx.x * (RH_BLOCK / G) + threadIdx.x / G;
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;
+  const int L = a.L, D = a.D;
+  const float* hrow = a.hist + b * a.hs + q * 4;
+  float4 t = f4_zero();
+  if (MODE == 0 || MODE == 1) t = gload<float4>(a.tgt + b * a.ts + q * 4);
+  float4 gp = f4_zero();
+  if (MODE == 3) gp = gload<float4>(a.g + b * D + q * 4);
+  float4 acc = f4_zero();
+  for (int l = ls; l < L; l += LS) {
+    const float4 h = gload<float4>(hrow + (int64_t)l * D);
+    if (MODE == 0) {
+      float* o = a.o1 + ((b * L + l) * 4) * D + q * 4;
+      if (live) {
+        gstore<float4>(o, t);
+        gstore<float4>(o + D, h);
+        gstore<float4>(o + 2 * D, f4_sub(t, h));
+        gstore<float4>(o + 3 * D, make_float4(t.x * h.x, t.y * h.y, t.z * h.z, t.w * h.w));
+      }
+    } else if (MODE == 1) {
+      const float* gi = a.g + ((b * L + l) * 4) * D + q * 4;
+      const float4 g0 = gload<float4>(gi), g1 = gload<float4>(gi + D), g2 = gload<float4>(gi + 2 * D),
+                   g3 = gload<float4>(gi + 3 * D);
+      // att_input = [t, h, t-h, t*h]
+      const float4 gh = make_float4(g1.x - g2.x + t.x * g3.x, g1.y - g2.y + t.y * g3.y, g1.z - g2.z + t.z * g3.z,
+                                    g1.w - g2.w + t.w * g3.w);
+      if (live) gstore<float4>(a.o1 + (b * L + l) * D + q * 4, gh);
+      acc = make_float4(acc.x + g0.x + g2.x + h.x * g3.x, acc.y + g0.y + g2.y + h.y * g3.y,
+                        acc.z + g0.z + g2.z + h.z * g3.z, acc.w + g0.w + g2.w + h.w * g3.w);
+    } else if (MODE == 2) {
+      acc = f4_fma(a.w[b * L + l], h, acc);
+    } else {
+      const float wl = a.w[b * L + l];
+      if (live) gstore<float4>(a.o1 + (b * L + l) * D + q * 4, f4_scale(gp, wl));
+      float d = f4_dot(gp, h);
+#pragma unroll
+      for (int m = 1; m < LPR; m <<= 1) d += __shfl_xor(d, m, RH_WAVE);
+      if (live && q == 0) a.o2[b * L + l] = d;
+    }
+  }
+  if (MODE == 1 || MODE == 2) {
+#pragma unroll
+    for (int m = LPR; m < G; m <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, m));
+    if (live && ls == 0) gstore<float4>((MODE == 1 ? a.o2 : a.o1) + b * D + q * 4, acc);
+  }
+}
+
+template <int LPR, int MODE>
+int att_launch_ls(const AttArgs& a, int ls, hipStream_t s) {
+#define RH_ATT(LSV)                                                                                    \
+  {                                                                                                    \
+    const unsigned grid = (unsigned)(((int64_t)a.B * LPR * LSV + RH_BLOCK - 1) / RH_BLOCK);            \
+    hipLaunchKernelGGL((att_kernel<LPR, LSV, MODE>), dim3(grid), dim3(RH_BLOCK), 0, s, a);             \
+    return 0;                                                                                          \
+  }
+  if constexpr (LPR * 16 <= RH_WAVE) {
+    if (ls >= 16) RH_ATT(16)
+  }
+  if constexpr (LPR * 4 <= RH_WAVE) {
+    if (ls >= 4) RH_ATT(4)
+  }
+  RH_ATT(1)
+#undef RH_ATT
+}
+
+template <int MODE>
+int att_dispatch(const AttArgs& a, hipStream_t s) {
+  const int lpr = a.D / 4;
+  int ls = 1;
+  while (ls < 16 && lpr * ls * 4 <= RH_WAVE && ls * 4 <= a.L) ls *= 4;
+  switch (lpr) {
+    case 1: return att_launch_ls<1, MODE>(a, ls, s);
+    case 2: return att_launch_ls<2, MODE>(a, ls, s);
+    case 4: return att_launch_ls<4, MODE>(a, ls, s);
+    case 8: return att_launch_ls<8, MODE>(a, ls, s);
+    case 16: return att_launch_ls<16, MODE>(a, ls, s);
+    case 32: return att_launch_ls<32, MODE>(a, ls, s);
+    default: return RH_E_UNSUPPORTED;
+  }
+}
+
+int att_check(const char* who, int B, int L, int D) {
+  RH_REQUIRE(B >= 0 && L >= 1, RH_E_BADARG, "%s: bad shape B=%d L=%d", who, B, L);
+  RH_REQUIRE(D > 0 && D % 4 == 0 && D <= 128 && ((D / 4) & (D / 4 - 1)) == 0, RH_E_UNSUPPORTED,
+             "%s: embed_dim %d unsupported (need 4,8,16,32,64,128)", who, D);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int rh_dice_nblocks(int64_t N) { return (int)dice_grid(N); }
+
+extern "C" int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_t N, int C, float* out, void* stream) {
+  RH_REQUIRE(x && alpha && out && N >= 0 && C >= 1, RH_E_BADARG, "rh_dice_fwd: bad arguments");
+  RH_REQUIRE(C <= 2048, RH_E_UNSUPPORTED, "rh_dice_fwd: %d neurons unsupported (max 2048)", C);
+  if (N == 0) return 0;
+  int rc = dice_dispatch<false>(x, nullptr, alpha, eps, N, C, out, nullptr, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_dice_fwd");
+  return 0;
+}
+
+extern "C" int rh_dice_bwd(const float* x, const float* g, const float* alpha, float eps, int64_t N, int C, float* gx,
+                           float* alpha_partial, void* stream) {
+  RH_REQUIRE(x && g && alpha && gx && alpha_partial && N >= 0 && C >= 1, RH_E_BADARG, "rh_dice_bwd: bad arguments");
+  RH_REQUIRE(C <= 2048, RH_E_UNSUPPORTED, "rh_dice_bwd: %d neurons unsupported (max 2048)", C);
+  int rc = dice_dispatch<true>(x, g, alpha, eps, N, C, gx, alpha_partial, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_dice_bwd");
+  return 0;
+}
+
+extern "C" int rh_din_att_input_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, int B,
+                                    int L, int D, float* out, void* stream) {
+  if (int rc = att_check("rh_din_att_input_fwd", B, L, D)) return rc;
+  RH_REQUIRE(hist && tgt && out, RH_E_BADARG, "rh_din_att_input_fwd: null pointer");
+  if (B == 0) return 0;
+  AttArgs a{hist, hist_stride, tgt, tgt_stride, nullptr, nullptr, out, nullptr, B, L, D};
+  int rc = att_dispatch<0>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_din_att_input_fwd");
+  return 0;
+}
+
+extern "C" int rh_din_att_input_bwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride,
+                                    const float* g, int B, int L, int D, float* g_hist, float* g_tgt, void* stream) {
+  if (int rc = att_check("rh_din_att_input_bwd", B, L, D)) return rc;
+  RH_REQUIRE(hist && tgt && g && g_hist && g_tgt, RH_E_BADARG, "rh_din_att_input_bwd: null pointer");
+  if (B == 0) return 0;
+  AttArgs a{hist, hist_stride, tgt, tgt_stride, nullptr, g, g_hist, g_tgt, B, L, D};
+  int rc = att_dispatch<1>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_din_att_input_bwd");
+  return 0;
+}
+
+extern "C" int rh_din_pool_fwd(const float* hist, int64_t hist_stride, const float* w, int B, int L, int D, float* out,
+                               void* stream) {
+  if (int rc = att_check("rh_din_pool_fwd", B, L, D)) return rc;
+  RH_REQUIRE(hist && w && out, RH_E_BADARG, "rh_din_pool_fwd: null pointer");
+  if (B == 0) return 0;
+  AttArgs a{hist, hist_stride, nullptr, 0, w, nullptr, out, nullptr, B, L, D};
+  int rc = att_dispatch<2>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_din_pool_fwd");
+  return 0;
+}
+
+extern "C" int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, const float* g, int B, int L,
+                               int D, float* g_hist, float* g_w, void* stream) {
+  if (int rc = att_check("rh_din_pool_bwd", B, L, D)) return rc;
+  RH_REQUIRE(hist && w && g && g_hist && g_w, RH_E_BADARG, "rh_din_pool_bwd: null pointer");
+  if (B == 0) return 0;
+  AttArgs a{hist, hist_stride, nullptr, 0, w, g, g_hist, g_w, B, L, D};
+  int rc = att_dispatch<3>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_din_pool_bwd");
+  return 0;
+}

@@ -7,6 +7,7 @@ target feature i by position.
 import torch
 from torch import nn
 
+from ... import ops
 from ...basic.layers import MLP, EmbeddingLayer
 
 
@@ -54,9 +55,10 @@ class ActivationUnit(nn.Module):
 
     def forward(self, history, target):
         B, L, D = history.shape
-        t = target.unsqueeze(1).expand(-1, L, -1)
-        att_input = torch.cat([t, history, t - history, t * history], dim=-1)
-        att_weight = self.attention(att_input.reshape(-1, 4 * D)).view(-1, L)
+        if not ops.din_dim_ok(D):
+            raise RuntimeError(f"torch_rechub_amd: ActivationUnit emb_dim={D} has no HIP kernel (4,8,16,32,64,128)")
+        att_input = ops.din_att_input(history, target)  # (B*L, 4D) = [t, h, t-h, t*h], one kernel
+        att_weight = self.attention(att_input).view(-1, L)
         if self.use_softmax:
             att_weight = att_weight.softmax(dim=-1)
-        return (att_weight.unsqueeze(-1) * history).sum(dim=1)
+        return ops.din_att_pool(att_weight, history)  # sum_l w_l * h_l, one kernel

@@ -556,3 +556,107 @@ def bn_relu_dropout(h, bn, p_drop):
               _p(bn.running_var), _p(None), 0.0, float(bn.eps), 0.0, 0, _p(None), _p(None), _p(None), _p(None), _p(out),
               _stream())
     return out
+
+
+# --------------------------------------------------------------------------------------------
+class _DiceFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, alpha, eps):
+        require_hip(x, alpha)
+        if x.dim() != 2 or x.dtype != torch.float32:
+            raise ValueError("Dice expects a float32 (N, num_neurons) tensor")
+        x = x.contiguous()
+        N, C = x.shape
+        out = torch.empty_like(x)
+        _lib.call("rh_dice_fwd", _p(x), _p(alpha), float(eps), N, C, _p(out), _stream())
+        ctx.eps = float(eps)
+        ctx.save_for_backward(x, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, alpha = ctx.saved_tensors
+        N, C = x.shape
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        partial = torch.empty(_lib.call("rh_dice_nblocks", N), dtype=torch.float32, device=x.device)
+        _lib.call("rh_dice_bwd", _p(x), _p(g), _p(alpha), ctx.eps, N, C, _p(gx), _p(partial), _stream())
+        return gx, partial.sum().reshape(1), None
+
+
+def dice(x, alpha, eps):
+    return _DiceFn.apply(x, alpha, eps)
+
+
+def _hist_layout(history):
+    """(B, L, D) view whose rows are contiguous over (L, D); returns (tensor, batch stride in floats)."""
+    if history.stride(2) != 1 or history.stride(1) != history.shape[2]:
+        history = history.contiguous()
+    return history, history.stride(0)
+
+
+class _AttInputFn(torch.autograd.Function):
+    """cat[t, h, t-h, t*h] over (B*L, 4D) without the expand / sub / mul / cat temporaries."""
+
+    @staticmethod
+    def forward(ctx, history, target):
+        require_hip(history, target)
+        history, hs = _hist_layout(history)
+        if target.stride(1) != 1:
+            target = target.contiguous()
+        B, L, D = history.shape
+        out = torch.empty((B * L, 4 * D), dtype=torch.float32, device=history.device)
+        _lib.call("rh_din_att_input_fwd", _p(history), hs, _p(target), target.stride(0), B, L, D, _p(out), _stream())
+        ctx.save_for_backward(history, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        history, target = ctx.saved_tensors
+        B, L, D = history.shape
+        g = g.contiguous()
+        g_hist = torch.empty((B, L, D), dtype=torch.float32, device=g.device)
+        g_tgt = torch.empty((B, D), dtype=torch.float32, device=g.device)
+        _lib.call("rh_din_att_input_bwd", _p(history), history.stride(0), _p(target), target.stride(0), _p(g), B, L, D,
+                  _p(g_hist), _p(g_tgt), _stream())
+        return g_hist, g_tgt
+
+
+class _AttPoolFn(torch.autograd.Function):
+    """(att_weight.unsqueeze(-1) * history).sum(dim=1)."""
+
+    @staticmethod
+    def forward(ctx, weight, history):
+        require_hip(weight, history)
+        history, hs = _hist_layout(history)
+        weight = weight.contiguous()
+        B, L, D = history.shape
+        out = torch.empty((B, D), dtype=torch.float32, device=history.device)
+        _lib.call("rh_din_pool_fwd", _p(history), hs, _p(weight), B, L, D, _p(out), _stream())
+        ctx.save_for_backward(weight, history)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, history = ctx.saved_tensors
+        B, L, D = history.shape
+        g = g.contiguous()
+        g_hist = torch.empty((B, L, D), dtype=torch.float32, device=g.device)
+        g_w = torch.empty((B, L), dtype=torch.float32, device=g.device)
+        _lib.call("rh_din_pool_bwd", _p(history), history.stride(0), _p(weight), _p(g), B, L, D, _p(g_hist), _p(g_w),
+                  _stream())
+        return g_w, g_hist
+
+
+def din_att_input(history, target):
+    return _AttInputFn.apply(history, target)
+
+
+def din_att_pool(weight, history):
+    return _AttPoolFn.apply(weight, history)
+
+
+def din_dim_ok(d):
+    q = d // 4
+    return d % 4 == 0 and 1 <= q <= 32 and (q & (q - 1)) == 0
