@@ -186,6 +186,16 @@ def build_model(rh, cfg):
     from torch_rechub.basic.features import DenseFeature, SequenceFeature, SparseFeature
     from torch_rechub.models.ranking import DCN, DIN, DCNv2, DeepFM, WideDeep
     D = 16
+    if cfg == "dssm":  # config 5: two-tower matching, mean-pooled history shares the item table
+        from torch_rechub.models.matching import DSSM
+        user = [SparseFeature("user_id", vocab_size=40, embed_dim=D),
+                SequenceFeature("hist_item", vocab_size=60, embed_dim=D, pooling="mean", shared_with="item_id",
+                                padding_idx=0)]
+        item = [SparseFeature("item_id", vocab_size=60, embed_dim=D, padding_idx=0),
+                SparseFeature("cate_id", vocab_size=12, embed_dim=D)]
+        tower = {"dims": [32, 16], "activation": "prelu"}
+        return DSSM(user, item, user_params=dict(tower), item_params=dict(tower), temperature=0.02), \
+            {"user_features": user, "item_features": item}
     mlp = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
     if cfg.startswith("din"):
         feats = [SparseFeature("user_id", vocab_size=30, embed_dim=D)]
@@ -282,7 +292,16 @@ def gen_model(rh, cfg):
     model.zero_grad()
     # the reference training loop itself: trainers/ctr_trainer.py:77-108 over three fixed batches
     wd = 1e-3
-    trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": wd}, n_epoch=1, device="cpu")
+    if cfg == "dssm":  # trainers/match_trainer.py:105-176, in-batch HARD negatives (deterministic: top-k, no RNG)
+        from torch_rechub.trainers import MatchTrainer
+        trainer = MatchTrainer(model, mode=0, in_batch_neg=True, in_batch_neg_ratio=3, hard_negative=True,
+                               optimizer_params={"lr": 1e-2, "weight_decay": wd}, n_epoch=1, device="cpu")
+        with torch.no_grad():
+            model.eval()
+            out["user_emb"], out["item_emb"] = npy(model.user_tower(x)), npy(model.item_tower(x))
+            model.train()
+    else:
+        trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": wd}, n_epoch=1, device="cpu")
     mean_loss = trainer.train_one_epoch(batches)
     out["train.lr"], out["train.wd"], out["train.mean_loss"] = np.array(1e-2), np.array(wd), np.array(mean_loss)
     for n, t in model.state_dict().items():
@@ -292,11 +311,14 @@ def gen_model(rh, cfg):
 
 
 CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-           "din_softmax"]
+           "din_softmax", "dssm"]
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     rh = import_reference()
-    gen_layers(rh)
+    only = sys.argv[1:]  # optional: regenerate just the named fixtures ("layers" or model configs)
+    if not only or "layers" in only:
+        gen_layers(rh)
     for cfg in CONFIGS:
-        gen_model(rh, cfg)
+        if not only or cfg in only:
+            gen_model(rh, cfg)

@@ -25,7 +25,7 @@ def layers_golden():
 
 
 MODEL_CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-                 "din_softmax"]
+                 "din_softmax", "dssm"]
 
 
 def features_from_spec(spec_json):
@@ -58,6 +58,11 @@ def build_amd_model(cfg, groups):
     """Same constructor calls as oracle/gen_golden.py::build_model, on the torch_rechub_amd classes."""
     from torch_rechub_amd.models.ranking import DCN, DIN, DCNv2, DeepFM, WideDeep
     mlp = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
+    if cfg == "dssm":
+        from torch_rechub_amd.models.matching import DSSM
+        tower = {"dims": [32, 16], "activation": "prelu"}
+        return DSSM(groups["user_features"], groups["item_features"], user_params=dict(tower), item_params=dict(tower),
+                    temperature=0.02)
     if cfg.startswith("din"):
         return DIN(groups["features"], groups["history_features"], groups["target_features"],
                    mlp_params={"dims": [32, 16], "dropout": 0.0},

@@ -74,8 +74,14 @@ def test_three_step_training_matches_reference_trainer(cfg, mode):
     params = {"lr": float(gold["train.lr"]), "weight_decay": float(gold["train.wd"])}
     if mode == "lazy":
         params["lazy_small_rows"] = 8  # push all but the tiniest tables through the claim / replay / sweep path
-    trainer = CTRTrainer(model, optimizer_params=params, n_epoch=1, device="cuda:0", show_progress=False,
-                         table_update=mode, lazy_k=2)
+    if cfg == "dssm":  # config 5: reference MatchTrainer with in-batch hard negatives (deterministic top-k)
+        from torch_rechub_amd.trainers import MatchTrainer
+        trainer = MatchTrainer(model, mode=0, in_batch_neg=True, in_batch_neg_ratio=3, hard_negative=True,
+                               optimizer_params=params, n_epoch=1, device="cuda:0", show_progress=False,
+                               table_update=mode, lazy_k=2)
+    else:
+        trainer = CTRTrainer(model, optimizer_params=params, n_epoch=1, device="cuda:0", show_progress=False,
+                             table_update=mode, lazy_k=2)
     mean_loss = trainer.train_one_epoch(batches)
     assert abs(mean_loss - float(gold["train.mean_loss"])) < 5e-5
     ref = golden_state(gold, "sd3.")
@@ -271,3 +277,37 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
         if k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias") or k.endswith("running_mean"):
             continue
         assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-5, rtol=1e-4)
+
+
+def test_dssm_towers_and_inbatch_sampling():
+    """Config 5 pieces: tower embeddings against the reference, in-batch sampler invariants (reference
+    tests/test_inbatch_sampling.py:12-30) on the device."""
+    from torch_rechub_amd.utils.match import gather_inbatch_logits, inbatch_negative_sampling
+    gold, model = load_model("dssm")
+    x, _ = golden_batch(gold, 0)
+    xd = to_dev(x)
+    model.eval()
+    with torch.no_grad():
+        u, it = model.user_tower(xd), model.item_tower(xd)
+    np.testing.assert_allclose(u.cpu().numpy(), gold["user_emb"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(it.cpu().numpy(), gold["item_emb"], rtol=1e-4, atol=2e-6)
+    model.mode = "user"
+    with torch.no_grad():
+        assert torch.equal(model(xd), u)
+    model.mode = None
+    scores = u @ it.t()
+    hard = inbatch_negative_sampling(scores, neg_ratio=3, hard_negative=True)
+    ref = torch.topk(scores.cpu().masked_fill(torch.eye(48, dtype=torch.bool), float("-inf")), 3, dim=1).indices
+    assert torch.equal(hard.cpu(), ref)
+    g = torch.Generator(device=dev()).manual_seed(1)
+    r1 = inbatch_negative_sampling(scores, neg_ratio=5, generator=g)
+    assert r1.shape == (48, 5) and r1.dtype == torch.int64
+    assert not (r1 == torch.arange(48, device=dev()).unsqueeze(1)).any()  # never the positive itself
+    assert all(len(set(row.tolist())) == 5 for row in r1.cpu())  # without replacement
+    g2 = torch.Generator(device=dev()).manual_seed(2)
+    assert not torch.equal(r1, inbatch_negative_sampling(scores, neg_ratio=5, generator=g2))
+    assert inbatch_negative_sampling(scores).shape == (48, 47)  # default: every other item of the batch
+    logits = gather_inbatch_logits(scores, hard)
+    assert torch.equal(logits[:, 0], torch.diagonal(scores)) and logits.shape == (48, 4)
+    known = torch.tensor([[1., 2, 3], [4, 5, 6], [7, 8, 0]], device=dev())
+    assert inbatch_negative_sampling(known, neg_ratio=1, hard_negative=True).flatten().tolist() == [2, 2, 1]

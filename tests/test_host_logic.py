@@ -179,3 +179,27 @@ def test_table_parameters_detection():
     names = {n for n, p in model.named_parameters() if any(p is q for q in table_parameters(model))}
     assert names == {"embedding.embed_dict.user_id.weight", "embedding.embed_dict.target_item.weight",
                      "embedding.embed_dict.target_cate.weight"}
+
+
+def test_inbatch_sampling_known_answers_cpu():
+    """The reference's own unit tests for the in-batch sampler (tests/test_inbatch_sampling.py:12-30)."""
+    from torch_rechub_amd.utils.match import gather_inbatch_logits, inbatch_negative_sampling
+    scores = torch.tensor([[1., 2, 3], [4, 5, 6], [7, 8, 0]])
+    assert inbatch_negative_sampling(scores, neg_ratio=1, hard_negative=True).flatten().tolist() == [2, 2, 1]
+    big = torch.randn(4, 4)
+    g = torch.Generator().manual_seed(0)
+    a = inbatch_negative_sampling(big, neg_ratio=3, generator=g)
+    assert a.shape == (4, 3) and not (a == torch.arange(4).unsqueeze(1)).any()
+    assert inbatch_negative_sampling(big, neg_ratio=2, generator=torch.Generator().manual_seed(1)).shape == (4, 2)
+    logits = gather_inbatch_logits(scores, torch.tensor([[2], [2], [1]]))
+    assert logits.tolist() == [[1., 3.], [5., 6.], [0., 8.]]
+    with pytest.raises(ValueError):
+        inbatch_negative_sampling(torch.zeros(1, 1))
+    with pytest.raises(ValueError):
+        inbatch_negative_sampling(torch.zeros(3))
+
+
+def test_match_trainer_rejects_models_without_towers():
+    from torch_rechub_amd.trainers import MatchTrainer
+    with pytest.raises(ValueError, match="does not support in-batch negative sampling"):
+        MatchTrainer(nn.Linear(2, 1), in_batch_neg=True, device="cuda:0")

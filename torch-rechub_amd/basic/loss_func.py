@@ -42,3 +42,12 @@ class RegularizationLoss(nn.Module):
             if l2 > 0:
                 total = total + l2 * (p * p).sum()
         return total
+
+
+class BPRLoss(nn.Module):
+    """-log(sigmoid(pos - neg)).mean() (API mirror of torch_rechub/basic/loss_func.py:95-107)."""
+
+    def forward(self, pos_score, neg_score, in_batch_neg=False):
+        pos_score = pos_score.view(-1)
+        diff = pos_score - neg_score if neg_score.dim() == 1 else pos_score.view(-1, 1) - neg_score
+        return -diff.sigmoid().log().mean()

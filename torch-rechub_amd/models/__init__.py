@@ -1,1 +1,1 @@
-from . import ranking  # noqa: F401
+from . import matching, ranking  # noqa: F401

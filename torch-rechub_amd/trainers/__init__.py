@@ -1,1 +1,2 @@
 from .ctr_trainer import CTRTrainer  # noqa: F401
+from .match_trainer import MatchTrainer  # noqa: F401

@@ -98,15 +98,21 @@ class CTRTrainer(object):
                     ops.grad_buffer(p).zero_()
                     p._rh_dirty = False
 
-    def train_step(self, x_dict, y):
-        """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
+    def _prepare_target(self, y):
+        return y.float()
+
+    def _compute_loss(self, x_dict, y):
+        """model forward + criterion + regularisation (trainers/ctr_trainer.py:86-95); overridden by MatchTrainer."""
         if self.loss_mode:
-            y_pred = self.model(x_dict)
-            loss = self.criterion(y_pred, y)
+            loss = self.criterion(self.model(x_dict), y)
         else:
             y_pred, other_loss = self.model(x_dict)
             loss = self.criterion(y_pred, y) + other_loss
-        loss = loss + self.reg_loss_fn(self.model)
+        return loss + self.reg_loss_fn(self.model)
+
+    def train_step(self, x_dict, y):
+        """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
+        loss = self._compute_loss(x_dict, y)
         report = loss.detach()
         if self.world > 1:
             loss = loss / self.world  # gradients are SUMMED over ranks: global-batch mean, as DataParallel
@@ -132,12 +138,7 @@ class CTRTrainer(object):
     def _phase_a(self, x_dict, y):
         self.dp.deferred_mode, self.dp.deferred = True, []
         self.bucket.defer = True
-        if self.loss_mode:
-            loss = self.criterion(self.model(x_dict), y)
-        else:
-            y_pred, other_loss = self.model(x_dict)
-            loss = self.criterion(y_pred, y) + other_loss
-        loss = loss + self.reg_loss_fn(self.model)
+        loss = self._compute_loss(x_dict, y)
         report = loss.detach()
         if self.world > 1:
             loss = loss / self.world
@@ -256,7 +257,7 @@ class CTRTrainer(object):
                 if not device_loader:
                     x_dict = {k: v.to(self.device, non_blocking=True) for k, v in x_dict.items()}
                     y = y.to(self.device, non_blocking=True)
-                loss = self.train_step(x_dict, y.float())
+                loss = self.train_step(x_dict, self._prepare_target(y))
                 run += loss
                 epoch += loss
                 batch_count += 1

@@ -1,0 +1,110 @@
+"""MatchTrainer (API mirror of torch_rechub/trainers/match_trainer.py:12-263) on the HIP hot path.
+
+Same constructor and training modes {0: point-wise BCE, 1: pair-wise BPR, 2: list-wise softmax}; with
+``in_batch_neg=True`` the step is: user/item towers -> (B, B) scores (library GEMM) -> batched in-batch negative
+sampling -> gather [positive, negatives] -> cross entropy / BPR (match_trainer.py:118-138).  Everything else — optimizer
+(TableAdam, lazy-exact), gradient bucket, RCCL data parallelism, hipGraph step — is inherited from CTRTrainer; in-batch
+negatives are taken from the local batch of each rank (the reference's in-batch branch is single-device, :119).
+"""
+import os
+
+import torch
+import tqdm
+
+from .. import ops
+from ..basic.loss_func import BPRLoss
+from ..utils.match import gather_inbatch_logits, inbatch_negative_sampling
+from .ctr_trainer import CTRTrainer
+
+
+class MatchTrainer(CTRTrainer):
+
+    def __init__(self, model, mode=0, in_batch_neg=False, in_batch_neg_ratio=None, hard_negative=False,
+                 sampler_seed=None, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
+                 scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
+                 model_path="./", model_logger=None, **kw):
+        if in_batch_neg and not (hasattr(model, "user_tower") and hasattr(model, "item_tower")):
+            raise ValueError(f"Model {type(model).__name__} does not support in-batch negative sampling. "
+                             "Only two-tower models with user_tower() and item_tower() methods are supported, "
+                             "such as DSSM, YoutubeDNN, MIND, GRU4Rec, SINE, ComiRec, SASRec, NARM, STAMP, etc.")
+        if mode not in (0, 1, 2):
+            raise ValueError("mode only contain value in %s, but got %s" % ([0, 1, 2], mode))
+        super().__init__(model, optimizer_fn=optimizer_fn, optimizer_params=optimizer_params,
+                         regularization_params=regularization_params, scheduler_fn=scheduler_fn,
+                         scheduler_params=scheduler_params, n_epoch=n_epoch, earlystop_patience=earlystop_patience,
+                         device=device, gpus=gpus, model_path=model_path, model_logger=model_logger, **kw)
+        self.mode = mode
+        self.in_batch_neg = in_batch_neg
+        self.in_batch_neg_ratio = in_batch_neg_ratio
+        self.hard_negative = hard_negative
+        self._sampler_generator = None
+        if sampler_seed is not None:
+            self._sampler_generator = torch.Generator(device=self.device)
+            self._sampler_generator.manual_seed(sampler_seed)
+        if mode == 0:
+            self.criterion = torch.nn.CrossEntropyLoss() if in_batch_neg else torch.nn.BCELoss()
+        elif mode == 1:
+            self.criterion = BPRLoss()
+        else:
+            self.criterion = torch.nn.CrossEntropyLoss()
+
+    def _prepare_target(self, y):
+        return y.float() if self.mode == 0 else y.long()
+
+    def _compute_loss(self, x_dict, y):
+        if self.in_batch_neg:
+            user_embedding = self.model.user_tower(x_dict)
+            item_embedding = self.model.item_tower(x_dict)
+            if user_embedding is None or item_embedding is None:
+                raise ValueError("Model must return user/item embeddings when in_batch_neg is True.")
+            if user_embedding.dim() > 2 and user_embedding.size(1) == 1:
+                user_embedding = user_embedding.squeeze(1)
+            if item_embedding.dim() > 2 and item_embedding.size(1) == 1:
+                item_embedding = item_embedding.squeeze(1)
+            if user_embedding.dim() != 2 or item_embedding.dim() != 2:
+                raise ValueError(f"In-batch negative sampling requires 2D embeddings, got shapes "
+                                 f"{user_embedding.shape} and {item_embedding.shape}")
+            scores = torch.matmul(user_embedding, item_embedding.t())
+            neg_indices = inbatch_negative_sampling(scores, neg_ratio=self.in_batch_neg_ratio,
+                                                    hard_negative=self.hard_negative, generator=self._sampler_generator)
+            logits = gather_inbatch_logits(scores, neg_indices)
+            if self.mode == 1:
+                loss = self.criterion(logits[:, 0], logits[:, 1:], in_batch_neg=True)
+            else:
+                targets = torch.zeros(logits.size(0), dtype=torch.long, device=self.device)
+                loss = self.criterion(logits, targets)
+        elif self.mode == 1:
+            pos_score, neg_score = self.model(x_dict)
+            loss = self.criterion(pos_score, neg_score)
+        else:
+            loss = self.criterion(self.model(x_dict), y)
+        return loss + self.reg_loss_fn(self.model)
+
+    def evaluate(self, model, data_loader):
+        self.flush()
+        model.eval()
+        targets, predicts = [], []
+        with torch.no_grad():
+            for x_dict, y in tqdm.tqdm(data_loader, desc="validation", smoothing=0, mininterval=1.0,
+                                       disable=not self.show_progress):
+                y_pred = model(self._to_device(x_dict))
+                targets.append(y.detach().float().reshape(-1).cpu())
+                predicts.append(y_pred.detach().float().reshape(-1).cpu())
+        ops.check_errors(self.device)
+        return self.evaluate_fn(torch.cat(targets).numpy(), torch.cat(predicts).numpy())
+
+    def inference_embedding(self, model, mode, data_loader, model_path):
+        assert mode in ["user", "item"], "Invalid mode={}.".format(mode)
+        self.flush()
+        model.mode = mode
+        model.load_state_dict(torch.load(os.path.join(model_path, "model.pth"), map_location=self.device,
+                                         weights_only=True))
+        model = model.to(self.device)
+        model.eval()
+        predicts = []
+        with torch.no_grad():
+            for x_dict in tqdm.tqdm(data_loader, desc="%s inference" % (mode), smoothing=0, mininterval=1.0,
+                                    disable=not self.show_progress):
+                predicts.append(model(self._to_device(x_dict)).data)
+        ops.check_errors(self.device)
+        return torch.cat(predicts, dim=0)

@@ -1,1 +1,1 @@
-from . import data  # noqa: F401
+from . import data, match  # noqa: F401

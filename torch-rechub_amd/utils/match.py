@@ -1,0 +1,37 @@
+"""In-batch negative sampling for two-tower training (API mirror of torch_rechub/utils/match.py:104-161).
+
+The reference loops ``for i in range(batch_size)`` in Python, launching a randperm / topk per row (O(B) tiny launches,
+SURVEY 3.5).  Here both modes are ONE batched device op over the (B, B) score matrix:
+  * hard negatives: top-k of the scores with the diagonal masked to -inf (same indices as the reference: its
+    known-answer test [[1,2,3],[4,5,6],[7,8,0]] -> [2,2,1] holds);
+  * random negatives: top-k of i.i.d. uniform keys with the diagonal masked, i.e. a uniformly random k-subset of the
+    other B-1 columns in random order — the distribution of ``candidates[randperm(B-1)[:k]]`` (the exact indices depend
+    on how the RNG stream is consumed, which the reference does not pin: its tests check shape, no self index and seed
+    sensitivity).
+"""
+import torch
+
+
+def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, generator=None):
+    if scores.dim() != 2:
+        raise ValueError(f"inbatch_negative_sampling expects 2D scores, got shape {tuple(scores.shape)}")
+    batch_size = scores.size(0)
+    if batch_size <= 1:
+        raise ValueError("In-batch negative sampling requires batch_size > 1")
+    max_neg = batch_size - 1
+    if neg_ratio is None or neg_ratio <= 0 or neg_ratio > max_neg:
+        neg_ratio = max_neg
+    device = scores.device
+    diag = torch.eye(batch_size, dtype=torch.bool, device=device)
+    if hard_negative:
+        keys = scores.detach().masked_fill(diag, float("-inf"))
+    else:
+        keys = torch.rand((batch_size, batch_size), device=device, generator=generator).masked_fill(diag, -1.0)
+    return torch.topk(keys, k=neg_ratio, dim=1).indices
+
+
+def gather_inbatch_logits(scores, neg_indices):
+    """(B, 1+K) logits: column 0 = scores[i, i] (the positive), then scores[i, neg_indices[i, j]]."""
+    positive_logits = torch.diagonal(scores).reshape(-1, 1)
+    negative_logits = torch.gather(scores, 1, neg_indices)
+    return torch.cat([positive_logits, negative_logits], dim=1)
