@@ -45,7 +45,8 @@ def test_full_shape_gather_is_a_copy_and_fm_lr_properties(criteo_tables, B):
         assert torch.equal(out[:, F * D:], dense)
         emb = out[:, :F * D].view(B, F, D).double()
         fm_ref = 0.5 * ((emb.sum(1)**2).sum(1) - (emb**2).sum((1, 2)))
-        np.testing.assert_allclose(fm.squeeze(1).cpu().numpy(), fm_ref.cpu().numpy(), rtol=2e-5, atol=1e-7)
+        # fm is a difference of two ~1.0 sums: absolute error is a few ulp of those, not of the (small) result
+        np.testing.assert_allclose(fm.squeeze(1).cpu().numpy(), fm_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
         # LR is linear in its weights: lr(2w) = 2 lr(w) with zero bias, exactly (power-of-two scaling)
         _, _, lr2 = ops.fused_embedding(call, lr_w * 2, lr_b)
         assert torch.equal(lr2, lr * 2)
@@ -71,8 +72,9 @@ def test_full_shape_backward_conserves_gradient_mass_and_touches_only_looked_up_
         touched = torch.unique(idx[:, f])
         nz = (grad != 0).any(dim=1)
         assert int(nz.sum()) <= touched.numel() and bool(nz[touched].float().mean() > 0.99)
-        untouched_sum = grad.abs().sum() - grad[touched].abs().sum()
-        assert float(untouched_sum) == 0.0
+        mask = torch.ones(grad.shape[0], dtype=torch.bool, device=dev())
+        mask[touched] = False
+        assert not bool((grad[mask] != 0).any())  # rows that were not looked up stay exactly zero
     for w in criteo_tables:
         ops.grad_buffer(w).zero_()
         w._rh_dirty = False
