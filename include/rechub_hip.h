@@ -155,6 +155,25 @@ int rh_cross_bwd(const float* x0, int64_t x0_stride, const float* x, int64_t x_s
                  float* wb_partials, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DCN-v2 cross layers: the streaming epilogues around the library GEMMs (all tensors contiguous fp32)
+ * rh_cross_v2_epilogue_* replaces: `x0 * self.w[i](x) + self.b[i] + x` of CrossNetV2.forward basic/layers.py:442-443
+ *   fwd: out = x0*y + b + x   (y = W_l x from the GEMM);  bwd: g_x0 = g*y, g_y = g*x0  (g_x = g, g_b = colsum(g))
+ * rh_cross_mix_epilogue_* replaces: the expert loop tail of CrossNetMix.forward basic/layers.py:491-503
+ *   fwd: out = sum_e gate[b,e] * x0 * (uv[e,b,:] + bias) + xl     uv (E,B,d) = U_e v_e from the batched GEMM,
+ *        gate (B,E) = softmax of the gating scores;
+ *   bwd: g_x0 = g * sum_e gate_e (uv_e + bias), g_uv[e] = g * gate_e * x0, g_gate[b,e] = sum_d g*x0*(uv_e + bias)
+ *        (g_xl = g, g_bias = colsum(g * x0 * sum_e gate_e) are the caller's).  d <= 2048, E <= 16.
+ */
+int rh_cross_v2_epilogue_fwd(const float* x0, const float* y, const float* b, const float* x, int B, int d, float* out,
+                             void* stream);
+int rh_cross_v2_epilogue_bwd(const float* x0, const float* y, const float* g, int B, int d, float* g_x0, float* g_y,
+                             void* stream);
+int rh_cross_mix_epilogue_fwd(const float* x0, const float* xl, const float* uv, const float* gate, const float* bias,
+                              int B, int d, int E, float* out, void* stream);
+int rh_cross_mix_epilogue_bwd(const float* x0, const float* uv, const float* gate, const float* bias, const float* g,
+                              int B, int d, int E, float* g_x0, float* g_uv, float* g_gate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * DIN: Dice activation and the memory-bound ends of the ActivationUnit
  * rh_dice_fwd/bwd replaces: Dice.forward torch_rechub/basic/activation.py:15-25 (row-wise statistics over the neurons)
  *   x (N, C) contiguous, alpha (1,), eps; bwd writes gx (N, C) and per-block partial sums of d/d alpha into

@@ -650,3 +650,36 @@ def test_din_attention_ends_vs_reference_formula(B, L, D, strided):
     close(hd.grad, hr.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="g_hist")
     close(td.grad, tr.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="g_tgt")
     close(wd.grad, wr.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="g_w")
+
+
+@pytest.mark.parametrize("B,d,E", [(4096, 429, 4), (257, 45, 3), (5, 1, 1), (64, 1100, 2)])
+def test_cross_mix_and_v2_epilogues_vs_reference_formula(B, d, E):
+    """Epilogues of basic/layers.py:442-443 and :491-503 against the same expressions in float64 torch (autograd)."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + d + E)
+    x0, xl = torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+    uv = torch.randn(E, B, d, generator=g)
+    gate = torch.softmax(torch.randn(B, E, generator=g), dim=1)
+    bias = torch.randn(d, generator=g) * 0.3
+    gy = torch.randn(B, d, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (x0, xl, uv, gate, bias)]
+    r0, rl, ruv, rg, rb = ref_in
+    ref = ((r0.unsqueeze(0) * (ruv + rb.view(1, 1, d))) * rg.t().unsqueeze(2)).sum(0) + rl
+    ref.backward(gy.double())
+    hip_in = [t.to(dev()).requires_grad_(True) for t in (x0, xl, uv, gate, bias)]
+    out = ops.cross_mix_epilogue(*hip_in)
+    out.backward(gy.to(dev()))
+    close(out, ref.detach().numpy(), rtol=2e-5, atol_scale=2e-6, what="mix out")
+    for name, h, r in zip(("g_x0", "g_xl", "g_uv", "g_gate", "g_bias"), hip_in, ref_in):
+        close(h.grad, r.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what="mix " + name)
+    # CrossNetV2 epilogue: x0 * y + b + x
+    y = torch.randn(B, d, generator=g)
+    ref2_in = [t.double().requires_grad_(True) for t in (x0, y, bias, xl)]
+    ref2 = ref2_in[0] * ref2_in[1] + ref2_in[2] + ref2_in[3]
+    ref2.backward(gy.double())
+    hip2_in = [t.to(dev()).requires_grad_(True) for t in (x0, y, bias, xl)]
+    out2 = ops.cross_v2_epilogue(*hip2_in)
+    out2.backward(gy.to(dev()))
+    close(out2, ref2.detach().numpy(), rtol=1e-6, atol_scale=1e-6, what="v2 out")
+    for name, h, r in zip(("g_x0", "g_y", "g_b", "g_x"), hip2_in, ref2_in):
+        close(h.grad, r.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="v2 " + name)

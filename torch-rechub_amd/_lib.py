@@ -37,6 +37,10 @@ SIGNATURES = {
     "rh_cross_max_layers": [c_int],
     "rh_cross_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_i64, c_int, c_ptr, c_ptr],
+    "rh_cross_v2_epilogue_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
+    "rh_cross_v2_epilogue_bwd": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_cross_mix_epilogue_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_cross_mix_epilogue_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_dice_nblocks": [c_i64],
     "rh_dice_fwd": [c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr],
     "rh_dice_bwd": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr],

@@ -10,8 +10,8 @@
 | MLP              | :254-292                    | nn.Linear / BatchNorm1d / activation / Dropout (hipBLASLt: true dense contraction) |
 | FM               | :295-319                    | ops.fm kernel; DeepFM fuses it into the gather kernel |
 | CrossNetwork     | :390-420                    | ops.cross_network: one wavefront per sample, all layers in registers |
-| CrossNetV2       | :423-444                    | library GEMM + fused epilogue                          |
-| CrossNetMix      | :447-506                    | experts batched into 3 GEMMs per layer (was 150 mm per step) |
+| CrossNetV2       | :423-444                    | library GEMM + ONE fused Hadamard/bias/residual kernel (ops.cross_v2_epilogue) |
+| CrossNetMix      | :447-506                    | experts batched into 3 GEMMs per layer (was 150 mm per step) + ONE fused bias/Hadamard/gate-mix/residual kernel |
 
 Tables stay ``nn.Embedding`` modules inside ``embed_dict`` (checkpoint ABI:
 ``embedding.embed_dict.<feature>.weight``); kernels read them in place.
@@ -282,8 +282,8 @@ class CrossNetV2(nn.Module):
     def forward(self, x):
         ops.require_hip(x)
         x0 = x
-        for i in range(self.num_layers):
-            x = torch.addcmul(x + self.b[i], x0, self.w[i](x))
+        for i in range(self.num_layers):  # (d, d) GEMM on hipBLASLt, then ONE fused Hadamard + bias + residual pass
+            x = ops.cross_v2_epilogue(x0, self.w[i](x), self.b[i], x)
         return x
 
 
@@ -322,6 +322,10 @@ class CrossNetMix(nn.Module):
             v = v.view(B, E, r).transpose(0, 1)  # (E, B, r)
             v = torch.tanh(torch.bmm(v, C.transpose(1, 2)))  # (E, B, r): C_e v
             uv = torch.bmm(v, U.transpose(1, 2))  # (E, B, d): U_e v
-            expert = x0.unsqueeze(0) * (uv + self.bias[i].view(1, 1, d))  # (E, B, d)
-            xl = (expert * gate.t().unsqueeze(2)).sum(dim=0) + xl
+            if d <= 2048 and E <= 16:
+                # bias + Hadamard with x0 + gate-weighted expert mix + residual: one pass (csrc/crossmix.hip)
+                xl = ops.cross_mix_epilogue(x0, xl, uv, gate, self.bias[i].view(d))
+            else:
+                expert = x0.unsqueeze(0) * (uv + self.bias[i].view(1, 1, d))  # (E, B, d)
+                xl = (expert * gate.t().unsqueeze(2)).sum(dim=0) + xl
         return xl

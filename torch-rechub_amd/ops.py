@@ -660,3 +660,63 @@ def din_att_pool(weight, history):
 def din_dim_ok(d):
     q = d // 4
     return d % 4 == 0 and 1 <= q <= 32 and (q & (q - 1)) == 0
+
+
+# --------------------------------------------------------------------------------------------
+class _CrossV2Epilogue(torch.autograd.Function):
+    """out = x0 * y + b + x  (y = W_l x): Hadamard + bias + residual of one CrossNetV2 layer in one pass."""
+
+    @staticmethod
+    def forward(ctx, x0, y, b, x):
+        require_hip(x0, y, b, x)
+        x0, y, b, x = x0.contiguous(), y.contiguous(), b.contiguous(), x.contiguous()
+        B, d = x.shape
+        out = torch.empty_like(x)
+        _lib.call("rh_cross_v2_epilogue_fwd", _p(x0), _p(y), _p(b), _p(x), B, d, _p(out), _stream())
+        ctx.save_for_backward(x0, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, y = ctx.saved_tensors
+        B, d = x0.shape
+        g = g.contiguous()
+        g_x0 = torch.empty_like(x0)
+        g_y = torch.empty_like(y)
+        _lib.call("rh_cross_v2_epilogue_bwd", _p(x0), _p(y), _p(g), B, d, _p(g_x0), _p(g_y), _stream())
+        return g_x0, g_y, g.sum(0), g
+
+
+def cross_v2_epilogue(x0, y, b, x):
+    return _CrossV2Epilogue.apply(x0, y, b, x)
+
+
+class _CrossMixEpilogue(torch.autograd.Function):
+    """out = sum_e gate_e * x0 * (uv_e + bias) + xl: bias + Hadamard + gated expert mix + residual in one pass."""
+
+    @staticmethod
+    def forward(ctx, x0, xl, uv, gate, bias):
+        require_hip(x0, xl, uv, gate, bias)
+        x0, xl, uv, gate, bias = x0.contiguous(), xl.contiguous(), uv.contiguous(), gate.contiguous(), bias.contiguous()
+        E, B, d = uv.shape
+        out = torch.empty_like(x0)
+        _lib.call("rh_cross_mix_epilogue_fwd", _p(x0), _p(xl), _p(uv), _p(gate), _p(bias), B, d, E, _p(out), _stream())
+        ctx.save_for_backward(x0, uv, gate, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, uv, gate, bias = ctx.saved_tensors
+        E, B, d = uv.shape
+        g = g.contiguous()
+        g_x0 = torch.empty_like(x0)
+        g_uv = torch.empty_like(uv)
+        g_gate = torch.empty_like(gate)
+        _lib.call("rh_cross_mix_epilogue_bwd", _p(x0), _p(uv), _p(gate), _p(bias), _p(g), B, d, E, _p(g_x0), _p(g_uv),
+                  _p(g_gate), _stream())
+        g_bias = (g * x0 * gate.sum(dim=1, keepdim=True)).sum(0)
+        return g_x0, g, g_uv, g_gate, g_bias
+
+
+def cross_mix_epilogue(x0, xl, uv, gate, bias):
+    return _CrossMixEpilogue.apply(x0, xl, uv, gate, bias)
