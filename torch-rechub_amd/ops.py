@@ -99,22 +99,35 @@ def check_errors(device=None):
 
 
 class _DescCache(object):
-    """Tiny LRU of host tuples -> device int64 descriptor tensors (no upload when pointers repeat)."""
+    """LRU of host tuples -> device int64 descriptor tensors (no upload when pointers repeat).
 
-    def __init__(self, cap=8):
+    An entry that was looked up while a hipGraph was being captured is PINNED: the graph keeps reading that device
+    tensor on every replay, so it must never be evicted (freed) afterwards."""
+
+    def __init__(self, cap=1024):
         self.cap = cap
         self.d = OrderedDict()
+        self.pinned = {}
 
     def get(self, key, device):
         k = (key, device)
+        t = self.pinned.get(k)
+        if t is not None:
+            return t
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         t = self.d.get(k)
         if t is None:
+            if capturing:
+                raise RuntimeError("torch_rechub_amd: a descriptor table would have to be uploaded during hipGraph "
+                                   "capture; run the step eagerly once with the same (static) buffers first")
             t = torch.tensor(key, dtype=torch.int64).to(device)
             self.d[k] = t
             if len(self.d) > self.cap:
                 self.d.popitem(last=False)
         else:
             self.d.move_to_end(k)
+        if capturing:
+            self.pinned[k] = t
         return t
 
 
@@ -126,9 +139,9 @@ class EmbedCall(object):
     idx     : index tensors per field, shape (B,), int64 or int32, on the device
     dense   : dense value tensors (B,), float32, appended after the sparse block
     """
-    _fcache = _DescCache(16)
-    _icache = _DescCache(16)
-    _dcache = _DescCache(16)
+    _fcache = _DescCache()
+    _icache = _DescCache()
+    _dcache = _DescCache()
 
     def __init__(self, weights, pads, idx, dense=(), want_fm=False, want_lr=False, slots=None, width=None,
                  field_split=0, samples_per_block=0):
