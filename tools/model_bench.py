@@ -86,15 +86,21 @@ def main():
         trainer, x, y = build(name, dev, a.batch, a.scale)
         trainer.model.train()
         trainer.optimizer.sync_hyper()
-        for _ in range(5):
+        print(f"  [{name}] built", flush=True)
+        for i in range(5):
             trainer.train_step(x, y)
+            if os.environ.get("MB_SYNC"):
+                torch.cuda.synchronize()
+                print(f"  [{name}] warm step {i} ok", flush=True)
         torch.cuda.synchronize()
+        print(f"  [{name}] warm-up done", flush=True)
         t0 = time.perf_counter()
         for _ in range(a.steps):
             trainer.train_step(x, y)
         trainer.flush()
         torch.cuda.synchronize()
         eager = (time.perf_counter() - t0) / a.steps
+        print(f"  [{name}] eager done {eager * 1e3:.3f} ms/step", flush=True)
         # hipGraph replay of the same step on the same static batch
         graph_ms = float("nan")
         try:
@@ -107,9 +113,11 @@ def main():
             gph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gph):
                 trainer.train_step(x, y)
+            print(f"  [{name}] captured", flush=True)
             for _ in range(3):
                 gph.replay()
             torch.cuda.synchronize()
+            print(f"  [{name}] replays ok", flush=True)
             t0 = time.perf_counter()
             for _ in range(a.steps):
                 gph.replay()

@@ -51,6 +51,13 @@ class MatchTrainer(CTRTrainer):
     def _prepare_target(self, y):
         return y.float() if self.mode == 0 else y.long()
 
+    def _zero_targets(self, n):
+        t = getattr(self, "_targets", None)
+        if t is None or t.numel() != n:
+            t = torch.zeros(n, dtype=torch.long, device=self.device)
+            self._targets = t  # class 0 = the positive logit; constant, so kept out of the per-step work
+        return t
+
     def _compute_loss(self, x_dict, y):
         if self.in_batch_neg:
             user_embedding = self.model.user_tower(x_dict)
@@ -71,8 +78,7 @@ class MatchTrainer(CTRTrainer):
             if self.mode == 1:
                 loss = self.criterion(logits[:, 0], logits[:, 1:], in_batch_neg=True)
             else:
-                targets = torch.zeros(logits.size(0), dtype=torch.long, device=self.device)
-                loss = self.criterion(logits, targets)
+                loss = self.criterion(logits, self._zero_targets(logits.size(0)))
         elif self.mode == 1:
             pos_score, neg_score = self.model(x_dict)
             loss = self.criterion(pos_score, neg_score)

@@ -11,6 +11,21 @@ SURVEY 3.5).  Here both modes are ONE batched device op over the (B, B) score ma
 """
 import torch
 
+_DIAG = {}
+
+
+def _diag_mask(n, device):
+    """Cached (n, n) boolean identity: built once, outside any hipGraph (an in-graph torch.eye re-creates it from a
+    memset node on every replay)."""
+    key = (n, str(device))
+    m = _DIAG.get(key)
+    if m is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("in-batch sampler: run one eager step before capturing a hipGraph")
+        m = torch.eye(n, dtype=torch.bool, device=device)
+        _DIAG[key] = m
+    return m
+
 
 def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, generator=None):
     if scores.dim() != 2:
@@ -22,7 +37,7 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
     if neg_ratio is None or neg_ratio <= 0 or neg_ratio > max_neg:
         neg_ratio = max_neg
     device = scores.device
-    diag = torch.eye(batch_size, dtype=torch.bool, device=device)
+    diag = _diag_mask(batch_size, device)
     if hard_negative:
         keys = scores.detach().masked_fill(diag, float("-inf"))
     else:
