@@ -275,6 +275,11 @@ int rh_batch_gather(const int64_t* perm, const int64_t* pos, int64_t N, int B, c
                     float* dense_out, float* label_out, void* stream);
 int rh_batch_advance(int64_t* pos, int64_t B, int64_t N, void* stream);
 
+/* In-batch negative sampling: out (B, K) int64, row i = K distinct columns drawn uniformly from {0..B-1} \ {i}.
+ * replaces: the per-row randperm loop of inbatch_negative_sampling, torch_rechub/utils/match.py:136-145
+ * rng (device int64 [2]): seed, call counter; bump the counter after the call with rh_batch_advance(rng + 1, 1, 0). */
+int rh_inbatch_sample(const int64_t* rng, int B, int K, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,53 @@ __global__ void batch_advance_kernel(int64_t* pos, int64_t B, int64_t N) {
   }
 }
 
+// In-batch negative sampling: row i draws K distinct columns uniformly from {0..B-1} \ {i} (Floyd's algorithm, one
+// thread per row, membership bitmap of the row in LDS).  Counter-based hash RNG (seed, call counter, row, draw): no
+// library RNG state, hipGraph-replayable; the caller bumps the counter with rh_batch_advance(rng + 1, 1, 0).
+// Reference: inbatch_negative_sampling torch_rechub/utils/match.py:136-145 (Python loop of randperm per row).
+static __device__ __forceinline__ uint32_t sample_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed + ctr * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+__global__ void inbatch_sample_kernel(const int64_t* __restrict__ rng, int B, int K, int words_per_row,
+                                      int64_t* __restrict__ out) {
+  extern __shared__ uint32_t bitmap[];  // [rows per block][words_per_row]
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t* mine = bitmap + (size_t)threadIdx.x * words_per_row;
+  for (int w = 0; w < words_per_row; ++w) mine[w] = 0u;
+  if (row >= B) return;
+  const uint64_t seed = (uint64_t)rng[0], ctr = (uint64_t)rng[1];
+  const int N = B - 1;  // candidates: every column but the row's own
+  int pos = 0;
+  for (int j = N - K; j < N; ++j) {
+    const uint32_t t = sample_hash(seed, ctr, (uint64_t)row * (uint64_t)K + (uint64_t)pos) % (uint32_t)(j + 1);
+    const bool taken = (mine[t >> 5] >> (t & 31)) & 1u;
+    const uint32_t pick = taken ? (uint32_t)j : t;
+    mine[pick >> 5] |= 1u << (pick & 31);
+    out[(int64_t)row * K + pos] = (int64_t)pick + (pick >= (uint32_t)row ? 1 : 0);
+    ++pos;
+  }
+}
+
 }  // namespace
+
+extern "C" int rh_inbatch_sample(const int64_t* rng, int B, int K, int64_t* out, void* stream) {
+  RH_REQUIRE(rng && out, RH_E_BADARG, "rh_inbatch_sample: null pointer");
+  RH_REQUIRE(B >= 2 && K >= 1 && K <= B - 1, RH_E_BADARG, "rh_inbatch_sample: need 1 <= K <= B-1 (B=%d K=%d)", B, K);
+  const int words = (B + 31) / 32;
+  int rows = 64;
+  while (rows > 1 && (size_t)rows * words * 4 > 48 * 1024) rows /= 2;
+  RH_REQUIRE((size_t)rows * words * 4 <= 64 * 1024, RH_E_UNSUPPORTED, "rh_inbatch_sample: batch %d too large", B);
+  const unsigned grid = (unsigned)((B + rows - 1) / rows);
+  hipLaunchKernelGGL(inbatch_sample_kernel, dim3(grid), dim3(rows), (size_t)rows * words * 4,
+                     reinterpret_cast<hipStream_t>(stream), rng, B, K, words, out);
+  RH_LAUNCH_CHECK("rh_inbatch_sample");
+  return 0;
+}
 
 extern "C" int rh_batch_gather(const int64_t* perm, const int64_t* pos, int64_t N, int B, const int64_t* sparse,
                                int F, const float* dense, int ND, const float* label, int64_t* sparse_out,

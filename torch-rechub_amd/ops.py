@@ -733,3 +733,21 @@ class _CrossMixEpilogue(torch.autograd.Function):
 
 def cross_mix_epilogue(x0, xl, uv, gate, bias):
     return _CrossMixEpilogue.apply(x0, xl, uv, gate, bias)
+
+
+# --------------------------------------------------------------------------------------------
+_sample_rng = {}
+
+
+def inbatch_sample(batch_size, k, device, seed=None):
+    """(B, K) int64: per row K distinct in-batch negatives (never the row itself), uniformly at random; hipGraph-safe."""
+    key = (str(device), seed)
+    st = _sample_rng.get(key)
+    if st is None:
+        s = torch.initial_seed() if seed is None else int(seed)
+        st = torch.tensor([s & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(device)
+        _sample_rng[key] = st
+    out = torch.empty((batch_size, k), dtype=torch.int64, device=device)
+    _lib.call("rh_inbatch_sample", _p(st), batch_size, k, _p(out), _stream())
+    _lib.call("rh_batch_advance", ctypes.c_void_p(st.data_ptr() + 8), 1, 0, _stream())
+    return out

@@ -4,10 +4,11 @@ The reference loops ``for i in range(batch_size)`` in Python, launching a randpe
 SURVEY 3.5).  Here both modes are ONE batched device op over the (B, B) score matrix:
   * hard negatives: top-k of the scores with the diagonal masked to -inf (same indices as the reference: its
     known-answer test [[1,2,3],[4,5,6],[7,8,0]] -> [2,2,1] holds);
-  * random negatives: top-k of i.i.d. uniform keys with the diagonal masked, i.e. a uniformly random k-subset of the
-    other B-1 columns in random order — the distribution of ``candidates[randperm(B-1)[:k]]`` (the exact indices depend
-    on how the RNG stream is consumed, which the reference does not pin: its tests check shape, no self index and seed
-    sensitivity).
+  * random negatives: a uniformly random k-subset of the other B-1 columns per row — on the GPU one HIP launch
+    (``rh_inbatch_sample``: Floyd's algorithm per row, counter-based RNG, hipGraph-replayable), on CPU tensors top-k of
+    i.i.d. uniform keys.  Same distribution of the SET as ``candidates[randperm(B-1)[:k]]`` (the loss does not depend on
+    the order); the exact indices depend on how an RNG stream is consumed, which the reference does not pin: its tests
+    check shape, no self index and seed sensitivity.
 """
 import torch
 
@@ -40,8 +41,13 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
     diag = _diag_mask(batch_size, device)
     if hard_negative:
         keys = scores.detach().masked_fill(diag, float("-inf"))
-    else:
-        keys = torch.rand((batch_size, batch_size), device=device, generator=generator).masked_fill(diag, -1.0)
+        return torch.topk(keys, k=neg_ratio, dim=1).indices
+    if scores.is_cuda and batch_size <= 65536:
+        # HIP sampler (Floyd's algorithm per row, counter-based RNG): one launch, replayable from a hipGraph
+        from .. import ops
+        seed = None if generator is None else generator.initial_seed()
+        return ops.inbatch_sample(batch_size, neg_ratio, device, seed)
+    keys = torch.rand((batch_size, batch_size), device=device, generator=generator).masked_fill(diag, -1.0)
     return torch.topk(keys, k=neg_ratio, dim=1).indices
 
 
