@@ -120,6 +120,30 @@ class KernelTimer(object):
         return {n: (sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None) for n, ev in self.events.items()}
 
 
+def gather_sweep(model, sparse_feas, dense_feas, vocabs, device, batches=(4096, 16384, 65536), iters=50):
+    """rh_embed_fwd (gather + FM + LR + dense concat) alone at several batch sizes: avg launch time and achieved GB/s."""
+    from torch_rechub_amd import ops
+    out = {}
+    g = torch.Generator(device=device).manual_seed(7)
+    w, b = model.linear.fc.weight, model.linear.fc.bias
+    with torch.no_grad():
+        for B in batches:
+            x = {f.name: torch.randint(0, v, (B,), device=device, generator=g) for f, v in zip(sparse_feas, vocabs)}
+            x.update({f.name: torch.rand(B, device=device, generator=g) for f in dense_feas})
+            call = model.embedding.make_call(x, sparse_feas, dense_feas, want_fm=True, want_lr=True)
+            for _ in range(5):
+                ops.fused_embedding(call, w, b)
+            timer = KernelTimer(["rh_embed_fwd"])
+            timer.install()
+            for _ in range(iters):
+                ops.fused_embedding(call, w, b)
+            ms = timer.mean_ms()["rh_embed_fwd"]
+            timer.remove()
+            gbs = FWD_BYTES_PER_SAMPLE * B / (ms * 1e-3) / 1e9
+            out[str(B)] = {"avg_ms": round(ms, 5), "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +233,7 @@ def main():
 
     # ---- per-kernel HIP-event timing of the same step (eager launches, same stream, after the headline loop) ----
     kernels = {}
+    gsweep = None
     if rank == 0:
         names = ["rh_embed_fwd", "rh_embed_bwd", "rh_adam_dense", "rh_adam_lazy_touched", "rh_adam_lazy_sweep",
                  "rh_batch_gather", "rh_embed_scatter_rows"]
@@ -242,6 +267,9 @@ def main():
             gbs = alg[n] / (t_ms * 1e-3) / 1e9
             kernels[n] = {"avg_ms": round(t_ms, 5), "algorithmic_bytes": alg[n], "achieved_GBps": round(gbs, 1),
                           "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        # the north-star kernel over batch sizes (same tables, same stream, HIP events): its bandwidth regime starts
+        # where the launch is no longer three dependent memory round trips long
+        gsweep = gather_sweep(model, sparse_feas, dense_feas, vocabs, device)
     elif world > 1:
         for _ in range(max(5, min(args.steps, 30))):  # keep the collectives of the profiling pass matched
             eager_step()
@@ -301,6 +329,7 @@ def main():
             },
             "roofline": roofline,
             "kernels": kernels,
+            "gather_kernel_sweep": gsweep,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -113,6 +113,17 @@ def main():
         n = sum(t.numel() for t in tables)
         us = timeit(opt.step_tables, 20, warm=3)
         print(f"adam dense {n} elems {us:9.1f} us  {28 * n / us / 1e3:7.0f} GB/s (alg 28 B/elem)", flush=True)
+        for k in (16, 32, 64):
+            for grid in (1024, 2048, 4096, 8192):
+                lazy = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5, lazy_k=k)
+                lazy.sync_hyper()
+                _lib.call("rh_set_tuning", 2, grid)
+                for _ in range(k + 2):  # reach the steady state: every swept row lags exactly k steps
+                    lazy.step_tables()
+                us = timeit(lazy.step_tables, 40, warm=0)
+                print(f"adam lazy  K={k:3d} grid={grid:5d} {us:9.1f} us per step (sweep only, no touched rows)", flush=True)
+                del lazy
+        _lib.call("rh_set_tuning", 2, 0)
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@
 #define RH_BLOCK 256
 
 void rh_set_error(const char* fmt, ...);
+extern "C" int rh_optim_set_tuning(int key, int value);
 
 #define RH_REQUIRE(cond, code, ...)  \
   do {                               \

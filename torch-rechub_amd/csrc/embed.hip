@@ -445,6 +445,7 @@ extern "C" int rh_set_tuning(int key, int value) {
     g_wide_atomics = value != 0;
     return 0;
   }
+  if (rh_optim_set_tuning(key, value) == 0) return 0;
   rh_set_error("rh_set_tuning: unknown key %d", key);
   return RH_E_BADARG;
 }

@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int kMaxTensors = 128;
+int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 2048 workgroups)
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -163,42 +164,64 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
   const int T = a.T;
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
-  for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += gridDim.x) {
+
+  // One unit of work = one table row of one virtual block.  The loads of unit n+1 are issued before unit n is
+  // replayed, so the (long, pure-ALU) replay of one row hides the HBM latency of the next.
+  struct Unit {
+    float *p, *g, *m, *v;
+    int* last;
+    int64_t r;
+    int old;
+    bool live, with_g;
+    float4 P, M, V, G;
+  };
+  auto fetch = [&](int64_t vb, Unit& u) {
+    u.live = false;
+    if (vb >= a.total_vblocks) return;
     int lo = 0, hi = T;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (a.vb_prefix[mid] <= vb) lo = mid; else hi = mid;
     }
     const int ti = lo;
-    float* p = reinterpret_cast<float*>(a.ldesc[0 * T + ti]);
-    float* g = reinterpret_cast<float*>(a.ldesc[1 * T + ti]);
-    float* m = reinterpret_cast<float*>(a.ldesc[2 * T + ti]);
-    float* v = reinterpret_cast<float*>(a.ldesc[3 * T + ti]);
-    int* last = reinterpret_cast<int*>(a.ldesc[4 * T + ti]);
+    u.p = reinterpret_cast<float*>(a.ldesc[0 * T + ti]);
+    u.g = reinterpret_cast<float*>(a.ldesc[1 * T + ti]);
+    u.m = reinterpret_cast<float*>(a.ldesc[2 * T + ti]);
+    u.v = reinterpret_cast<float*>(a.ldesc[3 * T + ti]);
+    u.last = reinterpret_cast<int*>(a.ldesc[4 * T + ti]);
     const int64_t rows = a.ldesc[5 * T + ti];
     const int64_t K = a.ldesc[6 * T + ti];
     const int64_t w = a.flush ? rows : a.ldesc[7 * T + ti];
     const int64_t wstart = a.flush ? 0 : ((int64_t)(t - 1) % K) * w;
     const int64_t local = (vb - a.vb_prefix[ti]) * RPB + slot;
-    const int64_t r = wstart + local;
-    if (local >= w || r >= rows) continue;
-    const int old = gload<int>(last + r);
-    if (old >= t) continue;  // already stepped by the touched pass
-    const bool with_g = (K == 1);  // dense tables receive their gradient here; others had it applied when touched
-    float4 P = gload<float4>(p + r * D + q * 4);
-    float4 M = gload<float4>(m + r * D + q * 4);
-    float4 V = gload<float4>(v + r * D + q * 4);
-    float4 G = with_g ? gload<float4>(g + r * D + q * 4) : f4_zero();
-    for (int j = old + 1; j < t; ++j) {
-      const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
-      adam_f4(P, f4_zero(), M, V, h, A, E);
+    u.r = wstart + local;
+    if (local >= w || u.r >= rows) return;
+    u.old = gload<int>(u.last + u.r);
+    u.with_g = (K == 1);  // dense tables receive their gradient here; others had it applied when touched
+    u.P = gload<float4>(u.p + u.r * D + q * 4);
+    u.M = gload<float4>(u.m + u.r * D + q * 4);
+    u.V = gload<float4>(u.v + u.r * D + q * 4);
+    u.G = u.with_g ? gload<float4>(u.g + u.r * D + q * 4) : f4_zero();
+    u.live = true;
+  };
+  Unit cur, nxt;
+  fetch(blockIdx.x, cur);
+  for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += gridDim.x) {
+    fetch(vb + gridDim.x, nxt);
+    if (cur.live && cur.old < t) {  // old >= t: already stepped by the touched pass
+      for (int j = cur.old + 1; j < t; ++j) {
+        const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
+        adam_f4(cur.P, f4_zero(), cur.M, cur.V, h, A, E);
+      }
+      adam_f4(cur.P, cur.G, cur.M, cur.V, h, h.A, h.E);
+      gstore<float4>(cur.p + cur.r * D + q * 4, cur.P);
+      gstore<float4>(cur.m + cur.r * D + q * 4, cur.M);
+      gstore<float4>(cur.v + cur.r * D + q * 4, cur.V);
+      if (cur.with_g && (cur.G.x != 0.f || cur.G.y != 0.f || cur.G.z != 0.f || cur.G.w != 0.f))
+        gstore<float4>(cur.g + cur.r * D + q * 4, f4_zero());
+      if (q == 0) cur.last[cur.r] = t;
     }
-    adam_f4(P, G, M, V, h, h.A, h.E);
-    gstore<float4>(p + r * D + q * 4, P);
-    gstore<float4>(m + r * D + q * 4, M);
-    gstore<float4>(v + r * D + q * 4, V);
-    if (with_g && (G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)) gstore<float4>(g + r * D + q * 4, f4_zero());
-    if (q == 0) last[r] = t;
+    cur = nxt;
   }
 }
 
@@ -278,8 +301,10 @@ int launch_sweep(LazySweepArgs& a, const int64_t* h_rows, const int64_t* h_windo
   for (int t = a.T + 1; t <= kMaxTensors; ++t) a.vb_prefix[t] = a.vb_prefix[a.T];
   a.total_vblocks = a.vb_prefix[a.T];
   if (a.total_vblocks == 0) return 0;
+  // persistent-style grid: each workgroup walks several virtual blocks so the prefetch has something to overlap
   int64_t grid = a.total_vblocks;
-  if (grid > 256 * 32) grid = 256 * 32;
+  const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 8;
+  if (grid > cap) grid = cap;
   hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR>), dim3((unsigned)grid), dim3(RH_BLOCK), 0, s, a);
   return 0;
 }
@@ -331,6 +356,14 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_small_kernel(const AdamSmallArg
 }
 
 }  // namespace
+
+extern "C" int rh_optim_set_tuning(int key, int value) {
+  if (key == RH_TUNE_SWEEP_GRID) {
+    g_sweep_grid = value;
+    return 0;
+  }
+  return RH_E_BADARG;
+}
 
 extern "C" int rh_adam_prepare(double* hyper, int64_t* step, float* ring, int ring_size, void* stream) {
   RH_REQUIRE(hyper != nullptr && step != nullptr, RH_E_BADARG, "rh_adam_prepare: null pointer");
