@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int kMaxTensors = 128;
+constexpr int kMaxRing = 1024;  // entries of the (A, E) ring kept in LDS by the lazy sweep
 int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 2048 workgroups)
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
@@ -164,6 +165,11 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
   const int T = a.T;
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
+  // The per-step (A, E) ring lives in LDS for the replay loop: a global load there would make every s_waitcnt vmcnt
+  // also wait for the prefetched rows of the next unit (vmcnt retires in order) and serialise memory behind the ALU.
+  __shared__ float ring_s[2 * kMaxRing];
+  for (int i = threadIdx.x; i < 2 * (a.ring_mask + 1); i += RH_BLOCK) ring_s[i] = a.ring[i];
+  __syncthreads();
 
   // One unit of work = one table row of one virtual block.  The loads of unit n+1 are issued before unit n is
   // replayed, so the (long, pure-ALU) replay of one row hides the HBM latency of the next.
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     fetch(vb + gridDim.x, nxt);
     if (cur.live && cur.old < t) {  // old >= t: already stepped by the touched pass
       for (int j = cur.old + 1; j < t; ++j) {
-        const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
+        const float A = ring_s[2 * (j & a.ring_mask)], E = ring_s[2 * (j & a.ring_mask) + 1];
         adam_f4(cur.P, f4_zero(), cur.M, cur.V, h, A, E);
       }
       adam_f4(cur.P, cur.G, cur.M, cur.V, h, h.A, h.E);
@@ -408,7 +414,8 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
                                   const double* hyper, const float* ring, int ring_size, int flush, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring, RH_E_BADARG, "rh_adam_lazy_sweep: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
-  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0, RH_E_BADARG, "rh_adam_lazy_sweep: ring_size");
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
+             "rh_adam_lazy_sweep: ring_size must be a power of two <= %d", kMaxRing);
   LazySweepArgs a;
   a.ldesc = ldesc;
   a.hyper = hyper;
