@@ -14,7 +14,7 @@ namespace {
 
 constexpr int kMaxTensors = 128;
 constexpr int kMaxRing = 1024;  // entries of the (A, E) ring kept in LDS by the lazy sweep
-int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 2048 workgroups)
+int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workgroups, the measured best)
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -309,7 +309,7 @@ int launch_sweep(LazySweepArgs& a, const int64_t* h_rows, const int64_t* h_windo
   if (a.total_vblocks == 0) return 0;
   // persistent-style grid: each workgroup walks several virtual blocks so the prefetch has something to overlap
   int64_t grid = a.total_vblocks;
-  const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 8;
+  const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
   if (grid > cap) grid = cap;
   hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR>), dim3((unsigned)grid), dim3(RH_BLOCK), 0, s, a);
   return 0;
