@@ -25,6 +25,11 @@ for s in $STAGES; do
                python tools/prof_summary.py "$OUT/pmc_$c" --pmc $c > "$OUT/pmc_${c}_summary.txt" 2>&1; head -30 "$OUT/pmc_${c}_summary.txt"
                find "$OUT/pmc_$c" -name '*.csv' -size +20M -delete
              done;;
+    pmcprobe) for c in FETCH_SIZE WRITE_SIZE; do
+               (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/probe_$c" -o probe -- python "$OLDPWD/tools/pmc_probe.py" > /dev/null 2> "$OLDPWD/$OUT/probe_$c.err"); echo "probe $c rc=$?"
+               python tools/prof_summary.py "$OUT/probe_$c" --pmc $c --tail 20 > "$OUT/probe_${c}_summary.txt" 2>&1; grep -E "rechub|adam_dense|kernel " "$OUT/probe_${c}_summary.txt"
+               find "$OUT/probe_$c" -name '*.csv' -size +5M -delete
+             done;;
     kbench)  timeout 600 python tools/kbench.py ${KBENCH_ARGS:-} > "$OUT/kbench.log" 2>&1; echo "rc=$?"; cat "$OUT/kbench.log";;
     *) echo "unknown stage $s";;
   esac

@@ -22,19 +22,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
     ap.add_argument("--pmc", default=None)
+    ap.add_argument("--tail", type=int, default=0, help="with --pmc: average only the LAST n dispatches of each kernel")
     a = ap.parse_args()
     if a.pmc:
         files = glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             sys.exit("no counter_collection.csv under " + a.dir)
-        acc = defaultdict(lambda: [0, 0.0])
+        vals = defaultdict(list)
         for f in files:
             for row in csv.DictReader(open(f)):
                 if row.get("Counter_Name") != a.pmc:
                     continue
-                k = short(row["Kernel_Name"])
-                acc[k][0] += 1
-                acc[k][1] += float(row["Counter_Value"])
+                vals[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+        acc = {}
+        for k, v in vals.items():
+            if a.tail:
+                v = v[-a.tail:]
+            acc[k] = [len(v), sum(v)]
         print(f"# rocprofv3 --pmc {a.pmc}: mean counter value per dispatch (raw counter units)")
         print(f"{'kernel':60s} {'dispatches':>10s} {'mean':>16s}")
         for k, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:25]:
