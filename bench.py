@@ -287,6 +287,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": None,
                         "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"]}
+            if dominant == "rh_adam_lazy_sweep" and args.lazy_k == 32 and args.vocab_scale == 1.0:
+                # measured with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel in this
+                # configuration (2*FETCH + WRITE, gfx950 correction, calibrated on rh_adam_dense): profiles/r01_pmc_traffic.md
+                roofline["traffic"] = 421.4e6
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
             if dominant == "rh_adam_lazy_sweep":
                 roofline["note"] = ("blocked-lazy exact Adam: this launch moves 1/K of the dense pass's bytes and replays "
                                     "the rest in registers (VALU-bound: %.0f M element-steps per launch, %.1f G "
