@@ -311,3 +311,23 @@ def test_dssm_towers_and_inbatch_sampling():
     assert torch.equal(logits[:, 0], torch.diagonal(scores)) and logits.shape == (48, 4)
     known = torch.tensor([[1., 2, 3], [4, 5, 6], [7, 8, 0]], device=dev())
     assert inbatch_negative_sampling(known, neg_ratio=1, hard_negative=True).flatten().tolist() == [2, 2, 1]
+
+
+def test_checkpoint_written_on_gpu_loads_into_the_reference_layout():
+    """model.pth from the HIP trainer -> strict load into the reference's module layout (oracle/cpu_port.PortDeepFM,
+    pinned key-for-key to the reference in tests/test_oracle_golden.py) -> same predictions on CPU."""
+    from oracle.cpu_port import PortDeepFM
+    from torch_rechub_amd.trainers import CTRTrainer
+    gold, model = load_model("deepfm_tutorial")
+    batches = [golden_batch(gold, i) for i in range(3)]
+    trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, device="cuda:0", show_progress=False)
+    trainer.train_one_epoch(batches)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    vocabs = {f"C{i + 1}": sd[f"embedding.embed_dict.C{i + 1}.weight"].shape[0] for i in range(26)}
+    port = PortDeepFM(vocabs, [f"I{i + 1}" for i in range(13)], dims=(32, 16), dropout=0.0)
+    port.load_state_dict(sd)  # strict: same keys, same shapes
+    port.eval()
+    model.eval()
+    x, _ = batches[0]
+    with torch.no_grad():
+        np.testing.assert_allclose(model(to_dev(x)).cpu().numpy(), port(x).numpy(), rtol=1e-5, atol=2e-6)

@@ -45,6 +45,22 @@ class PredictDataset(Dataset):
         return len(self.x[list(self.x.keys())[0]])
 
 
+class MatchDataGenerator(object):
+    """Loaders for two-tower training / retrieval evaluation (API mirror of torch_rechub/utils/data.py:41-58)."""
+
+    def __init__(self, x, y=[]):
+        super().__init__()
+        self.dataset = TorchDataset(x, y) if len(y) != 0 else PredictDataset(x)
+
+    def generate_dataloader(self, x_test_user, x_all_item, batch_size, num_workers=8):
+        train_dataloader = DataLoader(self.dataset, batch_size=batch_size, shuffle=True, num_workers=num_workers)
+        test_dataloader = DataLoader(PredictDataset(x_test_user), batch_size=batch_size, shuffle=False,
+                                     num_workers=num_workers)
+        item_dataloader = DataLoader(PredictDataset(x_all_item), batch_size=batch_size, shuffle=False,
+                                     num_workers=num_workers)
+        return train_dataloader, test_dataloader, item_dataloader
+
+
 class DataGenerator(object):
     """Host loader factory with the reference's signature and split semantics (utils/data.py:61-83)."""
 
