@@ -683,3 +683,100 @@ def test_cross_mix_and_v2_epilogues_vs_reference_formula(B, d, E):
     close(out2, ref2.detach().numpy(), rtol=1e-6, atol_scale=1e-6, what="v2 out")
     for name, h, r in zip(("g_x0", "g_y", "g_b", "g_x"), hip2_in, ref2_in):
         close(h.grad, r.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="v2 " + name)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# csrc/linear.hip: split-batch MFMA weight gradient, fused output head, BCE
+@pytest.mark.parametrize("B,N,K,pad", [(4096, 256, 429, 0), (4096, 128, 256, 0), (100, 1, 7, 0), (37, 70, 130, 3),
+                                       (1, 5, 3, 0), (8191, 64, 64, 0), (50000, 36, 64, 0)])
+def test_linear_wgrad_vs_float64(B, N, K, pad):
+    """dW = g^T x, db = colsum(g): f32 MFMA == k-ordered fmaf chain, so only the summation order differs from float64."""
+    from torch_rechub_amd import ops
+    gen = torch.Generator().manual_seed(B + N + K)
+    g = torch.randn(B, N, generator=gen)
+    xfull = torch.randn(B, K + pad, generator=gen)
+    gd, xd = g.to(dev()), xfull.to(dev())[:, :K]  # row stride K + pad
+    dW, db = ops.linear_wgrad(gd, xd)
+    ref_w = g.double().t() @ xfull[:, :K].double()
+    ref_b = g.double().sum(0)
+    scale = float(np.sqrt(B))
+    np.testing.assert_allclose(dW.cpu().numpy(), ref_w.numpy(), rtol=1e-5, atol=3e-6 * scale, err_msg="dW")
+    np.testing.assert_allclose(db.cpu().numpy(), ref_b.numpy(), rtol=1e-5, atol=3e-6 * scale, err_msg="db")
+    # deterministic (fixed split order) and re-entrant (the election counters are left zeroed)
+    dW2, db2 = ops.linear_wgrad(gd, xd)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    dW3, none = ops.linear_wgrad(gd, xd, want_bias=False)
+    assert none is None and torch.equal(dW, dW3)
+    assert int(ops._counters(dev()).abs().sum()) == 0
+
+
+def test_linear_function_matches_torch_autograd():
+    from torch_rechub_amd import ops
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(429, 256).to(dev())
+    x0 = torch.randn(4096, 429, device=dev())
+    gy = torch.randn(4096, 256, device=dev())
+    xa = x0.clone().requires_grad_(True)
+    lin(xa).backward(gy)
+    want = (xa.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin.zero_grad()
+    xb = x0.clone().requires_grad_(True)
+    out = ops.linear(xb, lin.weight, lin.bias)
+    assert torch.equal(out, lin(x0))
+    out.backward(gy)
+    assert torch.equal(xb.grad, want[0])
+    close(lin.weight.grad, want[1].cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="dW")
+    close(lin.bias.grad, want[2].cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="db")
+
+
+@pytest.mark.parametrize("B,K,bias,nextra", [(4096, 128, True, 2), (5, 4, True, 0), (1, 1024, False, 1), (777, 36, True, 1),
+                                             (70000, 64, True, 2)])
+def test_head_sigmoid_vs_autograd(B, K, bias, nextra):
+    from torch_rechub_amd import ops
+    gen = torch.Generator().manual_seed(B + K)
+    h0 = torch.randn(B, K, generator=gen).to(dev())
+    lin = torch.nn.Linear(K, 1, bias=bias).to(dev())
+    ex0 = [torch.randn(B, 1, generator=gen).to(dev()) for _ in range(nextra)]
+    gy = torch.randn(B, generator=gen).to(dev())
+
+    def run(fused):
+        lin.zero_grad()
+        h = h0.clone().requires_grad_(True)
+        ex = [e.clone().requires_grad_(True) for e in ex0]
+        if fused:
+            y = ops.head_sigmoid(h, lin.weight, lin.bias, *ex)
+        else:
+            z = lin(h.double()) if False else lin(h)
+            for e in ex:
+                z = z + e
+            y = torch.sigmoid(z.squeeze(1))
+        y.backward(gy)
+        return [y.detach(), h.grad, lin.weight.grad.clone()] + ([lin.bias.grad.clone()] if bias else []) + [e.grad for e in ex]
+
+    got, want = run(True), run(False)
+    names = ["y", "g_h", "g_w"] + (["g_b"] if bias else []) + [f"g_e{i}" for i in range(nextra)]
+    for n, a, b in zip(names, got, want):
+        assert a.shape == b.shape, n
+        close(a, b.cpu().numpy(), rtol=2e-5, atol_scale=2e-6 * (np.sqrt(B) if n in ("g_w", "g_b") else 1.0), what=n)
+    assert int(ops._counters(dev()).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B", [1, 100, 4096, 100001])
+def test_bce_mean_vs_torch(B):
+    from torch_rechub_amd import ops
+    gen = torch.Generator().manual_seed(B)
+    y0 = torch.rand(B, generator=gen)
+    if B >= 100:
+        y0[:4] = torch.tensor([0.0, 1.0, 1e-30, 1.0 - 1e-7])  # the -100 clamp and the 1e-12 guard of the backward
+    t = (torch.rand(B, generator=gen) < 0.3).float().to(dev())
+    ya = y0.to(dev()).requires_grad_(True)
+    la = torch.nn.BCELoss()(ya, t)
+    la.backward()
+    yb = y0.to(dev()).requires_grad_(True)
+    assert ops.bce_ok(torch.nn.BCELoss(), yb, t)
+    lb = ops.bce_mean(yb, t)
+    (lb * 1.0).backward()
+    assert lb.shape == la.shape
+    close(lb, la.detach().cpu().numpy(), rtol=2e-6, what="bce")
+    close(yb.grad, ya.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-7, what="bce grad")
+    assert not ops.bce_ok(torch.nn.BCELoss(reduction="sum"), yb, t)

@@ -106,6 +106,33 @@ def main():
                                           ops._p(o), d, ops._p(None), ops._p(gx), d, 1, ops._p(part), ops._stream()),
                         args.iters)
             print(f"cross bwd B={B:6d} {us:8.2f} us  {3 * B * d * 4 / us / 1e3:7.0f} GB/s", flush=True)
+    if "mlp" in what:
+        # DeepFM MLP pieces at B = 4096: library GEMM backward vs the split-batch MFMA weight gradient, and the head
+        for (B, N, K) in [(4096, 256, 429), (4096, 128, 256), (16384, 256, 429)]:
+            gg = torch.randn(B, N, device=dev)
+            xx = torch.randn(B, K, device=dev)
+            us_lib = timeit(lambda: (gg.t().mm(xx), gg.sum(0)), args.iters)
+            us = timeit(lambda: ops.linear_wgrad(gg, xx), args.iters)
+            fl = 2.0 * B * N * K
+            print(f"wgrad B={B} N={N} K={K}: library mm+sum {us_lib:7.2f} us | rh_linear_wgrad {us:7.2f} us "
+                  f"({fl / us / 1e6:6.1f} TFLOP/s f32 MFMA)", flush=True)
+        B, K = 4096, 128
+        h = torch.randn(B, K, device=dev, requires_grad=True)
+        lin = torch.nn.Linear(K, 1).to(dev)
+        e0 = torch.randn(B, 1, device=dev, requires_grad=True)
+        e1 = torch.randn(B, 1, device=dev, requires_grad=True)
+        t = (torch.rand(B, device=dev) < 0.3).float()
+
+        def ref_head():
+            y = torch.sigmoid((lin(h) + e0 + e1).squeeze(1))
+            torch.nn.BCELoss()(y, t).backward()
+
+        def my_head():
+            y = ops.head_sigmoid(h, lin.weight, lin.bias, e0, e1)
+            ops.bce_mean(y, t).backward()
+
+        print(f"head+bce fwd+bwd B={B} K={K}: torch {timeit(ref_head, args.iters):7.2f} us | fused {timeit(my_head, args.iters):7.2f} us",
+              flush=True)
     if "adam" in what:
         from torch_rechub_amd.optim import TableAdam
         opt = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5)

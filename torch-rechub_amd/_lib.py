@@ -48,6 +48,14 @@ SIGNATURES = {
     "rh_din_att_input_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "rh_din_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_din_pool_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_linear_wgrad_workspace": [c_int, c_int, c_int],
+    "rh_linear_wgrad_tiles": [c_int, c_int],
+    "rh_linear_wgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_head_nblocks": [c_int],
+    "rh_head_fwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
+    "rh_head_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bce_fwd": [c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
+    "rh_bce_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bn_act_nchunks": [c_int],
     "rh_bn_relu_dropout_fwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_int, c_ptr,
                                c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -63,10 +71,11 @@ SIGNATURES = {
     "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],
     "rh_inbatch_sample": [c_ptr, c_int, c_int, c_ptr, c_ptr],
 }
-_RESTYPES = {"rh_last_error": ctypes.c_char_p}
+_RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctypes.c_int64}
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
-                    "rh_bn_act_nchunks", "rh_dice_nblocks"}
+                    "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles",
+                    "rh_head_nblocks"}
 
 ABI_VERSION = 1
 _lib = None

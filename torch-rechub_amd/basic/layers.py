@@ -227,21 +227,46 @@ class MLP(nn.Module):
                 x.dtype == torch.float32 and (x.shape[0] > 1 or not bn.training) and
                 not (torch.is_grad_enabled() and not bn.training and x.requires_grad))
 
-    def forward(self, x):
-        # [Linear, BatchNorm1d, ReLU, Dropout] blocks: library GEMM + ONE fused epilogue (csrc/mlp.hip);
-        # any other activation (dice, prelu, sigmoid ...) runs the modules as they are.
-        mods = list(self.mlp)
+    @staticmethod
+    def _linear(lin, x):
+        return ops.linear(x, lin.weight, lin.bias) if type(lin) is nn.Linear and ops.linear_ok(x, lin.weight) else lin(x)
+
+    def _run(self, mods, x):
+        # [Linear, BatchNorm1d, ReLU, Dropout] blocks: library GEMM + ONE fused epilogue (csrc/mlp.hip); any other
+        # activation (dice, prelu, sigmoid ...) runs the modules as they are.  Every Linear's weight / bias gradient
+        # is the split-batch MFMA kernel of csrc/linear.hip.
         i = 0
         while i < len(mods):
             if i + 3 < len(mods) + 0 and isinstance(mods[i], nn.Linear) and self._fusable(mods[i + 1], mods[i + 2],
                                                                                             mods[i + 3], x):
-                h = mods[i](x)
+                h = self._linear(mods[i], x)
                 x = ops.bn_relu_dropout(h, mods[i + 1], mods[i + 3].p if mods[i + 3].training else 0.0)
                 i += 4
+            elif isinstance(mods[i], nn.Linear):
+                x = self._linear(mods[i], x)
+                i += 1
             else:
                 x = mods[i](x)
                 i += 1
         return x
+
+    def forward(self, x):
+        return self._run(list(self.mlp), x)
+
+    def sigmoid_head(self, x, *extras):
+        """sigmoid((sum(extras) + mlp(x)).squeeze(1)): the output Linear(., 1), the wide / FM terms of DeepFM / WideDeep
+        (deepfm.py:39-43, widedeep.py:35-39) and the sigmoid as ONE kernel (ops.head_sigmoid) when the shapes allow."""
+        mods = list(self.mlp)
+        if mods and type(mods[-1]) is nn.Linear and mods[-1].out_features == 1:
+            h = self._run(mods[:-1], x)
+            if ops.head_ok(h, mods[-1], extras):
+                return ops.head_sigmoid(h, mods[-1].weight, mods[-1].bias, *extras)
+            y = self._linear(mods[-1], h)
+        else:
+            y = self._run(mods, x)
+        for e in reversed(extras):
+            y = e + y
+        return torch.sigmoid(y.squeeze(1))
 
 
 class FM(nn.Module):

@@ -1,0 +1,448 @@
+// The MLP's GEMM-shaped and head-shaped pieces that the library does badly at CTR batch sizes.
+//
+// Reference:
+//   MLP (Linear -> BN -> act -> Dropout)* -> Linear(., 1)   torch_rechub/basic/layers.py:254-292
+//   DeepFM / WideDeep head: sigmoid(y_linear + y_fm + y_deep)  models/ranking/deepfm.py:39-43, widedeep.py:35-39
+//   CTRTrainer loss: torch.nn.BCELoss()(y_pred, y)             trainers/ctr_trainer.py:62, :93-95
+//
+// 1. linear_wgrad: dW = g^T x (N_out x K_in, reduction over the batch B) and db = colsum(g).  At B = 4096 the output is
+//    tiny (256 x 429) and the reduction long, so the library's single-pass kernels leave most CUs idle (26 us each for
+//    two of them in the round-1 profile).  Here: split over the batch, f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 ==
+//    fmaf chain), operands straight from global memory -- for dW both fragments are batch-major, so lane (i, k) of the
+//    A/B fragment reads g[b0+k][n0+i] / x[b0+k][k0+i]: 128-byte coalesced rows, no LDS staging -- partial tiles to a
+//    workspace, and the LAST block of each output tile sums the partials in split order (deterministic).  db falls out
+//    of the A fragments for free.  Roofline: f32 MFMA (157 TF).
+// 2. head: y = sigmoid(h . w + b + e0 + e1), the (., 1) output layer fused with the wide/FM terms and the sigmoid; the
+//    backward gives g_z, g_h, g_w, g_b in ONE launch (three GEMMs with a dimension of 1, two adds, sigmoid and their
+//    backward kernels in the reference).  Roofline: HBM (h read once per direction).
+// 3. bce: mean binary cross entropy and its backward, log clamped at -100 like torch.nn.BCELoss.
+#include "common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 64;               // output tile edge per block (2 x 2 MFMA tiles of 32 x 32 per wave)
+constexpr int kWaves = RH_BLOCK / RH_WAVE;
+constexpr int kTileElems = kTile * kTile;
+constexpr int kPartStride = kTileElems + kTile;  // tile + its db slice
+constexpr int kUnroll = 4;              // row pairs in flight per wave
+
+struct WgradArgs {
+  const float* g;  // (B, N), row stride ldg
+  int64_t ldg;
+  const float* x;  // (B, K), row stride ldx
+  int64_t ldx;
+  int B, N, K;
+  int S, rows_per_split;
+  float* partial;      // (S, tiles, kPartStride)
+  unsigned* counters;  // (tiles,) zero on entry, zero on exit
+  float* dW;           // (N, K) contiguous
+  float* db;           // (N,) or null
+};
+
+__global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ float red[];  // kWaves * kPartStride floats
+  __shared__ int is_last;
+  const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
+  const int half = lane >> 5, c = lane & 31;
+  const int k0 = blockIdx.x * kTile, n0 = blockIdx.y * kTile, s = blockIdx.z;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x, tiles = gridDim.x * gridDim.y;
+  const int b_lo = s * a.rows_per_split;
+  const int b_hi = min(a.B, b_lo + a.rows_per_split);
+
+  // Columns past N / K are clamped to column 0: their products land in tile rows / columns that are never stored, so
+  // the inner loop needs no column masks (and stays free of exec-masked loads).
+  const int na0 = n0 + c, na1 = n0 + 32 + c, kb0 = k0 + c, kb1 = k0 + 32 + c;
+  const float* ga0 = a.g + (na0 < a.N ? na0 : 0) + (int64_t)half * a.ldg;
+  const float* ga1 = a.g + (na1 < a.N ? na1 : 0) + (int64_t)half * a.ldg;
+  const float* xb0 = a.x + (kb0 < a.K ? kb0 : 0) + (int64_t)half * a.ldx;
+  const float* xb1 = a.x + (kb1 < a.K ? kb1 : 0) + (int64_t)half * a.ldx;
+
+  v16f acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
+  float bs0 = 0.f, bs1 = 0.f;
+  float fa0[kUnroll], fa1[kUnroll], fb0[kUnroll], fb1[kUnroll];
+  float qa0[kUnroll], qa1[kUnroll], qb0[kUnroll], qb1[kUnroll];
+  // wave w takes row pairs w, w + 4, ...; one iteration = kUnroll pairs = 16 dword loads, fetched one iteration ahead
+  auto fetch = [&](int p, float* A0, float* A1, float* B0, float* B1) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = p + 2 * kWaves * u;
+      A0[u] = gload<float>(ga0 + r * a.ldg);
+      A1[u] = gload<float>(ga1 + r * a.ldg);
+      B0[u] = gload<float>(xb0 + r * a.ldx);
+      B1[u] = gload<float>(xb1 + r * a.ldx);
+    }
+  };
+  auto issue = [&](const float* A0, const float* A1, const float* B0, const float* B1) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B0[u], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B1[u], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B0[u], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B1[u], acc11, 0, 0, 0);
+      bs0 += A0[u];
+      bs1 += A1[u];
+    }
+  };
+  constexpr int kStep = 2 * kWaves * kUnroll;
+  int p = b_lo + 2 * wave;
+  const int last_full = b_hi - (2 * kWaves * (kUnroll - 1) + 2);  // p <= last_full: every row of the iteration exists
+  if (p <= last_full) {
+    fetch(p, fa0, fa1, fb0, fb1);
+    while (true) {  // ping-pong between the two register sets; the branch conditions are wave-uniform
+      if (p + kStep > last_full) {
+        issue(fa0, fa1, fb0, fb1);
+        p += kStep;
+        break;
+      }
+      fetch(p + kStep, qa0, qa1, qb0, qb1);
+      issue(fa0, fa1, fb0, fb1);
+      p += kStep;
+      if (p + kStep > last_full) {
+        issue(qa0, qa1, qb0, qb1);
+        p += kStep;
+        break;
+      }
+      fetch(p + kStep, fa0, fa1, fb0, fb1);
+      issue(qa0, qa1, qb0, qb1);
+      p += kStep;
+    }
+  }
+  // ragged end of the last split: fewer than kStep rows, guarded per row
+  for (; p < b_hi; p += 2 * kWaves) {
+    const bool ok = p + half < b_hi;
+    const int64_t r = ok ? p : b_lo;
+    const float m = ok ? 1.f : 0.f;
+    const float t0 = gload<float>(ga0 + r * a.ldg) * m, t1 = gload<float>(ga1 + r * a.ldg) * m;
+    const float t2 = gload<float>(xb0 + r * a.ldx) * m, t3 = gload<float>(xb1 + r * a.ldx) * m;
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t2, acc00, 0, 0, 0);
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t3, acc01, 0, 0, 0);
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t2, acc10, 0, 0, 0);
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t3, acc11, 0, 0, 0);
+    bs0 += t0;
+    bs1 += t1;
+  }
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* mine = red + wave * kPartStride;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    mine[row * kTile + c] = acc00[r];
+    mine[row * kTile + 32 + c] = acc01[r];
+    mine[(32 + row) * kTile + c] = acc10[r];
+    mine[(32 + row) * kTile + 32 + c] = acc11[r];
+  }
+  bs0 += __shfl_xor(bs0, 32);
+  bs1 += __shfl_xor(bs1, 32);
+  if (half == 0) {
+    mine[kTileElems + c] = bs0;
+    mine[kTileElems + 32 + c] = bs1;
+  }
+  __syncthreads();
+  const bool direct = a.S == 1;
+  float* part = a.partial + ((int64_t)s * tiles + tile) * kPartStride;
+  for (int e = threadIdx.x; e < kPartStride; e += RH_BLOCK) {
+    float v = red[e];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) v += red[w * kPartStride + e];
+    if (!direct) {
+      part[e] = v;
+    } else if (e < kTileElems) {
+      const int n = n0 + e / kTile, k = k0 + e % kTile;
+      if (n < a.N && k < a.K) a.dW[(int64_t)n * a.K + k] = v;
+    } else if (a.db && blockIdx.x == 0 && n0 + e - kTileElems < a.N) {
+      a.db[n0 + e - kTileElems] = v;
+    }
+  }
+  if (direct) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(a.S - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const float* p0 = a.partial + (int64_t)tile * kPartStride;
+  const int64_t sstride = (int64_t)tiles * kPartStride;
+  for (int e = threadIdx.x; e < kPartStride; e += RH_BLOCK) {
+    float v = 0.f;
+    for (int q = 0; q < a.S; ++q) v += __builtin_nontemporal_load(p0 + q * sstride + e);
+    if (e < kTileElems) {
+      const int n = n0 + e / kTile, k = k0 + e % kTile;
+      if (n < a.N && k < a.K) a.dW[(int64_t)n * a.K + k] = v;
+    } else if (a.db && blockIdx.x == 0 && n0 + e - kTileElems < a.N) {
+      a.db[n0 + e - kTileElems] = v;
+    }
+  }
+  if (threadIdx.x == 0) a.counters[tile] = 0;
+}
+
+void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
+  *tiles_n = (N + kTile - 1) / kTile;
+  *tiles_k = (K + kTile - 1) / kTile;
+  const int tiles = *tiles_n * *tiles_k;
+  int s = 512 / tiles;
+  const int max_s = (B + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  int r = (B + s - 1) / s;
+  r = (r + 7) / 8 * 8;
+  *rps = r;
+  *S = (B + r - 1) / r;
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr int kHeadLanes = 16;                       // lanes per row
+constexpr int kHeadRows = RH_BLOCK / kHeadLanes;     // rows per block pass
+constexpr int kHeadMaxV4 = 16;                       // float4 per lane -> K <= 1024
+
+__device__ __forceinline__ float group_sum16(float v) {
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+
+__global__ __launch_bounds__(RH_BLOCK) void head_fwd_kernel(const float* __restrict__ h, int64_t ldh,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ e0, const float* __restrict__ e1,
+                                                            int B, int K, float* __restrict__ y) {
+  const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
+  const int nv = K / 4;
+  const float b0 = bias ? bias[0] : 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < B; row += (int64_t)gridDim.x * kHeadRows) {
+    float acc = 0.f;
+    for (int v = sub; v < nv; v += kHeadLanes) {
+      const float4 hv = gload<float4>(h + row * ldh + 4 * v);
+      const float4 wv = gload<float4>(w + 4 * v);
+      acc = fmaf(hv.x, wv.x, acc);
+      acc = fmaf(hv.y, wv.y, acc);
+      acc = fmaf(hv.z, wv.z, acc);
+      acc = fmaf(hv.w, wv.w, acc);
+    }
+    acc = group_sum16(acc);
+    if (sub == 0) {
+      float z = acc + b0;
+      if (e0) z += e0[row];
+      if (e1) z += e1[row];
+      y[row] = 1.f / (1.f + __expf(-z));
+    }
+  }
+}
+
+struct HeadBwdArgs {
+  const float* h;
+  int64_t ldh;
+  const float* w;
+  const float* y;
+  const float* g_y;
+  int B, K;
+  float* g_h;  // (B, K) contiguous
+  float* g_z;  // (B,)
+  float* partial;      // (gridDim.x, K + 1)
+  unsigned* counter;   // 1, zero on entry / exit
+  float* g_w;          // (K,)
+  float* g_b;          // (1,) or null
+};
+
+template <int MAXV>
+__global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a) {
+  __shared__ float red[kHeadRows][kHeadLanes * 4 + 1];
+  __shared__ float gb_red[kHeadRows];
+  __shared__ int is_last;
+  const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
+  const int K = a.K, nv = K / 4;
+  float4 wacc[MAXV];
+  float4 wv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    wacc[i] = f4_zero();
+    const int v = sub + i * kHeadLanes;
+    wv[i] = v < nv ? gload<float4>(a.w + 4 * v) : f4_zero();
+  }
+  float gb = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < a.B; row += (int64_t)gridDim.x * kHeadRows) {
+    const float yv = a.y[row];
+    const float gz = a.g_y[row] * yv * (1.f - yv);
+    if (sub == 0) {
+      a.g_z[row] = gz;
+      gb += gz;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = sub + i * kHeadLanes;
+      if (v < nv) {
+        const float4 hv = gload<float4>(a.h + row * a.ldh + 4 * v);
+        wacc[i].x = fmaf(gz, hv.x, wacc[i].x);
+        wacc[i].y = fmaf(gz, hv.y, wacc[i].y);
+        wacc[i].z = fmaf(gz, hv.z, wacc[i].z);
+        wacc[i].w = fmaf(gz, hv.w, wacc[i].w);
+        gstore<float4>(a.g_h + row * K + 4 * v, make_float4(gz * wv[i].x, gz * wv[i].y, gz * wv[i].z, gz * wv[i].w));
+      }
+    }
+  }
+  // block reduction over the kHeadRows row groups, 64 columns (16 lanes x float4) at a time
+  float* part = a.partial + (int64_t)blockIdx.x * (K + 1);
+  if (sub == 0) gb_red[grp] = gb;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    __syncthreads();
+    red[grp][sub * 4 + 0] = wacc[i].x;
+    red[grp][sub * 4 + 1] = wacc[i].y;
+    red[grp][sub * 4 + 2] = wacc[i].z;
+    red[grp][sub * 4 + 3] = wacc[i].w;
+    __syncthreads();
+    if (threadIdx.x < kHeadLanes * 4) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < kHeadRows; ++r) v += red[r][threadIdx.x];
+      const int col = i * kHeadLanes * 4 + threadIdx.x;
+      if (col < K) part[col] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int r = 0; r < kHeadRows; ++r) v += gb_red[r];
+    part[K] = v;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int col = threadIdx.x; col <= K; col += RH_BLOCK) {
+    float v = 0.f;
+    for (unsigned q = 0; q < gridDim.x; ++q) v += __builtin_nontemporal_load(a.partial + (int64_t)q * (K + 1) + col);
+    if (col < K) {
+      a.g_w[col] = v;
+    } else if (a.g_b) {
+      a.g_b[0] = v;
+    }
+  }
+  if (threadIdx.x == 0) *a.counter = 0;
+}
+
+int head_grid(int B) {
+  int g = (B + kHeadRows * 4 - 1) / (kHeadRows * 4);  // >= 4 rows per lane group
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr int kBceBlock = 1024;
+
+__global__ __launch_bounds__(kBceBlock) void bce_fwd_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                            int64_t B, float* __restrict__ loss) {
+  __shared__ float red[kBceBlock / RH_WAVE];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += kBceBlock) {
+    const float yv = y[i], tv = t[i];
+    const float ly = fmaxf(logf(yv), -100.f), l1y = fmaxf(log1pf(-yv), -100.f);
+    acc -= tv * ly + (1.f - tv) * l1y;
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int w = 0; w < kBceBlock / RH_WAVE; ++w) v += red[w];
+    loss[0] = v / (float)B;
+  }
+}
+
+__global__ __launch_bounds__(RH_BLOCK) void bce_bwd_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                           const float* __restrict__ g_loss, int64_t B,
+                                                           float* __restrict__ g_y) {
+  const float scale = g_loss[0] / (float)B;
+  for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < B; i += (int64_t)gridDim.x * RH_BLOCK) {
+    const float yv = y[i];
+    g_y[i] = scale * (yv - t[i]) / fmaxf((1.f - yv) * yv, 1e-12f);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t rh_linear_wgrad_workspace(int B, int N, int K) {
+  if (B < 1 || N < 1 || K < 1) return 0;
+  int tn, tk, S, rps;
+  wgrad_plan(B, N, K, &tn, &tk, &S, &rps);
+  return (int64_t)S * tn * tk * kPartStride;
+}
+
+extern "C" int rh_linear_wgrad_tiles(int N, int K) { return ((N + kTile - 1) / kTile) * ((K + kTile - 1) / kTile); }
+
+extern "C" int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K,
+                               float* dW, float* db, float* partial, unsigned* counters, void* stream) {
+  RH_REQUIRE(g && x && dW && partial && counters, RH_E_BADARG, "rh_linear_wgrad: null pointer");
+  RH_REQUIRE(B >= 1 && N >= 1 && K >= 1 && ldg >= N && ldx >= K, RH_E_BADARG,
+             "rh_linear_wgrad: bad shape B=%d N=%d K=%d ldg=%lld ldx=%lld", B, N, K, (long long)ldg, (long long)ldx);
+  WgradArgs a{g, ldg, x, ldx, B, N, K, 1, B, partial, counters, dW, db};
+  int tn, tk;
+  wgrad_plan(B, N, K, &tn, &tk, &a.S, &a.rows_per_split);
+  static bool attr_set = false;
+  const size_t lds = (size_t)kWaves * kPartStride * sizeof(float);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    RH_REQUIRE(e == hipSuccess, (int)e, "rh_linear_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, reinterpret_cast<hipStream_t>(stream), a);
+  RH_LAUNCH_CHECK("rh_linear_wgrad");
+  return 0;
+}
+
+extern "C" int rh_head_nblocks(int B) { return head_grid(B); }
+
+extern "C" int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0,
+                           const float* e1, int B, int K, float* y, void* stream) {
+  RH_REQUIRE(h && w && y, RH_E_BADARG, "rh_head_fwd: null pointer");
+  RH_REQUIRE(B >= 0 && K >= 4 && K % 4 == 0 && ldh >= K, RH_E_UNSUPPORTED, "rh_head_fwd: K=%d must be a multiple of 4", K);
+  if (B == 0) return 0;
+  int grid = (B + kHeadRows - 1) / kHeadRows;
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), h, ldh, w, bias,
+                     e0, e1, B, K, y);
+  RH_LAUNCH_CHECK("rh_head_fwd");
+  return 0;
+}
+
+extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K,
+                           float* g_h, float* g_z, float* g_w, float* g_b, float* partial, unsigned* counter,
+                           void* stream) {
+  RH_REQUIRE(h && w && y && g_y && g_h && g_z && g_w && partial && counter, RH_E_BADARG, "rh_head_bwd: null pointer");
+  RH_REQUIRE(B >= 1 && K >= 4 && K % 4 == 0 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
+             "rh_head_bwd: K=%d must be a multiple of 4 and <= %d", K, 4 * kHeadLanes * kHeadMaxV4);
+  HeadBwdArgs a{h, ldh, w, y, g_y, B, K, g_h, g_z, partial, counter, g_w, g_b};
+  const int need = (K / 4 + kHeadLanes - 1) / kHeadLanes;
+  const dim3 grid(head_grid(B)), block(RH_BLOCK);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (need <= 1) hipLaunchKernelGGL(head_bwd_kernel<1>, grid, block, 0, st, a);
+  else if (need <= 2) hipLaunchKernelGGL(head_bwd_kernel<2>, grid, block, 0, st, a);
+  else if (need <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, grid, block, 0, st, a);
+  else if (need <= 8) hipLaunchKernelGGL(head_bwd_kernel<8>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(head_bwd_kernel<16>, grid, block, 0, st, a);
+  RH_LAUNCH_CHECK("rh_head_bwd");
+  return 0;
+}
+
+extern "C" int rh_bce_fwd(const float* y, const float* t, int64_t B, float* loss, void* stream) {
+  RH_REQUIRE(y && t && loss && B >= 1, RH_E_BADARG, "rh_bce_fwd: bad arguments");
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(kBceBlock), 0, reinterpret_cast<hipStream_t>(stream), y, t, B, loss);
+  RH_LAUNCH_CHECK("rh_bce_fwd");
+  return 0;
+}
+
+extern "C" int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, float* g_y, void* stream) {
+  RH_REQUIRE(y && t && g_loss && g_y && B >= 1, RH_E_BADARG, "rh_bce_bwd: bad arguments");
+  int64_t grid = (B + RH_BLOCK - 1) / RH_BLOCK;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), y, t,
+                     g_loss, B, g_y);
+  RH_LAUNCH_CHECK("rh_bce_bwd");
+  return 0;
+}

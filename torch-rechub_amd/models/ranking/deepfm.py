@@ -49,6 +49,4 @@ class DeepFM(torch.nn.Module):
             input_fm = emb(x, self.fm_features, squeeze_dim=False)
             y_linear = self.linear(input_fm.flatten(start_dim=1))
             y_fm = self.fm(input_fm)
-        y_deep = self.mlp(input_deep)
-        y = y_linear + y_fm + y_deep
-        return torch.sigmoid(y.squeeze(1))
+        return self.mlp.sigmoid_head(input_deep, y_linear, y_fm)

@@ -19,5 +19,4 @@ class WideDeep(torch.nn.Module):
     def forward(self, x):
         input_wide = self.embedding(x, self.wide_features, squeeze_dim=True)
         input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)
-        y = self.linear(input_wide) + self.mlp(input_deep)
-        return torch.sigmoid(y.squeeze(1))
+        return self.mlp.sigmoid_head(input_deep, self.linear(input_wide))

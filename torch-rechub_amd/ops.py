@@ -572,6 +572,164 @@ def bn_relu_dropout(h, bn, p_drop):
 
 
 # --------------------------------------------------------------------------------------------
+# MLP GEMM backward (weight gradient), output head and loss (csrc/linear.hip)
+_counter_cache = {}
+_MAX_WGRAD_TILES = 4096
+
+
+def _counters(device):
+    """Zeroed uint32 scratch the split-reduction kernels use to elect their last block (they leave it zeroed);
+    one buffer per (device, stream) because concurrent launches must not share it."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _counter_cache.get(key)
+    if buf is None:
+        buf = torch.zeros(_MAX_WGRAD_TILES + 1, dtype=torch.int32, device=device)
+        _counter_cache[key] = buf
+    return buf
+
+
+def linear_wgrad(g, x, want_bias=True):
+    """(dW (N, K), db (N,) | None) = (g^T x, colsum(g)) for g (B, N), x (B, K): split-batch f32 MFMA kernel."""
+    require_hip(g, x)
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B, N = g.shape
+    K = x.shape[1]
+    dev = g.device
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev) if want_bias else None
+    if B == 0:
+        dW.zero_()
+        if db is not None:
+            db.zero_()
+        return dW, db
+    partial = torch.empty(_lib.call("rh_linear_wgrad_workspace", B, N, K), dtype=torch.float32, device=dev)
+    _lib.call("rh_linear_wgrad", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(dW), _p(db), _p(partial),
+              _p(_counters(dev)), _stream())
+    return dW, db
+
+
+def linear_ok(x, weight):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and
+            _lib.call("rh_linear_wgrad_tiles", weight.shape[0], weight.shape[1]) <= _MAX_WGRAD_TILES)
+
+
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear with the library GEMM forward / input gradient and the split-batch MFMA weight + bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = linear_wgrad(g, x, want_bias=ctx.has_bias)
+        return gx, dW, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear for 2-D fp32 HIP activations; see _LinearFn."""
+    if torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)) and linear_ok(
+            x, weight):
+        return _LinearFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def _col(t, B):
+    """(B,) contiguous view of a (B,) / (B, 1) tensor."""
+    if t is None:
+        return None
+    if t.numel() != B:
+        raise ValueError(f"head term of {tuple(t.shape)} does not match batch {B}")
+    return t.reshape(B).contiguous()
+
+
+class _HeadFn(torch.autograd.Function):
+    """y = sigmoid(h w^T + b + e0 + e1): the MLP's Linear(K, 1), the wide / FM terms and the sigmoid in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, e0, e1):
+        require_hip(h, weight)
+        if h.stride(1) != 1:
+            h = h.contiguous()
+        B, K = h.shape
+        c0, c1 = _col(e0, B), _col(e1, B)
+        y = torch.empty((B,), dtype=torch.float32, device=h.device)
+        _lib.call("rh_head_fwd", _p(h), h.stride(0), _p(weight), _p(bias), _p(c0), _p(c1), B, K, _p(y), _stream())
+        ctx.save_for_backward(h, weight, y)
+        ctx.shapes = (None if e0 is None else e0.shape, None if e1 is None else e1.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        h, weight, y = ctx.saved_tensors
+        s0, s1, has_bias = ctx.shapes
+        B, K = h.shape
+        dev = h.device
+        g_y = g_y.contiguous()
+        g_h = torch.empty((B, K), dtype=torch.float32, device=dev)
+        g_z = torch.empty((B,), dtype=torch.float32, device=dev)
+        g_w = torch.empty_like(weight)
+        g_b = torch.empty((1,), dtype=torch.float32, device=dev) if has_bias else None
+        partial = torch.empty((_lib.call("rh_head_nblocks", B), K + 1), dtype=torch.float32, device=dev)
+        ctr = _counters(dev)[_MAX_WGRAD_TILES:]
+        _lib.call("rh_head_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), B, K, _p(g_h), _p(g_z), _p(g_w),
+                  _p(g_b), _p(partial), _p(ctr), _stream())
+        return (g_h, g_w, g_b, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1))
+
+
+def head_ok(h, lin, extras):
+    K = lin.in_features
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and lin.out_features == 1 and K % 4 == 0 and
+            K <= 1024 and len(extras) <= 2 and h.shape[0] > 0 and all(e.numel() == h.shape[0] for e in extras))
+
+
+def head_sigmoid(h, weight, bias, *extras):
+    """sigmoid((h @ weight.T + bias + sum(extras)).squeeze(1)) -> (B,)"""
+    e = list(extras) + [None, None]
+    return _HeadFn.apply(h, weight, bias, e[0], e[1])
+
+
+class _BceFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, y, t):
+        require_hip(y, t)
+        y, t = y.contiguous(), t.contiguous()
+        loss = torch.empty((1,), dtype=torch.float32, device=y.device)
+        _lib.call("rh_bce_fwd", _p(y), _p(t), y.numel(), _p(loss), _stream())
+        ctx.save_for_backward(y, t)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        y, t = ctx.saved_tensors
+        g = g.contiguous().view(1)
+        g_y = torch.empty_like(y)
+        _lib.call("rh_bce_bwd", _p(y), _p(t), _p(g), y.numel(), _p(g_y), _stream())
+        return g_y, None
+
+
+def bce_ok(criterion, y, t):
+    return (type(criterion) is torch.nn.BCELoss and criterion.reduction == "mean" and criterion.weight is None and
+            y.is_cuda and y.dtype == torch.float32 and t.dtype == torch.float32 and y.dim() == 1 and
+            y.shape == t.shape and 0 < y.numel() <= (1 << 22) and not t.requires_grad)
+
+
+def bce_mean(y, t):
+    """torch.nn.BCELoss()(y, t) (mean reduction, log clamped at -100) in one launch each way."""
+    return _BceFn.apply(y, t)
+
+
+# --------------------------------------------------------------------------------------------
 class _DiceFn(torch.autograd.Function):
 
     @staticmethod

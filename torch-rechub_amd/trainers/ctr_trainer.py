@@ -104,11 +104,17 @@ class CTRTrainer(object):
     def _compute_loss(self, x_dict, y):
         """model forward + criterion + regularisation (trainers/ctr_trainer.py:86-95); overridden by MatchTrainer."""
         if self.loss_mode:
-            loss = self.criterion(self.model(x_dict), y)
+            loss = self._criterion(self.model(x_dict), y)
         else:
             y_pred, other_loss = self.model(x_dict)
-            loss = self.criterion(y_pred, y) + other_loss
+            loss = self._criterion(y_pred, y) + other_loss
         return loss + self.reg_loss_fn(self.model)
+
+    def _criterion(self, y_pred, y):
+        # torch.nn.BCELoss() (the reference default, ctr_trainer.py:62) runs as one HIP launch each way
+        if ops.bce_ok(self.criterion, y_pred, y):
+            return ops.bce_mean(y_pred, y)
+        return self.criterion(y_pred, y)
 
     def train_step(self, x_dict, y):
         """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
