@@ -203,24 +203,23 @@ int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, cons
  * rh_linear_wgrad replaces: the weight/bias gradient of every nn.Linear of MLP, torch_rechub/basic/layers.py:279,290
  *   (autograd's mm(g^T, x) + sum(g, 0)):  dW (N, K) = g^T x,  db (N,) = column sums of g (db may be NULL)
  *   g (B, N) row stride ldg, x (B, K) row stride ldx; batch split over blocks, f32 MFMA, partial tiles summed in split
- *   order by the last block of each tile (deterministic).  partial: rh_linear_wgrad_workspace(B, N, K) floats;
- *   counters: rh_linear_wgrad_tiles(N, K) uint32, ZERO on entry, left zero on exit (one buffer per stream).
+ *   order by a second small launch (deterministic).  partial: rh_linear_wgrad_workspace(B, N, K) floats.
  * rh_head_fwd/bwd replaces: MLP's output Linear(K, 1) + `y_linear + y_fm + y_deep` + torch.sigmoid(y.squeeze(1)),
  *   models/ranking/deepfm.py:39-43, widedeep.py:35-39:  y (B,) = sigmoid(h w^T + bias + e0 + e1)  (bias, e0, e1 optional)
  *   bwd: g_z = g_y y (1 - y) (also the gradient of e0 / e1), g_h (B, K) = g_z w, g_w (K,) = g_z^T h, g_b = sum g_z.
- *   K % 4 == 0, K <= 1024.  partial: rh_head_nblocks(B) * (K + 1) floats; counter: 1 uint32, zero on entry / exit.
+ *   K % 4 == 0, K <= 1024.  partial: rh_head_nblocks(B) * (K + 1) floats.
  * rh_bce_fwd/bwd replaces: torch.nn.BCELoss() (mean) of trainers/ctr_trainer.py:62,:93-95: log terms clamped at -100;
  *   loss (1,), g_loss (1,) device scalars.
  */
 int64_t rh_linear_wgrad_workspace(int B, int N, int K);
 int rh_linear_wgrad_tiles(int N, int K);
 int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* dW, float* db,
-                    float* partial, unsigned* counters, void* stream);
+                    float* partial, void* stream);
 int rh_head_nblocks(int B);
 int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
                 int K, float* y, void* stream);
 int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K, float* g_h,
-                float* g_z, float* g_w, float* g_b, float* partial, unsigned* counter, void* stream);
+                float* g_z, float* g_w, float* g_b, float* partial, void* stream);
 int rh_bce_fwd(const float* y, const float* t, int64_t B, float* loss, void* stream);
 int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, float* g_y, void* stream);
 

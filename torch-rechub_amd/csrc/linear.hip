@@ -10,7 +10,7 @@
 //    two of them in the round-1 profile).  Here: split over the batch, f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 ==
 //    fmaf chain), operands straight from global memory -- for dW both fragments are batch-major, so lane (i, k) of the
 //    A/B fragment reads g[b0+k][n0+i] / x[b0+k][k0+i]: 128-byte coalesced rows, no LDS staging -- partial tiles to a
-//    workspace, and the LAST block of each output tile sums the partials in split order (deterministic).  db falls out
+//    workspace, and a second small launch sums the partials in split order (deterministic).  db falls out
 //    of the A fragments for free.  Roofline: f32 MFMA (157 TF).
 // 2. head: y = sigmoid(h . w + b + e0 + e1), the (., 1) output layer fused with the wide/FM terms and the sigmoid; the
 //    backward gives g_z, g_h, g_w, g_b in ONE launch (three GEMMs with a dimension of 1, two adds, sigmoid and their
@@ -36,14 +36,12 @@ struct WgradArgs {
   int B, N, K;
   int S, rows_per_split;
   float* partial;      // (S, tiles, kPartStride)
-  unsigned* counters;  // (tiles,) zero on entry, zero on exit
   float* dW;           // (N, K) contiguous
   float* db;           // (N,) or null
 };
 
 __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
   extern __shared__ float red[];  // kWaves * kPartStride floats
-  __shared__ int is_last;
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int half = lane >> 5, c = lane & 31;
   const int k0 = blockIdx.x * kTile, n0 = blockIdx.y * kTile, s = blockIdx.z;
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
   // ragged end of the last split: fewer than kStep rows, guarded per row
   for (; p < b_hi; p += 2 * kWaves) {
     const bool ok = p + half < b_hi;
-    const int64_t r = ok ? p : b_lo;
+    const int64_t r = ok ? p : b_lo - half;  // (the fragment pointers already carry + half rows)
     const float m = ok ? 1.f : 0.f;
     const float t0 = gload<float>(ga0 + r * a.ldg) * m, t1 = gload<float>(ga1 + r * a.ldg) * m;
     const float t2 = gload<float>(xb0 + r * a.ldx) * m, t3 = gload<float>(xb1 + r * a.ldx) * m;
@@ -155,26 +153,32 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
       a.db[n0 + e - kTileElems] = v;
     }
   }
-  if (direct) return;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(a.S - 1);
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  const float* p0 = a.partial + (int64_t)tile * kPartStride;
+}
+
+// Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
+// "last block reduces" election needs a device-scope fence per block, which on this 8-XCD part writes back and
+// invalidates the XCD's whole L2 (measured: ~140 us for 500 blocks) -- a 3 us launch is the cheaper barrier.
+__global__ __launch_bounds__(RH_BLOCK) void wgrad_reduce_kernel(const WgradArgs a, int tiles_k, int tiles) {
+  const int tile = blockIdx.y;
+  const int e = blockIdx.x * RH_BLOCK + threadIdx.x;
+  if (e >= kPartStride) return;
+  const float* p0 = a.partial + (int64_t)tile * kPartStride + e;
   const int64_t sstride = (int64_t)tiles * kPartStride;
-  for (int e = threadIdx.x; e < kPartStride; e += RH_BLOCK) {
-    float v = 0.f;
-    for (int q = 0; q < a.S; ++q) v += __builtin_nontemporal_load(p0 + q * sstride + e);
-    if (e < kTileElems) {
-      const int n = n0 + e / kTile, k = k0 + e % kTile;
-      if (n < a.N && k < a.K) a.dW[(int64_t)n * a.K + k] = v;
-    } else if (a.db && blockIdx.x == 0 && n0 + e - kTileElems < a.N) {
-      a.db[n0 + e - kTileElems] = v;
-    }
+  float v = 0.f;
+  int q = 0;
+  for (; q + 4 <= a.S; q += 4) {
+    const float t0 = p0[(q + 0) * sstride], t1 = p0[(q + 1) * sstride];
+    const float t2 = p0[(q + 2) * sstride], t3 = p0[(q + 3) * sstride];
+    v = (((v + t0) + t1) + t2) + t3;
   }
-  if (threadIdx.x == 0) a.counters[tile] = 0;
+  for (; q < a.S; ++q) v += p0[q * sstride];
+  const int n0 = (tile / tiles_k) * kTile, k0 = (tile % tiles_k) * kTile;
+  if (e < kTileElems) {
+    const int n = n0 + e / kTile, k = k0 + e % kTile;
+    if (n < a.N && k < a.K) a.dW[(int64_t)n * a.K + k] = v;
+  } else if (a.db && tile % tiles_k == 0 && n0 + e - kTileElems < a.N) {
+    a.db[n0 + e - kTileElems] = v;
+  }
 }
 
 void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
@@ -241,7 +245,6 @@ struct HeadBwdArgs {
   float* g_h;  // (B, K) contiguous
   float* g_z;  // (B,)
   float* partial;      // (gridDim.x, K + 1)
-  unsigned* counter;   // 1, zero on entry / exit
   float* g_w;          // (K,)
   float* g_b;          // (1,) or null
 };
@@ -250,7 +253,6 @@ template <int MAXV>
 __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a) {
   __shared__ float red[kHeadRows][kHeadLanes * 4 + 1];
   __shared__ float gb_red[kHeadRows];
-  __shared__ int is_last;
   const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
   const int K = a.K, nv = K / 4;
   float4 wacc[MAXV];
@@ -307,22 +309,18 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
     for (int r = 0; r < kHeadRows; ++r) v += gb_red[r];
     part[K] = v;
   }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  for (int col = threadIdx.x; col <= K; col += RH_BLOCK) {
-    float v = 0.f;
-    for (unsigned q = 0; q < gridDim.x; ++q) v += __builtin_nontemporal_load(a.partial + (int64_t)q * (K + 1) + col);
-    if (col < K) {
-      a.g_w[col] = v;
-    } else if (a.g_b) {
-      a.g_b[0] = v;
-    }
+}
+
+__global__ __launch_bounds__(RH_BLOCK) void head_reduce_kernel(const HeadBwdArgs a, int nblocks) {
+  const int col = blockIdx.x * RH_BLOCK + threadIdx.x;
+  if (col > a.K) return;
+  float v = 0.f;
+  for (int q = 0; q < nblocks; ++q) v += a.partial[(int64_t)q * (a.K + 1) + col];
+  if (col < a.K) {
+    a.g_w[col] = v;
+  } else if (a.g_b) {
+    a.g_b[0] = v;
   }
-  if (threadIdx.x == 0) *a.counter = 0;
 }
 
 int head_grid(int B) {
@@ -376,11 +374,11 @@ extern "C" int64_t rh_linear_wgrad_workspace(int B, int N, int K) {
 extern "C" int rh_linear_wgrad_tiles(int N, int K) { return ((N + kTile - 1) / kTile) * ((K + kTile - 1) / kTile); }
 
 extern "C" int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K,
-                               float* dW, float* db, float* partial, unsigned* counters, void* stream) {
-  RH_REQUIRE(g && x && dW && partial && counters, RH_E_BADARG, "rh_linear_wgrad: null pointer");
+                               float* dW, float* db, float* partial, void* stream) {
+  RH_REQUIRE(g && x && dW && partial, RH_E_BADARG, "rh_linear_wgrad: null pointer");
   RH_REQUIRE(B >= 1 && N >= 1 && K >= 1 && ldg >= N && ldx >= K, RH_E_BADARG,
              "rh_linear_wgrad: bad shape B=%d N=%d K=%d ldg=%lld ldx=%lld", B, N, K, (long long)ldg, (long long)ldx);
-  WgradArgs a{g, ldg, x, ldx, B, N, K, 1, B, partial, counters, dW, db};
+  WgradArgs a{g, ldg, x, ldx, B, N, K, 1, B, partial, dW, db};
   int tn, tk;
   wgrad_plan(B, N, K, &tn, &tk, &a.S, &a.rows_per_split);
   static bool attr_set = false;
@@ -391,7 +389,11 @@ extern "C" int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int6
     RH_REQUIRE(e == hipSuccess, (int)e, "rh_linear_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, reinterpret_cast<hipStream_t>(stream), a);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
+  if (a.S > 1)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartStride + RH_BLOCK - 1) / RH_BLOCK, tk * tn), dim3(RH_BLOCK), 0, st, a,
+                       tk, tk * tn);
   RH_LAUNCH_CHECK("rh_linear_wgrad");
   return 0;
 }
@@ -412,12 +414,11 @@ extern "C" int rh_head_fwd(const float* h, int64_t ldh, const float* w, const fl
 }
 
 extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K,
-                           float* g_h, float* g_z, float* g_w, float* g_b, float* partial, unsigned* counter,
-                           void* stream) {
-  RH_REQUIRE(h && w && y && g_y && g_h && g_z && g_w && partial && counter, RH_E_BADARG, "rh_head_bwd: null pointer");
+                           float* g_h, float* g_z, float* g_w, float* g_b, float* partial, void* stream) {
+  RH_REQUIRE(h && w && y && g_y && g_h && g_z && g_w && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
   RH_REQUIRE(B >= 1 && K >= 4 && K % 4 == 0 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
              "rh_head_bwd: K=%d must be a multiple of 4 and <= %d", K, 4 * kHeadLanes * kHeadMaxV4);
-  HeadBwdArgs a{h, ldh, w, y, g_y, B, K, g_h, g_z, partial, counter, g_w, g_b};
+  HeadBwdArgs a{h, ldh, w, y, g_y, B, K, g_h, g_z, partial, g_w, g_b};
   const int need = (K / 4 + kHeadLanes - 1) / kHeadLanes;
   const dim3 grid(head_grid(B)), block(RH_BLOCK);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -426,6 +427,7 @@ extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const fl
   else if (need <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, grid, block, 0, st, a);
   else if (need <= 8) hipLaunchKernelGGL(head_bwd_kernel<8>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(head_bwd_kernel<16>, grid, block, 0, st, a);
+  hipLaunchKernelGGL(head_reduce_kernel, dim3((K + 1 + RH_BLOCK - 1) / RH_BLOCK), block, 0, st, a, (int)grid.x);
   RH_LAUNCH_CHECK("rh_head_bwd");
   return 0;
 }

@@ -573,19 +573,7 @@ def bn_relu_dropout(h, bn, p_drop):
 
 # --------------------------------------------------------------------------------------------
 # MLP GEMM backward (weight gradient), output head and loss (csrc/linear.hip)
-_counter_cache = {}
 _MAX_WGRAD_TILES = 4096
-
-
-def _counters(device):
-    """Zeroed uint32 scratch the split-reduction kernels use to elect their last block (they leave it zeroed);
-    one buffer per (device, stream) because concurrent launches must not share it."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    buf = _counter_cache.get(key)
-    if buf is None:
-        buf = torch.zeros(_MAX_WGRAD_TILES + 1, dtype=torch.int32, device=device)
-        _counter_cache[key] = buf
-    return buf
 
 
 def linear_wgrad(g, x, want_bias=True):
@@ -607,7 +595,7 @@ def linear_wgrad(g, x, want_bias=True):
         return dW, db
     partial = torch.empty(_lib.call("rh_linear_wgrad_workspace", B, N, K), dtype=torch.float32, device=dev)
     _lib.call("rh_linear_wgrad", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(dW), _p(db), _p(partial),
-              _p(_counters(dev)), _stream())
+              _stream())
     return dW, db
 
 
@@ -680,9 +668,8 @@ class _HeadFn(torch.autograd.Function):
         g_w = torch.empty_like(weight)
         g_b = torch.empty((1,), dtype=torch.float32, device=dev) if has_bias else None
         partial = torch.empty((_lib.call("rh_head_nblocks", B), K + 1), dtype=torch.float32, device=dev)
-        ctr = _counters(dev)[_MAX_WGRAD_TILES:]
         _lib.call("rh_head_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), B, K, _p(g_h), _p(g_z), _p(g_w),
-                  _p(g_b), _p(partial), _p(ctr), _stream())
+                  _p(g_b), _p(partial), _stream())
         return (g_h, g_w, g_b, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1))
 
 
