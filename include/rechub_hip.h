@@ -220,6 +220,9 @@ int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, 
                 int K, float* y, void* stream);
 int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K, float* g_h,
                 float* g_z, float* g_w, float* g_b, float* partial, void* stream);
+/* Column sums of the per-block partial buffers the backward kernels emit (replaces the trailing `.sum(0)` / `.sum()`
+ * launches of autograd): out (cols,) = sum over rows of a (rows, cols); optionally vsum (1,) = sum of v (n,). */
+int rh_colsum(const float* a, int rows, int cols, float* out, const float* v, int64_t n, float* vsum, void* stream);
 int rh_bce_fwd(const float* y, const float* t, int64_t B, float* loss, void* stream);
 int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, float* g_y, void* stream);
 
@@ -228,8 +231,10 @@ int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, f
  * replaces: nn.BatchNorm1d -> ReLU -> nn.Dropout of MLP, torch_rechub/basic/layers.py:281-287, and their autograd
  * h (B,C) pre-BN activations; training: batch statistics (biased variance), running stats updated with `momentum`
  * (unbiased variance), num_batches_tracked += 1; eval: running statistics, no dropout.
- * rng (device int64 [2]): seed, call counter (bumped by the forward); saved_ctr (device int64 [1]): the counter this call
- * used — the backward recomputes the same dropout mask from it (nothing is stored).
+ * rng (device int64 [4]): seed, call counter (bumped by the forward), block ticket (zero on entry / exit), spare;
+ * saved_ctr (device int64 [1]): the counter this call used — the backward recomputes the same dropout mask from it
+ * (nothing is stored).  B <= 8192 and C % 4 == 0: ONE launch per direction (a block owns 4 whole columns in registers);
+ * otherwise partial sums -> finalize -> apply.
  * partial: (rh_bn_act_nchunks(B), 2, C) floats; stat: (4, C) floats (mean, rstd kept for the backward).
  */
 int rh_bn_act_nchunks(int B);

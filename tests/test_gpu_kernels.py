@@ -535,7 +535,8 @@ def test_adam_lazy_rows_lag_at_most_k_steps():
     assert int(lag.min()) >= 0 and int(lag.max()) < 8
 
 
-@pytest.mark.parametrize("B,C,p", [(4096, 256, 0.0), (4096, 128, 0.0), (37, 32, 0.0), (1000, 200, 0.0), (513, 16, 0.0)])
+@pytest.mark.parametrize("B,C,p", [(4096, 256, 0.0), (4096, 128, 0.0), (37, 32, 0.0), (1000, 200, 0.0), (513, 16, 0.0),
+                                   (8192, 64, 0.0), (2, 8, 0.0), (20000, 64, 0.0), (1000, 30, 0.0)])
 def test_bn_relu_dropout_vs_torch_modules(B, C, p):
     """Fused epilogue == nn.BatchNorm1d -> ReLU -> Dropout(p=0) (outputs, running stats, all gradients) and eval mode."""
     from torch_rechub_amd import ops
@@ -568,9 +569,10 @@ def test_bn_relu_dropout_vs_torch_modules(B, C, p):
               what="eval")
 
 
-def test_fused_dropout_statistics_and_backward_mask():
+@pytest.mark.parametrize("B", [4096, 10000])  # one-launch column-owner path / three-launch path
+def test_fused_dropout_statistics_and_backward_mask(B):
     from torch_rechub_amd import ops
-    B, C, p = 4096, 256, 0.2
+    C, p = 256, 0.2
     bn = torch.nn.BatchNorm1d(C).to(dev())
     h = (torch.randn(B, C, device=dev()) + 1.0).requires_grad_(True)
     y = ops.bn_relu_dropout(h, bn, p)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "rh_head_nblocks": [c_int],
     "rh_head_fwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_head_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_colsum": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bce_fwd": [c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bce_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bn_act_nchunks": [c_int],

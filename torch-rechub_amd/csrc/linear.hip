@@ -311,16 +311,55 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
   }
 }
 
-__global__ __launch_bounds__(RH_BLOCK) void head_reduce_kernel(const HeadBwdArgs a, int nblocks) {
-  const int col = blockIdx.x * RH_BLOCK + threadIdx.x;
-  if (col > a.K) return;
-  float v = 0.f;
-  for (int q = 0; q < nblocks; ++q) v += a.partial[(int64_t)q * (a.K + 1) + col];
-  if (col < a.K) {
-    a.g_w[col] = v;
-  } else if (a.g_b) {
-    a.g_b[0] = v;
+// Column sums of a (rows, cols) partial buffer -> out[0 .. split) and out2[0 .. cols - split); the extra last block sums
+// the vector v (n,) into vsum.  32 columns x 8 row groups per block: 128-byte coalesced reads, fixed summation order.
+constexpr int kCsCols = 32, kCsGroups = RH_BLOCK / kCsCols;
+
+__global__ __launch_bounds__(RH_BLOCK) void colsum_kernel(const float* __restrict__ a, int rows, int cols,
+                                                          float* __restrict__ out, int split, float* __restrict__ out2,
+                                                          const float* __restrict__ v, int64_t n,
+                                                          float* __restrict__ vsum) {
+  __shared__ float red[kCsGroups][kCsCols + 1];
+  const int nb_cols = (cols + kCsCols - 1) / kCsCols;
+  if ((int)blockIdx.x < nb_cols) {
+    const int c = threadIdx.x % kCsCols, grp = threadIdx.x / kCsCols;
+    const int col = blockIdx.x * kCsCols + c;
+    float acc = 0.f;
+    if (col < cols) {
+      int r = grp;
+      for (; r + 3 * kCsGroups < rows; r += 4 * kCsGroups) {
+        const float t0 = a[(int64_t)r * cols + col], t1 = a[(int64_t)(r + kCsGroups) * cols + col];
+        const float t2 = a[(int64_t)(r + 2 * kCsGroups) * cols + col], t3 = a[(int64_t)(r + 3 * kCsGroups) * cols + col];
+        acc = (((acc + t0) + t1) + t2) + t3;
+      }
+      for (; r < rows; r += kCsGroups) acc += a[(int64_t)r * cols + col];
+    }
+    red[grp][c] = acc;
+    __syncthreads();
+    if (grp == 0 && col < cols) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < kCsGroups; ++q) t += red[q][c];
+      if (col < split) {
+        out[col] = t;
+      } else if (out2) {
+        out2[col - split] = t;
+      }
+    }
+  } else {
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += RH_BLOCK) acc += v[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x % RH_WAVE == 0) red[0][threadIdx.x / RH_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) vsum[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
   }
+}
+
+void launch_colsum(const float* a, int rows, int cols, float* out, int split, float* out2, const float* v, int64_t n,
+                   float* vsum, hipStream_t st) {
+  const int nb = (cols + kCsCols - 1) / kCsCols + (v ? 1 : 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(RH_BLOCK), 0, st, a, rows, cols, out, split, out2, v, n, vsum);
 }
 
 int head_grid(int B) {
@@ -427,8 +466,17 @@ extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const fl
   else if (need <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, grid, block, 0, st, a);
   else if (need <= 8) hipLaunchKernelGGL(head_bwd_kernel<8>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(head_bwd_kernel<16>, grid, block, 0, st, a);
-  hipLaunchKernelGGL(head_reduce_kernel, dim3((K + 1 + RH_BLOCK - 1) / RH_BLOCK), block, 0, st, a, (int)grid.x);
+  launch_colsum(partial, (int)grid.x, K + 1, g_w, K, g_b, nullptr, 0, nullptr, st);
   RH_LAUNCH_CHECK("rh_head_bwd");
+  return 0;
+}
+
+extern "C" int rh_colsum(const float* a, int rows, int cols, float* out, const float* v, int64_t n, float* vsum,
+                         void* stream) {
+  RH_REQUIRE((a && out && rows >= 0 && cols >= 1) || (!a && v), RH_E_BADARG, "rh_colsum: bad arguments");
+  RH_REQUIRE(!v || (vsum && n >= 0), RH_E_BADARG, "rh_colsum: vector sum needs an output");
+  launch_colsum(a, a ? rows : 0, a ? cols : 0, out, cols, nullptr, v, n, vsum, reinterpret_cast<hipStream_t>(stream));
+  RH_LAUNCH_CHECK("rh_colsum");
   return 0;
 }
 

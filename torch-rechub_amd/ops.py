@@ -327,8 +327,13 @@ class _EmbedFused(torch.autograd.Function):
             if any_table:
                 for w in {id(w): w for w in call.weights if w.requires_grad}.values():
                     _publish_grad(w)
-        g_w = partial.sum(0).view_as(lr_w) if want_wgrad else None
-        g_b = g_lr.sum().reshape(1) if (g_lr is not None and ctx.has_lr_b and ctx.needs_input_grad[2]) else None
+        want_b = g_lr is not None and ctx.has_lr_b and ctx.needs_input_grad[2]
+        g_w = torch.empty_like(lr_w) if want_wgrad else None
+        g_b = torch.empty((1,), dtype=torch.float32, device=dev) if want_b else None
+        if want_wgrad or want_b:  # one launch: column sums of the per-block LR partials + sum of g_lr
+            glc = g_lr.contiguous() if want_b else None
+            _lib.call("rh_colsum", _p(partial), nchunks if want_wgrad else 0, F * D, _p(g_w), _p(glc),
+                      glc.numel() if want_b else 0, _p(g_b), _stream())
         return (None, g_w, g_b) + (None,) * len(call.weights)
 
 
@@ -515,7 +520,7 @@ def _dropout_rng(device):
     """Device-resident (seed, call counter) of the fused dropout; seeded from torch's generator on first use."""
     st = _rng_state.get(device)
     if st is None:
-        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(device)
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0, 0], dtype=torch.int64).to(device)
         _rng_state[device] = st
     return st
 
