@@ -231,10 +231,9 @@ int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, f
  * replaces: nn.BatchNorm1d -> ReLU -> nn.Dropout of MLP, torch_rechub/basic/layers.py:281-287, and their autograd
  * h (B,C) pre-BN activations; training: batch statistics (biased variance), running stats updated with `momentum`
  * (unbiased variance), num_batches_tracked += 1; eval: running statistics, no dropout.
- * rng (device int64 [4]): seed, call counter (bumped by the forward), block ticket (zero on entry / exit), spare;
+ * rng (device int64 [2+]): seed, call counter (bumped by the forward);
  * saved_ctr (device int64 [1]): the counter this call used — the backward recomputes the same dropout mask from it
- * (nothing is stored).  B <= 8192 and C % 4 == 0: ONE launch per direction (a block owns 4 whole columns in registers);
- * otherwise partial sums -> finalize -> apply.
+ * (nothing is stored).  B <= 8192: two launches per direction (partial sums; finalize folded into apply), else three.
  * partial: (rh_bn_act_nchunks(B), 2, C) floats; stat: (4, C) floats (mean, rstd kept for the backward).
  */
 int rh_bn_act_nchunks(int B);

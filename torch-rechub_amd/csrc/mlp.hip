@@ -5,7 +5,7 @@
 //     layers.append(activation_layer(activation)); layers.append(nn.Dropout(p=dropout))
 // The Linear stays a library GEMM (true dense contraction); what follows it is 7 ATen kernels forward
 // (batch_norm_collect_statistics, transform_input, running-stat updates, relu, dropout) and 4 backward.  Here:
-//   B > 8192 or C % 4 != 0 (three launches per direction):
+//   B > 8192 (three launches per direction; B <= 8192 folds the finalize into the apply launch, see below):
 //   forward : column partial sums -> finalize (mean, rstd, running stats, num_batches_tracked, dropout counter)
 //             -> y = dropout(relu((h - mean) * rstd * gamma + beta))
 //   backward: g1 = dy * keep/(1-p) * [bn > 0]; column partial sums of g1, g1*xhat -> finalize (dgamma, dbeta)
@@ -37,6 +37,8 @@ struct BnArgs {
   int64_t* rng;        // [0] = seed, [1] = running call counter
   int64_t* saved_ctr;  // (1,) counter value used by this call (written forward, read backward)
   int B, C, nchunks;
+  int rows_per_chunk;  // rows per partial chunk
+  int bookkeep;        // partial kernel also advances the dropout counter / num_batches_tracked (fused-finalize path)
   float momentum, eps, p_drop;
   int training;
 };
@@ -57,8 +59,13 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
   const int RS = RH_BLOCK / CW;
   const int c = blockIdx.x * CW + threadIdx.x % CW;
   const int rsub = threadIdx.x / CW;
-  const int r0 = blockIdx.y * kRowsPerChunk;
-  const int r1 = min(r0 + kRowsPerChunk, a.B);
+  const int r0 = blockIdx.y * a.rows_per_chunk;
+  const int r1 = min(r0 + a.rows_per_chunk, a.B);
+  if (MODE == 0 && a.bookkeep && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    a.saved_ctr[0] = a.rng[1];  // dropout stream of this call (the apply launch reads saved_ctr)
+    a.rng[1] += 1;
+    if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
+  }
   float s1 = 0.f, s2 = 0.f;
   if (c < a.C) {
     if (MODE == 0) {
@@ -197,182 +204,105 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_kernel(const BnArgs a) {
   }
 }
 
-// ---- column-owner variant (B <= 8192, C % 4 == 0): ONE launch per direction --------------------------------------
-// A block owns 4 columns and holds their whole (B x 4) slab in registers (float4 per row, kColThreads rows per pass),
-// so statistics, finalize and apply need no cross-block reduction and no second pass over h: the three launches above
-// become one, and h / dy are read exactly once.  The 16-byte-per-row access wastes sector bandwidth (4x) but the slabs
-// are a few MB and L2 / Infinity-Cache resident right after the GEMM that produced them; at CTR batch sizes this
-// path is launch-latency bound, which is what it removes.
-constexpr int kColThreads = 512;
-constexpr int kColWaves = kColThreads / RH_WAVE;
-constexpr int kColMaxR = 16;
+// ---- B <= 8192: finalize folded into the apply launch (two launches per direction) ---------------------------------
+// 64-row chunks give <= 128 partial rows, few enough for every apply block to re-reduce the partials of ITS 32 columns
+// (<= 32 KB from L2) instead of waiting for a finalize launch.  Block = 32 columns x 8 row lanes: 128-byte row segments.
+constexpr int kFusedRows = 64;       // rows per partial chunk on this path
+constexpr int kFusedMaxChunks = 128;
+constexpr int kSlabCols = 32, kSlabLanes = RH_BLOCK / kSlabCols;
 
-template <int R, bool BWD>
-__global__ __launch_bounds__(kColThreads) void bn_col_kernel(const BnArgs a) {
-  __shared__ float red[kColWaves][8];
-  const int tid = threadIdx.x, lane = tid % RH_WAVE, wave = tid / RH_WAVE;
-  const int c0 = blockIdx.x * 4;
-  const int B = a.B, C = a.C;
-  float4 hv[R], gv[BWD ? R : 1];
+template <int MODE>  // 0 forward, 1 backward
+__global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, int rows_per_block) {
+  __shared__ float red[2][kSlabLanes][kSlabCols + 1];
+  const int cl = threadIdx.x % kSlabCols, grp = threadIdx.x / kSlabCols;
+  const int c = blockIdx.x * kSlabCols + cl;
+  const bool cok = c < a.C;
+  float s1 = 0.f, s2 = 0.f;
+  if (cok) {
+    for (int k = grp; k < a.nchunks; k += kSlabLanes) {  // fixed order: deterministic
+      s1 += a.partial[((int64_t)k * 2 + 0) * a.C + c];
+      s2 += a.partial[((int64_t)k * 2 + 1) * a.C + c];
+    }
+  }
+  red[0][grp][cl] = s1;
+  red[1][grp][cl] = s2;
+  __syncthreads();
+  s1 = red[0][0][cl];
+  s2 = red[1][0][cl];
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int row = tid + i * kColThreads;
-    const int64_t off = (int64_t)(row < B ? row : 0) * C + c0;
-    hv[i] = gload<float4>(a.h + off);
-    if (BWD) gv[i] = gload<float4>(a.dy + off);
+  for (int q = 1; q < kSlabLanes; ++q) {
+    s1 += red[0][q][cl];
+    s2 += red[1][q][cl];
+  }
+  if (!cok) return;
+  const float n = (float)a.B, inv_n = 1.f / n;
+  const float g = a.gamma[c], bt = a.beta[c];
+  float mean, rstd;
+  if (MODE == 0) {
+    const float m1 = s1 / n;
+    mean = a.h[c] + m1;
+    float var = s2 / n - m1 * m1;
+    var = var > 0.f ? var : 0.f;
+    rstd = rsqrtf(var + a.eps);
+    if (blockIdx.y == 0 && grp == 0) {
+      a.stat[c] = mean;
+      a.stat[a.C + c] = rstd;
+      if (a.running_mean != nullptr) {
+        const float unbiased = a.B > 1 ? var * (n / (n - 1.f)) : var;
+        a.running_mean[c] = fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
+        a.running_var[c] = fmaf(a.momentum, unbiased - a.running_var[c], a.running_var[c]);
+      }
+    }
+  } else {
+    mean = a.stat[c];
+    rstd = a.stat[a.C + c];
+    if (blockIdx.y == 0 && grp == 0) {
+      a.dbeta[c] = s1;
+      a.dgamma[c] = s2;
+    }
   }
   const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
   uint64_t seed = 0, ctr = 0;
-  if (a.p_drop > 0.f || !BWD) {
+  if (a.p_drop > 0.f) {
     seed = (uint64_t)a.rng[0];
-    ctr = BWD ? (uint64_t)a.saved_ctr[0] : (uint64_t)a.rng[1];
+    ctr = (uint64_t)a.saved_ctr[0];
   }
-  const float4 gm = gload<float4>(a.gamma + c0), bt = gload<float4>(a.beta + c0);
-  float4 mean, rstd;
-  float4 s1 = f4_zero(), s2 = f4_zero();
-  if (!BWD) {
-    const float4 shift = gload<float4>(a.h + c0);
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      if (tid + i * kColThreads < B) {
-        const float4 x = make_float4(hv[i].x - shift.x, hv[i].y - shift.y, hv[i].z - shift.z, hv[i].w - shift.w);
-        s1 = f4_add(s1, x);
-        s2 = make_float4(fmaf(x.x, x.x, s2.x), fmaf(x.y, x.y, s2.y), fmaf(x.z, x.z, s2.z), fmaf(x.w, x.w, s2.w));
-      }
-    }
-    mean = shift;  // completed below
-    rstd = f4_zero();
-  } else {
-    mean = gload<float4>(a.stat + c0);
-    rstd = gload<float4>(a.stat + C + c0);
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int row = tid + i * kColThreads;
-      const float4 xh = make_float4((hv[i].x - mean.x) * rstd.x, (hv[i].y - mean.y) * rstd.y,
-                                    (hv[i].z - mean.z) * rstd.z, (hv[i].w - mean.w) * rstd.w);
-      float4 g1 = make_float4(fmaf(xh.x, gm.x, bt.x) > 0.f ? gv[i].x : 0.f, fmaf(xh.y, gm.y, bt.y) > 0.f ? gv[i].y : 0.f,
-                              fmaf(xh.z, gm.z, bt.z) > 0.f ? gv[i].z : 0.f, fmaf(xh.w, gm.w, bt.w) > 0.f ? gv[i].w : 0.f);
-      if (a.p_drop > 0.f) {
-        const uint64_t e = (uint64_t)row * C + c0;
-        g1.x = drop_hash(seed, ctr, e + 0) >= thr ? g1.x * keep_scale : 0.f;
-        g1.y = drop_hash(seed, ctr, e + 1) >= thr ? g1.y * keep_scale : 0.f;
-        g1.z = drop_hash(seed, ctr, e + 2) >= thr ? g1.z * keep_scale : 0.f;
-        g1.w = drop_hash(seed, ctr, e + 3) >= thr ? g1.w * keep_scale : 0.f;
-      }
-      if (row >= B) g1 = f4_zero();
-      hv[i] = xh;
-      gv[i] = g1;
-      s1 = f4_add(s1, g1);
-      s2 = make_float4(fmaf(g1.x, xh.x, s2.x), fmaf(g1.y, xh.y, s2.y), fmaf(g1.z, xh.z, s2.z), fmaf(g1.w, xh.w, s2.w));
-    }
-  }
-  // block reduction of the 8 column sums: wavefront butterflies, then the 8 wavefronts in fixed order
-  float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = wave_sum(v[k]);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[wave][k] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float t = red[0][k];
-#pragma unroll
-    for (int w = 1; w < kColWaves; ++w) t += red[w][k];
-    v[k] = t;
-  }
-  const float n = (float)B, inv_n = 1.f / n;
-  if (!BWD) {
-    float mu[4], rs[4], var[4];
-    const float sh[4] = {mean.x, mean.y, mean.z, mean.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float m1 = v[k] / n;
-      mu[k] = sh[k] + m1;
-      var[k] = fmaxf(v[4 + k] / n - m1 * m1, 0.f);
-      rs[k] = rsqrtf(var[k] + a.eps);
-    }
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a.stat[c0 + k] = mu[k];
-        a.stat[C + c0 + k] = rs[k];
-        if (a.running_mean != nullptr) {
-          const float unbiased = B > 1 ? var[k] * (n / (n - 1.f)) : var[k];
-          a.running_mean[c0 + k] = fmaf(a.momentum, mu[k] - a.running_mean[c0 + k], a.running_mean[c0 + k]);
-          a.running_var[c0 + k] = fmaf(a.momentum, unbiased - a.running_var[c0 + k], a.running_var[c0 + k]);
-        }
-      }
-    }
-    mean = make_float4(mu[0], mu[1], mu[2], mu[3]);
-    rstd = make_float4(rs[0], rs[1], rs[2], rs[3]);
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int row = tid + i * kColThreads;
-      if (row < B) {
-        float4 y = make_float4(fmaxf(fmaf((hv[i].x - mean.x) * rstd.x, gm.x, bt.x), 0.f),
-                               fmaxf(fmaf((hv[i].y - mean.y) * rstd.y, gm.y, bt.y), 0.f),
-                               fmaxf(fmaf((hv[i].z - mean.z) * rstd.z, gm.z, bt.z), 0.f),
-                               fmaxf(fmaf((hv[i].w - mean.w) * rstd.w, gm.w, bt.w), 0.f));
-        if (a.p_drop > 0.f) {
-          const uint64_t e = (uint64_t)row * C + c0;
-          y.x = drop_hash(seed, ctr, e + 0) >= thr ? y.x * keep_scale : 0.f;
-          y.y = drop_hash(seed, ctr, e + 1) >= thr ? y.y * keep_scale : 0.f;
-          y.z = drop_hash(seed, ctr, e + 2) >= thr ? y.z * keep_scale : 0.f;
-          y.w = drop_hash(seed, ctr, e + 3) >= thr ? y.w * keep_scale : 0.f;
-        }
-        gstore<float4>(a.out + (int64_t)row * C + c0, y);
-      }
-    }
-    // The call counter is read by every block above; the LAST block to get here bumps it (ticket in rng[2]), so no
-    // block can see the next call's value.  Only this scalar is exchanged, so no cache-wide fence is involved.
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.rng + 2);
-      if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
-        a.saved_ctr[0] = (int64_t)ctr;
-        a.rng[1] = (int64_t)ctr + 1;
-        if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
-        atomicExch(ticket, 0ull);
-      }
-    }
-  } else {
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a.dbeta[c0 + k] = v[k];
-        a.dgamma[c0 + k] = v[4 + k];
-      }
-    }
-    const float4 sg = make_float4(v[0] * inv_n, v[1] * inv_n, v[2] * inv_n, v[3] * inv_n);
-    const float4 sx = make_float4(v[4] * inv_n, v[5] * inv_n, v[6] * inv_n, v[7] * inv_n);
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int row = tid + i * kColThreads;
-      if (row < B) {
-        const float4 dx = make_float4(gm.x * rstd.x * (gv[i].x - sg.x - hv[i].x * sx.x),
-                                      gm.y * rstd.y * (gv[i].y - sg.y - hv[i].y * sx.y),
-                                      gm.z * rstd.z * (gv[i].z - sg.z - hv[i].z * sx.z),
-                                      gm.w * rstd.w * (gv[i].w - sg.w - hv[i].w * sx.w));
-        gstore<float4>(a.out + (int64_t)row * C + c0, dx);
-      }
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, a.B);
+  const float sg = s1 * inv_n, sgx = s2 * inv_n;
+#pragma unroll 4
+  for (int r = r0 + grp; r < r1; r += kSlabLanes) {
+    const int64_t i = (int64_t)r * a.C + c;
+    const float xhat = (a.h[i] - mean) * rstd;
+    const float bn = fmaf(xhat, g, bt);
+    if (MODE == 1) {
+      float g1 = bn > 0.f ? a.dy[i] : 0.f;
+      if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
+      a.out[i] = g * rstd * (g1 - sg - xhat * sgx);
+    } else {
+      float y = bn > 0.f ? bn : 0.f;
+      if (a.p_drop > 0.f) y = drop_hash(seed, ctr, (uint64_t)i) >= thr ? y * keep_scale : 0.f;
+      a.out[i] = y;
     }
   }
 }
 
-bool col_path_ok(int B, int C) { return C % 4 == 0 && B <= kColThreads * kColMaxR; }
+bool fused_path_ok(int B) { return (B + kFusedRows - 1) / kFusedRows <= kFusedMaxChunks; }
 
-template <bool BWD>
-void launch_col(const BnArgs& a, hipStream_t s) {
-  const dim3 grid((unsigned)(a.C / 4)), block(kColThreads);
-  const int need = (a.B + kColThreads - 1) / kColThreads;
-  if (need <= 1) hipLaunchKernelGGL((bn_col_kernel<1, BWD>), grid, block, 0, s, a);
-  else if (need <= 2) hipLaunchKernelGGL((bn_col_kernel<2, BWD>), grid, block, 0, s, a);
-  else if (need <= 4) hipLaunchKernelGGL((bn_col_kernel<4, BWD>), grid, block, 0, s, a);
-  else if (need <= 8) hipLaunchKernelGGL((bn_col_kernel<8, BWD>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((bn_col_kernel<16, BWD>), grid, block, 0, s, a);
+template <int MODE>
+void launch_fused(BnArgs a, hipStream_t s) {
+  a.rows_per_chunk = kFusedRows;
+  a.nchunks = (a.B + kFusedRows - 1) / kFusedRows;
+  a.bookkeep = MODE == 0 ? 1 : 0;
+  const int cw = kSlabCols;  // 32 columns x 8 row lanes: C/32 x nchunks blocks, 8 rows per thread
+  hipLaunchKernelGGL((bn_partial_kernel<MODE>), dim3((unsigned)((a.C + cw - 1) / cw), (unsigned)a.nchunks), dim3(RH_BLOCK), 0,
+                     s, a, cw);
+  const int slabs = (a.C + kSlabCols - 1) / kSlabCols;
+  int gy = (512 + slabs - 1) / slabs;                 // ~512 blocks in total
+  int rpb = (a.B + gy - 1) / gy;
+  rpb = (rpb + kSlabLanes - 1) / kSlabLanes * kSlabLanes;
+  gy = (a.B + rpb - 1) / rpb;
+  hipLaunchKernelGGL((bn_apply_fin_kernel<MODE>), dim3((unsigned)slabs, (unsigned)gy), dim3(RH_BLOCK), 0, s, a, rpb);
 }
 
 int col_width(int C) {
@@ -403,7 +333,7 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
   BnArgs a{};
   a.h = h; a.out = out; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.num_batches_tracked = num_batches_tracked; a.partial = partial; a.stat = stat; a.rng = rng; a.saved_ctr = saved_ctr;
-  a.B = B; a.C = C; a.nchunks = rh_bn_act_nchunks(B); a.momentum = momentum; a.eps = eps; a.p_drop = p_drop;
+  a.B = B; a.C = C; a.nchunks = rh_bn_act_nchunks(B); a.rows_per_chunk = kRowsPerChunk; a.momentum = momentum; a.eps = eps; a.p_drop = p_drop;
   a.training = training;
   if (!training) {
     RH_REQUIRE(running_mean && running_var, RH_E_BADARG, "rh_bn_relu_dropout_fwd: eval mode needs running statistics");
@@ -413,9 +343,9 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
     return 0;
   }
   RH_REQUIRE(partial && stat && rng && saved_ctr, RH_E_BADARG, "rh_bn_relu_dropout_fwd: training needs workspaces");
-  if (col_path_ok(B, C)) {
-    launch_col<false>(a, s);
-    RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd(column-owner)");
+  if (fused_path_ok(B)) {
+    launch_fused<0>(a, s);
+    RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd(fused finalize)");
     return 0;
   }
   const int CW = col_width(C);
@@ -438,10 +368,10 @@ extern "C" int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, in
   BnArgs a{};
   a.h = h; a.dy = dy; a.out = dx; a.gamma = gamma; a.beta = beta; a.partial = partial; a.stat = stat;
   a.dgamma = dgamma; a.dbeta = dbeta; a.rng = const_cast<int64_t*>(rng); a.saved_ctr = const_cast<int64_t*>(saved_ctr);
-  a.B = B; a.C = C; a.nchunks = rh_bn_act_nchunks(B); a.p_drop = p_drop; a.training = 1;
-  if (col_path_ok(B, C)) {
-    launch_col<true>(a, s);
-    RH_LAUNCH_CHECK("rh_bn_relu_dropout_bwd(column-owner)");
+  a.B = B; a.C = C; a.nchunks = rh_bn_act_nchunks(B); a.rows_per_chunk = kRowsPerChunk; a.p_drop = p_drop; a.training = 1;
+  if (fused_path_ok(B)) {
+    launch_fused<1>(a, s);
+    RH_LAUNCH_CHECK("rh_bn_relu_dropout_bwd(fused finalize)");
     return 0;
   }
   const int CW = col_width(C);
