@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librechub_hip.so")
+# RECHUB_HIP_LIB: load another build of the same ABI (kernel experiments); default is the in-tree library
+LIB_PATH = os.environ.get("RECHUB_HIP_LIB") or os.path.join(_HERE, "csrc", "librechub_hip.so")
 
 c_int = ctypes.c_int
 c_i64 = ctypes.c_int64

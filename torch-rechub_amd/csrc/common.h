@@ -82,6 +82,17 @@ static __device__ __forceinline__ float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, RH_WAVE);
   return v;
 }
+// minimum over all 64 lanes as a wavefront-uniform (SGPR) value: DPP within each row of 16 lanes (no LDS traffic, unlike
+// __shfl_xor = ds_bpermute), then one readlane per row
+static __device__ __forceinline__ int wave_min_uniform(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+  const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
 // hardware fp32 atomic add on global memory (global_atomic_add_f32, result unused)
 static __device__ __forceinline__ void gatomic_add_f32(float* p, float v) {
   (void)__builtin_amdgcn_global_atomic_fadd_f32(
