@@ -53,6 +53,8 @@ const char* rh_last_error(void);
 /* tuning knobs (process-wide; defaults are the measured winners) */
 #define RH_TUNE_WIDE_ATOMICS 1 /* 1: table-gradient atomics carry whole rows per request (default), 0: 16 B pieces */
 #define RH_TUNE_SWEEP_GRID 2   /* workgroups of rh_adam_lazy_sweep (0 = default 8192) */
+#define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per sweep workgroup (<= 56 KiB): caps its residency so that kernels on
+                                  other streams find free wave slots while it runs */
 int rh_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------

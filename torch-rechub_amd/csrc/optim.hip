@@ -15,6 +15,7 @@ namespace {
 constexpr int kMaxTensors = 128;
 constexpr int kMaxRing = 1024;  // entries of the (A, E) ring kept in LDS by the lazy sweep
 int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workgroups, the measured best)
+int g_sweep_lds_pad = 0;  // tuning knob RH_TUNE_SWEEP_LDS_PAD: extra dynamic LDS bytes per workgroup (caps residency)
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -333,7 +334,7 @@ int launch_sweep(LazySweepArgs& a, const int64_t* h_rows, const int64_t* h_windo
   int64_t grid = a.total_vblocks;
   const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR>), dim3((unsigned)grid), dim3(RH_BLOCK), 0, s, a);
+  hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)g_sweep_lds_pad, s, a);
   return 0;
 }
 
@@ -388,6 +389,10 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_small_kernel(const AdamSmallArg
 extern "C" int rh_optim_set_tuning(int key, int value) {
   if (key == RH_TUNE_SWEEP_GRID) {
     g_sweep_grid = value;
+    return 0;
+  }
+  if (key == RH_TUNE_SWEEP_LDS_PAD) {
+    g_sweep_lds_pad = value < 0 ? 0 : (value > 56 * 1024 ? 56 * 1024 : value);
     return 0;
   }
   return RH_E_BADARG;

@@ -83,6 +83,9 @@ class CTRTrainer(object):
         if use_graph is None:
             use_graph = os.environ.get("RECHUB_HIPGRAPH", "0") == "1"
         self.use_graph = bool(use_graph)
+        # data-parallel hipGraph layout: "split" = [graph A] -> eager RCCL -> [graph B]; "single" = collectives captured
+        # (default; RCCL >= 2.9 launches are capturable; falls back to "split" if the capture raises)
+        self.dp_graph = os.environ.get("RECHUB_DP_GRAPH", "single")
         self.show_progress = show_progress and self.rank == 0
         self._graph = None
         self._graph_b = None
@@ -139,8 +142,9 @@ class CTRTrainer(object):
         self.optimizer.step()
         return report
 
-    # -- split step for hipGraph + RCCL: [graph A: batch, forward, backward, pack] -> eager collectives ->
-    #    [graph B: scatter gathered rows, optimizer].  Collectives stay outside the graphs. ------------------------
+    # -- data-parallel step in three phases: [A: batch, forward, backward, pack] -> [X: RCCL collectives] ->
+    #    [B: scatter gathered rows, optimizer].  Under hipGraph the three are captured as ONE graph (dp_graph =
+    #    "single"), or A and B as two graphs with the collectives launched eagerly between them ("split"). ---------
     def _phase_a(self, x_dict, y):
         self.dp.deferred_mode, self.dp.deferred = True, []
         self.bucket.defer = True
@@ -206,6 +210,22 @@ class CTRTrainer(object):
                     x, y = loader.load_next()
                     self._graph_loss = self.train_step(x, y)
                 return total, self.GRAPH_WARMUP
+            if self.dp_graph == "single":
+                # RCCL collectives captured with the rest of the step: one hipGraph launch per step
+                try:
+                    with torch.cuda.graph(self._graph):
+                        x, y = loader.load_next()
+                        self._graph_loss = self._split_step(x, y)
+                    self._graph_b = None
+                    return total, self.GRAPH_WARMUP
+                except RuntimeError as e:  # collective not capturable with this RCCL build: use the split layout
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the RCCL collectives failed ({e}); using the split-graph step")
+                    torch.cuda.synchronize()
+                    self.dp_graph = "split"
+                    self.bucket.defer = False
+                    self.dp.deferred_mode = False
+                    self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 x, y = loader.load_next()
                 self._graph_loss, self._deferred_static = self._phase_a(x, y)
@@ -217,7 +237,7 @@ class CTRTrainer(object):
             self._graph_b.replay()
             return total + self._graph_loss, self.GRAPH_WARMUP + 1
         self._graph.replay()
-        if split:
+        if split and self._graph_b is not None:
             self.bucket._deferred_runs = [(0, len(self.bucket.params))]
             self._phase_x(self._deferred_static)
             self._graph_b.replay()
