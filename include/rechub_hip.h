@@ -284,14 +284,26 @@ int rh_adam_small(const int64_t* sdesc, int T, const int64_t* h_numel, const flo
  * rh_adam_lazy_touched: for every lookup of the batch (index columns in idesc, as rh_embed_bwd) claim the row,
  *       replay it to step t-1, apply step t with its gradient row, re-zero the gradient row.
  *       field_table (device int64 [2*F]): table index of field f (-1 = skip), padding_idx (-1 = none)
- * rh_adam_lazy_sweep: bring window (t-1) mod K_t of every table up to date (flush != 0: all rows).
+ * rh_adam_lazy_sweep: bring window (t-1) mod K_t of every table up to date.  mode: RH_SWEEP_WINDOW = every table,
+ *       RH_SWEEP_FLUSH = all rows of every table, RH_SWEEP_LAZY_TABLES = windows of the K_t > 1 tables only,
+ *       RH_SWEEP_DENSE_TABLES = the K_t == 1 tables only (these take their gradient in the sweep).
  * Call order per step: rh_adam_prepare, rh_adam_lazy_touched (once per index batch), rh_adam_lazy_sweep.
+ * t_value < 0: the sweep belongs to the step in hyper (in line, before the next rh_adam_prepare).  t_value = s >= 0:
+ * deferred sweep of step s, step number by value and (A_s, E_s) from the ring -- it only touches rows that are NOT at
+ * step >= s, so it may run on another stream concurrently with the whole of step s + 1 (its rh_adam_prepare,
+ * forward, backward, rh_adam_lazy_touched), PROVIDED step s + 1 brought its own rows up to step s before the sweep
+ * was launched (rh_adam_lazy_touched under the hyper of step s = the pre-gather refresh) and the sweep has finished
+ * before step s + 2 refreshes its rows.
  */
+#define RH_SWEEP_WINDOW 0
+#define RH_SWEEP_FLUSH 1
+#define RH_SWEEP_LAZY_TABLES 2
+#define RH_SWEEP_DENSE_TABLES 3
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int32_t* err_flag, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                       const double* hyper, const float* ring, int ring_size, int flush, void* stream);
+                       const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident minibatch assembly (columnar dataset already in HBM)

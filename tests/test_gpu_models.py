@@ -239,10 +239,11 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph", [False, "single", "split"])
 def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, monkeypatch, use_graph):
     """RECHUB_FORCE_DP: dense all-reduce on the side stream + all-gather of (indices, gradient rows) + row scatter
-    (+ the two-graph split step) on a world of one must reproduce the single-GPU fused path."""
+    (eager, captured as one hipGraph with the RCCL launches inside, or as the two-graph split step) on a world of one
+    must reproduce the single-GPU fused path."""
     from torch_rechub_amd import ops
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
@@ -261,13 +262,14 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
     mk = lambda: DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
     la = ta.train_one_epoch(mk())
     monkeypatch.setenv("RECHUB_FORCE_DP", "1")
+    monkeypatch.setenv("RECHUB_DP_GRAPH", use_graph or "single")
     tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
-                    use_graph=use_graph)
+                    use_graph=bool(use_graph))
     assert tb.dp is not None and ops._sparse_exchange is not None
     try:
         lb = tb.train_one_epoch(mk())
         if use_graph:
-            assert tb._graph is not None and tb._graph_b is not None
+            assert tb._graph is not None and tb.dp_graph == use_graph and (tb._graph_b is None) == (use_graph == "single")
     finally:
         tb.dp.close()
     assert abs(la - lb) < 1e-5

@@ -81,8 +81,11 @@ def test_full_shape_backward_conserves_gradient_mass_and_touches_only_looked_up_
         w.grad = None
 
 
-def test_full_shape_lazy_adam_equals_dense_adam_bitwise(criteo_tables):
-    """Three steps at the real table sizes: blocked-lazy exact Adam == dense pass, bit for bit, after the flush."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_full_shape_lazy_adam_equals_dense_adam_bitwise(criteo_tables, overlap):
+    """Five steps at the real table sizes: blocked-lazy exact Adam == dense pass, bit for bit, after the flush -- also
+    when the window sweep of each step is deferred to a side stream and runs concurrently with the next step's
+    (refreshed) lookups and gradient writes."""
     from torch_rechub_amd import ops
     from torch_rechub_amd.optim import TableAdam
     F = 26
@@ -90,8 +93,14 @@ def test_full_shape_lazy_adam_equals_dense_adam_bitwise(criteo_tables):
     Bp = [torch.nn.Parameter(t.detach().clone()) for t in criteo_tables]
     dense = TableAdam(A, table_params=A, lr=1e-3, weight_decay=1e-5)
     lazy = TableAdam(Bp, table_params=Bp, lr=1e-3, weight_decay=1e-5, lazy_k=2)
-    for step in range(3):
+    lazy.overlap_sweep = overlap
+    for step in range(5):
         idx, _ = batch(4096, 100 + step)
+        cols = [idx[:, f] for f in range(F)]
+        key = tuple([c.data_ptr() for c in cols] + [idx.stride(0)] * F + list(range(F)))
+        idesc = ops.EmbedCall._icache.get(key, dev())
+        ops._pre_gather(Bp, [None] * F, idesc, 1, 4096, F, 16)  # what the forward does: refresh (+ fork the sweep)
+        assert lazy._sweep_inflight == (overlap and step > 0)
         g_rows = torch.randn(4096, 16, device=dev())
         for f in range(F):
             dense_g = torch.zeros_like(A[f])
@@ -100,11 +109,10 @@ def test_full_shape_lazy_adam_equals_dense_adam_bitwise(criteo_tables):
                 ops.grad_buffer(P).copy_(dense_g)
                 P._rh_dirty = True
             del dense_g
-        cols = [idx[:, f] for f in range(F)]
-        key = tuple([c.data_ptr() for c in cols] + [idx.stride(0)] * F + list(range(F)))
-        ops._log_touch(Bp, [None] * F, ops.EmbedCall._icache.get(key, dev()), 1, 4096, F, 16, cols)
+        ops._log_touch(Bp, [None] * F, idesc, 1, 4096, F, 16, cols)
         lazy.step()
         dense.step()
+        assert lazy._sweep_inflight == (overlap and step > 0) and lazy._sweep_pending == overlap  # joined by the NEXT refresh
     lazy.flush()
     torch.cuda.synchronize()
     for f in range(F):

@@ -110,10 +110,10 @@ def main():
                 for _ in range(2):
                     trainer.train_step(x, y)
             torch.cuda.current_stream().wait_stream(s)
-            gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph):
-                trainer.train_step(x, y)
-            print(f"  [{name}] captured", flush=True)
+            from torch_rechub_amd.graphs import SegmentedGraph
+            gph = SegmentedGraph()  # lets the optimizer cut the step where it launches its side-stream sweep
+            gph.capture(lambda: trainer.train_step(x, y))
+            print(f"  [{name}] captured ({len(gph.segments)} segments)", flush=True)
             for _ in range(3):
                 gph.replay()
             torch.cuda.synchronize()

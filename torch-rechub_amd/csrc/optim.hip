@@ -170,6 +170,7 @@ struct LazySweepArgs {
   int ring_mask;
   int T;
   int flush;  // 1: window = whole table
+  int64_t t_value;  // >= 0: the step this sweep belongs to, by value (deferred sweep); < 0: hyper[12]
   int64_t total_vblocks;
   int64_t vb_prefix[kMaxTensors + 1];
 };
@@ -178,8 +179,12 @@ template <int LPR>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySweepArgs a) {
   constexpr int RPB = RH_BLOCK / LPR;  // rows per block
   constexpr int D = 4 * LPR;
-  const AdamScalars h = load_scalars(a.hyper);
-  const int t = (int)a.hyper[12];
+  AdamScalars h = load_scalars(a.hyper);
+  const int t = a.t_value >= 0 ? (int)a.t_value : (int)a.hyper[12];
+  if (a.t_value >= 0) {  // deferred: hyper[12..14] may already belong to the next step; the ring entry of t does not
+    h.A = a.ring[2 * (t & a.ring_mask)];
+    h.E = a.ring[2 * (t & a.ring_mask) + 1];
+  }
   const int T = a.T;
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
@@ -320,11 +325,13 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
 }
 
 template <int LPR>
-int launch_sweep(LazySweepArgs& a, const int64_t* h_rows, const int64_t* h_window, hipStream_t s) {
+int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_t* h_window, hipStream_t s) {
   constexpr int RPB = RH_BLOCK / LPR;
   a.vb_prefix[0] = 0;
   for (int t = 0; t < a.T; ++t) {
-    const int64_t w = a.flush ? h_rows[t] : (h_window[t] < h_rows[t] ? h_window[t] : h_rows[t]);
+    int64_t w = a.flush ? h_rows[t] : (h_window[t] < h_rows[t] ? h_window[t] : h_rows[t]);
+    const bool dense_table = h_window[t] >= h_rows[t];  // K_t == 1
+    if ((mode == RH_SWEEP_LAZY_TABLES && dense_table) || (mode == RH_SWEEP_DENSE_TABLES && !dense_table)) w = 0;
     a.vb_prefix[t + 1] = a.vb_prefix[t] + (w + RPB - 1) / RPB;
   }
   for (int t = a.T + 1; t <= kMaxTensors; ++t) a.vb_prefix[t] = a.vb_prefix[a.T];
@@ -438,8 +445,10 @@ extern "C" int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel
 }
 
 extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                                  const double* hyper, const float* ring, int ring_size, int flush, void* stream) {
+                                  const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
+                                  void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring, RH_E_BADARG, "rh_adam_lazy_sweep: null pointer");
+  RH_REQUIRE(mode >= RH_SWEEP_WINDOW && mode <= RH_SWEEP_DENSE_TABLES, RH_E_BADARG, "rh_adam_lazy_sweep: mode %d", mode);
   RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_sweep: ring_size must be a power of two <= %d", kMaxRing);
@@ -449,16 +458,17 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
   a.ring = ring;
   a.ring_mask = ring_size - 1;
   a.T = T;
-  a.flush = flush;
+  a.flush = mode == RH_SWEEP_FLUSH ? 1 : 0;
+  a.t_value = t_value;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
-    case 1: rc = launch_sweep<1>(a, h_rows, h_window, s); break;
-    case 2: rc = launch_sweep<2>(a, h_rows, h_window, s); break;
-    case 4: rc = launch_sweep<4>(a, h_rows, h_window, s); break;
-    case 8: rc = launch_sweep<8>(a, h_rows, h_window, s); break;
-    case 16: rc = launch_sweep<16>(a, h_rows, h_window, s); break;
-    case 32: rc = launch_sweep<32>(a, h_rows, h_window, s); break;
+    case 1: rc = launch_sweep<1>(a, mode, h_rows, h_window, s); break;
+    case 2: rc = launch_sweep<2>(a, mode, h_rows, h_window, s); break;
+    case 4: rc = launch_sweep<4>(a, mode, h_rows, h_window, s); break;
+    case 8: rc = launch_sweep<8>(a, mode, h_rows, h_window, s); break;
+    case 16: rc = launch_sweep<16>(a, mode, h_rows, h_window, s); break;
+    case 32: rc = launch_sweep<32>(a, mode, h_rows, h_window, s); break;
     default: break;
   }
   RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: embed_dim %d unsupported", D);

@@ -1,0 +1,85 @@
+"""hipGraph capture in segments with eager actions between them.
+
+A hipGraph replays its kernel nodes in order on one queue (measured on ROCm 7: parallel branches of a captured graph
+do not overlap), and a graph node cannot wait for work that was launched outside the graph.  The deferred lazy-Adam
+sweep needs both: it runs on a side stream UNDER the next training step, and it takes the step number by value.  So
+the training step is captured as consecutive graphs ("segments") sharing one memory pool, and whoever needs an eager
+launch at a given point of the step calls ``cut(fn)`` there while the capture is running: the current segment is
+closed, ``fn`` is remembered, and a new segment begins.  ``replay()`` launches segment, fn, segment, fn ...
+
+Only one SegmentedGraph can capture at a time; ``active()`` returns it (or None).
+"""
+import gc
+
+import torch
+
+_active = None
+
+
+def active():
+    """The SegmentedGraph whose capture is running on this thread, or None."""
+    return _active
+
+
+class SegmentedGraph(object):
+
+    def __init__(self):
+        self.segments = []   # [CUDAGraph, eager fn | None]: fn runs after the graph
+        self.before = []     # eager fns that run before the first segment of every replay
+        self._stream = None
+        self._pool = None
+
+    # -- capture ---------------------------------------------------------------------------
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()  # one private pool: later segments read earlier ones' tensors
+        g.capture_begin(pool=self._pool)
+        self.segments.append([g, None])
+
+    def capture(self, fn):
+        """Run ``fn()`` under capture (it may call ``cut``); returns fn's result.  Nothing is executed on the device."""
+        global _active
+        if _active is not None:
+            raise RuntimeError("a segmented capture is already running")
+        torch.cuda.synchronize()
+        gc.collect()
+        self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        _active = self
+        try:
+            with torch.cuda.stream(self._stream):
+                self._begin()
+                try:
+                    out = fn()
+                finally:
+                    self.segments[-1][0].capture_end()
+        finally:
+            _active = None
+        torch.cuda.current_stream().wait_stream(self._stream)
+        return out
+
+    def cut(self, fn):
+        """Close the running segment; ``fn`` will be called (eagerly, on the replaying stream) at this point of every
+        replay.  It is NOT called now: a capture does not execute anything."""
+        if _active is not self:
+            raise RuntimeError("cut() outside this graph's capture")
+        self.segments[-1][0].capture_end()
+        self.segments[-1][1] = fn
+        self._begin()
+
+    def at_start(self, fn):
+        """``fn`` runs eagerly before the first segment of every replay."""
+        self.before.append(fn)
+
+    # -- replay ----------------------------------------------------------------------------
+    def replay(self):
+        for fn in self.before:
+            fn()
+        for g, fn in self.segments:
+            g.replay()
+            if fn is not None:
+                fn()
+
+    def pool(self):
+        return self._pool

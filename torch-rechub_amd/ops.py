@@ -227,9 +227,14 @@ def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep):
                           keep=keep))
 
 
-def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D):
+def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D, training=None):
+    """``training``: the lookup is part of a differentiated forward (a backward / optimizer step follows).  Inside an
+    autograd.Function.forward grad mode is off, so the callers pass ctx.needs_input_grad; None = ask grad mode."""
+    if training is None:
+        training = torch.is_grad_enabled()
     for lst in _listeners():
-        lst.on_gather(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D))
+        lst.on_gather(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
+                           training=bool(training)))
 
 
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
@@ -273,7 +278,7 @@ class _EmbedFused(torch.autograd.Function):
                 raise ValueError("fused LR weight must be contiguous float32 with F*D elements")
             require_hip(lr_w, lr_b)
         ddesc = call.ddesc()
-        _pre_gather(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D)
+        _pre_gather(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, training=any(ctx.needs_input_grad))
         _lib.call("rh_embed_fwd", _p(call.fdesc(False)), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(ddesc),
                   len(call.dense), call.dense_col, _p(out), out.stride(0), _p(lr_w if call.want_lr else None),
                   _p(lr_b if call.want_lr else None), _p(lr), _p(fm), _p(s_sum), call.field_split,
@@ -404,7 +409,7 @@ class _SeqPoolFn(torch.autograd.Function):
         if _lazy_listeners:
             flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
             _pre_gather([weight], [None], EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device),
-                        1 if idx.dtype == torch.int64 else 0, B * L, 1, D)
+                        1 if idx.dtype == torch.int64 else 0, B * L, 1, D, training=any(ctx.needs_input_grad))
         _lib.call("rh_seq_pool_fwd", _p(weight), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
                   idx.stride(1), B, L, D, mode, sentinel, _p(out), out.stride(0), _p(err_flag(weight.device)),
                   _stream())

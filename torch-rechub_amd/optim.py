@@ -13,10 +13,14 @@ Reference: CTRTrainer builds ``optimizer_fn(model.parameters(), lr=1e-3, weight_
 It IS a ``torch.optim.Adam`` (schedulers, ``state_dict`` and ``param_groups`` work unchanged).
 """
 import ctypes
+import os
 
 import torch
 
-from . import _lib, ops
+from . import _lib, graphs, ops
+
+
+SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  # rh_adam_lazy_sweep modes
 
 
 class TableAdam(torch.optim.Adam):
@@ -85,6 +89,23 @@ class TableAdam(torch.optim.Adam):
                 self._ft_cache = {}
                 self._touch_log = []
                 self._table_ids = {id(p) for p in tables}
+                # Deferred sweep (opt-in, RECHUB_SWEEP_OVERLAP=1): the window sweep of step s (lazy tables) is launched
+                # on a side stream at the start of step s + 1, right after that step's rows were refreshed, with its
+                # step number BY VALUE; it then runs under the whole of step s + 1 (forward, backward, exchange,
+                # optimizer: none of them touches a row that is behind step s) and is joined before step s + 2
+                # refreshes its rows.  The launch is eager, so inside a hipGraph capture it needs a
+                # graphs.SegmentedGraph (plain captures sweep in line).  Exact (bit-identical after flush(), see
+                # tests/test_gpu_properties.py) but OFF by default: on MI355X the VALU-saturating sweep and the
+                # step's ~40 dependent small kernels contend for the same wave slots, so the overlap hides only
+                # ~40 us of the 185 us sweep and the two extra graph boundaries cost ~30 us.
+                self.overlap_sweep = os.environ.get("RECHUB_SWEEP_OVERLAP", "0") == "1"
+                self._sweep_pending = False   # sweep of the last completed step not launched yet
+                self._sweep_inflight = False  # ... launched on the side stream, not joined yet
+                self._side = None
+                self._host_step = 0           # completed steps (host mirror of _t_step)
+                self._gathers = 0             # training-mode gathers seen since the last step
+                self._gathers_per_step = None  # learned from the previous step: the sweep forks at the LAST gather
+                self._join_seg = None
                 ops.add_lazy_listener(self)  # on_gather: refresh rows before they are read; on_touch: log lookups
 
     # ------------------------------------------------------------------------------------
@@ -187,8 +208,57 @@ class TableAdam(torch.optim.Adam):
         """Pre-gather event: replay the rows of this index batch up to the last completed step (their gradient rows are
         zero at this point, so this is the pure wd*p replay); the forward then reads exactly what a dense optimizer
         would have left in the table.  Unconditional, so that a captured hipGraph always contains the launch."""
-        if any(id(w) in self._table_ids for w in rec["weights"]):
-            self._touch(rec, self._lazy_setup(), ops._stream())
+        if not any(id(w) in self._table_ids for w in rec["weights"]):
+            return
+        seg = graphs.active()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._sweep_inflight:  # the previous step's sweep must be done before rows are refreshed again
+            if capturing and seg is not None:
+                if self._join_seg is not seg:
+                    seg.at_start(self._join_sweep)  # replayed steps: join eagerly before the first segment
+                    self._join_seg = seg
+                self._sweep_inflight = False
+            elif capturing:
+                raise RuntimeError("TableAdam: a deferred table sweep is in flight on the side stream; call "
+                                   "optimizer.flush() before capturing a training step into a plain hipGraph "
+                                   "(or capture with torch_rechub_amd.graphs.SegmentedGraph)")
+            else:
+                self._join_sweep()
+        self._touch(rec, self._lazy_setup(), ops._stream())
+        if rec.get("training", torch.is_grad_enabled()):
+            self._gathers += 1
+            if self._sweep_pending and self._gathers >= (self._gathers_per_step or 1):
+                if not capturing:
+                    self._fork_sweep()
+                elif seg is not None:
+                    seg.cut(self._fork_sweep)  # every replay: eager side-stream launch after the refresh above
+                    self._sweep_pending, self._sweep_inflight = False, True
+                # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
+
+    def _sweep(self, mode, stream, t_value=-1):
+        for D, grp in self._lazy_setup().items():
+            _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
+                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
+                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, mode, t_value, stream)
+
+    def _fork_sweep(self):
+        """Launch the sweep of the last completed step on the side stream, ordered after everything queued so far."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self._tables[0].device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+        self._sweep_pending, self._sweep_inflight = False, True
+
+    def _join_sweep(self):
+        if self._sweep_inflight:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._sweep_inflight = False
+
+    def _advance_host_step(self):
+        """Replay-time mirror of what step_tables() does on the host in an eager step."""
+        self._host_step += 1
+        self._sweep_pending = self.overlap_sweep
 
     def on_touch(self, rec):
         if any(id(w) in self._table_ids for w in rec["weights"]):
@@ -199,28 +269,44 @@ class TableAdam(torch.optim.Adam):
         for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
             self._touch(rec, groups, stream)
         del self._touch_log[:]
-        for D, grp in groups.items():
-            _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
-                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
-                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 0, stream)
+        if self.overlap_sweep:
+            self._sweep(SWEEP_DENSE_TABLES, stream)  # small tables take their gradient now; the rest is deferred
+            self._sweep_pending = True
+        else:
+            self._sweep(SWEEP_WINDOW, stream)
         self._lazy_dirty = True
+
+    def _finish_sweep(self):
+        """A sweep that was not forked (no training-mode gather since the last step, or a plain hipGraph capture)
+        runs in line, before the step counter moves."""
+        if self._sweep_pending:
+            self._sweep(SWEEP_LAZY_TABLES, ops._stream())
+            self._sweep_pending = False
 
     def flush(self):
         """Bring every table row up to the current step (no-op in dense mode).  Must run before the weights are read
         by anything but the training step: evaluation, state_dict, checkpointing."""
-        if self.lazy_k > 1 and self._lazy_dirty and self._tables:
-            stream = ops._stream()
-            for D, grp in self._lazy_setup().items():
-                _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
-                          ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
-                          ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 1, stream)
-            self._lazy_dirty = False
+        if self.lazy_k > 1 and self._tables:
+            self._join_sweep()
+            self._sweep_pending = False  # subsumed: the flush visits every row
+            if self._lazy_dirty:
+                self._sweep(SWEEP_FLUSH, ops._stream())
+                self._lazy_dirty = False
 
     def step_tables(self):
         """One Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
         if not self._tables and self._bucket is None:
             return
         stream = ops._stream()
+        if self.lazy_k > 1 and self._tables:
+            self._finish_sweep()
+            if self._gathers:
+                self._gathers_per_step, self._gathers = self._gathers, 0
+            seg = graphs.active()
+            if seg is not None:
+                seg.cut(self._advance_host_step)  # replays count their steps on the host too (sweep step by value)
+            elif not torch.cuda.is_current_stream_capturing():
+                self._host_step += 1
         _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
                   stream)
         if self._bucket is not None:
@@ -287,6 +373,8 @@ class TableAdam(torch.optim.Adam):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        if self.lazy_k > 1 and self._tables:
+            self._join_sweep()
         super().load_state_dict(state_dict)
         if self._tables:
             for i, p in enumerate(self._tables):
@@ -294,8 +382,14 @@ class TableAdam(torch.optim.Adam):
                 self._t_m[i].copy_(st["exp_avg"])
                 self._t_v[i].copy_(st["exp_avg_sq"])
                 st["exp_avg"], st["exp_avg_sq"] = self._t_m[i], self._t_v[i]
-            self._t_step.fill_(int(float(self.state[self._tables[0]]["step"])))
+            t = int(float(self.state[self._tables[0]]["step"]))
+            self._t_step.fill_(t)
             self._t_hyper_host = None
+            if self.lazy_k > 1:  # a checkpoint is a flushed state: every row is at step t
+                self._join_sweep()
+                self._sweep_pending, self._lazy_dirty, self._host_step = False, False, t
+                for last in self._t_last:
+                    last.fill_(t)
         if self._bucket is not None:
             for i, p in enumerate(self._bucket.params):
                 st = self.state[p]

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import tqdm
 
-from .. import ops
+from .. import graphs, ops
 from ..basic.callback import EarlyStopper
 from ..basic.loss_func import RegularizationLoss
 from ..distributed import DataParallelContext, DenseGradBucket, table_parameters
@@ -204,18 +204,21 @@ class CTRTrainer(object):
                     x, y = loader.load_next()
                     total += self._split_step(x, y) if split else self.train_step(x, y)
             torch.cuda.current_stream().wait_stream(side)
-            self._graph = torch.cuda.CUDAGraph()
+            # Segmented capture: the optimizer cuts the step where it launches the deferred table sweep eagerly on
+            # its side stream (graphs.SegmentedGraph); without cuts this is one ordinary hipGraph.
+            self._graph = graphs.SegmentedGraph()
+
+            def whole_step():
+                x, y = loader.load_next()
+                return self._split_step(x, y) if split else self.train_step(x, y)
+
             if not split:
-                with torch.cuda.graph(self._graph):
-                    x, y = loader.load_next()
-                    self._graph_loss = self.train_step(x, y)
+                self._graph_loss = self._graph.capture(whole_step)
                 return total, self.GRAPH_WARMUP
             if self.dp_graph == "single":
-                # RCCL collectives captured with the rest of the step: one hipGraph launch per step
+                # RCCL collectives captured with the rest of the step: no eager launches but the table sweep
                 try:
-                    with torch.cuda.graph(self._graph):
-                        x, y = loader.load_next()
-                        self._graph_loss = self._split_step(x, y)
+                    self._graph_loss = self._graph.capture(whole_step)
                     self._graph_b = None
                     return total, self.GRAPH_WARMUP
                 except RuntimeError as e:  # collective not capturable with this RCCL build: use the split layout
@@ -225,7 +228,10 @@ class CTRTrainer(object):
                     self.dp_graph = "split"
                     self.bucket.defer = False
                     self.dp.deferred_mode = False
-                    self._graph = torch.cuda.CUDAGraph()
+            if getattr(self.optimizer, "lazy_k", 0) > 1:
+                self.optimizer._join_sweep()  # plain captures cannot hold the eager side-stream sweep:
+                self.optimizer.overlap_sweep = False  # from here on the window sweep runs in line
+            self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 x, y = loader.load_next()
                 self._graph_loss, self._deferred_static = self._phase_a(x, y)
