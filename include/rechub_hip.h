@@ -213,6 +213,18 @@ int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, cons
  * rh_bce_fwd/bwd replaces: torch.nn.BCELoss() (mean) of trainers/ctr_trainer.py:62,:93-95: log terms clamped at -100;
  *   loss (1,), g_loss (1,) device scalars.
  */
+/* rh_linear_fwd / rh_linear_dgrad replace: the forward y = x W^T + b and the input gradient g_x = g W of the same
+ *   nn.Linear modules (aten::addmm / mm) at CTR batch sizes, where one 64x64 f32-MFMA tile per workgroup fills the chip
+ *   exactly once (csrc/gemm.hip).  x (M, K) row stride ldx, w (N, K) row stride ldw, bias (N,) or NULL, y (M, N).
+ *   stats (NULL or (rh_gemm_stats_slabs(M), 2, N) floats): per 32-row slab of y and column, the slab sum and
+ *   M2 = sum (y - slab mean)^2 -- the input rh_bn_relu_dropout_fwd takes with partial_rows = 32.
+ *   rh_linear_dgrad: g (M, N), w (N, K) -> gx (M, K).  Exact f32 (MFMA f32 == fmaf chain); summation order over k is
+ *   permuted inside each 32-wide K tile. */
+int rh_gemm_stats_slabs(int M);
+int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
+                  float* y, int64_t ldy, float* stats, void* stream);
+int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
+                    int64_t ldgx, void* stream);
 int64_t rh_linear_wgrad_workspace(int B, int N, int K);
 int rh_linear_wgrad_tiles(int N, int K);
 int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* dW, float* db,
@@ -233,16 +245,19 @@ int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, f
  * replaces: nn.BatchNorm1d -> ReLU -> nn.Dropout of MLP, torch_rechub/basic/layers.py:281-287, and their autograd
  * h (B,C) pre-BN activations; training: batch statistics (biased variance), running stats updated with `momentum`
  * (unbiased variance), num_batches_tracked += 1; eval: running statistics, no dropout.
- * rng (device int64 [2+]): seed, call counter (bumped by the forward);
+ * rng (device int64 [4]): seed, call counter (bumped by the forward), block ticket (zero on entry / exit), spare;
  * saved_ctr (device int64 [1]): the counter this call used — the backward recomputes the same dropout mask from it
  * (nothing is stored).  B <= 8192: two launches per direction (partial sums; finalize folded into apply), else three.
  * partial: (rh_bn_act_nchunks(B), 2, C) floats; stat: (4, C) floats (mean, rstd kept for the backward).
+ * partial_rows > 0 (forward): `partial` ALREADY holds, per partial_rows-row slab and column, the slab's sum and its
+ * M2 = sum (h - slab mean)^2 -- rh_linear_fwd writes exactly that (32-row slabs) from its accumulators, so the
+ * statistics pass over h disappears; the slabs are combined with Chan's parallel-variance formula in slab order.
  */
 int rh_bn_act_nchunks(int B);
 int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
-                           int training, int64_t* rng, int64_t* saved_ctr, float* partial, float* stat, float* out,
-                           void* stream);
+                           int training, int64_t* rng, int64_t* saved_ctr, float* partial, int partial_rows, float* stat,
+                           float* out, void* stream);
 int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta,
                            float p_drop, const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat,
                            float* dx, float* dgamma, float* dbeta, void* stream);

@@ -723,9 +723,9 @@ def test_linear_function_matches_torch_autograd():
     lin.zero_grad()
     xb = x0.clone().requires_grad_(True)
     out = ops.linear(xb, lin.weight, lin.bias)
-    assert torch.equal(out, lin(x0))
+    close(out, lin(x0).detach().cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="y")  # own MFMA GEMM: other k order
     out.backward(gy)
-    assert torch.equal(xb.grad, want[0])
+    close(xb.grad, want[0].cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="g_x")
     close(lin.weight.grad, want[1].cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="dW")
     close(lin.bias.grad, want[2].cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="db")
 
@@ -780,3 +780,76 @@ def test_bce_mean_vs_torch(B):
     close(lb, la.detach().cpu().numpy(), rtol=2e-6, what="bce")
     close(yb.grad, ya.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-7, what="bce grad")
     assert not ops.bce_ok(torch.nn.BCELoss(reduction="sum"), yb, t)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# csrc/gemm.hip: f32-MFMA tile GEMMs of the MLP (forward + BN statistics epilogue, input gradient)
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 429), (4096, 128, 256), (4096, 1, 128), (100, 70, 33), (33, 5, 7),
+                                   (1, 64, 64), (2048, 429, 256), (16384, 36, 64), (4000, 200, 130)])
+def test_linear_forward_and_input_gradient_vs_float64(M, N, K, monkeypatch):
+    from torch_rechub_amd import _lib, ops
+    monkeypatch.setattr(ops, "_GEMM_MAX_M", 16384)  # the opt-in f32-MFMA tile GEMMs (RECHUB_OWN_GEMM=1)
+    gen = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) * 0.1, torch.randn(N, generator=gen)
+    g = torch.randn(M, N, generator=gen)
+    xd, wd, bd, gd = x.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True), g.to(dev())
+    assert ops._own_gemm(M, N, K)
+    y, stats = ops.linear_stats(xd, wd, bd)
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 2e-6 * np.sqrt(K)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=tol * float(ref.abs().max()), err_msg="y")
+    # BN statistics epilogue: per 32-row slab (sum, M2 about the slab mean) of y
+    slabs = _lib.call("rh_gemm_stats_slabs", M)
+    assert stats.shape == (slabs, 2, N)
+    yd = y.detach().double().cpu()
+    for k in (0, slabs // 2, slabs - 1):
+        blk = yd[32 * k:32 * (k + 1)]
+        np.testing.assert_allclose(stats[k, 0].cpu().numpy(), blk.sum(0).numpy(), rtol=1e-5, atol=1e-4, err_msg="slab sum")
+        np.testing.assert_allclose(stats[k, 1].cpu().numpy(), ((blk - blk.mean(0))**2).sum(0).numpy(), rtol=1e-4, atol=1e-4,
+                                   err_msg="slab M2")
+    y.backward(gd)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), (g.double() @ w.double()).numpy(), rtol=1e-5,
+                               atol=2e-6 * np.sqrt(N) * float((g.double() @ w.double()).abs().max()), err_msg="g_x")
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), (g.double().t() @ x.double()).numpy(), rtol=1e-5, atol=3e-6 * np.sqrt(M) * 4,
+                               err_msg="g_w")
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), g.double().sum(0).numpy(), rtol=1e-5, atol=3e-6 * np.sqrt(M) * 4)
+    # plain linear (no statistics) gives the same output bits
+    assert torch.equal(ops.linear(xd.detach(), wd.detach(), bd.detach()), y.detach())
+
+
+@pytest.mark.parametrize("B,C", [(4096, 256), (4000, 128), (100, 36), (8192, 64)])
+def test_bn_from_gemm_statistics_matches_torch_modules(B, C, monkeypatch):
+    """Linear -> BatchNorm1d -> ReLU with the statistics taken from the GEMM epilogue (one BN launch) == torch modules,
+    including a column whose mean is 1000x its spread (the slab-wise M2 does not cancel)."""
+    from torch_rechub_amd import ops
+    monkeypatch.setattr(ops, "_GEMM_MAX_M", 16384)
+    torch.manual_seed(B + C)
+    K = 48
+    lin = torch.nn.Linear(K, C).to(dev())
+    with torch.no_grad():
+        lin.bias[0] = 1000.0
+        lin.weight[0] *= 0.01
+    bn_ref, bn_mine = torch.nn.BatchNorm1d(C).to(dev()), torch.nn.BatchNorm1d(C).to(dev())
+    x = torch.randn(B, K, device=dev())
+    gy = torch.randn(B, C, device=dev())
+    ya = torch.relu(bn_ref(lin(x)))
+    ya.backward(gy)
+    want = [ya.detach(), lin.weight.grad.clone(), bn_ref.weight.grad.clone(), bn_ref.bias.grad.clone()]
+    lin.zero_grad()
+    h, stats = ops.linear_stats(x, lin.weight, lin.bias)
+    assert stats is not None
+    ctr0 = int(ops._dropout_rng(dev())[1])
+    yb = ops.bn_relu_dropout(h, bn_mine, 0.0, stats=stats)
+    yb.backward(gy)
+    torch.cuda.synchronize()
+    assert int(ops._dropout_rng(dev())[1]) == ctr0 + 1 and int(ops._dropout_rng(dev())[2]) == 0  # counter advanced once, ticket reset
+    # column 0 sits at 1000 +- 0.1: its fp32 inputs carry ~6e-4 of a standard deviation of rounding noise themselves
+    close(yb[:, 1:], want[0][:, 1:].cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="bn(relu(linear)) out")
+    close(yb[:, 0], want[0][:, 0].cpu().numpy(), rtol=5e-3, atol_scale=5e-3, what="ill-conditioned column")
+    close(lin.weight.grad[1:], want[1][1:].cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dW through BN")
+    close(bn_mine.weight.grad[1:], want[2][1:].cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dgamma")
+    close(bn_mine.bias.grad[1:], want[3][1:].cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dbeta")
+    close(bn_mine.running_mean, bn_ref.running_mean.cpu().numpy(), rtol=1e-5, what="running_mean")
+    close(bn_mine.running_var[1:], bn_ref.running_var[1:].cpu().numpy(), rtol=1e-4, atol_scale=1e-6, what="running_var")
+    close(bn_mine.running_var[:1], bn_ref.running_var[:1].cpu().numpy(), rtol=1e-2, what="running_var, ill-conditioned column")
+    assert int(bn_mine.num_batches_tracked) == 1

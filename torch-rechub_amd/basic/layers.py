@@ -239,8 +239,12 @@ class MLP(nn.Module):
         while i < len(mods):
             if i + 3 < len(mods) + 0 and isinstance(mods[i], nn.Linear) and self._fusable(mods[i + 1], mods[i + 2],
                                                                                             mods[i + 3], x):
-                h = self._linear(mods[i], x)
-                x = ops.bn_relu_dropout(h, mods[i + 1], mods[i + 3].p if mods[i + 3].training else 0.0)
+                lin, bn = mods[i], mods[i + 1]
+                if type(lin) is nn.Linear and bn.training and ops.linear_ok(x, lin.weight):
+                    h, stats = ops.linear_stats(x, lin.weight, lin.bias)  # GEMM epilogue emits the BN statistics
+                else:
+                    h, stats = self._linear(lin, x), None
+                x = ops.bn_relu_dropout(h, bn, mods[i + 3].p if mods[i + 3].training else 0.0, stats=stats)
                 i += 4
             elif isinstance(mods[i], nn.Linear):
                 x = self._linear(mods[i], x)

@@ -1,0 +1,286 @@
+// f32 GEMMs of the MLP at CTR batch sizes (M = batch = 4096, N, K <= 512), on the f32 MFMA.
+//
+// Reference: every nn.Linear of MLP, torch_rechub/basic/layers.py:279,290 -- forward y = x W^T + b and the input
+// gradient g_x = g W (aten::addmm / mm).  At M = 4096 the library picks 256x16 / 224x32 macro-tiles that run at
+// 20-45 TF (9-21 us per GEMM in the round-1 profile); these shapes are small enough that one 64x64 (or 32x64) tile per
+// workgroup fills the chip exactly once, so a plain LDS-tiled kernel on v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered
+// fmaf chain) gets close to the 157 TF f32 matrix peak without any tuning database.
+//
+//   C[M, N] = A[M, K] * op(B) (+ bias[N])
+//     B_KMAJOR = true  : B is (N, K) row-major, C = A B^T      (forward: B = weight)
+//     B_KMAJOR = false : B is (K, N) row-major, C = A B        (input gradient: A = g, B = weight)
+//   Workgroup = WM x WN wavefronts, each owning one 32x32 accumulator tile; K is walked in tiles of 32 through two LDS
+//   buffers (global -> registers for tile t+1 is issued before the MFMAs of tile t).  Within a K tile MFMA step s takes
+//   the k pair {s, 16 + s}: lane (i, kk) then reads 16 CONSECUTIVE floats of its row -> four ds_read_b128 per operand per
+//   tile instead of sixteen ds_read_b32 (the summation order inside a tile is permuted, the result is the same f32 sum
+//   up to reassociation).  Rows of A / B are only 4-byte aligned (K = 429): the global loads are dwordx4 in unaligned
+//   mode, tails are zero-filled.
+//   STATS (forward in front of BatchNorm): the epilogue also emits, per 32-row slab of the output and per column, the
+//   slab's sum and its M2 = sum (x - slab mean)^2 computed from the accumulators in registers (two passes, no
+//   cancellation) -- the BatchNorm statistics then need no separate pass over h (csrc/mlp.hip combines the slabs with
+//   Chan's formula, in slab order: deterministic).
+// Roofline: f32 MFMA (157 TF); 0.9 GFLOP for the 4096 x 429 x 256 layer = 5.7 us at peak.
+#include "common.h"
+
+#ifndef RH_PROBE
+#define RH_PROBE 0  // tools/_probe: 1 = no global traffic inside the K loop, 2 = no MFMA
+#endif
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32;          // K tile
+constexpr int kLd = kBK + 4;     // LDS row stride of a k-major tile: 16-byte aligned rows, conflict-light b128 reads
+
+struct GemmArgs {
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  const float* bias;  // (N,) or null
+  float* C;
+  int64_t ldc;
+  int M, N, K;
+  float* stats;  // STATS: (ceil(M / 32), 2, N): slab sum, slab M2
+};
+
+static __device__ __forceinline__ float4 load4_guard(const float* row, int k, int K, bool row_ok) {
+  if (!row_ok || k >= K) return f4_zero();
+  if (k + 3 < K) return gload<float4>(row + k);
+  float4 v = f4_zero();
+  v.x = row[k];
+  if (k + 1 < K) v.y = row[k + 1];
+  if (k + 2 < K) v.z = row[k + 2];
+  return v;
+}
+
+template <int WM, int WN, bool B_KMAJOR, bool STATS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a) {
+  constexpr int NT = 64 * WM * WN;      // threads
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int A_V4 = BM * kBK / 4 / NT;              // float4 per thread per A tile
+  constexpr int B_V4 = BN * kBK / 4 / NT;              // float4 per thread per B tile
+  constexpr int kLdN = BN + 4;                         // row stride of the n-major B tile (B_KMAJOR = false)
+  constexpr int A_TILE = BM * kLd;
+  constexpr int B_TILE = B_KMAJOR ? BN * kLd : kBK * kLdN;
+  __shared__ float lds[2 * (A_TILE + B_TILE)];
+  const int tid = threadIdx.x, lane = tid % RH_WAVE, wave = tid / RH_WAVE;
+  const int wm = wave / WN, wn = wave % WN;
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber them so that the tiles_n
+  // workgroups sharing one slab of A -- and neighbouring slabs -- sit on the same XCD: A then comes from HBM once.
+  int bid = blockIdx.y * gridDim.x + blockIdx.x;
+  const int nblk = gridDim.x * gridDim.y;
+  if (nblk % 8 == 0) bid = (bid % 8) * (nblk / 8) + bid / 8;
+  const int m0 = (bid / (int)gridDim.x) * BM, n0 = (bid % (int)gridDim.x) * BN;
+  const int li = lane & 31, kk = lane >> 5;
+
+  float4 ra0[A_V4], rb0[B_V4], ra1[A_V4], rb1[B_V4];
+  // Per-thread source pointers of its float4 pieces (rows past M / N are clamped: they only feed accumulator rows /
+  // columns that are never stored).  Interior tiles use plain vector loads; only the last K tile and workgroups on the
+  // N edge of an n-major B take the guarded path.
+  const float* pa[A_V4];
+  const float* pb[B_V4];
+#pragma unroll
+  for (int v = 0; v < A_V4; ++v) {
+    const int e = tid + v * NT;
+    const int row = m0 + e / 8;
+    pa[v] = a.A + (int64_t)(row < a.M ? row : 0) * a.lda + (e % 8) * 4;
+  }
+#pragma unroll
+  for (int v = 0; v < B_V4; ++v) {
+    const int e = tid + v * NT;
+    if (B_KMAJOR) {
+      const int row = n0 + e / 8;
+      pb[v] = a.B + (int64_t)(row < a.N ? row : 0) * a.ldb + (e % 8) * 4;
+    } else {
+      pb[v] = a.B + (int64_t)(e / (BN / 4)) * a.ldb + n0 + (e % (BN / 4)) * 4;
+    }
+  }
+  const bool edge_n = !B_KMAJOR && n0 + BN > a.N;
+  auto gfetch = [&](int k0, float4* ra, float4* rb) {
+    if (k0 + kBK <= a.K && !edge_n) {  // wavefront-uniform
+#pragma unroll
+      for (int v = 0; v < A_V4; ++v) ra[v] = gload<float4>(pa[v] + k0);
+#pragma unroll
+      for (int v = 0; v < B_V4; ++v) rb[v] = gload<float4>(B_KMAJOR ? pb[v] + k0 : pb[v] + (int64_t)k0 * a.ldb);
+      return;
+    }
+#pragma unroll
+    for (int v = 0; v < A_V4; ++v) {
+      const int e = tid + v * NT;            // float4 index in the (BM x 8) tile
+      ra[v] = load4_guard(pa[v] - (e % 8) * 4, k0 + (e % 8) * 4, a.K, true);
+    }
+#pragma unroll
+    for (int v = 0; v < B_V4; ++v) {
+      const int e = tid + v * NT;
+      if (B_KMAJOR) {
+        rb[v] = load4_guard(pb[v] - (e % 8) * 4, k0 + (e % 8) * 4, a.K, true);
+      } else {
+        const int r = e / (BN / 4), c = (e % (BN / 4)) * 4;  // r = k within the tile, c = n within the tile
+        const int k = k0 + r;
+        rb[v] = load4_guard(a.B + (int64_t)(k < a.K ? k : 0) * a.ldb, n0 + c, a.N, k < a.K);
+      }
+    }
+  };
+  auto lstore = [&](int buf, const float4* ra, const float4* rb) {
+    float* As = lds + buf * (A_TILE + B_TILE);
+    float* Bs = As + A_TILE;
+#pragma unroll
+    for (int v = 0; v < A_V4; ++v) {
+      const int e = tid + v * NT;
+      const int r = e / 8, c = (e % 8) * 4;
+      *reinterpret_cast<float4*>(As + r * kLd + c) = ra[v];
+    }
+#pragma unroll
+    for (int v = 0; v < B_V4; ++v) {
+      const int e = tid + v * NT;
+      if (B_KMAJOR) {
+        const int r = e / 8, c = (e % 8) * 4;
+        *reinterpret_cast<float4*>(Bs + r * kLd + c) = rb[v];
+      } else {
+        const int r = e / (BN / 4), c = (e % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(Bs + r * kLdN + c) = rb[v];
+      }
+    }
+  };
+
+  // fragment reads of one K tile: 16 floats of A and of B per lane (k pairs {s, 16 + s}, see the header)
+  auto lfrag = [&](int buf, float* fa, float* fb) {
+    const float* As = lds + buf * (A_TILE + B_TILE) + (wm * 32 + li) * kLd + kk * 16;
+    const float* Bs = lds + buf * (A_TILE + B_TILE) + A_TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(As + 4 * q);
+      fa[4 * q] = v.x, fa[4 * q + 1] = v.y, fa[4 * q + 2] = v.z, fa[4 * q + 3] = v.w;
+    }
+    if (B_KMAJOR) {
+      const float* Br = Bs + (wn * 32 + li) * kLd + kk * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(Br + 4 * q);
+        fb[4 * q] = v.x, fb[4 * q + 1] = v.y, fb[4 * q + 2] = v.z, fb[4 * q + 3] = v.w;
+      }
+    } else {
+      const float* Bc = Bs + (kk * 16) * kLdN + wn * 32 + li;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fb[s] = Bc[s * kLdN];
+    }
+  };
+
+  // Software pipeline, one barrier per K tile.  At the top of iteration t: tile t's fragments are in registers, tile
+  // t+1 is in LDS, tiles t+2 and t+3 are in flight from global memory (two register sets: a first touch of A costs an
+  // HBM round trip, longer than the 16 MFMAs of one tile).  The iteration issues the LDS reads of tile t+1, runs the
+  // MFMAs of tile t under them, parks tile t+2 in the LDS buffer tile t came from and fetches tile t+4.
+  v16f acc = {};
+  const int ntiles = (a.K + kBK - 1) / kBK;
+  float fa0[16], fb0[16], fa1[16], fb1[16];
+  gfetch(0, ra0, rb0);
+  if (ntiles > 1) gfetch(kBK, ra1, rb1);
+  lstore(0, ra0, rb0);
+  if (ntiles > 1) lstore(1, ra1, rb1);
+  if (RH_PROBE != 1 && ntiles > 2) gfetch(2 * kBK, ra0, rb0);
+  if (RH_PROBE != 1 && ntiles > 3) gfetch(3 * kBK, ra1, rb1);
+  __syncthreads();
+  lfrag(0, fa0, fb0);
+  __syncthreads();  // every wavefront has tile 0 in registers before buffer 0 is overwritten below
+  auto step = [&](int t, float* fa, float* fb, float* fan, float* fbn, float4* ra, float4* rb) {
+    // The dependent MFMA chain occupies the wavefront's issue slot for 16 x 64 cycles; the LDS / global work of the
+    // iteration is placed INSIDE it in program order (sched_barrier pins it) so that it runs under the MFMAs
+    // instead of after them.
+    if (t + 1 < ntiles) lfrag((t + 1) & 1, fan, fbn);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (RH_PROBE == 2) acc[s] += fa[s] * fb[s];
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+      if (RH_PROBE != 1 && s == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntiles) lstore(t & 1, ra, rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (RH_PROBE != 1 && s == 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 4 < ntiles) gfetch((t + 4) * kBK, ra, rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, fa0, fb0, fa1, fb1, ra0, rb0);
+    if (t + 1 < ntiles) step(t + 1, fa1, fb1, fa0, fb0, ra1, rb1);
+  }
+
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int col = n0 + wn * 32 + li;
+  const bool cok = col < a.N;
+  const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+  const int rbase = m0 + wm * 32 + 4 * kk;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[r] += bv;
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    if (cok && row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[r];
+  }
+  if (STATS) {
+    // slab = the 32 rows of this wavefront's tile; rows past M count as absent
+    const int slab = (m0 / BM) * WM + wm;
+    const int nrows = min(32, a.M - (m0 + wm * 32));
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += (rbase + (r & 3) + 8 * (r >> 2) < a.M) ? acc[r] : 0.f;
+    s += __shfl_xor(s, 32);
+    const float mean = nrows > 0 ? s / (float)nrows : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc[r] - mean;
+      m2 += (rbase + (r & 3) + 8 * (r >> 2) < a.M) ? d * d : 0.f;
+    }
+    m2 += __shfl_xor(m2, 32);
+    if (kk == 0 && cok && nrows > 0) {
+      a.stats[((int64_t)slab * 2 + 0) * a.N + col] = s;
+      a.stats[((int64_t)slab * 2 + 1) * a.N + col] = m2;
+    }
+  }
+}
+
+template <bool B_KMAJOR, bool STATS>
+void launch(const GemmArgs& a, hipStream_t s) {
+  // one tile per workgroup; 64x64 tiles unless that leaves most of the 256 CUs idle
+  const int64_t big = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  if (big >= 192) {
+    hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm_f32_kernel<1, 2, B_KMAJOR, STATS>), dim3((a.N + 63) / 64, (a.M + 31) / 32), dim3(128), 0, s, a);
+  }
+}
+
+}  // namespace
+
+extern "C" int rh_gemm_stats_slabs(int M) { return (M + 31) / 32; }
+
+extern "C" int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N,
+                             int K, float* y, int64_t ldy, float* stats, void* stream) {
+  RH_REQUIRE(x && w && y, RH_E_BADARG, "rh_linear_fwd: null pointer");
+  RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N, RH_E_BADARG,
+             "rh_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
+  GemmArgs a{x, ldx, w, ldw, bias, y, ldy, M, N, K, stats};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stats) launch<true, true>(a, s);
+  else launch<true, false>(a, s);
+  RH_LAUNCH_CHECK("rh_linear_fwd");
+  return 0;
+}
+
+extern "C" int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
+                               int64_t ldgx, void* stream) {
+  // gx (M, K) = g (M, N) w (N, K): a GEMM with reduction length N and output width K
+  RH_REQUIRE(g && w && gx, RH_E_BADARG, "rh_linear_dgrad: null pointer");
+  RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldg >= N && ldw >= K && ldgx >= K, RH_E_BADARG,
+             "rh_linear_dgrad: bad shape M=%d N=%d K=%d", M, N, K);
+  GemmArgs a{g, ldg, w, ldw, nullptr, gx, ldgx, M, /*N=*/K, /*K=*/N, nullptr};
+  launch<false, false>(a, reinterpret_cast<hipStream_t>(stream));
+  RH_LAUNCH_CHECK("rh_linear_dgrad");
+  return 0;
+}

@@ -102,55 +102,91 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
       s1 += red[0][k * CW + threadIdx.x];
       s2 += red[1][k * CW + threadIdx.x];
     }
+    if (MODE == 0) {
+      // forward partials are (chunk sum, chunk M2 about the chunk mean): what Chan's parallel-variance combination
+      // takes, and what the GEMM epilogue (csrc/gemm.hip) emits directly from its accumulators
+      const float nk = (float)(r1 - r0);
+      const float sum = fmaf(nk, a.h[c], s1);
+      s2 = fmaxf(s2 - s1 * s1 / nk, 0.f);
+      s1 = sum;
+    }
     a.partial[((int64_t)blockIdx.y * 2 + 0) * a.C + c] = s1;
     a.partial[((int64_t)blockIdx.y * 2 + 1) * a.C + c] = s2;
   }
 }
 
+// Chan et al. combination of per-chunk (sum_k, M2_k, n_k): mean = sum_k sum_k / n, M2 = sum_k [M2_k + n_k (mean_k - mean)^2].
+// Two passes over one column's partials by GROUPS cooperating threads (fixed order: deterministic); returns mean and
+// the biased variance to every thread of the column.  red: [2][GROUPS][COLS + 1] floats of LDS.
+template <int GROUPS, int COLS, int MAXIT>
+static __device__ __forceinline__ void chan_combine(const BnArgs& a, int c, int cl, int grp, bool cok, float* red,
+                                                    float& mean, float& var) {
+  // MAXIT * GROUPS >= nchunks on the fused path: every thread's partials are loaded up front (independent loads, one
+  // latency), then both passes run from registers; longer chunk lists (3-launch path) fall back to a second read.
+  float ps[MAXIT], pm[MAXIT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int k = grp + i * GROUPS;
+    const bool ok = cok && k < a.nchunks;
+    ps[i] = ok ? a.partial[((int64_t)k * 2 + 0) * a.C + c] : 0.f;
+    pm[i] = ok ? a.partial[((int64_t)k * 2 + 1) * a.C + c] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) s += ps[i];
+  if (cok)
+    for (int k = grp + MAXIT * GROUPS; k < a.nchunks; k += GROUPS) s += a.partial[((int64_t)k * 2 + 0) * a.C + c];
+  red[grp * (COLS + 1) + cl] = s;
+  __syncthreads();
+  s = red[cl];
+#pragma unroll
+  for (int q = 1; q < GROUPS; ++q) s += red[q * (COLS + 1) + cl];
+  mean = s / (float)a.B;
+  __syncthreads();
+  const float full = (float)a.rows_per_chunk, inv_full = 1.f / full;
+  const int last = a.nchunks - 1;
+  const float tail = (float)(a.B - last * a.rows_per_chunk), inv_tail = 1.f / tail;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int k = grp + i * GROUPS;
+    if (cok && k < a.nchunks) {
+      const float d = ps[i] * (k == last ? inv_tail : inv_full) - mean;
+      m2 += fmaf((k == last ? tail : full) * d, d, pm[i]);
+    }
+  }
+  if (cok) {
+    for (int k = grp + MAXIT * GROUPS; k < a.nchunks; k += GROUPS) {
+      const float d = a.partial[((int64_t)k * 2 + 0) * a.C + c] * (k == last ? inv_tail : inv_full) - mean;
+      m2 += fmaf((k == last ? tail : full) * d, d, a.partial[((int64_t)k * 2 + 1) * a.C + c]);
+    }
+  }
+  red[grp * (COLS + 1) + cl] = m2;
+  __syncthreads();
+  m2 = red[cl];
+#pragma unroll
+  for (int q = 1; q < GROUPS; ++q) m2 += red[q * (COLS + 1) + cl];
+  var = fmaxf(m2 / (float)a.B, 0.f);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
-  __shared__ float red[2][RH_BLOCK];
   constexpr int GROUPS = RH_BLOCK / kFinCols;
-  const int c = blockIdx.x * kFinCols + threadIdx.x % kFinCols;
+  __shared__ float red[2 * GROUPS * (kFinCols + 1)];
+  const int cl = threadIdx.x % kFinCols;
+  const int c = blockIdx.x * kFinCols + cl;
   const int grp = threadIdx.x / kFinCols;
+  const bool cok = c < a.C;
   if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     a.saved_ctr[0] = a.rng[1];  // dropout stream of this call
     a.rng[1] += 1;
     if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
   }
-  float s1 = 0.f, s2 = 0.f;
-  if (c < a.C) {
-    // chunk partials are summed in a fixed order (group-strided, then across groups): deterministic
-    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = grp;
-    for (; k + 3 * GROUPS < a.nchunks; k += 4 * GROUPS) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        t1[u] += a.partial[((int64_t)(k + u * GROUPS) * 2 + 0) * a.C + c];
-        t2[u] += a.partial[((int64_t)(k + u * GROUPS) * 2 + 1) * a.C + c];
-      }
-    }
-    for (; k < a.nchunks; k += GROUPS) {
-      t1[0] += a.partial[((int64_t)k * 2 + 0) * a.C + c];
-      t2[0] += a.partial[((int64_t)k * 2 + 1) * a.C + c];
-    }
-    s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
-    s2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
-  }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
-  __syncthreads();
-  if (grp != 0 || c >= a.C) return;
-  for (int g2 = 1; g2 < GROUPS; ++g2) {
-    s1 += red[0][g2 * kFinCols + threadIdx.x];
-    s2 += red[1][g2 * kFinCols + threadIdx.x];
-  }
   if (MODE == 0) {
+    float mean, var;
+    chan_combine<GROUPS, kFinCols, 16>(a, c, cl, grp, cok, red, mean, var);
+    if (grp != 0 || !cok) return;
     const float n = (float)a.B;
-    const float m1 = s1 / n;
-    const float mean = a.h[c] + m1;
-    float var = s2 / n - m1 * m1;  // biased variance (normalisation)
-    var = var > 0.f ? var : 0.f;
     a.stat[c] = mean;
     a.stat[a.C + c] = rsqrtf(var + a.eps);
     if (a.running_mean != nullptr) {
@@ -158,12 +194,30 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
       a.running_mean[c] = fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
       a.running_var[c] = fmaf(a.momentum, unbiased - a.running_var[c], a.running_var[c]);
     }
-  } else {
-    a.stat[2 * a.C + c] = s1;  // sum g1        = dbeta
-    a.stat[3 * a.C + c] = s2;  // sum g1 * xhat = dgamma
-    a.dbeta[c] = s1;
-    a.dgamma[c] = s2;
+    return;
   }
+  float s1 = 0.f, s2 = 0.f;
+  if (cok) {
+    // chunk partials are summed in a fixed order (group-strided, then across groups): deterministic
+    for (int k = grp; k < a.nchunks; k += GROUPS) {
+      s1 += a.partial[((int64_t)k * 2 + 0) * a.C + c];
+      s2 += a.partial[((int64_t)k * 2 + 1) * a.C + c];
+    }
+  }
+  red[grp * (kFinCols + 1) + cl] = s1;
+  red[(GROUPS + grp) * (kFinCols + 1) + cl] = s2;
+  __syncthreads();
+  if (grp != 0 || !cok) return;
+  s1 = red[cl];
+  s2 = red[GROUPS * (kFinCols + 1) + cl];
+  for (int g2 = 1; g2 < GROUPS; ++g2) {
+    s1 += red[g2 * (kFinCols + 1) + cl];
+    s2 += red[(GROUPS + g2) * (kFinCols + 1) + cl];
+  }
+  a.stat[2 * a.C + c] = s1;  // sum g1        = dbeta
+  a.stat[3 * a.C + c] = s2;  // sum g1 * xhat = dgamma
+  a.dbeta[c] = s1;
+  a.dgamma[c] = s2;
 }
 
 // MODE 0 forward apply, MODE 1 backward dx, MODE 2 eval-mode forward (running statistics, no dropout)
@@ -213,38 +267,22 @@ constexpr int kSlabCols = 32, kSlabLanes = RH_BLOCK / kSlabCols;
 
 template <int MODE>  // 0 forward, 1 backward
 __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, int rows_per_block) {
-  __shared__ float red[2][kSlabLanes][kSlabCols + 1];
+  __shared__ float red[2 * kSlabLanes * (kSlabCols + 1)];
   const int cl = threadIdx.x % kSlabCols, grp = threadIdx.x / kSlabCols;
   const int c = blockIdx.x * kSlabCols + cl;
   const bool cok = c < a.C;
-  float s1 = 0.f, s2 = 0.f;
-  if (cok) {
-    for (int k = grp; k < a.nchunks; k += kSlabLanes) {  // fixed order: deterministic
-      s1 += a.partial[((int64_t)k * 2 + 0) * a.C + c];
-      s2 += a.partial[((int64_t)k * 2 + 1) * a.C + c];
-    }
-  }
-  red[0][grp][cl] = s1;
-  red[1][grp][cl] = s2;
-  __syncthreads();
-  s1 = red[0][0][cl];
-  s2 = red[1][0][cl];
-#pragma unroll
-  for (int q = 1; q < kSlabLanes; ++q) {
-    s1 += red[0][q][cl];
-    s2 += red[1][q][cl];
-  }
-  if (!cok) return;
-  const float n = (float)a.B, inv_n = 1.f / n;
-  const float g = a.gamma[c], bt = a.beta[c];
-  float mean, rstd;
+  // forward with partials from the GEMM epilogue (a.bookkeep == 2): nothing ran before this launch that could have
+  // advanced the dropout counter, so every block reads it here and the LAST block to finish advances it (ticket in
+  // rng[2]; only that scalar is exchanged, so no cache-wide fence is needed)
+  uint64_t ctr_now = 0;
+  if (MODE == 0 && a.bookkeep == 2) ctr_now = (uint64_t)a.rng[1];
+  float s1 = 0.f, s2 = 0.f, mean, rstd;
   if (MODE == 0) {
-    const float m1 = s1 / n;
-    mean = a.h[c] + m1;
-    float var = s2 / n - m1 * m1;
-    var = var > 0.f ? var : 0.f;
+    float var;
+    chan_combine<kSlabLanes, kSlabCols, kFusedMaxChunks / kSlabLanes>(a, c, cl, grp, cok, red, mean, var);
     rstd = rsqrtf(var + a.eps);
-    if (blockIdx.y == 0 && grp == 0) {
+    if (cok && blockIdx.y == 0 && grp == 0) {
+      const float n = (float)a.B;
       a.stat[c] = mean;
       a.stat[a.C + c] = rstd;
       if (a.running_mean != nullptr) {
@@ -254,24 +292,54 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
       }
     }
   } else {
-    mean = a.stat[c];
-    rstd = a.stat[a.C + c];
-    if (blockIdx.y == 0 && grp == 0) {
-      a.dbeta[c] = s1;
-      a.dgamma[c] = s2;
+    {
+      constexpr int MAXIT = kFusedMaxChunks / kSlabLanes;  // fixed order: deterministic; loads issued together
+      float p1[MAXIT], p2[MAXIT];
+#pragma unroll
+      for (int i = 0; i < MAXIT; ++i) {
+        const int k = grp + i * kSlabLanes;
+        const bool ok = cok && k < a.nchunks;
+        p1[i] = ok ? a.partial[((int64_t)k * 2 + 0) * a.C + c] : 0.f;
+        p2[i] = ok ? a.partial[((int64_t)k * 2 + 1) * a.C + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < MAXIT; ++i) {
+        s1 += p1[i];
+        s2 += p2[i];
+      }
+    }
+    red[grp * (kSlabCols + 1) + cl] = s1;
+    red[(kSlabLanes + grp) * (kSlabCols + 1) + cl] = s2;
+    __syncthreads();
+    s1 = red[cl];
+    s2 = red[kSlabLanes * (kSlabCols + 1) + cl];
+#pragma unroll
+    for (int q = 1; q < kSlabLanes; ++q) {
+      s1 += red[q * (kSlabCols + 1) + cl];
+      s2 += red[(kSlabLanes + q) * (kSlabCols + 1) + cl];
+    }
+    if (cok) {
+      mean = a.stat[c];
+      rstd = a.stat[a.C + c];
+      if (blockIdx.y == 0 && grp == 0) {
+        a.dbeta[c] = s1;
+        a.dgamma[c] = s2;
+      }
     }
   }
+  const float inv_n = 1.f / (float)a.B;
+  const float g = cok ? a.gamma[c] : 0.f, bt = cok ? a.beta[c] : 0.f;
   const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
   uint64_t seed = 0, ctr = 0;
   if (a.p_drop > 0.f) {
     seed = (uint64_t)a.rng[0];
-    ctr = (uint64_t)a.saved_ctr[0];
+    ctr = (MODE == 0 && a.bookkeep == 2) ? ctr_now : (uint64_t)a.saved_ctr[0];
   }
   const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, a.B);
   const float sg = s1 * inv_n, sgx = s2 * inv_n;
 #pragma unroll 4
-  for (int r = r0 + grp; r < r1; r += kSlabLanes) {
+  for (int r = r0 + grp; cok && r < r1; r += kSlabLanes) {
     const int64_t i = (int64_t)r * a.C + c;
     const float xhat = (a.h[i] - mean) * rstd;
     const float bn = fmaf(xhat, g, bt);
@@ -285,18 +353,38 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
       a.out[i] = y;
     }
   }
+  if (MODE == 0 && a.bookkeep == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.rng + 2);
+      const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y;
+      if (atomicAdd(ticket, 1ull) == nblk - 1) {
+        a.saved_ctr[0] = (int64_t)ctr_now;
+        a.rng[1] = (int64_t)ctr_now + 1;
+        if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
+        atomicExch(ticket, 0ull);
+      }
+    }
+  }
 }
 
 bool fused_path_ok(int B) { return (B + kFusedRows - 1) / kFusedRows <= kFusedMaxChunks; }
 
+// partial_rows > 0: a.partial already holds (sum, M2) per partial_rows-row slab (written by the GEMM in front)
 template <int MODE>
-void launch_fused(BnArgs a, hipStream_t s) {
-  a.rows_per_chunk = kFusedRows;
-  a.nchunks = (a.B + kFusedRows - 1) / kFusedRows;
-  a.bookkeep = MODE == 0 ? 1 : 0;
-  const int cw = kSlabCols;  // 32 columns x 8 row lanes: C/32 x nchunks blocks, 8 rows per thread
-  hipLaunchKernelGGL((bn_partial_kernel<MODE>), dim3((unsigned)((a.C + cw - 1) / cw), (unsigned)a.nchunks), dim3(RH_BLOCK), 0,
-                     s, a, cw);
+void launch_fused(BnArgs a, hipStream_t s, int partial_rows = 0) {
+  if (partial_rows > 0) {
+    a.rows_per_chunk = partial_rows;
+    a.nchunks = (a.B + partial_rows - 1) / partial_rows;
+    a.bookkeep = 2;  // the apply launch advances the dropout counter itself (last block)
+  } else {
+    a.rows_per_chunk = kFusedRows;
+    a.nchunks = (a.B + kFusedRows - 1) / kFusedRows;
+    a.bookkeep = MODE == 0 ? 1 : 0;
+    const int cw = kSlabCols;  // 32 columns x 8 row lanes: C/32 x nchunks blocks, 8 rows per thread
+    hipLaunchKernelGGL((bn_partial_kernel<MODE>), dim3((unsigned)((a.C + cw - 1) / cw), (unsigned)a.nchunks),
+                       dim3(RH_BLOCK), 0, s, a, cw);
+  }
   const int slabs = (a.C + kSlabCols - 1) / kSlabCols;
   int gy = (512 + slabs - 1) / slabs;                 // ~512 blocks in total
   int rpb = (a.B + gy - 1) / gy;
@@ -325,7 +413,8 @@ extern "C" int rh_bn_act_nchunks(int B) { return (B + kRowsPerChunk - 1) / kRows
 extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float momentum, float eps, float p_drop, int training, int64_t* rng,
-                                      int64_t* saved_ctr, float* partial, float* stat, float* out, void* stream) {
+                                      int64_t* saved_ctr, float* partial, int partial_rows, float* stat, float* out,
+                                      void* stream) {
   RH_REQUIRE(h && gamma && beta && out, RH_E_BADARG, "rh_bn_relu_dropout_fwd: null pointer");
   RH_REQUIRE(B >= 1 && C >= 1, RH_E_BADARG, "rh_bn_relu_dropout_fwd: bad shape B=%d C=%d", B, C);
   RH_REQUIRE(p_drop >= 0.f && p_drop < 1.f, RH_E_BADARG, "rh_bn_relu_dropout_fwd: p must be in [0, 1)");
@@ -343,14 +432,20 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
     return 0;
   }
   RH_REQUIRE(partial && stat && rng && saved_ctr, RH_E_BADARG, "rh_bn_relu_dropout_fwd: training needs workspaces");
-  if (fused_path_ok(B)) {
-    launch_fused<0>(a, s);
+  RH_REQUIRE(partial_rows >= 0, RH_E_BADARG, "rh_bn_relu_dropout_fwd: partial_rows");
+  if (partial_rows > 0 ? (B + partial_rows - 1) / partial_rows <= kFusedMaxChunks : fused_path_ok(B)) {
+    launch_fused<0>(a, s, partial_rows);
     RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd(fused finalize)");
     return 0;
   }
-  const int CW = col_width(C);
-  const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
-  hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, a, CW);
+  if (partial_rows > 0) {
+    a.rows_per_chunk = partial_rows;
+    a.nchunks = (B + partial_rows - 1) / partial_rows;
+  } else {
+    const int CW = col_width(C);
+    const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
+    hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, a, CW);
+  }
   hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
   hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(apply_grid((int64_t)B * C)), dim3(RH_BLOCK), 0, s, a);
   RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd");

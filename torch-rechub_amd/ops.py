@@ -11,6 +11,7 @@ backward scatter-adds into it and publishes it as ``weight.grad``; ``FusedDenseA
 touched rows inside its own pass.  A stock ``torch.optim`` optimizer sees an ordinary dense ``.grad``.
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
@@ -531,23 +532,27 @@ def _dropout_rng(device):
 
 
 class _BnReluDropoutFn(torch.autograd.Function):
-    """y = dropout(relu(batch_norm(h))) for one MLP hidden layer (training mode); see csrc/mlp.hip."""
+    """y = dropout(relu(batch_norm(h))) for one MLP hidden layer (training mode); see csrc/mlp.hip.
+    ``stats``: per-32-row-slab (sum, M2) of h from the GEMM that produced it (ops.linear_stats), or None."""
 
     @staticmethod
-    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop):
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, stats):
         require_hip(h, gamma, beta)
         h = h.contiguous()
         B, C = h.shape
         dev = h.device
         out = torch.empty_like(h)
-        nch = _lib.call("rh_bn_act_nchunks", B)
-        partial = torch.empty((nch, 2, C), dtype=torch.float32, device=dev)
+        if stats is not None:
+            partial, prow = stats, 32
+        else:
+            partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
+            prow = 0
         stat = torch.empty((4, C), dtype=torch.float32, device=dev)
         saved_ctr = torch.empty(1, dtype=torch.int64, device=dev)
         rng = _dropout_rng(dev)
         _lib.call("rh_bn_relu_dropout_fwd", _p(h), B, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                   _p(num_batches_tracked), float(momentum), float(eps), float(p_drop), 1, _p(rng), _p(saved_ctr),
-                  _p(partial), _p(stat), _p(out), _stream())
+                  _p(partial), prow, _p(stat), _p(out), _stream())
         ctx.p_drop = float(p_drop)
         ctx.save_for_backward(h, gamma, beta, stat, saved_ctr)
         return out
@@ -564,19 +569,19 @@ class _BnReluDropoutFn(torch.autograd.Function):
         partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
         _lib.call("rh_bn_relu_dropout_bwd", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop, _p(_dropout_rng(dev)),
                   _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), _stream())
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_relu_dropout(h, bn, p_drop):
+def bn_relu_dropout(h, bn, p_drop, stats=None):
     """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``."""
     if bn.training:
         return _BnReluDropoutFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                      bn.momentum, bn.eps, p_drop)
+                                      bn.momentum, bn.eps, p_drop, stats)
     require_hip(h)
     h = h.contiguous()
     out = torch.empty_like(h)
     _lib.call("rh_bn_relu_dropout_fwd", _p(h), h.shape[0], h.shape[1], _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
-              _p(bn.running_var), _p(None), 0.0, float(bn.eps), 0.0, 0, _p(None), _p(None), _p(None), _p(None), _p(out),
+              _p(bn.running_var), _p(None), 0.0, float(bn.eps), 0.0, 0, _p(None), _p(None), _p(None), 0, _p(None), _p(out),
               _stream())
     return out
 
@@ -614,31 +619,77 @@ def linear_ok(x, weight):
             _lib.call("rh_linear_wgrad_tiles", weight.shape[0], weight.shape[1]) <= _MAX_WGRAD_TILES)
 
 
+# Forward / input-gradient GEMMs: hipBLASLt by default.  RECHUB_OWN_GEMM=1 routes batch-sized problems (M <= 16384,
+# N, K <= 1024) through the f32-MFMA tile kernel of csrc/gemm.hip, whose epilogue also emits the BatchNorm statistics.
+# Measured on MI355X at B = 4096 (round 1): 16.4 / 10.6 us vs the library's 20.9 / 12.0 us for the two forward GEMMs,
+# but the whole step is 4 % slower because the per-32-row statistics slabs make the BN apply prologue heavier --
+# kept opt-in until that is fixed.
+_GEMM_MAX_M = 16384 if os.environ.get("RECHUB_OWN_GEMM", "0") == "1" else 0
+_GEMM_MAX_NK = 1024
+
+
+def _own_gemm(M, N, K):
+    return 0 < M <= _GEMM_MAX_M and N <= _GEMM_MAX_NK and K <= _GEMM_MAX_NK
+
+
 class _LinearFn(torch.autograd.Function):
-    """nn.Linear with the library GEMM forward / input gradient and the split-batch MFMA weight + bias gradient."""
+    """nn.Linear: forward and input gradient on the f32-MFMA tile kernel at CTR batch sizes (library GEMM otherwise),
+    weight + bias gradient on the split-batch MFMA kernel.  With ``want_stats`` the forward also returns the per-slab
+    (sum, M2) of its output for the BatchNorm that follows."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        M, K = x.shape
+        N = weight.shape[0]
+        stats = None
+        if _own_gemm(M, N, K) and weight.is_contiguous() and x.stride(1) == 1:
+            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            if want_stats:
+                stats = torch.empty((_lib.call("rh_gemm_stats_slabs", M), 2, N), dtype=torch.float32, device=x.device)
+            _lib.call("rh_linear_fwd", _p(x), x.stride(0), _p(weight), K, _p(bias), M, N, K, _p(y), N, _p(stats),
+                      _stream())
+        else:
+            y = torch.nn.functional.linear(x, weight, bias)
+        if want_stats:
+            if stats is None:
+                return y, None
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *unused):
         x, weight = ctx.saved_tensors
-        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            M, N = g.shape
+            K = weight.shape[1]
+            if _own_gemm(M, K, N) and weight.is_contiguous() and g.stride(1) == 1:
+                gx = torch.empty((M, K), dtype=torch.float32, device=g.device)
+                _lib.call("rh_linear_dgrad", _p(g), g.stride(0), _p(weight), K, M, N, K, _p(gx), K, _stream())
+            else:
+                gx = g.mm(weight)
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dW, db = linear_wgrad(g, x, want_bias=ctx.has_bias)
-        return gx, dW, db
+        return gx, dW, db, None
 
 
 def linear(x, weight, bias=None):
     """F.linear for 2-D fp32 HIP activations; see _LinearFn."""
-    if torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)) and linear_ok(
-            x, weight):
-        return _LinearFn.apply(x, weight, bias)
+    if linear_ok(x, weight) and (_own_gemm(x.shape[0], weight.shape[0], weight.shape[1]) or (
+            torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)))):
+        return _LinearFn.apply(x, weight, bias, False)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+def linear_stats(x, weight, bias=None):
+    """(F.linear(x, weight, bias), per-32-row-slab (sum, M2) of it or None): the Linear in front of a BatchNorm1d."""
+    if linear_ok(x, weight):
+        return _LinearFn.apply(x, weight, bias, True)
+    return torch.nn.functional.linear(x, weight, bias), None
 
 
 def _col(t, B):
