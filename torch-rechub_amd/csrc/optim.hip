@@ -53,7 +53,8 @@ __global__ void adam_prepare_kernel(double* hyper, int64_t* step, float* ring, i
 }
 
 struct AdamScalars {
-  float b2, wd, one_m_b1, one_m_b2;
+  float b1, b2, wd, one_m_b1, one_m_b2;
+  float c1wd, c2wd2;  // (1-b1)*wd, (1-b2)*wd^2: the zero-gradient form below
   float A, E;  // per-step: A = lr/(1-b1^t)*sqrt(1-b2^t), E = eps*sqrt(1-b2^t)
 };
 
@@ -75,7 +76,8 @@ static __device__ __forceinline__ void adam_elem(float& p, float g, float& m, fl
 // same order, same rounding as adam_elem, element for element.  Measured cost model on MI355X (sweep at K = 32, steady
 // state, variants with sqrt / rcp removed): a v_pk_*_f32 and a v_sqrt/v_rcp each cost 8 cycles per wavefront, a plain
 // VALU op 4 -> 18 pk + 8 transcendental + 2 plain = 216 cycles per 256 element-steps = 185 us per 540 M element-steps,
-// which is what the sweep takes: it is bound by f32 VALU throughput (9 flop-ops + sqrt + rcp per element-step).
+// which is what the sweep took with this function in its replay loop: it is bound by f32 VALU throughput (9 flop-ops +
+// sqrt + rcp per element-step; 8 with the zero-gradient form below, which the replay loops use).
 typedef float rh_v2f __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ void adam_pair(rh_v2f& p, rh_v2f g, rh_v2f& m, rh_v2f& v, const AdamScalars& h,
                                                  float A, float E) {
@@ -86,21 +88,50 @@ static __device__ __forceinline__ void adam_pair(rh_v2f& p, rh_v2f g, rh_v2f& m,
   d = rh_v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
   p = __builtin_elementwise_fma(rh_v2f{-A, -A}, m * d, p);
 }
-static __device__ __forceinline__ void adam_f4(float4& P, const float4 G, float4& M, float4& V, const AdamScalars& h,
-                                               float A, float E) {
+// An element whose data gradient is EXACTLY zero (every replayed step of the lazy kernels; untouched rows in the dense
+// pass) has g = wd*p, and the same update needs one operation less when g is never formed:
+//   m = b1*m + (1-b1)*wd*p,  v = b2*v + (1-b2)*wd^2*p^2          (8 instead of 9 packed ops + sqrt + rcp)
+// Same real-number result as adam_pair with g = 0, different rounding -- so EVERY kernel applies this form to every
+// element with a zero gradient and adam_pair to the others (adam_f4 selects per element): lazy == dense stays
+// bit-identical, and the replay loop, which the step time hangs on, runs the short form unconditionally.
+static __device__ __forceinline__ void adam_pair_zero_g(rh_v2f& p, rh_v2f& m, rh_v2f& v, const AdamScalars& h, float A,
+                                                        float E) {
+  m = __builtin_elementwise_fma(rh_v2f{h.c1wd, h.c1wd}, p, m * h.b1);
+  v = __builtin_elementwise_fma(rh_v2f{h.c2wd2, h.c2wd2}, p * p, v * h.b2);
+  rh_v2f d = rh_v2f{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)} + E;
+  d = rh_v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  p = __builtin_elementwise_fma(rh_v2f{-A, -A}, m * d, p);
+}
+static __device__ __forceinline__ void adam_f4_zero_g(float4& P, float4& M, float4& V, const AdamScalars& h, float A,
+                                                      float E) {
   rh_v2f p0{P.x, P.y}, p1{P.z, P.w}, m0{M.x, M.y}, m1{M.z, M.w}, v0{V.x, V.y}, v1{V.z, V.w};
-  adam_pair(p0, rh_v2f{G.x, G.y}, m0, v0, h, A, E);
-  adam_pair(p1, rh_v2f{G.z, G.w}, m1, v1, h, A, E);
+  adam_pair_zero_g(p0, m0, v0, h, A, E);
+  adam_pair_zero_g(p1, m1, v1, h, A, E);
   P = make_float4(p0.x, p0.y, p1.x, p1.y);
   M = make_float4(m0.x, m0.y, m1.x, m1.y);
   V = make_float4(v0.x, v0.y, v1.x, v1.y);
 }
+// one step with a gradient that may be zero element-wise
+static __device__ __forceinline__ void adam_f4(float4& P, const float4 G, float4& M, float4& V, const AdamScalars& h,
+                                               float A, float E) {
+  float4 Pz = P, Mz = M, Vz = V;
+  adam_f4_zero_g(Pz, Mz, Vz, h, A, E);
+  rh_v2f p0{P.x, P.y}, p1{P.z, P.w}, m0{M.x, M.y}, m1{M.z, M.w}, v0{V.x, V.y}, v1{V.z, V.w};
+  adam_pair(p0, rh_v2f{G.x, G.y}, m0, v0, h, A, E);
+  adam_pair(p1, rh_v2f{G.z, G.w}, m1, v1, h, A, E);
+  P = make_float4(G.x == 0.f ? Pz.x : p0.x, G.y == 0.f ? Pz.y : p0.y, G.z == 0.f ? Pz.z : p1.x, G.w == 0.f ? Pz.w : p1.y);
+  M = make_float4(G.x == 0.f ? Mz.x : m0.x, G.y == 0.f ? Mz.y : m0.y, G.z == 0.f ? Mz.z : m1.x, G.w == 0.f ? Mz.w : m1.y);
+  V = make_float4(G.x == 0.f ? Vz.x : v0.x, G.y == 0.f ? Vz.y : v0.y, G.z == 0.f ? Vz.z : v1.x, G.w == 0.f ? Vz.w : v1.y);
+}
 static __device__ __forceinline__ AdamScalars load_scalars(const double* hyper) {
   AdamScalars h;
+  h.b1 = (float)hyper[1];
   h.b2 = (float)hyper[2];
   h.wd = (float)hyper[4];
   h.one_m_b1 = (float)hyper[10];
   h.one_m_b2 = (float)hyper[11];
+  h.c1wd = h.one_m_b1 * h.wd;
+  h.c2wd2 = h.one_m_b2 * h.wd * h.wd;
   h.A = (float)hyper[13];
   h.E = (float)hyper[14];
   return h;
@@ -233,29 +264,36 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     u.G = u.with_g ? gload<float4>(u.g + u.r * D + q * 4) : f4_zero();
     u.live = true;
   };
-  Unit cur, nxt;
-  fetch(blockIdx.x, cur);
-  for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += gridDim.x) {
-    fetch(vb + gridDim.x, nxt);
-    const bool work = cur.live && cur.old < t;  // old >= t: already stepped by the touched pass
+  auto process = [&](Unit& u) {
+    const bool work = u.live && u.old < t;  // old >= t: already stepped by the touched pass
     // The replay loop runs on a wavefront-uniform counter (scalar ALU, ring entry read once per wavefront) from the
     // oldest row of the wavefront; rows that are more recent join later under the exec mask.
-    const int first = work ? cur.old + 1 : t;
+    const int first = work ? u.old + 1 : t;
     const int jmin = wave_min_uniform(first);
     for (int j = jmin; j < t; ++j) {
       const float A = ring_s[2 * (j & a.ring_mask)], E = ring_s[2 * (j & a.ring_mask) + 1];
-      if (j >= first) adam_f4(cur.P, f4_zero(), cur.M, cur.V, h, A, E);
+      if (j >= first) adam_f4_zero_g(u.P, u.M, u.V, h, A, E);
     }
     if (work) {
-      adam_f4(cur.P, cur.G, cur.M, cur.V, h, h.A, h.E);
-      gstore<float4>(cur.p + cur.r * D + q * 4, cur.P);
-      gstore<float4>(cur.m + cur.r * D + q * 4, cur.M);
-      gstore<float4>(cur.v + cur.r * D + q * 4, cur.V);
-      if (cur.with_g && (cur.G.x != 0.f || cur.G.y != 0.f || cur.G.z != 0.f || cur.G.w != 0.f))
-        gstore<float4>(cur.g + cur.r * D + q * 4, f4_zero());
-      if (q == 0) cur.last[cur.r] = t;
+      // lazy tables never carry a gradient here (their rows got it in the touched pass): short form, no select
+      if (u.with_g) adam_f4(u.P, u.G, u.M, u.V, h, h.A, h.E);
+      else adam_f4_zero_g(u.P, u.M, u.V, h, h.A, h.E);
+      gstore<float4>(u.p + u.r * D + q * 4, u.P);
+      gstore<float4>(u.m + u.r * D + q * 4, u.M);
+      gstore<float4>(u.v + u.r * D + q * 4, u.V);
+      if (u.with_g && (u.G.x != 0.f || u.G.y != 0.f || u.G.z != 0.f || u.G.w != 0.f))
+        gstore<float4>(u.g + u.r * D + q * 4, f4_zero());
+      if (q == 0) u.last[u.r] = t;
     }
-    cur = nxt;
+  };
+  // two units ping-pong (no register copies): the loads of one are in flight while the other is replayed
+  Unit ua, ub;
+  fetch(blockIdx.x, ua);
+  for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += 2 * (int64_t)gridDim.x) {
+    fetch(vb + gridDim.x, ub);
+    process(ua);
+    fetch(vb + 2 * (int64_t)gridDim.x, ua);
+    process(ub);
   }
 }
 
@@ -314,7 +352,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
     const float4 G = gload<float4>(g + r * D + q * 4);
     for (int j = old + 1; j < t; ++j) {
       const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
-      adam_f4(P, f4_zero(), M, V, h, A, E);
+      adam_f4_zero_g(P, M, V, h, A, E);
     }
     adam_f4(P, G, M, V, h, h.A, h.E);
     gstore<float4>(p + r * D + q * 4, P);
