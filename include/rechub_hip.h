@@ -216,13 +216,17 @@ int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, cons
 /* rh_linear_fwd / rh_linear_dgrad replace: the forward y = x W^T + b and the input gradient g_x = g W of the same
  *   nn.Linear modules (aten::addmm / mm) at CTR batch sizes, where one 64x64 f32-MFMA tile per workgroup fills the chip
  *   exactly once (csrc/gemm.hip).  x (M, K) row stride ldx, w (N, K) row stride ldw, bias (N,) or NULL, y (M, N).
- *   stats (NULL or (rh_gemm_stats_slabs(M), 2, N) floats): per 32-row slab of y and column, the slab sum and
- *   M2 = sum (y - slab mean)^2 -- the input rh_bn_relu_dropout_fwd takes with partial_rows = 32.
+ *   stats (NULL or (ceil(M / R), 2, N) floats, R = rh_gemm_stats_rows(M, N) = 64 or 32): per R-row slab of y and
+ *   column, the slab sum and M2 = sum (y - slab mean)^2 -- the input rh_bn_relu_dropout_fwd takes with partial_rows = R.
+ *   bn_rng / bn_saved_ctr / bn_batches (optional, with stats): the consuming rh_bn_relu_dropout_fwd call's dropout
+ *   state (rng[1] = call counter) and num_batches_tracked; the GEMM then performs that call's bookkeeping
+ *   (saved_ctr = rng[1]++, batches += 1) and rh_bn_relu_dropout_fwd (partial_rows > 0) then advances nothing.
  *   rh_linear_dgrad: g (M, N), w (N, K) -> gx (M, K).  Exact f32 (MFMA f32 == fmaf chain); summation order over k is
  *   permuted inside each 32-wide K tile. */
-int rh_gemm_stats_slabs(int M);
+int rh_gemm_stats_rows(int M, int N);
 int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
-                  float* y, int64_t ldy, float* stats, void* stream);
+                  float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr, int64_t* bn_batches,
+                  void* stream);
 int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
                     int64_t ldgx, void* stream);
 int64_t rh_linear_wgrad_workspace(int B, int N, int K);
@@ -250,8 +254,10 @@ int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, f
  * (nothing is stored).  B <= 8192: two launches per direction (partial sums; finalize folded into apply), else three.
  * partial: (rh_bn_act_nchunks(B), 2, C) floats; stat: (4, C) floats (mean, rstd kept for the backward).
  * partial_rows > 0 (forward): `partial` ALREADY holds, per partial_rows-row slab and column, the slab's sum and its
- * M2 = sum (h - slab mean)^2 -- rh_linear_fwd writes exactly that (32-row slabs) from its accumulators, so the
+ * M2 = sum (h - slab mean)^2 -- rh_linear_fwd writes exactly that (64- or 32-row slabs) from its accumulators, so the
  * statistics pass over h disappears; the slabs are combined with Chan's parallel-variance formula in slab order.
+ * rng / num_batches_tracked were then already advanced by rh_linear_fwd (it was given the same pointers): this call
+ * reads saved_ctr and advances nothing.
  */
 int rh_bn_act_nchunks(int B);
 int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,

@@ -20,13 +20,13 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-40s %7.2f us\n", name, ms / 200 * 1e3);
   };
-  time("fwd 4096x256x32 (1 tile)", [&] { rh_linear_fwd(x, 32, w, 32, b, M, N, 32, y, N, nullptr, nullptr); });
-  time("fwd 4096x256x128 (4 tiles)", [&] { rh_linear_fwd(x, 128, w, 128, b, M, N, 128, y, N, nullptr, nullptr); });
-  time("fwd 4096x256x256 (8 tiles)", [&] { rh_linear_fwd(x, 256, w, 256, b, M, N, 256, y, N, nullptr, nullptr); });
-  time("fwd 4096x256x416 (13 tiles, aligned)", [&] { rh_linear_fwd(x, 416, w, 416, b, M, N, 416, y, N, nullptr, nullptr); });
-  time("fwd 4096x256x429 (+stats)", [&] { rh_linear_fwd(x, K, w, K, b, M, N, K, y, N, st, nullptr); });
-  time("fwd 4096x256x429", [&] { rh_linear_fwd(x, K, w, K, b, M, N, K, y, N, nullptr, nullptr); });
-  time("fwd 4096x128x256", [&] { rh_linear_fwd(x, 256, w, 256, b, M, 128, 256, y, 128, nullptr, nullptr); });
+  time("fwd 4096x256x32 (1 tile)", [&] { rh_linear_fwd(x, 32, w, 32, b, M, N, 32, y, N, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  time("fwd 4096x256x128 (4 tiles)", [&] { rh_linear_fwd(x, 128, w, 128, b, M, N, 128, y, N, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  time("fwd 4096x256x256 (8 tiles)", [&] { rh_linear_fwd(x, 256, w, 256, b, M, N, 256, y, N, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  time("fwd 4096x256x416 (13 tiles, aligned)", [&] { rh_linear_fwd(x, 416, w, 416, b, M, N, 416, y, N, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  time("fwd 4096x256x429 (+stats)", [&] { rh_linear_fwd(x, K, w, K, b, M, N, K, y, N, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  time("fwd 4096x256x429", [&] { rh_linear_fwd(x, K, w, K, b, M, N, K, y, N, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  time("fwd 4096x128x256", [&] { rh_linear_fwd(x, 256, w, 256, b, M, 128, 256, y, 128, nullptr, nullptr, nullptr, nullptr, nullptr); });
   time("dgrad 4096x256 -> 429", [&] { rh_linear_dgrad(x, 256, w, 429, M, 256, 429, y, 429, nullptr); });
   time("dgrad 4096x128 -> 256", [&] { rh_linear_dgrad(x, 128, w, 256, M, 128, 256, y, 256, nullptr); });
   return 0;

@@ -49,8 +49,9 @@ SIGNATURES = {
     "rh_din_att_input_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "rh_din_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_din_pool_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
-    "rh_gemm_stats_slabs": [c_int],
-    "rh_linear_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr],
+    "rh_gemm_stats_rows": [c_int, c_int],
+    "rh_linear_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                      c_ptr],
     "rh_linear_dgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr],
     "rh_linear_wgrad_workspace": [c_int, c_int, c_int],
     "rh_linear_wgrad_tiles": [c_int, c_int],
@@ -80,7 +81,7 @@ _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctyp
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
                     "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles",
-                    "rh_head_nblocks", "rh_gemm_stats_slabs"}
+                    "rh_head_nblocks", "rh_gemm_stats_rows"}
 
 ABI_VERSION = 1
 _lib = None

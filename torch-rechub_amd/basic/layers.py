@@ -241,7 +241,7 @@ class MLP(nn.Module):
                                                                                             mods[i + 3], x):
                 lin, bn = mods[i], mods[i + 1]
                 if type(lin) is nn.Linear and bn.training and ops.linear_ok(x, lin.weight):
-                    h, stats = ops.linear_stats(x, lin.weight, lin.bias)  # GEMM epilogue emits the BN statistics
+                    h, stats = ops.linear_stats(x, lin.weight, lin.bias, bn)  # GEMM epilogue emits the BN statistics
                 else:
                     h, stats = self._linear(lin, x), None
                 x = ops.bn_relu_dropout(h, bn, mods[i + 3].p if mods[i + 3].training else 0.0, stats=stats)

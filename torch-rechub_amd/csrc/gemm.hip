@@ -15,11 +15,13 @@
 //   tile instead of sixteen ds_read_b32 (the summation order inside a tile is permuted, the result is the same f32 sum
 //   up to reassociation).  Rows of A / B are only 4-byte aligned (K = 429): the global loads are dwordx4 in unaligned
 //   mode, tails are zero-filled.
-//   STATS (forward in front of BatchNorm): the epilogue also emits, per 32-row slab of the output and per column, the
+//   STATS (forward in front of BatchNorm): the epilogue also emits, per tile-row slab of the output and per column, the
 //   slab's sum and its M2 = sum (x - slab mean)^2 computed from the accumulators in registers (two passes, no
 //   cancellation) -- the BatchNorm statistics then need no separate pass over h (csrc/mlp.hip combines the slabs with
 //   Chan's formula, in slab order: deterministic).
 // Roofline: f32 MFMA (157 TF); 0.9 GFLOP for the 4096 x 429 x 256 layer = 5.7 us at peak.
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef RH_PROBE
@@ -42,7 +44,10 @@ struct GemmArgs {
   float* C;
   int64_t ldc;
   int M, N, K;
-  float* stats;  // STATS: (ceil(M / 32), 2, N): slab sum, slab M2
+  float* stats;  // STATS: (ceil(M / BM), 2, N): slab sum, slab M2 (BM = rows of the workgroup tile)
+  int64_t* bn_rng;        // STATS, optional: the consumer's (seed, call counter) -- see rh_linear_fwd
+  int64_t* bn_saved_ctr;
+  int64_t* bn_batches;
 };
 
 static __device__ __forceinline__ float4 load4_guard(const float* row, int k, int K, bool row_ok) {
@@ -97,13 +102,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
       pb[v] = a.B + (int64_t)(e / (BN / 4)) * a.ldb + n0 + (e % (BN / 4)) * 4;
     }
   }
-  const bool edge_n = !B_KMAJOR && n0 + BN > a.N;
+  // n-major B on the N edge: only the few float4 pieces that straddle column N take the guarded load
+  bool bfull[B_V4];
+#pragma unroll
+  for (int v = 0; v < B_V4; ++v) bfull[v] = B_KMAJOR || n0 + ((tid + v * NT) % (BN / 4)) * 4 + 3 < a.N;
+  auto bload = [&](int v, int k0) -> float4 {
+    if (B_KMAJOR) return gload<float4>(pb[v] + k0);
+    if (bfull[v]) return gload<float4>(pb[v] + (int64_t)k0 * a.ldb);
+    const int c = ((tid + v * NT) % (BN / 4)) * 4;
+    return load4_guard(pb[v] + (int64_t)k0 * a.ldb - (n0 + c), n0 + c, a.N, true);
+  };
   auto gfetch = [&](int k0, float4* ra, float4* rb) {
-    if (k0 + kBK <= a.K && !edge_n) {  // wavefront-uniform
+    if (k0 + kBK <= a.K) {  // wavefront-uniform
 #pragma unroll
       for (int v = 0; v < A_V4; ++v) ra[v] = gload<float4>(pa[v] + k0);
 #pragma unroll
-      for (int v = 0; v < B_V4; ++v) rb[v] = gload<float4>(B_KMAJOR ? pb[v] + k0 : pb[v] + (int64_t)k0 * a.ldb);
+      for (int v = 0; v < B_V4; ++v) rb[v] = bload(v, k0);
       return;
     }
 #pragma unroll
@@ -184,31 +198,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   __syncthreads();
   lfrag(0, fa0, fb0);
   __syncthreads();  // every wavefront has tile 0 in registers before buffer 0 is overwritten below
-  auto step = [&](int t, float* fa, float* fb, float* fan, float* fbn, float4* ra, float4* rb) {
+  // One K tile.  FULL = true: the steady state (every tile it touches exists and is a full interior tile) -- straight-line
+  // code, so the compiler's waitcnt insertion sees exactly which loads are outstanding; FULL = false: run-time checks.
+  auto step = [&](auto full, int t, float* fa, float* fb, float* fan, float* fbn, float4* ra, float4* rb) {
+    constexpr bool FULL = decltype(full)::value;
     // The dependent MFMA chain occupies the wavefront's issue slot for 16 x 64 cycles; the LDS / global work of the
     // iteration is placed INSIDE it in program order (sched_barrier pins it) so that it runs under the MFMAs
     // instead of after them.
-    if (t + 1 < ntiles) lfrag((t + 1) & 1, fan, fbn);
+    if (FULL || t + 1 < ntiles) lfrag((t + 1) & 1, fan, fbn);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       if (RH_PROBE == 2) acc[s] += fa[s] * fb[s];
       else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
       if (RH_PROBE != 1 && s == 3) {
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < ntiles) lstore(t & 1, ra, rb);
+        if (FULL || t + 2 < ntiles) lstore(t & 1, ra, rb);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (RH_PROBE != 1 && s == 7) {
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 4 < ntiles) gfetch((t + 4) * kBK, ra, rb);
+        if (FULL) {
+#pragma unroll
+          for (int v = 0; v < A_V4; ++v) ra[v] = gload<float4>(pa[v] + (t + 4) * kBK);
+#pragma unroll
+          for (int v = 0; v < B_V4; ++v) rb[v] = bload(v, (t + 4) * kBK);
+        } else if (t + 4 < ntiles) {
+          gfetch((t + 4) * kBK, ra, rb);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, fa0, fb0, fa1, fb1, ra0, rb0);
-    if (t + 1 < ntiles) step(t + 1, fa1, fb1, fa0, fb0, ra1, rb1);
+  int t = 0;
+  const int fast_tiles = a.K / kBK;  // tiles [0, fast_tiles) are full interior tiles
+  for (; t + 5 < fast_tiles; t += 2) {
+    step(std::true_type{}, t, fa0, fb0, fa1, fb1, ra0, rb0);
+    step(std::true_type{}, t + 1, fa1, fb1, fa0, fb0, ra1, rb1);
+  }
+  for (; t < ntiles; t += 2) {
+    step(std::false_type{}, t, fa0, fb0, fa1, fb1, ra0, rb0);
+    if (t + 1 < ntiles) step(std::false_type{}, t + 1, fa1, fb1, fa0, fb0, ra1, rb1);
   }
 
   // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -222,10 +252,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
     const int row = rbase + (r & 3) + 8 * (r >> 2);
     if (cok && row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[r];
   }
+  if (STATS && a.bn_rng != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    // the BatchNorm + Dropout launch that consumes `stats` is a single launch of many blocks: it cannot advance its own
+    // call counter without a grid-wide election, so the producer does it (one thread, once per forward)
+    a.bn_saved_ctr[0] = a.bn_rng[1];
+    a.bn_rng[1] += 1;
+    if (a.bn_batches != nullptr) a.bn_batches[0] += 1;
+  }
   if (STATS) {
-    // slab = the 32 rows of this wavefront's tile; rows past M count as absent
-    const int slab = (m0 / BM) * WM + wm;
-    const int nrows = min(32, a.M - (m0 + wm * 32));
+    // slab = the BM rows of this workgroup's tile (rows past M count as absent).  Per wavefront: sum and M2 about its
+    // own mean over its 32 rows (two passes over the accumulators); the WM wavefronts of a column are then merged with
+    // Chan's formula through LDS (the K-loop buffers are free by now).
+    const int nrows = max(0, min(32, a.M - (m0 + wm * 32)));
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += (rbase + (r & 3) + 8 * (r >> 2) < a.M) ? acc[r] : 0.f;
@@ -238,18 +276,48 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
       m2 += (rbase + (r & 3) + 8 * (r >> 2) < a.M) ? d * d : 0.f;
     }
     m2 += __shfl_xor(m2, 32);
-    if (kk == 0 && cok && nrows > 0) {
-      a.stats[((int64_t)slab * 2 + 0) * a.N + col] = s;
-      a.stats[((int64_t)slab * 2 + 1) * a.N + col] = m2;
+    if (WM == 1) {
+      if (kk == 0 && cok && nrows > 0) {
+        a.stats[((int64_t)(m0 / BM) * 2 + 0) * a.N + col] = s;
+        a.stats[((int64_t)(m0 / BM) * 2 + 1) * a.N + col] = m2;
+      }
+    } else {
+      float* ex = lds;  // [WM][WN * 32][2]
+      if (kk == 0) {
+        ex[((wm * WN + wn) * 32 + li) * 2 + 0] = s;
+        ex[((wm * WN + wn) * 32 + li) * 2 + 1] = m2;
+      }
+      __syncthreads();
+      if (wm == 0 && kk == 0 && cok) {
+        float tot = 0.f, ntot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          tot += ex[((w * WN + wn) * 32 + li) * 2];
+          ntot += (float)max(0, min(32, a.M - (m0 + w * 32)));
+        }
+        const float gmean = tot / ntot;
+        float m2t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          const float nw = (float)max(0, min(32, a.M - (m0 + w * 32)));
+          if (nw > 0.f) {
+            const float d = ex[((w * WN + wn) * 32 + li) * 2] / nw - gmean;
+            m2t += fmaf(nw * d, d, ex[((w * WN + wn) * 32 + li) * 2 + 1]);
+          }
+        }
+        a.stats[((int64_t)(m0 / BM) * 2 + 0) * a.N + col] = tot;
+        a.stats[((int64_t)(m0 / BM) * 2 + 1) * a.N + col] = m2t;
+      }
     }
   }
 }
 
+// one tile per workgroup; 64x64 tiles unless that leaves most of the 256 CUs idle
+bool big_tiles(int M, int N) { return (int64_t)((M + 63) / 64) * ((N + 63) / 64) >= 192; }
+
 template <bool B_KMAJOR, bool STATS>
 void launch(const GemmArgs& a, hipStream_t s) {
-  // one tile per workgroup; 64x64 tiles unless that leaves most of the 256 CUs idle
-  const int64_t big = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
-  if (big >= 192) {
+  if (big_tiles(a.M, a.N)) {
     hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL((gemm_f32_kernel<1, 2, B_KMAJOR, STATS>), dim3((a.N + 63) / 64, (a.M + 31) / 32), dim3(128), 0, s, a);
@@ -258,14 +326,17 @@ void launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int rh_gemm_stats_slabs(int M) { return (M + 31) / 32; }
+extern "C" int rh_gemm_stats_rows(int M, int N) { return big_tiles(M, N) ? 64 : 32; }
 
 extern "C" int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N,
-                             int K, float* y, int64_t ldy, float* stats, void* stream) {
+                             int K, float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr,
+                             int64_t* bn_batches, void* stream) {
   RH_REQUIRE(x && w && y, RH_E_BADARG, "rh_linear_fwd: null pointer");
   RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N, RH_E_BADARG,
              "rh_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
-  GemmArgs a{x, ldx, w, ldw, bias, y, ldy, M, N, K, stats};
+  RH_REQUIRE(bn_rng == nullptr || (stats != nullptr && bn_saved_ctr != nullptr), RH_E_BADARG,
+             "rh_linear_fwd: the BatchNorm call counter needs stats and saved_ctr");
+  GemmArgs a{x, ldx, w, ldw, bias, y, ldy, M, N, K, stats, bn_rng, bn_saved_ctr, bn_batches};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats) launch<true, true>(a, s);
   else launch<true, false>(a, s);
@@ -279,7 +350,7 @@ extern "C" int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int6
   RH_REQUIRE(g && w && gx, RH_E_BADARG, "rh_linear_dgrad: null pointer");
   RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldg >= N && ldw >= K && ldgx >= K, RH_E_BADARG,
              "rh_linear_dgrad: bad shape M=%d N=%d K=%d", M, N, K);
-  GemmArgs a{g, ldg, w, ldw, nullptr, gx, ldgx, M, /*N=*/K, /*K=*/N, nullptr};
+  GemmArgs a{g, ldg, w, ldw, nullptr, gx, ldgx, M, /*N=*/K, /*K=*/N, nullptr, nullptr, nullptr, nullptr};
   launch<false, false>(a, reinterpret_cast<hipStream_t>(stream));
   RH_LAUNCH_CHECK("rh_linear_dgrad");
   return 0;

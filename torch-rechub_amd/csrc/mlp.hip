@@ -38,7 +38,7 @@ struct BnArgs {
   int64_t* saved_ctr;  // (1,) counter value used by this call (written forward, read backward)
   int B, C, nchunks;
   int rows_per_chunk;  // rows per partial chunk
-  int bookkeep;        // partial kernel also advances the dropout counter / num_batches_tracked (fused-finalize path)
+  int bookkeep;        // this launch sequence advances the dropout counter / num_batches_tracked (partial or finalize kernel)
   float momentum, eps, p_drop;
   int training;
 };
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
   const int c = blockIdx.x * kFinCols + cl;
   const int grp = threadIdx.x / kFinCols;
   const bool cok = c < a.C;
-  if (MODE == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (MODE == 0 && a.bookkeep && blockIdx.x == 0 && threadIdx.x == 0) {
     a.saved_ctr[0] = a.rng[1];  // dropout stream of this call
     a.rng[1] += 1;
     if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
@@ -271,11 +271,6 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
   const int cl = threadIdx.x % kSlabCols, grp = threadIdx.x / kSlabCols;
   const int c = blockIdx.x * kSlabCols + cl;
   const bool cok = c < a.C;
-  // forward with partials from the GEMM epilogue (a.bookkeep == 2): nothing ran before this launch that could have
-  // advanced the dropout counter, so every block reads it here and the LAST block to finish advances it (ticket in
-  // rng[2]; only that scalar is exchanged, so no cache-wide fence is needed)
-  uint64_t ctr_now = 0;
-  if (MODE == 0 && a.bookkeep == 2) ctr_now = (uint64_t)a.rng[1];
   float s1 = 0.f, s2 = 0.f, mean, rstd;
   if (MODE == 0) {
     float var;
@@ -334,7 +329,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
   uint64_t seed = 0, ctr = 0;
   if (a.p_drop > 0.f) {
     seed = (uint64_t)a.rng[0];
-    ctr = (MODE == 0 && a.bookkeep == 2) ? ctr_now : (uint64_t)a.saved_ctr[0];
+    ctr = (uint64_t)a.saved_ctr[0];
   }
   const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, a.B);
   const float sg = s1 * inv_n, sgx = s2 * inv_n;
@@ -353,19 +348,6 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
       a.out[i] = y;
     }
   }
-  if (MODE == 0 && a.bookkeep == 2) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.rng + 2);
-      const unsigned long long nblk = (unsigned long long)gridDim.x * gridDim.y;
-      if (atomicAdd(ticket, 1ull) == nblk - 1) {
-        a.saved_ctr[0] = (int64_t)ctr_now;
-        a.rng[1] = (int64_t)ctr_now + 1;
-        if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
-        atomicExch(ticket, 0ull);
-      }
-    }
-  }
 }
 
 bool fused_path_ok(int B) { return (B + kFusedRows - 1) / kFusedRows <= kFusedMaxChunks; }
@@ -376,7 +358,7 @@ void launch_fused(BnArgs a, hipStream_t s, int partial_rows = 0) {
   if (partial_rows > 0) {
     a.rows_per_chunk = partial_rows;
     a.nchunks = (a.B + partial_rows - 1) / partial_rows;
-    a.bookkeep = 2;  // the apply launch advances the dropout counter itself (last block)
+    a.bookkeep = 0;  // the GEMM that wrote the partials advanced the dropout counter / num_batches_tracked
   } else {
     a.rows_per_chunk = kFusedRows;
     a.nchunks = (a.B + kFusedRows - 1) / kFusedRows;
@@ -438,13 +420,16 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
     RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd(fused finalize)");
     return 0;
   }
+  a.bookkeep = partial_rows > 0 ? 0 : 1;  // 3-launch path: the finalize launch does the bookkeeping unless the GEMM did
   if (partial_rows > 0) {
     a.rows_per_chunk = partial_rows;
     a.nchunks = (B + partial_rows - 1) / partial_rows;
   } else {
     const int CW = col_width(C);
     const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
-    hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, a, CW);
+    BnArgs ap = a;
+    ap.bookkeep = 0;  // the finalize launch below does it
+    hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, ap, CW);
   }
   hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
   hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(apply_grid((int64_t)B * C)), dim3(RH_BLOCK), 0, s, a);

@@ -533,22 +533,27 @@ def _dropout_rng(device):
 
 class _BnReluDropoutFn(torch.autograd.Function):
     """y = dropout(relu(batch_norm(h))) for one MLP hidden layer (training mode); see csrc/mlp.hip.
-    ``stats``: per-32-row-slab (sum, M2) of h from the GEMM that produced it (ops.linear_stats), or None."""
+    ``stats`` / ``stats_ctr``: per-slab (sum, M2) of h and the dropout counter drawn by the GEMM that produced h
+    (ops.linear_stats), or None."""
 
     @staticmethod
-    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, stats):
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, stats,
+                stats_ctr):
         require_hip(h, gamma, beta)
         h = h.contiguous()
         B, C = h.shape
         dev = h.device
         out = torch.empty_like(h)
         if stats is not None:
-            partial, prow = stats, 32
+            partial, prow = stats, _lib.call("rh_gemm_stats_rows", B, C)  # the slab height rh_linear_fwd used
+            if tuple(stats.shape) != (-(-B // prow), 2, C):
+                raise ValueError("BatchNorm statistics slabs do not match the activations")
         else:
             partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
             prow = 0
         stat = torch.empty((4, C), dtype=torch.float32, device=dev)
-        saved_ctr = torch.empty(1, dtype=torch.int64, device=dev)
+        # with GEMM-provided statistics the GEMM already drew this call's dropout counter (and counted the batch)
+        saved_ctr = stats_ctr if stats is not None else torch.empty(1, dtype=torch.int64, device=dev)
         rng = _dropout_rng(dev)
         _lib.call("rh_bn_relu_dropout_fwd", _p(h), B, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                   _p(num_batches_tracked), float(momentum), float(eps), float(p_drop), 1, _p(rng), _p(saved_ctr),
@@ -569,14 +574,16 @@ class _BnReluDropoutFn(torch.autograd.Function):
         partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
         _lib.call("rh_bn_relu_dropout_bwd", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop, _p(_dropout_rng(dev)),
                   _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), _stream())
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def bn_relu_dropout(h, bn, p_drop, stats=None):
-    """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``."""
+    """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``.
+    ``stats``: the (statistics, counter) pair ops.linear_stats returned for this very ``bn``, or None."""
     if bn.training:
+        st, ctr = stats if stats is not None else (None, None)
         return _BnReluDropoutFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                      bn.momentum, bn.eps, p_drop, stats)
+                                      bn.momentum, bn.eps, p_drop, st, ctr)
     require_hip(h)
     h = h.contiguous()
     out = torch.empty_like(h)
@@ -619,13 +626,14 @@ def linear_ok(x, weight):
             _lib.call("rh_linear_wgrad_tiles", weight.shape[0], weight.shape[1]) <= _MAX_WGRAD_TILES)
 
 
-# Forward / input-gradient GEMMs: hipBLASLt by default.  RECHUB_OWN_GEMM=1 routes batch-sized problems (M <= 16384,
-# N, K <= 1024) through the f32-MFMA tile kernel of csrc/gemm.hip, whose epilogue also emits the BatchNorm statistics.
-# Measured on MI355X at B = 4096 (round 1): 16.4 / 10.6 us vs the library's 20.9 / 12.0 us for the two forward GEMMs,
-# but the whole step is 4 % slower because the per-32-row statistics slabs make the BN apply prologue heavier --
-# kept opt-in until that is fixed.
-_GEMM_MAX_M = 16384 if os.environ.get("RECHUB_OWN_GEMM", "0") == "1" else 0
+# Forward / input-gradient GEMMs: hipBLASLt by default.  RECHUB_OWN_GEMM=1 (or "fwd": forward only) routes batch-sized
+# problems (M <= 16384, N, K <= 1024) through the f32-MFMA tile kernel of csrc/gemm.hip, whose epilogue also emits the
+# BatchNorm statistics (one BN launch less per layer).  Measured on MI355X at B = 4096 (round 1, same box A/B): the
+# whole step is within +-0.5 % of the library path (0.4331 vs 0.4325 ms) -- parity, not yet a win, so it stays opt-in
+# (DESIGN.md 3.8).
+_GEMM_MAX_M = 16384 if os.environ.get("RECHUB_OWN_GEMM", "0") in ("1", "fwd") else 0
 _GEMM_MAX_NK = 1024
+_GEMM_DGRAD = os.environ.get("RECHUB_OWN_GEMM", "0") != "fwd"  # "fwd": own forward GEMMs only
 
 
 def _own_gemm(M, N, K):
@@ -638,25 +646,30 @@ class _LinearFn(torch.autograd.Function):
     (sum, M2) of its output for the BatchNorm that follows."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, want_stats):
+    def forward(ctx, x, weight, bias, bn_batches):
+        want_stats = bn_batches is not None
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         M, K = x.shape
         N = weight.shape[0]
-        stats = None
+        stats = ctr = None
         if _own_gemm(M, N, K) and weight.is_contiguous() and x.stride(1) == 1:
             y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            rng = None
             if want_stats:
-                stats = torch.empty((_lib.call("rh_gemm_stats_slabs", M), 2, N), dtype=torch.float32, device=x.device)
-            _lib.call("rh_linear_fwd", _p(x), x.stride(0), _p(weight), K, _p(bias), M, N, K, _p(y), N, _p(stats),
-                      _stream())
+                rows = _lib.call("rh_gemm_stats_rows", M, N)
+                stats = torch.empty((-(-M // rows), 2, N), dtype=torch.float32, device=x.device)
+                ctr = torch.empty(1, dtype=torch.int64, device=x.device)
+                rng = _dropout_rng(x.device)
+            _lib.call("rh_linear_fwd", _p(x), x.stride(0), _p(weight), K, _p(bias), M, N, K, _p(y), N, _p(stats), _p(rng),
+                      _p(ctr), _p(bn_batches if want_stats else None), _stream())
         else:
             y = torch.nn.functional.linear(x, weight, bias)
         if want_stats:
             if stats is None:
-                return y, None
-            ctx.mark_non_differentiable(stats)
-            return y, stats
+                return y, None, None
+            ctx.mark_non_differentiable(stats, ctr)
+            return y, stats, ctr
         return y
 
     @staticmethod
@@ -666,7 +679,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             M, N = g.shape
             K = weight.shape[1]
-            if _own_gemm(M, K, N) and weight.is_contiguous() and g.stride(1) == 1:
+            if _GEMM_DGRAD and _own_gemm(M, K, N) and weight.is_contiguous() and g.stride(1) == 1:
                 gx = torch.empty((M, K), dtype=torch.float32, device=g.device)
                 _lib.call("rh_linear_dgrad", _p(g), g.stride(0), _p(weight), K, M, N, K, _p(gx), K, _stream())
             else:
@@ -681,14 +694,17 @@ def linear(x, weight, bias=None):
     """F.linear for 2-D fp32 HIP activations; see _LinearFn."""
     if linear_ok(x, weight) and (_own_gemm(x.shape[0], weight.shape[0], weight.shape[1]) or (
             torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)))):
-        return _LinearFn.apply(x, weight, bias, False)
+        return _LinearFn.apply(x, weight, bias, None)
     return torch.nn.functional.linear(x, weight, bias)
 
 
-def linear_stats(x, weight, bias=None):
-    """(F.linear(x, weight, bias), per-32-row-slab (sum, M2) of it or None): the Linear in front of a BatchNorm1d."""
+def linear_stats(x, weight, bias, bn):
+    """The Linear in front of the training-mode BatchNorm1d ``bn``: returns (h, stats) where stats is None or the pair
+    (per-slab (sum, M2) of h, dropout counter) to hand to ``bn_relu_dropout(h, bn, p, stats=stats)`` -- the GEMM then
+    has already counted the batch for ``bn`` and drawn the dropout counter of that call."""
     if linear_ok(x, weight):
-        return _LinearFn.apply(x, weight, bias, True)
+        h, st, ctr = _LinearFn.apply(x, weight, bias, bn.num_batches_tracked)
+        return h, (None if st is None else (st, ctr))
     return torch.nn.functional.linear(x, weight, bias), None
 
 
