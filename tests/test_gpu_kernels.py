@@ -860,3 +860,36 @@ def test_bn_from_gemm_statistics_matches_torch_modules(B, C, monkeypatch):
     var0 = 0.9 + 0.1 * float(h0.var(unbiased=True))
     close(bn_mine.running_var[:1], np.array([var0]), rtol=1e-3, what="running_var, ill-conditioned column vs float64")
     assert int(bn_mine.num_batches_tracked) == 1
+
+
+def test_empty_batch_goes_through_every_op():
+    """B = 0 (the tail of a dataset that divides evenly, an empty shard): every op returns an empty tensor of the right
+    shape and its backward leaves zero gradients, as the reference's eager ops do."""
+    from torch_rechub_amd import ops
+    tables = [torch.nn.Parameter(torch.randn(v, 16, device=dev())) for v in (7, 300)]
+    idx = torch.zeros((0, 2), dtype=torch.int64, device=dev())
+    dn = torch.zeros((0, 3), device=dev())
+    lr_w = torch.nn.Parameter(torch.randn(1, 32, device=dev()))
+    lr_b = torch.nn.Parameter(torch.zeros(1, device=dev()))
+    call = ops.EmbedCall(tables, [None, None], [idx[:, 0], idx[:, 1]], [dn[:, j] for j in range(3)], want_fm=True, want_lr=True)
+    out, fm, lr = ops.fused_embedding(call, lr_w, lr_b)
+    assert out.shape == (0, 35) and fm.shape == (0, 1) and lr.shape == (0, 1)
+    (out.sum() + fm.sum() + lr.sum()).backward()
+    assert all(float(t.grad.abs().sum()) == 0.0 for t in tables) and float(lr_w.grad.abs().sum()) == 0.0
+    x = torch.zeros((0, 5, 16), device=dev(), requires_grad=True)
+    assert ops.fm(x, True).shape == (0, 1)
+    seq = ops.seq_pool(tables[1], torch.zeros((0, 4), dtype=torch.int64, device=dev()), "mean", None)
+    assert seq.shape == (0, 16)
+    xc = torch.zeros((0, 429), device=dev(), requires_grad=True)
+    W = torch.randn(3, 429, device=dev(), requires_grad=True)
+    Bv = torch.zeros(3, 429, device=dev(), requires_grad=True)
+    yc = ops.cross_network(xc, W, Bv)
+    assert yc.shape == (0, 429)
+    yc.sum().backward()
+    assert float(W.grad.abs().sum()) == 0.0
+    lin = torch.nn.Linear(8, 4).to(dev())
+    h = ops.linear(torch.zeros((0, 8), device=dev(), requires_grad=True), lin.weight, lin.bias)
+    assert h.shape == (0, 4)
+    h.sum().backward()
+    assert float(lin.weight.grad.abs().sum()) == 0.0 and float(lin.bias.grad.abs().sum()) == 0.0
+    ops.check_errors()

@@ -21,8 +21,22 @@ from . import _lib
 _NULL = ctypes.c_void_p(0)
 
 
+_empty_stub = {}
+
+
 def _p(t):
-    return _NULL if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer of a tensor for the C ABI.  An EMPTY tensor has a null data_ptr(); the entry points check their
+    pointers before they look at the sizes (and then return at once for B = 0), so empties are passed as a pointer to
+    a small per-device stub allocation."""
+    if t is None:
+        return _NULL
+    if t.numel() == 0:
+        stub = _empty_stub.get(t.device)
+        if stub is None:
+            stub = torch.zeros(64, dtype=torch.float32, device=t.device)
+            _empty_stub[t.device] = stub
+        return ctypes.c_void_p(stub.data_ptr())
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _stream():
@@ -336,7 +350,10 @@ class _EmbedFused(torch.autograd.Function):
         want_b = g_lr is not None and ctx.has_lr_b and ctx.needs_input_grad[2]
         g_w = torch.empty_like(lr_w) if want_wgrad else None
         g_b = torch.empty((1,), dtype=torch.float32, device=dev) if want_b else None
-        if want_wgrad or want_b:  # one launch: column sums of the per-block LR partials + sum of g_lr
+        if B == 0:  # empty batch: nothing was launched; the parameter gradients are exact zeros
+            g_w = None if g_w is None else g_w.zero_()
+            g_b = None if g_b is None else g_b.zero_()
+        elif want_wgrad or want_b:  # one launch: column sums of the per-block LR partials + sum of g_lr
             glc = g_lr.contiguous() if want_b else None
             _lib.call("rh_colsum", _p(partial), nchunks if want_wgrad else 0, F * D, _p(g_w), _p(glc),
                       glc.numel() if want_b else 0, _p(g_b), _stream())
@@ -487,6 +504,8 @@ class _CrossFn(torch.autograd.Function):
         L = W.shape[0]
         seg = ctx.seg
         g = g.contiguous()
+        if B == 0:
+            return g, torch.zeros_like(W), torch.zeros_like(Bv)
         gW = torch.empty_like(W)
         gB = torch.empty_like(Bv)
         nblocks = _lib.call("rh_cross_bwd_nblocks", B)
