@@ -305,6 +305,8 @@ int rh_adam_small(const int64_t* sdesc, int T, const int64_t* h_numel, const flo
  * rh_adam_lazy_touched: for every lookup of the batch (index columns in idesc, as rh_embed_bwd) claim the row,
  *       replay it to step t-1, apply step t with its gradient row, re-zero the gradient row.
  *       field_table (device int64 [2*F]): table index of field f (-1 = skip), padding_idx (-1 = none)
+ *       refresh != 0: the pre-gather pass (rows about to be READ are brought to the hyper step; their gradient rows
+ *       are zero by construction and are neither read nor written)
  * rh_adam_lazy_sweep: bring window (t-1) mod K_t of every table up to date.  mode: RH_SWEEP_WINDOW = every table,
  *       RH_SWEEP_FLUSH = all rows of every table, RH_SWEEP_LAZY_TABLES = windows of the K_t > 1 tables only,
  *       RH_SWEEP_DENSE_TABLES = the K_t == 1 tables only (these take their gradient in the sweep).
@@ -322,7 +324,7 @@ int rh_adam_small(const int64_t* sdesc, int T, const int64_t* h_numel, const flo
 #define RH_SWEEP_DENSE_TABLES 3
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
-                         int ring_size, int samples_per_block, int32_t* err_flag, void* stream);
+                         int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
 

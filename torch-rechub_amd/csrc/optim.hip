@@ -308,7 +308,9 @@ struct LazyTouchedArgs {
   int* err;
 };
 
-template <int LPR, typename IdxT>
+// REFRESH: the pre-gather pass -- the rows carry no gradient yet (their gradient rows are zero), so they are neither
+// read nor re-zeroed and the closing step is the zero-gradient form too (a quarter less traffic per row)
+template <int LPR, typename IdxT, bool REFRESH>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
   constexpr int LPP = RH_BLOCK / LPR;
   constexpr int D = 4 * LPR;
@@ -349,16 +351,18 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
     float4 P = gload<float4>(p + r * D + q * 4);
     float4 M = gload<float4>(m + r * D + q * 4);
     float4 V = gload<float4>(v + r * D + q * 4);
-    const float4 G = gload<float4>(g + r * D + q * 4);
+    float4 G = f4_zero();
+    if (!REFRESH) G = gload<float4>(g + r * D + q * 4);
     for (int j = old + 1; j < t; ++j) {
       const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
       adam_f4_zero_g(P, M, V, h, A, E);
     }
-    adam_f4(P, G, M, V, h, h.A, h.E);
+    if (REFRESH) adam_f4_zero_g(P, M, V, h, h.A, h.E);
+    else adam_f4(P, G, M, V, h, h.A, h.E);
     gstore<float4>(p + r * D + q * 4, P);
     gstore<float4>(m + r * D + q * 4, M);
     gstore<float4>(v + r * D + q * 4, V);
-    gstore<float4>(g + r * D + q * 4, f4_zero());
+    if (!REFRESH) gstore<float4>(g + r * D + q * 4, f4_zero());
   }
 }
 
@@ -516,7 +520,8 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
 
 extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                                     int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
-                                    int ring_size, int samples_per_block, int32_t* err_flag, void* stream) {
+                                    int ring_size, int samples_per_block, int refresh, int32_t* err_flag,
+                                    void* stream) {
   RH_REQUIRE(ldesc && field_table && idesc && hyper && ring, RH_E_BADARG, "rh_adam_lazy_touched: null pointer");
   RH_REQUIRE(T >= 1 && F >= 1 && F <= 65535 && B >= 0, RH_E_BADARG, "rh_adam_lazy_touched: bad shape");
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0, RH_E_BADARG, "rh_adam_lazy_touched: ring_size");
@@ -526,10 +531,14 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
   const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)F);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define RH_LT(LPR)                                                                                             \
-  if (idx_is_i64)                                                                                              \
-    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t>), grid, dim3(RH_BLOCK), 0, s, a);              \
+  if (idx_is_i64 && refresh)                                                                                   \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t, true>), grid, dim3(RH_BLOCK), 0, s, a);        \
+  else if (idx_is_i64)                                                                                         \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t, false>), grid, dim3(RH_BLOCK), 0, s, a);       \
+  else if (refresh)                                                                                            \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t, true>), grid, dim3(RH_BLOCK), 0, s, a);        \
   else                                                                                                         \
-    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t>), grid, dim3(RH_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t, false>), grid, dim3(RH_BLOCK), 0, s, a);
   switch (D / 4) {
     case 1: RH_LT(1) break;
     case 2: RH_LT(2) break;

@@ -302,11 +302,7 @@ class _EmbedFused(torch.autograd.Function):
         ctx.has_lr_b = lr_b is not None
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(out, s_sum, lr_w if call.want_lr else None)
-        outs = [out]
-        nd = []
-        outs.append(fm)
-        outs.append(lr)
-        return tuple(outs)
+        return out, fm, lr
 
     @staticmethod
     def backward(ctx, g_out, g_fm, g_lr):

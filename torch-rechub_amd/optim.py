@@ -197,12 +197,13 @@ class TableAdam(torch.optim.Adam):
             self._ft_cache[ids] = ft
         return ft
 
-    def _touch(self, rec, groups, stream):
+    def _touch(self, rec, groups, stream, refresh=False):
         grp = groups.get(rec["D"])
         if grp is not None:
             _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
-                      ops._p(self._t_ring), self.RING, 64, ops._p(ops.err_flag(self._tables[0].device)), stream)
+                      ops._p(self._t_ring), self.RING, 64, 1 if refresh else 0,
+                      ops._p(ops.err_flag(self._tables[0].device)), stream)
 
     def on_gather(self, rec):
         """Pre-gather event: replay the rows of this index batch up to the last completed step (their gradient rows are
@@ -224,7 +225,7 @@ class TableAdam(torch.optim.Adam):
                                    "(or capture with torch_rechub_amd.graphs.SegmentedGraph)")
             else:
                 self._join_sweep()
-        self._touch(rec, self._lazy_setup(), ops._stream())
+        self._touch(rec, self._lazy_setup(), ops._stream(), refresh=True)
         if rec.get("training", torch.is_grad_enabled()):
             self._gathers += 1
             if self._sweep_pending and self._gathers >= (self._gathers_per_step or 1):
