@@ -16,6 +16,8 @@ backward reduces DENSE full-table gradients onto gpus[0].  Here each rank owns a
 BatchNorm statistics stay per rank, which is what DataParallel replicas do.
 Works with the ``nccl`` (= RCCL) backend on GPUs and with ``gloo`` on CPU tensors (tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -42,10 +44,22 @@ def pack_indices(idx_list):
     return torch.stack(idx_list, dim=1)
 
 
+# RECHUB_EMULATE_WORLD=N (single-GPU study of the per-rank cost of an N-rank job): the gathers return N copies of the
+# local shard, so that the scatter / optimizer passes see the row volume of N ranks.  Gradients are N-fold then: for
+# timing only.
+_EMULATE_WORLD = int(os.environ.get("RECHUB_EMULATE_WORLD", "0"))
+
+
 def all_gather_cat(t, group=None, out=None):
     """Concatenate ``t`` from every rank along dim 0 (rank order), optionally into a preallocated ``out``."""
     world = dist.get_world_size(group)
     t = t.contiguous()
+    if _EMULATE_WORLD > 1 and world == 1:
+        if out is None or out.shape[0] != _EMULATE_WORLD * t.shape[0]:
+            out = torch.empty((_EMULATE_WORLD * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        for r in range(_EMULATE_WORLD):
+            out[r * t.shape[0]:(r + 1) * t.shape[0]].copy_(t)
+        return out
     if out is None:
         out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     try:
@@ -215,11 +229,10 @@ class DataParallelContext(object):
         for i, (call, rows) in enumerate(deferred):
             packed = pack_indices(call.idx)
             bufs = self._gather_bufs.get(i)
-            if bufs is None or bufs[1].shape[1:] != rows.shape[1:] or bufs[1].shape[0] != self.world * rows.shape[0]:
-                bufs = (torch.empty((self.world * packed.shape[0], packed.shape[1]), dtype=packed.dtype,
-                                    device=packed.device),
-                        torch.empty((self.world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype,
-                                    device=rows.device))
+            w = max(self.world, _EMULATE_WORLD)
+            if bufs is None or bufs[1].shape[1:] != rows.shape[1:] or bufs[1].shape[0] != w * rows.shape[0]:
+                bufs = (torch.empty((w * packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device),
+                        torch.empty((w * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device))
                 self._gather_bufs[i] = bufs
             all_gather_cat(packed, self.group, out=bufs[0])
             all_gather_cat(rows, self.group, out=bufs[1])
