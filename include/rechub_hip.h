@@ -247,6 +247,8 @@ int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, f
 /* ---------------------------------------------------------------------------------------------
  * MLP hidden-layer epilogue: BatchNorm1d + ReLU + Dropout fused (the Linear in front stays a library GEMM)
  * replaces: nn.BatchNorm1d -> ReLU -> nn.Dropout of MLP, torch_rechub/basic/layers.py:281-287, and their autograd
+ * relu = 1: the MLP hidden layer BatchNorm1d -> ReLU -> Dropout; relu = 0: BatchNorm1d (-> Dropout) only, for the layers
+ * whose activation is Dice / PReLU / ... (MLP of DIN's ActivationUnit, the DSSM towers).
  * h (B,C) pre-BN activations; training: batch statistics (biased variance), running stats updated with `momentum`
  * (unbiased variance), num_batches_tracked += 1; eval: running statistics, no dropout.
  * rng (device int64 [4]): seed, call counter (bumped by the forward), block ticket (zero on entry / exit), spare;
@@ -263,10 +265,10 @@ int rh_bn_act_nchunks(int B);
 int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
                            int training, int64_t* rng, int64_t* saved_ctr, float* partial, int partial_rows, float* stat,
-                           float* out, void* stream);
+                           float* out, int relu, void* stream);
 int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta,
                            float p_drop, const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat,
-                           float* dx, float* dgamma, float* dbeta, void* stream);
+                           float* dx, float* dgamma, float* dbeta, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense Adam with coupled L2, torch.optim.Adam semantics over every row of every table

@@ -893,3 +893,33 @@ def test_empty_batch_goes_through_every_op():
     h.sum().backward()
     assert float(lin.weight.grad.abs().sum()) == 0.0 and float(lin.bias.grad.abs().sum()) == 0.0
     ops.check_errors()
+
+
+@pytest.mark.parametrize("B,C", [(4096, 64), (20000, 36), (300, 256), (409600, 128)])
+def test_batchnorm_only_mode_vs_torch(B, C):
+    """relu=False: the kernels do BatchNorm1d alone (the layers in front of Dice / PReLU), forward, backward, running stats."""
+    from torch_rechub_amd import ops
+    torch.manual_seed(B + C)
+    h0 = (torch.randn(B, C) * 2 + torch.randn(C)).to(dev())
+    bn_ref, bn_mine = torch.nn.BatchNorm1d(C).to(dev()), torch.nn.BatchNorm1d(C).to(dev())
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5)
+        bn_ref.bias.normal_()
+    bn_mine.load_state_dict(bn_ref.state_dict())
+    gy = torch.randn(B, C, device=dev())
+    ha = h0.clone().requires_grad_(True)
+    bn_ref(ha).backward(gy)
+    hb = h0.clone().requires_grad_(True)
+    yb = ops.bn_relu_dropout(hb, bn_mine, 0.0, relu=False)
+    yb.backward(gy)
+    with torch.no_grad():
+        want = torch.nn.functional.batch_norm(h0, None, None, bn_ref.weight, bn_ref.bias, True)
+    close(yb, want.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="bn out")
+    assert bool((yb < 0).any())  # no rectification
+    close(hb.grad, ha.grad.cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dx")
+    close(bn_mine.weight.grad, bn_ref.weight.grad.cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dgamma")
+    close(bn_mine.bias.grad, bn_ref.bias.grad.cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="dbeta")
+    close(bn_mine.running_var, bn_ref.running_var.cpu().numpy(), rtol=2e-5, what="running_var")
+    bn_mine.eval(), bn_ref.eval()
+    with torch.no_grad():
+        close(ops.bn_relu_dropout(h0, bn_mine, 0.0, relu=False), bn_ref(h0).cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="eval")

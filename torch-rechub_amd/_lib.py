@@ -64,9 +64,9 @@ SIGNATURES = {
     "rh_bce_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bn_act_nchunks": [c_int],
     "rh_bn_relu_dropout_fwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_int, c_ptr,
-                               c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
+                               c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     "rh_bn_relu_dropout_bwd": [c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                               c_ptr, c_ptr],
+                               c_ptr, c_int, c_ptr],
     "rh_adam_prepare": [c_ptr, c_ptr, c_ptr, c_int, c_ptr],
     "rh_adam_small": [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,

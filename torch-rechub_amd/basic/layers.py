@@ -221,11 +221,14 @@ class MLP(nn.Module):
         self.mlp = nn.Sequential(*layers)
 
     @staticmethod
-    def _fusable(bn, act, drop, x):
-        return (isinstance(bn, nn.BatchNorm1d) and isinstance(act, nn.ReLU) and isinstance(drop, nn.Dropout) and
-                bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda and x.dim() == 2 and
-                x.dtype == torch.float32 and (x.shape[0] > 1 or not bn.training) and
+    def _bn_ok(bn, x):
+        return (isinstance(bn, nn.BatchNorm1d) and bn.affine and bn.track_running_stats and bn.momentum is not None and
+                x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and (x.shape[0] > 1 or not bn.training) and
                 not (torch.is_grad_enabled() and not bn.training and x.requires_grad))
+
+    @classmethod
+    def _fusable(cls, bn, act, drop, x):
+        return cls._bn_ok(bn, x) and isinstance(act, nn.ReLU) and isinstance(drop, nn.Dropout)
 
     @staticmethod
     def _linear(lin, x):
@@ -246,6 +249,11 @@ class MLP(nn.Module):
                     h, stats = self._linear(lin, x), None
                 x = ops.bn_relu_dropout(h, bn, mods[i + 3].p if mods[i + 3].training else 0.0, stats=stats)
                 i += 4
+            elif (i + 1 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and
+                  self._bn_ok(mods[i + 1], x)):
+                # Linear -> BatchNorm1d in front of Dice / PReLU / ...: the normalisation alone through the same kernels
+                x = ops.bn_relu_dropout(self._linear(mods[i], x), mods[i + 1], 0.0, relu=False)
+                i += 2
             elif isinstance(mods[i], nn.Linear):
                 x = self._linear(mods[i], x)
                 i += 1

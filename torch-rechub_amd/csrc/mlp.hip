@@ -41,6 +41,7 @@ struct BnArgs {
   int bookkeep;        // this launch sequence advances the dropout counter / num_batches_tracked (partial or finalize kernel)
   float momentum, eps, p_drop;
   int training;
+  int relu;            // 1: ReLU after the normalisation (MLP hidden layer); 0: BatchNorm only (Dice / PReLU follow)
 };
 
 static __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
         const int64_t i = (int64_t)r * a.C + c;
         const float xhat = (a.h[i] - mean) * rstd;
         const float bn = fmaf(xhat, g, bt);
-        float g1 = bn > 0.f ? a.dy[i] : 0.f;
+        float g1 = (!a.relu || bn > 0.f) ? a.dy[i] : 0.f;
         if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
         s1 += g1;
         s2 = fmaf(g1, xhat, s2);
@@ -246,12 +247,12 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_kernel(const BnArgs a) {
     const float xhat = (a.h[i] - mean) * rstd;
     const float bn = fmaf(xhat, g, a.beta[c]);
     if (MODE == 1) {
-      float g1 = bn > 0.f ? a.dy[i] : 0.f;
+      float g1 = (!a.relu || bn > 0.f) ? a.dy[i] : 0.f;
       if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
       const float sg = a.stat[2 * a.C + c], sgx = a.stat[3 * a.C + c];
       a.out[i] = g * rstd * (g1 - sg * inv_n - xhat * (sgx * inv_n));
     } else {
-      float y = bn > 0.f ? bn : 0.f;
+      float y = (!a.relu || bn > 0.f) ? bn : 0.f;
       if (MODE == 0 && a.p_drop > 0.f) y = drop_hash(seed, ctr, (uint64_t)i) >= thr ? y * keep_scale : 0.f;
       a.out[i] = y;
     }
@@ -339,11 +340,11 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
     const float xhat = (a.h[i] - mean) * rstd;
     const float bn = fmaf(xhat, g, bt);
     if (MODE == 1) {
-      float g1 = bn > 0.f ? a.dy[i] : 0.f;
+      float g1 = (!a.relu || bn > 0.f) ? a.dy[i] : 0.f;
       if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
       a.out[i] = g * rstd * (g1 - sg - xhat * sgx);
     } else {
-      float y = bn > 0.f ? bn : 0.f;
+      float y = (!a.relu || bn > 0.f) ? bn : 0.f;
       if (a.p_drop > 0.f) y = drop_hash(seed, ctr, (uint64_t)i) >= thr ? y * keep_scale : 0.f;
       a.out[i] = y;
     }
@@ -375,12 +376,6 @@ void launch_fused(BnArgs a, hipStream_t s, int partial_rows = 0) {
   hipLaunchKernelGGL((bn_apply_fin_kernel<MODE>), dim3((unsigned)slabs, (unsigned)gy), dim3(RH_BLOCK), 0, s, a, rpb);
 }
 
-int col_width(int C) {
-  int cw = 32;
-  while (cw < C && cw < RH_BLOCK) cw *= 2;
-  return cw;
-}
-
 unsigned apply_grid(int64_t n) {
   int64_t g = (n + RH_BLOCK * 4 - 1) / (RH_BLOCK * 4);
   if (g < 1) g = 1;
@@ -390,13 +385,21 @@ unsigned apply_grid(int64_t n) {
 
 }  // namespace
 
-extern "C" int rh_bn_act_nchunks(int B) { return (B + kRowsPerChunk - 1) / kRowsPerChunk; }
+// rows per partial chunk on the three-launch path: 16 for batch-sized inputs (enough workgroups to fill the chip), growing
+// with B so that the finalize launch never has more than ~512 chunks per column to combine (DIN: B * L = 409600 rows)
+static int big_chunk_rows(int B) {
+  int r = kRowsPerChunk;
+  while ((B + r - 1) / r > 512) r *= 2;
+  return r;
+}
+
+extern "C" int rh_bn_act_nchunks(int B) { return (B + kRowsPerChunk - 1) / kRowsPerChunk; }  // upper bound (workspace size)
 
 extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float momentum, float eps, float p_drop, int training, int64_t* rng,
                                       int64_t* saved_ctr, float* partial, int partial_rows, float* stat, float* out,
-                                      void* stream) {
+                                      int relu, void* stream) {
   RH_REQUIRE(h && gamma && beta && out, RH_E_BADARG, "rh_bn_relu_dropout_fwd: null pointer");
   RH_REQUIRE(B >= 1 && C >= 1, RH_E_BADARG, "rh_bn_relu_dropout_fwd: bad shape B=%d C=%d", B, C);
   RH_REQUIRE(p_drop >= 0.f && p_drop < 1.f, RH_E_BADARG, "rh_bn_relu_dropout_fwd: p must be in [0, 1)");
@@ -404,8 +407,10 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
   BnArgs a{};
   a.h = h; a.out = out; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.num_batches_tracked = num_batches_tracked; a.partial = partial; a.stat = stat; a.rng = rng; a.saved_ctr = saved_ctr;
-  a.B = B; a.C = C; a.nchunks = rh_bn_act_nchunks(B); a.rows_per_chunk = kRowsPerChunk; a.momentum = momentum; a.eps = eps; a.p_drop = p_drop;
+  a.B = B; a.C = C; a.rows_per_chunk = big_chunk_rows(B); a.nchunks = (B + a.rows_per_chunk - 1) / a.rows_per_chunk;
+  a.momentum = momentum; a.eps = eps; a.p_drop = p_drop;
   a.training = training;
+  a.relu = relu != 0;
   if (!training) {
     RH_REQUIRE(running_mean && running_var, RH_E_BADARG, "rh_bn_relu_dropout_fwd: eval mode needs running statistics");
     a.p_drop = 0.f;
@@ -425,7 +430,7 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
     a.rows_per_chunk = partial_rows;
     a.nchunks = (B + partial_rows - 1) / partial_rows;
   } else {
-    const int CW = col_width(C);
+    const int CW = kSlabCols;  // 32 columns x 8 row lanes per block: (C / 32) x nchunks blocks
     const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
     BnArgs ap = a;
     ap.bookkeep = 0;  // the finalize launch below does it
@@ -439,7 +444,7 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
 
 extern "C" int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma,
                                       const float* beta, float p_drop, const int64_t* rng, const int64_t* saved_ctr,
-                                      float* partial, float* stat, float* dx, float* dgamma, float* dbeta,
+                                      float* partial, float* stat, float* dx, float* dgamma, float* dbeta, int relu,
                                       void* stream) {
   RH_REQUIRE(h && dy && gamma && beta && rng && saved_ctr && partial && stat && dx && dgamma && dbeta, RH_E_BADARG,
              "rh_bn_relu_dropout_bwd: null pointer");
@@ -448,13 +453,15 @@ extern "C" int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, in
   BnArgs a{};
   a.h = h; a.dy = dy; a.out = dx; a.gamma = gamma; a.beta = beta; a.partial = partial; a.stat = stat;
   a.dgamma = dgamma; a.dbeta = dbeta; a.rng = const_cast<int64_t*>(rng); a.saved_ctr = const_cast<int64_t*>(saved_ctr);
-  a.B = B; a.C = C; a.nchunks = rh_bn_act_nchunks(B); a.rows_per_chunk = kRowsPerChunk; a.p_drop = p_drop; a.training = 1;
+  a.B = B; a.C = C; a.rows_per_chunk = big_chunk_rows(B); a.nchunks = (B + a.rows_per_chunk - 1) / a.rows_per_chunk;
+  a.p_drop = p_drop; a.training = 1;
+  a.relu = relu != 0;
   if (fused_path_ok(B)) {
     launch_fused<1>(a, s);
     RH_LAUNCH_CHECK("rh_bn_relu_dropout_bwd(fused finalize)");
     return 0;
   }
-  const int CW = col_width(C);
+  const int CW = kSlabCols;  // 32 columns x 8 row lanes per block: (C / 32) x nchunks blocks
   const dim3 pg((unsigned)((C + CW - 1) / CW), (unsigned)a.nchunks);
   hipLaunchKernelGGL((bn_partial_kernel<1>), pg, dim3(RH_BLOCK), 0, s, a, CW);
   hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);

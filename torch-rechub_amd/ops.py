@@ -553,7 +553,7 @@ class _BnReluDropoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, stats,
-                stats_ctr):
+                stats_ctr, relu):
         require_hip(h, gamma, beta)
         h = h.contiguous()
         B, C = h.shape
@@ -572,8 +572,9 @@ class _BnReluDropoutFn(torch.autograd.Function):
         rng = _dropout_rng(dev)
         _lib.call("rh_bn_relu_dropout_fwd", _p(h), B, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                   _p(num_batches_tracked), float(momentum), float(eps), float(p_drop), 1, _p(rng), _p(saved_ctr),
-                  _p(partial), prow, _p(stat), _p(out), _stream())
+                  _p(partial), prow, _p(stat), _p(out), 1 if relu else 0, _stream())
         ctx.p_drop = float(p_drop)
+        ctx.relu = bool(relu)
         ctx.save_for_backward(h, gamma, beta, stat, saved_ctr)
         return out
 
@@ -588,23 +589,24 @@ class _BnReluDropoutFn(torch.autograd.Function):
         dbeta = torch.empty_like(beta)
         partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
         _lib.call("rh_bn_relu_dropout_bwd", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop, _p(_dropout_rng(dev)),
-                  _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), _stream())
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+                  _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), 1 if ctx.relu else 0, _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def bn_relu_dropout(h, bn, p_drop, stats=None):
-    """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``.
+def bn_relu_dropout(h, bn, p_drop, stats=None, relu=True):
+    """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``
+    (``relu=False``: BatchNorm1d + Dropout only, for layers whose activation is Dice / PReLU / ...).
     ``stats``: the (statistics, counter) pair ops.linear_stats returned for this very ``bn``, or None."""
     if bn.training:
         st, ctr = stats if stats is not None else (None, None)
         return _BnReluDropoutFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                      bn.momentum, bn.eps, p_drop, st, ctr)
+                                      bn.momentum, bn.eps, p_drop, st, ctr, relu)
     require_hip(h)
     h = h.contiguous()
     out = torch.empty_like(h)
     _lib.call("rh_bn_relu_dropout_fwd", _p(h), h.shape[0], h.shape[1], _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
               _p(bn.running_var), _p(None), 0.0, float(bn.eps), 0.0, 0, _p(None), _p(None), _p(None), 0, _p(None), _p(out),
-              _stream())
+              1 if relu else 0, _stream())
     return out
 
 
