@@ -188,9 +188,26 @@ int rh_cross_mix_epilogue_bwd(const float* x0, const float* uv, const float* gat
  *   w (B, L) contiguous -> out (B, D);  bwd: g (B, D) -> g_hist (B, L, D), g_w (B, L)
  */
 int rh_dice_nblocks(int64_t N);
-int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_t N, int C, float* out, void* stream);
+int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_t N, int C, const float* bn_scale,
+                const float* bn_shift, float* out, void* stream);
 int rh_dice_bwd(const float* x, const float* g, const float* alpha, float eps, int64_t N, int C, float* gx,
                 float* alpha_partial, void* stream);
+/* BatchNorm1d -> Dice of the ActivationUnit's MLP (basic/layers.py:281-287 with activation "dice"), the normalisation
+ * folded into the Dice passes so that the normalised tensor is never materialised:
+ *   forward : rh_bn_stats_fwd (batch statistics -> stat (6, C): mean, rstd, -, -, scale, shift; running stats,
+ *             num_batches_tracked; eval: from the running statistics) then rh_dice_fwd(h, ..., stat + 4C, stat + 5C, out)
+ *   backward: rh_bn_dice_bwd_stats (g = dL/d out -> per-block (sum g_x, sum g_x * xhat) rows, col_partial
+ *             (rh_bn_dice_stats_blocks(N), 2, C), and alpha partial sums (same number of blocks)),
+ *             rh_bn_finalize_bwd (-> stat rows 2, 3, dgamma, dbeta), rh_bn_dice_bwd_apply (-> dh).   C <= 512. */
+int rh_bn_stats_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
+                    float* partial, float* stat, void* stream);
+int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta, void* stream);
+int rh_bn_dice_stats_blocks(int64_t N);
+int rh_bn_dice_bwd_stats(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                         const float* stat, const float* gamma, float* col_partial, float* alpha_partial, void* stream);
+int rh_bn_dice_bwd_apply(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                         const float* stat, const float* gamma, float* dh, void* stream);
 int rh_din_att_input_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, int B, int L,
                          int D, float* out, void* stream);
 int rh_din_att_input_bwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* g,

@@ -923,3 +923,39 @@ def test_batchnorm_only_mode_vs_torch(B, C):
     bn_mine.eval(), bn_ref.eval()
     with torch.no_grad():
         close(ops.bn_relu_dropout(h0, bn_mine, 0.0, relu=False), bn_ref(h0).cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="eval")
+
+
+@pytest.mark.parametrize("N,C", [(25600, 256), (1000, 128), (77, 36), (300, 200), (409600, 64)])
+def test_bn_dice_folded_vs_modules(N, C):
+    """Linear's BatchNorm1d -> Dice with the normalisation folded into the Dice passes == the two modules one after the
+    other (float64 Dice formula on torch's BatchNorm output): outputs, all gradients, running statistics, eval mode."""
+    from torch_rechub_amd import ops
+    torch.manual_seed(N + C)
+    h0 = (torch.randn(N, C) * 1.5 + torch.randn(C)).to(dev())
+    bn_ref, bn_mine = torch.nn.BatchNorm1d(C).to(dev()), torch.nn.BatchNorm1d(C).to(dev())
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5)
+        bn_ref.bias.normal_()
+    bn_mine.load_state_dict(bn_ref.state_dict())
+    alpha0 = torch.randn(1)
+    gy = torch.randn(N, C, device=dev())
+    ha = h0.clone().requires_grad_(True)
+    al_a = alpha0.double().to(dev()).requires_grad_(True)
+    ya = _dice_ref(bn_ref(ha).double(), al_a)
+    ya.backward(gy.double())
+    hb = h0.clone().requires_grad_(True)
+    al_b = alpha0.to(dev()).requires_grad_(True)
+    yb = ops.bn_dice(hb, bn_mine, al_b, 1e-3)
+    yb.backward(gy)
+    close(yb, ya.detach().cpu().numpy(), rtol=2e-4, atol_scale=5e-6, what="out")
+    close(hb.grad, ha.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dh")
+    close(bn_mine.weight.grad, bn_ref.weight.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dgamma")
+    close(bn_mine.bias.grad, bn_ref.bias.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dbeta")
+    close(al_b.grad, al_a.grad.cpu().numpy(), rtol=1e-3, atol_scale=1e-4, what="dalpha")
+    close(bn_mine.running_mean, bn_ref.running_mean.cpu().numpy(), rtol=1e-5, what="running_mean")
+    close(bn_mine.running_var, bn_ref.running_var.cpu().numpy(), rtol=2e-5, what="running_var")
+    assert int(bn_mine.num_batches_tracked) == 1
+    bn_ref.eval(), bn_mine.eval()
+    with torch.no_grad():
+        close(ops.bn_dice(h0, bn_mine, al_b.detach(), 1e-3), _dice_ref(bn_ref(h0).double(), al_a.detach()).cpu().numpy(),
+              rtol=2e-4, atol_scale=5e-6, what="eval")

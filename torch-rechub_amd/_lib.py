@@ -43,8 +43,13 @@ SIGNATURES = {
     "rh_cross_mix_epilogue_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_cross_mix_epilogue_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_dice_nblocks": [c_i64],
-    "rh_dice_fwd": [c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr],
+    "rh_dice_fwd": [c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_dice_bwd": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_bn_stats_fwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_bn_finalize_bwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_dice_stats_blocks": [c_i64],
+    "rh_bn_dice_bwd_stats": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_dice_bwd_apply": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_din_att_input_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_din_att_input_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "rh_din_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
@@ -81,7 +86,7 @@ _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctyp
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
                     "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles",
-                    "rh_head_nblocks", "rh_gemm_stats_rows"}
+                    "rh_head_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks"}
 
 ABI_VERSION = 1
 _lib = None

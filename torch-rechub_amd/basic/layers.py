@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from .activation import activation_layer
+from .activation import Dice, activation_layer
 from .features import DenseFeature, SequenceFeature, SparseFeature
 
 
@@ -249,6 +249,12 @@ class MLP(nn.Module):
                     h, stats = self._linear(lin, x), None
                 x = ops.bn_relu_dropout(h, bn, mods[i + 3].p if mods[i + 3].training else 0.0, stats=stats)
                 i += 4
+            elif (i + 2 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and
+                  type(mods[i + 2]) is Dice and self._bn_ok(mods[i + 1], x) and mods[i].out_features <= 512 and
+                  not (torch.is_grad_enabled() and not mods[i + 1].training)):
+                # Linear -> BatchNorm1d -> Dice (DIN's ActivationUnit): the normalisation is folded into the Dice passes
+                x = ops.bn_dice(self._linear(mods[i], x), mods[i + 1], mods[i + 2].alpha, mods[i + 2].epsilon)
+                i += 3
             elif (i + 1 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and
                   self._bn_ok(mods[i + 1], x)):
                 # Linear -> BatchNorm1d in front of Dice / PReLU / ...: the normalisation alone through the same kernels

@@ -8,6 +8,7 @@
 //   ActivationUnit.forward  torch_rechub/models/ranking/din.py:77-92
 //       att_input = cat[t, h, t-h, t*h] over (B, L, 4D)   and   output = (att_weight.unsqueeze(-1) * history).sum(1)
 // Roofline: HBM; one pass over the data per kernel (Dice: read x, write out; backward: read x, g, write gx).
+// With a BatchNorm1d in front the normalisation is folded into the same passes (see dice_kernel).
 #include "common.h"
 
 namespace {
@@ -15,23 +16,72 @@ namespace {
 constexpr int kWaves = RH_BLOCK / RH_WAVE;
 
 // One wavefront per row; lane owns elements lane + 64*k (coalesced).  EPL = ceil(C / 64) <= 32.
-template <int EPL, bool BWD>
-__global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ alpha_p, float eps, int64_t N, int C,
-                                                        float* __restrict__ out, float* __restrict__ alpha_partial) {
+//
+// With a BatchNorm1d in front (MLP of DIN's ActivationUnit: Linear -> BatchNorm1d -> Dice, layers.py:281-287) the
+// normalisation is folded in: the kernels read the PRE-BatchNorm activations h and form x = h * scale[c] + shift[c]
+// on the fly (scale = gamma * rstd, shift = beta - mean * scale, written by the statistics launch of csrc/mlp.hip), so
+// the normalised tensor is never materialised: forward = statistics pass + ONE pass (read h, write out) instead of
+// statistics + normalise + Dice; backward = two row passes over (h, g):
+//   MODE 2 forms g_x = dL/dx of Dice in registers and accumulates, per lane-owned column, sum g_x and sum g_x * xhat
+//          (what BatchNorm's backward needs) -> per-block partial rows (blocks, 2, C), summed by mlp.hip's finalize;
+//   MODE 3 recomputes g_x and writes dh = gamma * rstd * (g_x - mean_b(g_x) - xhat * mean_b(g_x * xhat)).
+// MODE 0 forward, MODE 1 plain Dice backward (no BatchNorm in front).
+struct DiceArgs {
+  const float* x;          // (N, C): Dice input, or the pre-BatchNorm activations h when scale != null
+  const float* g;          // backward: gradient of the Dice output
+  const float* alpha;
+  float eps;
+  int64_t N;
+  int C;
+  float* out;              // forward: Dice output; MODE 1: g_x; MODE 3: dh
+  float* alpha_partial;    // (blocks,) partial sums of dL/dalpha (MODE 1 and 2)
+  const float* scale;      // (C,) BatchNorm folded affine, or null
+  const float* shift;
+  const float* stat;       // MODE 2/3: (>= 4, C) mean, rstd, sum g_x, sum g_x * xhat
+  const float* gamma;
+  float* col_partial;      // MODE 2: (blocks, 2, C)
+};
+
+template <int EPL, int MODE>
+__global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
   __shared__ float red[kWaves];
+  extern __shared__ float colred[];  // MODE 2: kWaves * 2 * EPL * 64 floats
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int64_t nw = (int64_t)gridDim.x * kWaves;
-  const float alpha = alpha_p[0];
+  const int C = a.C;
+  const float alpha = a.alpha[0];
   const float invC = 1.f / (float)C;
+  const bool bn = a.scale != nullptr;
+  float sc[EPL], sh[EPL];                       // folded BatchNorm affine of the lane's columns
+  float mu[EPL], rsd[EPL], gm[EPL], sg[EPL], sgx[EPL];  // MODE 2 / 3
+  float cs1[EPL], cs2[EPL];                     // MODE 2: column sums over this wavefront's rows
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const int e = lane + RH_WAVE * k;
+    const bool ok = e < C;
+    sc[k] = (bn && ok) ? a.scale[e] : 1.f;
+    sh[k] = (bn && ok) ? a.shift[e] : 0.f;
+    cs1[k] = cs2[k] = 0.f;
+    if (MODE >= 2) {
+      mu[k] = ok ? a.stat[e] : 0.f;
+      rsd[k] = ok ? a.stat[C + e] : 0.f;
+      gm[k] = ok ? a.gamma[e] : 0.f;
+      if (MODE == 3) {
+        const float inv_n = 1.f / (float)a.N;
+        sg[k] = ok ? a.stat[2 * C + e] * inv_n : 0.f;
+        sgx[k] = ok ? a.stat[3 * C + e] * inv_n : 0.f;
+      }
+    }
+  }
   float acc_alpha = 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * kWaves + wave; r < N; r += nw) {
-    float v[EPL];
+  for (int64_t r = (int64_t)blockIdx.x * kWaves + wave; r < a.N; r += nw) {
+    float hraw[EPL], v[EPL];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
-      v[k] = e < C ? x[r * C + e] : 0.f;
+      hraw[k] = e < C ? a.x[r * C + e] : 0.f;
+      v[k] = e < C ? fmaf(hraw[k], sc[k], sh[k]) : 0.f;
       s += v[k];
     }
     const float avg = wave_sum(s) * invC;
@@ -42,15 +92,15 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const float* __restrict_
       const float c = e < C ? v[k] - avg : 0.f;
       q = fmaf(c, c, q);
     }
-    const float var = wave_sum(q) + eps * (float)C;
+    const float var = wave_sum(q) + a.eps * (float)C;
     const float rs = rsqrtf(var);
-    if (!BWD) {
+    if (MODE == 0) {
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         const int e = lane + RH_WAVE * k;
         if (e < C) {
           const float ps = 1.f / (1.f + expf(-(v[k] - avg) * rs));
-          out[r * C + e] = ps * v[k] + (1.f - ps) * alpha * v[k];
+          a.out[r * C + e] = ps * v[k] + (1.f - ps) * alpha * v[k];
         }
       }
     } else {
@@ -60,13 +110,13 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const float* __restrict_
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         const int e = lane + RH_WAVE * k;
-        gk[k] = e < C ? g[r * C + e] : 0.f;
+        gk[k] = e < C ? a.g[r * C + e] : 0.f;
         const float c = v[k] - avg;
         psk[k] = 1.f / (1.f + expf(-c * rs));
         tk[k] = e < C ? gk[k] * v[k] * (1.f - alpha) * psk[k] * (1.f - psk[k]) : 0.f;  // dL/dz
         st += tk[k];
         stc = fmaf(tk[k], c, stc);
-        acc_alpha += e < C ? gk[k] * v[k] * (1.f - psk[k]) : 0.f;
+        if (MODE != 3) acc_alpha += e < C ? gk[k] * v[k] * (1.f - psk[k]) : 0.f;
       }
       st = wave_sum(st);
       stc = wave_sum(stc);
@@ -76,19 +126,47 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const float* __restrict_
         const int e = lane + RH_WAVE * k;
         if (e < C) {
           const float c = v[k] - avg;
-          out[r * C + e] = gk[k] * (alpha + (1.f - alpha) * psk[k]) + rs * tk[k] - rs * invC * st - rs3 * c * stc;
+          const float gx = gk[k] * (alpha + (1.f - alpha) * psk[k]) + rs * tk[k] - rs * invC * st - rs3 * c * stc;
+          if (MODE == 1) {
+            a.out[r * C + e] = gx;
+          } else {
+            const float xhat = (hraw[k] - mu[k]) * rsd[k];
+            if (MODE == 2) {
+              cs1[k] += gx;
+              cs2[k] = fmaf(gx, xhat, cs2[k]);
+            } else {
+              a.out[r * C + e] = gm[k] * rsd[k] * (gx - sg[k] - xhat * sgx[k]);
+            }
+          }
         }
       }
     }
   }
-  if (BWD) {
+  if (MODE == 1 || MODE == 2) {
     acc_alpha = wave_sum(acc_alpha);
     if (lane == 0) red[wave] = acc_alpha;
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int w = 0; w < kWaves; ++w) t += red[w];
-      alpha_partial[blockIdx.x] = t;
+      a.alpha_partial[blockIdx.x] = t;
+    }
+  }
+  if (MODE == 2) {
+    // the wavefronts of the block are summed in wavefront order: deterministic per-block partial rows
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      colred[(wave * 2 + 0) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs1[k];
+      colred[(wave * 2 + 1) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs2[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * EPL * RH_WAVE; i += RH_BLOCK) {
+      const int which = i / (EPL * RH_WAVE), e = i % (EPL * RH_WAVE);
+      if (e < C) {
+        float t = 0.f;
+        for (int w = 0; w < kWaves; ++w) t += colred[(w * 2 + which) * EPL * RH_WAVE + e];
+        a.col_partial[((int64_t)blockIdx.x * 2 + which) * C + e] = t;
+      }
     }
   }
 }
@@ -99,25 +177,33 @@ int dice_epl(int C) {
   return e;
 }
 
-unsigned dice_grid(int64_t N) {
+unsigned dice_grid(int64_t N, int cap = 256 * 16) {
   int64_t g = (N + kWaves - 1) / kWaves;
-  if (g > 256 * 16) g = 256 * 16;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (unsigned)g;
 }
+constexpr int kStatsBlocks = 512;  // MODE 2: few enough partial rows for the column finalize to combine quickly
 
-template <bool BWD>
-int dice_dispatch(const float* x, const float* g, const float* alpha, float eps, int64_t N, int C, float* out,
-                  float* partial, hipStream_t s) {
-  const unsigned grid = dice_grid(N);
-#define RH_DICE(E) hipLaunchKernelGGL((dice_kernel<E, BWD>), dim3(grid), dim3(RH_BLOCK), 0, s, x, g, alpha, eps, N, C, out, partial)
-  switch (dice_epl(C)) {
+template <int MODE>
+int dice_dispatch(const DiceArgs& a, hipStream_t s) {
+  const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : dice_grid(a.N);
+#define RH_DICE(E)                                                                                          \
+  hipLaunchKernelGGL((dice_kernel<E, MODE>), dim3(grid), dim3(RH_BLOCK),                                    \
+                     MODE == 2 ? (size_t)kWaves * 2 * E * RH_WAVE * sizeof(float) : 0, s, a)
+  switch (dice_epl(a.C)) {
     case 1: RH_DICE(1); break;
     case 2: RH_DICE(2); break;
     case 4: RH_DICE(4); break;
     case 8: RH_DICE(8); break;
-    case 16: RH_DICE(16); break;
-    case 32: RH_DICE(32); break;
+    case 16:
+      if (MODE >= 2) return RH_E_UNSUPPORTED;  // the folded-BatchNorm modes keep 9 values per owned column in registers
+      RH_DICE(16);
+      break;
+    case 32:
+      if (MODE >= 2) return RH_E_UNSUPPORTED;
+      RH_DICE(32);
+      break;
     default: return RH_E_UNSUPPORTED;
   }
 #undef RH_DICE
@@ -237,12 +323,16 @@ int att_check(const char* who, int B, int L, int D) {
 }  // namespace
 
 extern "C" int rh_dice_nblocks(int64_t N) { return (int)dice_grid(N); }
+extern "C" int rh_bn_dice_stats_blocks(int64_t N) { return (int)dice_grid(N, kStatsBlocks); }
 
-extern "C" int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_t N, int C, float* out, void* stream) {
+extern "C" int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_t N, int C, const float* bn_scale,
+                           const float* bn_shift, float* out, void* stream) {
   RH_REQUIRE(x && alpha && out && N >= 0 && C >= 1, RH_E_BADARG, "rh_dice_fwd: bad arguments");
+  RH_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), RH_E_BADARG, "rh_dice_fwd: scale and shift go together");
   RH_REQUIRE(C <= 2048, RH_E_UNSUPPORTED, "rh_dice_fwd: %d neurons unsupported (max 2048)", C);
   if (N == 0) return 0;
-  int rc = dice_dispatch<false>(x, nullptr, alpha, eps, N, C, out, nullptr, reinterpret_cast<hipStream_t>(stream));
+  DiceArgs a{x, nullptr, alpha, eps, N, C, out, nullptr, bn_scale, bn_shift, nullptr, nullptr, nullptr};
+  int rc = dice_dispatch<0>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_dice_fwd");
   return 0;
@@ -252,9 +342,35 @@ extern "C" int rh_dice_bwd(const float* x, const float* g, const float* alpha, f
                            float* alpha_partial, void* stream) {
   RH_REQUIRE(x && g && alpha && gx && alpha_partial && N >= 0 && C >= 1, RH_E_BADARG, "rh_dice_bwd: bad arguments");
   RH_REQUIRE(C <= 2048, RH_E_UNSUPPORTED, "rh_dice_bwd: %d neurons unsupported (max 2048)", C);
-  int rc = dice_dispatch<true>(x, g, alpha, eps, N, C, gx, alpha_partial, reinterpret_cast<hipStream_t>(stream));
+  DiceArgs a{x, g, alpha, eps, N, C, gx, alpha_partial, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int rc = dice_dispatch<1>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_dice_bwd");
+  return 0;
+}
+
+extern "C" int rh_bn_dice_bwd_stats(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                                    const float* stat, const float* gamma, float* col_partial, float* alpha_partial,
+                                    void* stream) {
+  RH_REQUIRE(h && g && alpha && stat && gamma && col_partial && alpha_partial && N >= 1 && C >= 1, RH_E_BADARG,
+             "rh_bn_dice_bwd_stats: bad arguments");
+  RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_bwd_stats: %d neurons unsupported (max 512)", C);
+  DiceArgs a{h, g, alpha, eps, N, C, nullptr, alpha_partial, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma,
+             col_partial};
+  int rc = dice_dispatch<2>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_bn_dice_bwd_stats");
+  return 0;
+}
+
+extern "C" int rh_bn_dice_bwd_apply(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                                    const float* stat, const float* gamma, float* dh, void* stream) {
+  RH_REQUIRE(h && g && alpha && stat && gamma && dh && N >= 1 && C >= 1, RH_E_BADARG, "rh_bn_dice_bwd_apply: bad arguments");
+  RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_bwd_apply: %d neurons unsupported (max 512)", C);
+  DiceArgs a{h, g, alpha, eps, N, C, dh, nullptr, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma, nullptr};
+  int rc = dice_dispatch<3>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_bn_dice_bwd_apply");
   return 0;
 }
 

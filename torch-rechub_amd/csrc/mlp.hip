@@ -41,6 +41,7 @@ struct BnArgs {
   int bookkeep;        // this launch sequence advances the dropout counter / num_batches_tracked (partial or finalize kernel)
   float momentum, eps, p_drop;
   int training;
+  int affine_out;      // forward finalize also writes stat rows 4, 5: scale = gamma*rstd, shift = beta - mean*scale
   int relu;            // 1: ReLU after the normalisation (MLP hidden layer); 0: BatchNorm only (Dice / PReLU follow)
 };
 
@@ -179,8 +180,10 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
   const int grp = threadIdx.x / kFinCols;
   const bool cok = c < a.C;
   if (MODE == 0 && a.bookkeep && blockIdx.x == 0 && threadIdx.x == 0) {
-    a.saved_ctr[0] = a.rng[1];  // dropout stream of this call
-    a.rng[1] += 1;
+    if (a.bookkeep != 2) {
+      a.saved_ctr[0] = a.rng[1];  // dropout stream of this call
+      a.rng[1] += 1;
+    }
     if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
   }
   if (MODE == 0) {
@@ -188,8 +191,14 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
     chan_combine<GROUPS, kFinCols, 16>(a, c, cl, grp, cok, red, mean, var);
     if (grp != 0 || !cok) return;
     const float n = (float)a.B;
+    const float rstd = rsqrtf(var + a.eps);
     a.stat[c] = mean;
-    a.stat[a.C + c] = rsqrtf(var + a.eps);
+    a.stat[a.C + c] = rstd;
+    if (a.affine_out) {
+      const float scale = a.gamma[c] * rstd;
+      a.stat[4 * a.C + c] = scale;
+      a.stat[5 * a.C + c] = fmaf(-mean, scale, a.beta[c]);
+    }
     if (a.running_mean != nullptr) {
       const float unbiased = a.B > 1 ? var * (n / (n - 1.f)) : var;
       a.running_mean[c] = fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
@@ -219,6 +228,18 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
   a.stat[3 * a.C + c] = s2;  // sum g1 * xhat = dgamma
   a.dbeta[c] = s1;
   a.dgamma[c] = s2;
+}
+
+// eval mode of rh_bn_stats_fwd: the folded affine from the running statistics
+__global__ __launch_bounds__(RH_BLOCK) void bn_eval_affine_kernel(const BnArgs a) {
+  const int c = blockIdx.x * RH_BLOCK + threadIdx.x;
+  if (c >= a.C) return;
+  const float mean = a.running_mean[c], rstd = rsqrtf(a.running_var[c] + a.eps);
+  const float scale = a.gamma[c] * rstd;
+  a.stat[c] = mean;
+  a.stat[a.C + c] = rstd;
+  a.stat[4 * a.C + c] = scale;
+  a.stat[5 * a.C + c] = fmaf(-mean, scale, a.beta[c]);
 }
 
 // MODE 0 forward apply, MODE 1 backward dx, MODE 2 eval-mode forward (running statistics, no dropout)
@@ -439,6 +460,46 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
   hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
   hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(apply_grid((int64_t)B * C)), dim3(RH_BLOCK), 0, s, a);
   RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd");
+  return 0;
+}
+
+// Statistics only (no apply): for the activations that fold the normalisation into their own pass (csrc/din.hip: Dice).
+// stat (6, C): mean, rstd, -, -, scale = gamma * rstd, shift = beta - mean * scale.  eval: running statistics.
+extern "C" int rh_bn_stats_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
+                               float* partial, float* stat, void* stream) {
+  RH_REQUIRE(h && gamma && beta && stat && B >= 1 && C >= 1, RH_E_BADARG, "rh_bn_stats_fwd: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  BnArgs a{};
+  a.h = h; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.num_batches_tracked = num_batches_tracked; a.partial = partial; a.stat = stat; a.B = B; a.C = C;
+  a.momentum = momentum; a.eps = eps; a.training = training; a.affine_out = 1;
+  if (!training) {
+    RH_REQUIRE(running_mean && running_var, RH_E_BADARG, "rh_bn_stats_fwd: eval mode needs running statistics");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)((C + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK), 0, s, a);
+    RH_LAUNCH_CHECK("rh_bn_stats_fwd(eval)");
+    return 0;
+  }
+  RH_REQUIRE(partial, RH_E_BADARG, "rh_bn_stats_fwd: training needs the partial workspace");
+  a.rows_per_chunk = big_chunk_rows(B);
+  a.nchunks = (B + a.rows_per_chunk - 1) / a.rows_per_chunk;
+  const dim3 pg((unsigned)((C + kSlabCols - 1) / kSlabCols), (unsigned)a.nchunks);
+  hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, a, kSlabCols);
+  a.bookkeep = 2;  // count the batch; there is no dropout stream to advance
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
+  RH_LAUNCH_CHECK("rh_bn_stats_fwd");
+  return 0;
+}
+
+// Column sums of (rows, 2, C) partials -> stat rows 2, 3 (sum g, sum g * xhat) and dbeta / dgamma.
+extern "C" int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta,
+                                  void* stream) {
+  RH_REQUIRE(partial && stat && dgamma && dbeta && rows >= 1 && C >= 1, RH_E_BADARG, "rh_bn_finalize_bwd: bad arguments");
+  BnArgs a{};
+  a.partial = partial; a.stat = stat; a.dgamma = dgamma; a.dbeta = dbeta; a.C = C; a.nchunks = rows; a.B = 1;
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  RH_LAUNCH_CHECK("rh_bn_finalize_bwd");
   return 0;
 }
 

@@ -821,7 +821,7 @@ class _DiceFn(torch.autograd.Function):
         x = x.contiguous()
         N, C = x.shape
         out = torch.empty_like(x)
-        _lib.call("rh_dice_fwd", _p(x), _p(alpha), float(eps), N, C, _p(out), _stream())
+        _lib.call("rh_dice_fwd", _p(x), _p(alpha), float(eps), N, C, _p(None), _p(None), _p(out), _stream())
         ctx.eps = float(eps)
         ctx.save_for_backward(x, alpha)
         return out
@@ -839,6 +839,65 @@ class _DiceFn(torch.autograd.Function):
 
 def dice(x, alpha, eps):
     return _DiceFn.apply(x, alpha, eps)
+
+
+class _BnDiceFn(torch.autograd.Function):
+    """Dice(BatchNorm1d(h)) with the normalisation folded into the Dice passes (csrc/din.hip, csrc/mlp.hip): the
+    normalised tensor is never written.  Training mode; running statistics and num_batches_tracked updated in place."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, alpha, eps):
+        require_hip(h, gamma, beta, alpha)
+        h = h.contiguous()
+        N, C = h.shape
+        dev = h.device
+        stat = torch.empty((6, C), dtype=torch.float32, device=dev)
+        partial = torch.empty((_lib.call("rh_bn_act_nchunks", N), 2, C), dtype=torch.float32, device=dev)
+        _lib.call("rh_bn_stats_fwd", _p(h), N, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                  _p(num_batches_tracked), float(momentum), float(bn_eps), 1, _p(partial), _p(stat), _stream())
+        out = torch.empty_like(h)
+        _lib.call("rh_dice_fwd", _p(h), _p(alpha), float(eps), N, C, _p(stat[4]), _p(stat[5]), _p(out), _stream())
+        ctx.eps = float(eps)
+        ctx.save_for_backward(h, gamma, alpha, stat)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, gamma, alpha, stat = ctx.saved_tensors
+        N, C = h.shape
+        dev = h.device
+        g = g.contiguous()
+        nb = _lib.call("rh_bn_dice_stats_blocks", N)
+        col_partial = torch.empty((nb, 2, C), dtype=torch.float32, device=dev)
+        alpha_partial = torch.empty((nb,), dtype=torch.float32, device=dev)
+        _lib.call("rh_bn_dice_bwd_stats", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(col_partial),
+                  _p(alpha_partial), _stream())
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        _lib.call("rh_bn_finalize_bwd", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _stream())
+        dh = torch.empty_like(h)
+        _lib.call("rh_bn_dice_bwd_apply", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(dh), _stream())
+        return dh, dgamma, dbeta, None, None, None, None, None, alpha_partial.sum().reshape(1), None
+
+
+def bn_dice_ok(h, bn, dice_mod):
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and h.shape[1] <= 512 and h.shape[0] > 1 and
+            bn.affine and bn.track_running_stats and bn.momentum is not None)
+
+
+def bn_dice(h, bn, alpha, eps):
+    """Dice(bn(h)) for a Linear -> BatchNorm1d -> Dice block: folded into two passes over h (training) or one (eval)."""
+    if bn.training:
+        return _BnDiceFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                               bn.eps, alpha, eps)
+    require_hip(h)
+    h = h.contiguous()
+    N, C = h.shape
+    stat = torch.empty((6, C), dtype=torch.float32, device=h.device)
+    _lib.call("rh_bn_stats_fwd", _p(h), N, C, _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(None),
+              0.0, float(bn.eps), 0, _p(None), _p(stat), _stream())
+    out = torch.empty_like(h)
+    _lib.call("rh_dice_fwd", _p(h), _p(alpha), float(eps), N, C, _p(stat[4]), _p(stat[5]), _p(out), _stream())
+    return out
 
 
 def _hist_layout(history):
