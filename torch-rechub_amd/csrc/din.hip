@@ -183,7 +183,7 @@ unsigned dice_grid(int64_t N, int cap = 256 * 16) {
   if (g < 1) g = 1;
   return (unsigned)g;
 }
-constexpr int kStatsBlocks = 512;  // MODE 2: few enough partial rows for the column finalize to combine quickly
+constexpr int kStatsBlocks = 2048;  // MODE 2: few enough partial rows for the column finalize to combine quickly
 
 template <int MODE>
 int dice_dispatch(const DiceArgs& a, hipStream_t s) {
