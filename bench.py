@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink every table")
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
-    ap.add_argument("--lazy-k", type=int, default=32)
+    ap.add_argument("--lazy-k", type=int, default=64)
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives, split graphs) even on one GPU")
     return ap.parse_args()
@@ -296,10 +296,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": None,
                         "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"]}
-            if dominant == "rh_adam_lazy_sweep" and args.lazy_k == 32 and args.vocab_scale == 1.0:
+            pmc_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
+            if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0:
                 # measured with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel in this
                 # configuration (2*FETCH + WRITE, gfx950 correction, calibrated on rh_adam_dense): profiles/r01_pmc_traffic.md
-                roofline["traffic"] = 421.4e6
+                roofline["traffic"] = pmc_traffic
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
             if dominant == "rh_adam_lazy_sweep":
                 roofline["note"] = ("blocked-lazy exact Adam: this launch moves 1/K of the dense pass's bytes and replays "

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One fixed configuration per kernel, so that `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE` gives a clean mean per launch:
   rh_adam_dense (known byte count: calibration of the counters), rh_embed_fwd / rh_embed_bwd at B=4096 (Criteo shape),
-  rh_adam_lazy_sweep in steady state (K=32, no flush inside the measured launches).
+  rh_adam_lazy_sweep in steady state (K=64, no flush inside the measured launches).
 Run:  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tools/pmc_probe.py
 """
 import os
@@ -37,8 +37,8 @@ def main():
         torch.autograd.backward([out, fm, lr], [torch.randn_like(out), torch.randn_like(fm), torch.randn_like(lr)])
         for w in tables:
             ops.grad_buffer(w).zero_()
-    lazy = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5, lazy_k=32)
-    for _ in range(32 + 20):  # first 32 launches reach the steady state (every swept row lags 32 steps)
+    lazy = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5, lazy_k=64)
+    for _ in range(64 + 20):  # first 64 launches reach the steady state (every swept row lags 64 steps)
         lazy.step_tables()
     torch.cuda.synchronize()
     print("pmc probe done")

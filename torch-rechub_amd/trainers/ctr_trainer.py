@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=32):
+                 table_update=None, lazy_k=64):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
