@@ -303,6 +303,13 @@ def main():
                 roofline["traffic"] = pmc_traffic
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
             if dominant == "rh_adam_lazy_sweep":
+                # the kernel's own bound: one replay iteration = 16 packed f32 ops (4 cycles / wavefront) + 4 sqrt + 4 rcp
+                # (8 cycles each, measured) + 2 scalar-ish VALU ops = 136 cycles per 256 element-steps on each of the
+                # 1024 SIMDs at 2.4 GHz (csrc/optim.hip)
+                valu_peak = 1024 * 2.4e9 / 136 * 256
+                es = total_elems / (k["avg_ms"] * 1e-3)
+                roofline["valu"] = {"achieved": round(es / 1e9, 1), "peak": round(valu_peak / 1e9, 1),
+                                    "unit": "G element-steps/s", "frac": round(es / valu_peak, 4)}
                 roofline["note"] = ("blocked-lazy exact Adam: this launch moves 1/K of the dense pass's bytes and replays "
                                     "the rest in registers (VALU-bound: %.0f M element-steps per launch, %.1f G "
                                     "element-steps/s); the dense pass it replaces is rh_adam_dense at 64-75 %% of HBM "
