@@ -210,8 +210,8 @@ def build_model(rh, cfg):
         return model, {"features": feats, "history_features": hist, "target_features": tgt}
     dense = [DenseFeature(f"I{i + 1}") for i in range(13)]
     vocabs = [3, 4, 10, 27, 105, 305, 583, 40, 1460, 24, 18, 15, 633] * 2
-    if cfg == "dcnv2_full_stacked":
-        vocabs = vocabs[:6]  # keeps the (d, d) cross weights of the fixture small
+    if cfg in ("dcnv2_full_stacked", "fibinet", "fibinet_each"):
+        vocabs = vocabs[:6]  # keeps the (d, d) cross weights / the F (F - 1) D wide MLP input of the fixture small
     sparse = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=D) for i, v in enumerate(vocabs)]
     if cfg == "deepfm_tutorial":  # tutorials/00: deep = dense + sparse, fm = sparse
         return DeepFM(dense + sparse, sparse, mlp), {"deep_features": dense + sparse, "fm_features": sparse}
@@ -226,6 +226,13 @@ def build_model(rh, cfg):
     if cfg == "dcnv2_full_stacked":
         return DCNv2(dense + sparse, 2, mlp, model_structure="stacked", use_low_rank_mixture=False), \
             {"features": dense + sparse}
+    if cfg == "afm":
+        from torch_rechub.models.ranking import AFM
+        return AFM(sparse, D, t=8), {"fm_features": sparse}
+    if cfg in ("fibinet", "fibinet_each"):
+        from torch_rechub.models.ranking import FiBiNet
+        kind = "field_interaction" if cfg == "fibinet" else "field_each"
+        return FiBiNet(sparse, mlp, reduction_ratio=3, bilinear_type=kind), {"features": sparse}
     raise ValueError(cfg)
 
 
@@ -311,7 +318,7 @@ def gen_model(rh, cfg):
 
 
 CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-           "din_softmax", "dssm"]
+           "din_softmax", "dssm", "afm", "fibinet", "fibinet_each"]
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

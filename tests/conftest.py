@@ -25,7 +25,7 @@ def layers_golden():
 
 
 MODEL_CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-                 "din_softmax", "dssm"]
+                 "din_softmax", "dssm", "afm", "fibinet", "fibinet_each"]
 
 
 def features_from_spec(spec_json):
@@ -77,6 +77,13 @@ def build_amd_model(cfg, groups):
         return DCNv2(groups["features"], 3, mlp, low_rank=8, num_experts=3)
     if cfg == "dcnv2_full_stacked":
         return DCNv2(groups["features"], 2, mlp, model_structure="stacked", use_low_rank_mixture=False)
+    if cfg == "afm":
+        from torch_rechub_amd.models.ranking import AFM
+        return AFM(groups["fm_features"], 16, t=8)
+    if cfg in ("fibinet", "fibinet_each"):
+        from torch_rechub_amd.models.ranking import FiBiNet
+        return FiBiNet(groups["features"], mlp, reduction_ratio=3,
+                       bilinear_type="field_interaction" if cfg == "fibinet" else "field_each")
     raise ValueError(cfg)
 
 

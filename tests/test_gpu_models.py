@@ -59,9 +59,18 @@ def test_forward_loss_and_gradients_match_reference(cfg):
     # atol is tied to the largest gradient of the model: a Linear bias in front of BatchNorm has an exactly-zero
     # gradient mathematically and ~1e-8 of rounding noise on either side
     gmax = max(float(np.abs(gold["grad." + n]).max()) for n, _ in model.named_parameters())
+    noise = set()  # biases of a Linear feeding a BatchNorm1d: both sides hold rounding noise only, which grows with fan-in
+    for mn, m in model.named_modules():
+        if isinstance(m, torch.nn.Sequential):
+            mods = list(m)
+            noise |= {f"{mn}.{i}.bias" for i in range(len(mods) - 1)
+                      if isinstance(mods[i], torch.nn.Linear) and isinstance(mods[i + 1], torch.nn.BatchNorm1d)}
     for n, p in model.named_parameters():
         ref = gold["grad." + n]
         got = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        if n in noise:
+            assert np.abs(got).max() <= 1e-5 * max(gmax, 1e-3) + 1e-6 and np.abs(ref).max() <= 1e-5 * max(gmax, 1e-3) + 1e-6, n
+            continue
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * gmax, err_msg=f"{cfg}: grad of {n}")
 
 

@@ -372,3 +372,46 @@ class CrossNetMix(nn.Module):
                 expert = x0.unsqueeze(0) * (uv + self.bias[i].view(1, 1, d))  # (E, B, d)
                 xl = (expert * gate.t().unsqueeze(2)).sum(dim=0) + xl
         return xl
+
+
+class SENETLayer(nn.Module):
+    """SENET field gating: a = relu(W2 relu(W1 mean_d(x))), out = x * a[..., None] (reference layers.py:509-529)."""
+
+    def __init__(self, num_fields, reduction_ratio=3):
+        super().__init__()
+        hidden = max(1, int(num_fields / reduction_ratio))
+        self.mlp = nn.Sequential(nn.Linear(num_fields, hidden, bias=False), nn.ReLU(), nn.Linear(hidden, num_fields, bias=False),
+                                 nn.ReLU())
+
+    def forward(self, x):
+        return x * self.mlp(x.mean(dim=-1)).unsqueeze(-1)
+
+
+class BiLinearInteractionLayer(nn.Module):
+    """(W v_i) * v_j for every field pair i < j (reference layers.py:532-565); W shared ("field_all"), one per left
+    field ("field_each") or one per pair ("field_interaction").  Same parameters as the reference (``bilinear_layer`` is a
+    Linear or a ModuleList of Linear(D, D, bias=False)); evaluated as one batched product over the pairs."""
+
+    def __init__(self, input_dim, num_fields, bilinear_type="field_interaction"):
+        super().__init__()
+        self.bilinear_type = bilinear_type
+        pairs = [(i, j) for i in range(num_fields) for j in range(i + 1, num_fields)]
+        self.register_buffer("_left", torch.tensor([i for i, _ in pairs], dtype=torch.long), persistent=False)
+        self.register_buffer("_right", torch.tensor([j for _, j in pairs], dtype=torch.long), persistent=False)
+        if bilinear_type == "field_all":
+            self.bilinear_layer = nn.Linear(input_dim, input_dim, bias=False)
+        elif bilinear_type == "field_each":
+            self.bilinear_layer = nn.ModuleList([nn.Linear(input_dim, input_dim, bias=False) for _ in range(num_fields)])
+        elif bilinear_type == "field_interaction":
+            self.bilinear_layer = nn.ModuleList([nn.Linear(input_dim, input_dim, bias=False) for _ in pairs])
+        else:
+            raise NotImplementedError()
+
+    def forward(self, x):
+        left, right = x[:, self._left], x[:, self._right]  # (B, P, D)
+        if self.bilinear_type == "field_all":
+            return self.bilinear_layer(left) * right
+        w = torch.stack([lin.weight for lin in self.bilinear_layer])  # (F or P, D_out, D_in)
+        if self.bilinear_type == "field_each":
+            w = w[self._left]
+        return torch.einsum("bpi,poi->bpo", left, w) * right
