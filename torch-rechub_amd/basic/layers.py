@@ -415,3 +415,36 @@ class BiLinearInteractionLayer(nn.Module):
         if self.bilinear_type == "field_each":
             w = w[self._left]
         return torch.einsum("bpi,poi->bpo", left, w) * right
+
+
+class InteractingLayer(nn.Module):
+    """AutoInt's multi-head self-attention over the fields with a projected residual and a ReLU
+    (reference layers.py:973-1044); W_Q / W_K / W_V / W_Res are applied as one product over their concatenation."""
+
+    def __init__(self, embed_dim, num_heads=2, dropout=0.0, residual=True):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.head_dim = embed_dim // num_heads
+        self.scale = self.head_dim**-0.5
+        self.residual = residual
+        self.W_Q = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.W_K = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.W_V = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.W_Res = nn.Linear(embed_dim, embed_dim, bias=False) if residual else None
+        self.dropout = nn.Dropout(dropout) if dropout > 0 else None
+
+    def forward(self, x):
+        B, Fn, D = x.shape
+        H, Dh = self.num_heads, self.head_dim
+        ws = [self.W_Q.weight, self.W_K.weight, self.W_V.weight] + ([self.W_Res.weight] if self.W_Res is not None else [])
+        proj = (x.reshape(B * Fn, D) @ torch.cat(ws, dim=0).t()).view(B, Fn, len(ws), H, Dh)
+        q, k, v = (proj[:, :, i].transpose(1, 2) for i in range(3))  # (B, H, F, Dh)
+        w = torch.softmax((q @ k.transpose(-2, -1)) * self.scale, dim=-1)
+        if self.dropout is not None:
+            w = self.dropout(w)
+        out = (w @ v).transpose(1, 2).reshape(B, Fn, D)
+        if self.W_Res is not None:
+            out = out + proj[:, :, 3].reshape(B, Fn, D)
+        return torch.relu(out)

@@ -1,5 +1,6 @@
 """Ranking models on the hot path (reference torch_rechub/models/ranking/__init__.py)."""
 from .afm import AFM
+from .autoint import AutoInt
 from .dcn import DCN
 from .dcn_v2 import DCNv2
 from .deepfm import DeepFM
@@ -7,4 +8,4 @@ from .din import DIN, ActivationUnit
 from .fibinet import FiBiNet
 from .widedeep import WideDeep
 
-__all__ = ["WideDeep", "DeepFM", "DCN", "DCNv2", "DIN", "AFM", "FiBiNet"]
+__all__ = ["WideDeep", "DeepFM", "DCN", "DCNv2", "DIN", "AFM", "FiBiNet", "AutoInt"]
