@@ -229,6 +229,10 @@ def build_model(rh, cfg):
     if cfg == "afm":
         from torch_rechub.models.ranking import AFM
         return AFM(sparse, D, t=8), {"fm_features": sparse}
+    if cfg in ("edcn", "edcn_attention"):
+        from torch_rechub.models.ranking import EDCN
+        kind = "hadamard_product" if cfg == "edcn" else "attention_pooling"
+        return EDCN(sparse[:6], 2, {"dropout": 0.0, "activation": "relu"}, bridge_type=kind), {"features": sparse[:6]}
     if cfg == "autoint":
         from torch_rechub.models.ranking import AutoInt
         return AutoInt(sparse[:9], dense[:4], num_layers=2, num_heads=2, dropout=0.0, mlp_params=mlp), \
@@ -322,7 +326,7 @@ def gen_model(rh, cfg):
 
 
 CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-           "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint"]
+           "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention"]
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -25,7 +25,7 @@ def layers_golden():
 
 
 MODEL_CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-                 "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint"]
+                 "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention"]
 
 
 def features_from_spec(spec_json):
@@ -80,6 +80,10 @@ def build_amd_model(cfg, groups):
     if cfg == "afm":
         from torch_rechub_amd.models.ranking import AFM
         return AFM(groups["fm_features"], 16, t=8)
+    if cfg in ("edcn", "edcn_attention"):
+        from torch_rechub_amd.models.ranking import EDCN
+        return EDCN(groups["features"], 2, {"dropout": 0.0, "activation": "relu"},
+                    bridge_type="hadamard_product" if cfg == "edcn" else "attention_pooling")
     if cfg == "autoint":
         from torch_rechub_amd.models.ranking import AutoInt
         return AutoInt(groups["sparse_features"], groups["dense_features"], num_layers=2, num_heads=2, dropout=0.0,

@@ -448,3 +448,15 @@ class InteractingLayer(nn.Module):
         if self.W_Res is not None:
             out = out + proj[:, :, 3].reshape(B, Fn, D)
         return torch.relu(out)
+
+
+class CrossLayer(nn.Module):
+    """One cross step without the residual: (w . x_i) * x_0 + b (reference layers.py:371-387; EDCN adds the residual)."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.w = nn.Linear(input_dim, 1, bias=False)
+        self.b = nn.Parameter(torch.zeros(input_dim))
+
+    def forward(self, x_0, x_i):
+        return self.w(x_i) * x_0 + self.b

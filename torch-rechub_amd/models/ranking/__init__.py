@@ -5,7 +5,8 @@ from .dcn import DCN
 from .dcn_v2 import DCNv2
 from .deepfm import DeepFM
 from .din import DIN, ActivationUnit
+from .edcn import EDCN
 from .fibinet import FiBiNet
 from .widedeep import WideDeep
 
-__all__ = ["WideDeep", "DeepFM", "DCN", "DCNv2", "DIN", "AFM", "FiBiNet", "AutoInt"]
+__all__ = ["WideDeep", "DeepFM", "DCN", "DCNv2", "DIN", "AFM", "FiBiNet", "AutoInt", "EDCN"]
