@@ -304,7 +304,7 @@ class TableAdam(torch.optim.Adam):
             if self._gathers:
                 self._gathers_per_step, self._gathers = self._gathers, 0
             seg = graphs.active()
-            if seg is not None:
+            if seg is not None and self.overlap_sweep:
                 seg.cut(self._advance_host_step)  # replays count their steps on the host too (sweep step by value)
             elif not torch.cuda.is_current_stream_capturing():
                 self._host_step += 1
