@@ -1,12 +1,22 @@
-"""Ranking models on the hot path (reference torch_rechub/models/ranking/__init__.py)."""
-from .afm import AFM
-from .autoint import AutoInt
-from .dcn import DCN
-from .dcn_v2 import DCNv2
-from .deepfm import DeepFM
-from .din import DIN, ActivationUnit
-from .edcn import EDCN
-from .fibinet import FiBiNet
-from .widedeep import WideDeep
+"""Ranking models on the hot path (the names torch_rechub/models/ranking/__init__.py exports, as far as mirrored)."""
+from importlib import import_module
 
-__all__ = ["WideDeep", "DeepFM", "DCN", "DCNv2", "DIN", "AFM", "FiBiNet", "AutoInt", "EDCN"]
+# module -> public classes; `from torch_rechub_amd.models.ranking import DeepFM` etc. work as in the reference
+_EXPORTS = {
+    "afm": ("AFM",),
+    "autoint": ("AutoInt",),
+    "dcn": ("DCN",),
+    "dcn_v2": ("DCNv2",),
+    "deepfm": ("DeepFM",),
+    "din": ("DIN", "ActivationUnit"),
+    "edcn": ("EDCN",),
+    "fibinet": ("FiBiNet",),
+    "widedeep": ("WideDeep",),
+}
+__all__ = []
+for _module, _names in _EXPORTS.items():
+    _loaded = import_module(f"{__name__}.{_module}")
+    for _n in _names:
+        globals()[_n] = getattr(_loaded, _n)
+        __all__.append(_n)
+del _module, _names, _loaded, _n

@@ -1,41 +1,48 @@
-"""DCN-v2 (API mirror of torch_rechub/models/ranking/dcn_v2.py:13-59)."""
-import torch
+"""DCN-v2 (API mirror of torch_rechub/models/ranking/dcn_v2.py:13-59).
 
+Three wirings of one cross stack (``CrossNetMix`` with low-rank experts, or full-rank ``CrossNetV2``) and one MLP:
+"crossnet_only", "stacked" (MLP after the cross stack) and "parallel" (both on the embeddings, concatenated), followed
+by an LR and a sigmoid.  Module names follow the reference (``crossnet``, ``stacked_dnn`` / ``parallel_dnn``,
+``linear``) so its checkpoints load.  The dense contractions stay library GEMMs; everything around them is
+``rh_cross_v2_epilogue_*`` / ``rh_cross_mix_epilogue_*`` (basic/layers.py).
+"""
+import torch
+from torch import nn
+
+from ... import ops
 from ...basic.layers import LR, MLP, CrossNetMix, CrossNetV2, EmbeddingLayer
 
+_STRUCTURES = ("crossnet_only", "stacked", "parallel")
 
-class DCNv2(torch.nn.Module):
+
+class DCNv2(nn.Module):
 
     def __init__(self, features, n_cross_layers, mlp_params, model_structure="parallel", use_low_rank_mixture=True,
                  low_rank=32, num_experts=4, **kwargs):
         super().__init__()
-        self.features = features
-        self.dims = sum(fea.embed_dim for fea in features)
+        assert model_structure in _STRUCTURES, "model_structure={} not supported!".format(model_structure)
+        width = sum(f.embed_dim for f in features)
+        self.features, self.dims, self.model_structure = features, width, model_structure
         self.embedding = EmbeddingLayer(features)
-        if use_low_rank_mixture:
-            self.crossnet = CrossNetMix(self.dims, n_cross_layers, low_rank=low_rank, num_experts=num_experts)
-        else:
-            self.crossnet = CrossNetV2(self.dims, n_cross_layers)
-        self.model_structure = model_structure
-        assert self.model_structure in ["crossnet_only", "stacked", "parallel"], \
-            "model_structure={} not supported!".format(self.model_structure)
-        if self.model_structure == "stacked":
-            self.stacked_dnn = MLP(self.dims, output_layer=False, **mlp_params)
-            final_dim = mlp_params["dims"][-1]
-        if self.model_structure == "parallel":
-            self.parallel_dnn = MLP(self.dims, output_layer=False, **mlp_params)
-            final_dim = mlp_params["dims"][-1] + self.dims
-        if self.model_structure == "crossnet_only":
-            final_dim = self.dims
-        self.linear = LR(final_dim)
+        self.crossnet = (CrossNetMix(width, n_cross_layers, low_rank=low_rank, num_experts=num_experts)
+                         if use_low_rank_mixture else CrossNetV2(width, n_cross_layers))
+        out_width = width
+        if model_structure == "stacked":
+            self.stacked_dnn = MLP(width, output_layer=False, **mlp_params)
+            out_width = mlp_params["dims"][-1]
+        elif model_structure == "parallel":
+            self.parallel_dnn = MLP(width, output_layer=False, **mlp_params)
+            out_width = width + mlp_params["dims"][-1]
+        self.linear = LR(out_width)
 
     def forward(self, x):
-        embed_x = self.embedding(x, self.features, squeeze_dim=True)
-        cross_out = self.crossnet(embed_x)
-        if self.model_structure == "crossnet_only":
-            final_out = cross_out
-        elif self.model_structure == "stacked":
-            final_out = self.stacked_dnn(cross_out)
-        else:
-            final_out = torch.cat([cross_out, self.parallel_dnn(embed_x)], dim=1)
-        return torch.sigmoid(self.linear(final_out).squeeze(1))
+        h = self.embedding(x, self.features, squeeze_dim=True)
+        z = self.crossnet(h)
+        if self.model_structure == "stacked":
+            z = self.stacked_dnn(z)
+        elif self.model_structure == "parallel":
+            z = torch.cat((z, self.parallel_dnn(h)), dim=1)
+        fc = self.linear.fc
+        if ops.head_ok(z, fc, ()):
+            return ops.head_sigmoid(z, fc.weight, fc.bias)
+        return torch.sigmoid(fc(z).squeeze(1))
