@@ -73,11 +73,10 @@ static __device__ __forceinline__ void adam_elem(float& p, float g, float& m, fl
   p = fmaf(-A, m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + E), p);
 }
 // Two elements at a time on 64-bit register pairs: everything but sqrt / rcp is a v_pk_* instruction.  Same operations,
-// same order, same rounding as adam_elem, element for element.  Measured cost model on MI355X (sweep at K = 32, steady
-// state, variants with sqrt / rcp removed): a v_pk_*_f32 and a v_sqrt/v_rcp each cost 8 cycles per wavefront, a plain
-// VALU op 4 -> 18 pk + 8 transcendental + 2 plain = 216 cycles per 256 element-steps = 185 us per 540 M element-steps,
-// which is what the sweep took with this function in its replay loop: it is bound by f32 VALU throughput (9 flop-ops +
-// sqrt + rcp per element-step; 8 with the zero-gradient form below, which the replay loops use).
+// same order, same rounding as adam_elem, element for element.  Measured on MI355X (rocprofv3 SQ counters on the sweep,
+// and variants with sqrt / rcp removed): v_pk_*_f32 issue at 4 cycles per wavefront, v_sqrt_f32 / v_rcp_f32 at 8; the
+// replay loop (zero-gradient form below: 16 packed + 8 transcendental + 2 plain ops per 256 element-steps = 136 cycles)
+// keeps the VALU ~80 % busy -- the sweep is bound by f32 VALU throughput, half of it the two transcendentals.
 typedef float rh_v2f __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ void adam_pair(rh_v2f& p, rh_v2f g, rh_v2f& m, rh_v2f& v, const AdamScalars& h,
                                                  float A, float E) {
