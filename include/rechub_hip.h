@@ -226,7 +226,7 @@ int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, cons
  * rh_head_fwd/bwd replaces: MLP's output Linear(K, 1) + `y_linear + y_fm + y_deep` + torch.sigmoid(y.squeeze(1)),
  *   models/ranking/deepfm.py:39-43, widedeep.py:35-39:  y (B,) = sigmoid(h w^T + bias + e0 + e1)  (bias, e0, e1 optional)
  *   bwd: g_z = g_y y (1 - y) (also the gradient of e0 / e1), g_h (B, K) = g_z w, g_w (K,) = g_z^T h, g_b = sum g_z.
- *   K % 4 == 0, K <= 1024.  partial: rh_head_nblocks(B) * (K + 1) floats.
+ *   1 <= K <= 1024 (rows of h may be only 4-byte aligned).  partial: rh_head_nblocks(B) * (K + 1) floats.
  * rh_bce_fwd/bwd replaces: torch.nn.BCELoss() (mean) of trainers/ctr_trainer.py:62,:93-95: log terms clamped at -100;
  *   loss (1,), g_loss (1,) device scalars.
  */

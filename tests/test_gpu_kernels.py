@@ -731,7 +731,8 @@ def test_linear_function_matches_torch_autograd():
 
 
 @pytest.mark.parametrize("B,K,bias,nextra", [(4096, 128, True, 2), (5, 4, True, 0), (1, 1024, False, 1), (777, 36, True, 1),
-                                             (70000, 64, True, 2)])
+                                             (70000, 64, True, 2), (4096, 557, True, 0), (33, 3, True, 1), (100, 1, False, 0),
+                                             (512, 1023, True, 2)])
 def test_head_sigmoid_vs_autograd(B, K, bias, nextra):
     from torch_rechub_amd import ops
     gen = torch.Generator().manual_seed(B + K)

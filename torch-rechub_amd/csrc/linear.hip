@@ -225,6 +225,7 @@ __global__ __launch_bounds__(RH_BLOCK) void head_fwd_kernel(const float* __restr
       acc = fmaf(hv.z, wv.z, acc);
       acc = fmaf(hv.w, wv.w, acc);
     }
+    if (sub < K - 4 * nv) acc = fmaf(h[row * ldh + 4 * nv + sub], w[4 * nv + sub], acc);  // K % 4 tail columns
     acc = group_sum16(acc);
     if (sub == 0) {
       float z = acc + b0;
@@ -264,12 +265,21 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
     wv[i] = v < nv ? gload<float4>(a.w + 4 * v) : f4_zero();
   }
   float gb = 0.f;
+  // K % 4 tail columns 4 nv + sub (sub < K - 4 nv <= 3): one scalar lane each
+  const bool has_tail = sub < K - 4 * nv;
+  const int tcol = 4 * nv + sub;
+  const float tw = has_tail ? a.w[tcol] : 0.f;
+  float tacc = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < a.B; row += (int64_t)gridDim.x * kHeadRows) {
     const float yv = a.y[row];
     const float gz = a.g_y[row] * yv * (1.f - yv);
     if (sub == 0) {
       a.g_z[row] = gz;
       gb += gz;
+    }
+    if (has_tail) {
+      tacc = fmaf(gz, a.h[row * a.ldh + tcol], tacc);
+      a.g_h[row * K + tcol] = gz * tw;
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -304,6 +314,14 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
     }
   }
   __syncthreads();
+  if (sub < 4) red[grp][sub] = tacc;
+  __syncthreads();
+  if ((int)threadIdx.x < K - 4 * nv) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < kHeadRows; ++r) v += red[r][threadIdx.x];
+    part[4 * nv + threadIdx.x] = v;
+  }
   if (threadIdx.x == 0) {
     float v = 0.f;
     for (int r = 0; r < kHeadRows; ++r) v += gb_red[r];
@@ -442,7 +460,7 @@ extern "C" int rh_head_nblocks(int B) { return head_grid(B); }
 extern "C" int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0,
                            const float* e1, int B, int K, float* y, void* stream) {
   RH_REQUIRE(h && w && y, RH_E_BADARG, "rh_head_fwd: null pointer");
-  RH_REQUIRE(B >= 0 && K >= 4 && K % 4 == 0 && ldh >= K, RH_E_UNSUPPORTED, "rh_head_fwd: K=%d must be a multiple of 4", K);
+  RH_REQUIRE(B >= 0 && K >= 1 && ldh >= K, RH_E_UNSUPPORTED, "rh_head_fwd: bad width K=%d", K);
   if (B == 0) return 0;
   int grid = (B + kHeadRows - 1) / kHeadRows;
   if (grid > 256 * 8) grid = 256 * 8;
@@ -455,10 +473,10 @@ extern "C" int rh_head_fwd(const float* h, int64_t ldh, const float* w, const fl
 extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K,
                            float* g_h, float* g_z, float* g_w, float* g_b, float* partial, void* stream) {
   RH_REQUIRE(h && w && y && g_y && g_h && g_z && g_w && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
-  RH_REQUIRE(B >= 1 && K >= 4 && K % 4 == 0 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
-             "rh_head_bwd: K=%d must be a multiple of 4 and <= %d", K, 4 * kHeadLanes * kHeadMaxV4);
+  RH_REQUIRE(B >= 1 && K >= 1 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
+             "rh_head_bwd: K=%d unsupported (1 .. %d)", K, 4 * kHeadLanes * kHeadMaxV4);
   HeadBwdArgs a{h, ldh, w, y, g_y, B, K, g_h, g_z, partial, g_w, g_b};
-  const int need = (K / 4 + kHeadLanes - 1) / kHeadLanes;
+  const int need = K < 4 ? 1 : (K / 4 + kHeadLanes - 1) / kHeadLanes;
   const dim3 grid(head_grid(B)), block(RH_BLOCK);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (need <= 1) hipLaunchKernelGGL(head_bwd_kernel<1>, grid, block, 0, st, a);

@@ -4,7 +4,7 @@ Reference forward: flattened gather -> CrossNetwork and MLP (no output layer) si
 concatenation -> sigmoid.  Attribute names / checkpoint keys are the reference's (``embedding``, ``cn``, ``mlp``,
 ``linear.fc``).  Here the gather is one fused HIP launch, the cross stack one launch per direction
 (``rh_cross_fwd/bwd``), the MLP the fused BatchNorm path, and the final LR + sigmoid the head kernel when its width
-allows (a multiple of 4; the Criteo shape 429 + 128 = 557 is not, so it stays a library GEMV there).
+allows (up to 1024 columns).
 """
 import torch
 from torch import nn

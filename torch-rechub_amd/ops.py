@@ -769,8 +769,8 @@ class _HeadFn(torch.autograd.Function):
 
 def head_ok(h, lin, extras):
     K = lin.in_features
-    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and lin.out_features == 1 and K % 4 == 0 and
-            K <= 1024 and len(extras) <= 2 and h.shape[0] > 0 and all(e.numel() == h.shape[0] for e in extras))
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and lin.out_features == 1 and 1 <= K <= 1024 and
+            len(extras) <= 2 and h.shape[0] > 0 and all(e.numel() == h.shape[0] for e in extras))
 
 
 def head_sigmoid(h, weight, bias, *extras):
