@@ -149,6 +149,11 @@ def gather_sweep(model, sparse_feas, dense_feas, vocabs, device, batches=(4096, 
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the result JSON: RCCL / the runtime print banners on fd 1 (seen: "RCCL version :
+    # ..." after the collectives), so everything else is sent to stderr for the lifetime of the process.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,7 +361,7 @@ def main():
             "gather_kernel_sweep": gsweep,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
