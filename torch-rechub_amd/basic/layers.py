@@ -17,7 +17,6 @@ Tables stay ``nn.Embedding`` modules inside ``embed_dict`` (checkpoint ABI:
 ``embedding.embed_dict.<feature>.weight``); kernels read them in place.
 """
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import ops

@@ -4,7 +4,6 @@ Same classification rules: parameters of normalisation layers are skipped, param
 ``nn.Embedding`` / ``nn.EmbeddingBag`` modules use the embedding coefficients, everything else the
 dense ones.  Returns the python float 0.0 when nothing applies (the trainer adds it to the loss).
 """
-import torch
 from torch import nn
 
 _NORMS = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.LayerNorm, nn.GroupNorm, nn.InstanceNorm1d,

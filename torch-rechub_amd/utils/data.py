@@ -10,7 +10,6 @@ Two loaders with the same batch contract ``(x_dict, y)`` as the reference:
   host->device copy in the step and the whole train step can be captured in a hipGraph.
   ``x_dict`` values are column views of the static (B,F) / (B,ND) buffers.
 """
-import ctypes
 
 import torch
 from torch.utils.data import DataLoader, Dataset, random_split
