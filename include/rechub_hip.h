@@ -366,6 +366,27 @@ int rh_batch_advance(int64_t* pos, int64_t B, int64_t N, void* stream);
  * rng (device int64 [2]): seed, call counter; bump the counter after the call with rh_batch_advance(rng + 1, 1, 0). */
 int rh_inbatch_sample(const int64_t* rng, int B, int K, int64_t* out, void* stream);
 
+/* The same draw for rows [row0, row0 + B) of a (cols x cols) problem: out (B, K), row r = K distinct columns from
+ * {0..cols-1} \ {row0 + r}.  The random stream is keyed by the global row, so ranks holding slices of one global batch
+ * (cross-rank in-batch negatives: their item embeddings all-gathered into `cols` candidates) draw what one process
+ * would draw.  rh_inbatch_sample(rng, B, K, ...) == rh_inbatch_sample_rows(rng, B, B, 0, K, ...).
+ * replaces: torch_rechub/utils/match.py:136-145 on the single-device branch of match_trainer.py:118-138 */
+int rh_inbatch_sample_rows(const int64_t* rng, int B, int cols, int row0, int K, int64_t* out, void* stream);
+
+/* ---- row-sharded tables (one shard per rank) -----------------------------------------------------------------------
+ * Global row g of a table lives on rank g % world as local row g / world.  rh_shard_localize rewrites an index matrix
+ * idx (n_rows, F) (int64 / int32, contiguous: the all-gathered indices of the global batch) for this rank's shards:
+ *   local[i, f] = g / world   if g % world == rank and g != pad[f]
+ *               = sink[f]     otherwise (the shard's all-zero row, passed to the gather / scatter / optimizer kernels as
+ *                             the field's padding_idx: read as zeros, never updated)
+ * desc (device int64 [3F]): vocab[F] | pad[F] (-1: none) | sink[F].  g outside [0, vocab) sets RH_FLAG_INDEX_OOB
+ * (and maps to the sink row).  The gathers of all ranks over `local` sum to the reference's lookup, one non-zero
+ * contributor per element.
+ * replaces: nn.Embedding lookup on a replicated table, torch_rechub/basic/layers.py:83-99 under
+ *           nn.DataParallel (trainers/ctr_trainer.py:53-55), which broadcasts every table every step. */
+int rh_shard_localize(const void* idx, int idx_is_i64, int64_t n_rows, int F, const int64_t* desc, int world, int rank,
+                      int32_t* local, int32_t* err_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

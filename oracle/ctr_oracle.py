@@ -310,3 +310,78 @@ def batch_gather(perm, pos, B, sparse, dense, label):
     N = perm.shape[0]
     rows = perm[(pos + np.arange(B)) % N]
     return sparse[rows], (None if dense is None else dense[rows]), label[rows]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Row-sharded tables: the lookup of layers.py:83-99 computed from per-rank shards (no reference code does this;
+# the reference result it must equal is embedding_gather above on the full tables)
+# ---------------------------------------------------------------------------------------------------
+def shard_rows(table, world, rank):
+    """Shard of a full (vocab, D) table: rows rank, rank + world, ... followed by zero rows up to ceil(vocab / world)
+    and the all-zero sink row."""
+    n = -(-table.shape[0] // world)
+    local = np.zeros((n + 1, table.shape[1]), dtype=table.dtype)
+    mine = table[rank::world]
+    local[:mine.shape[0]] = mine
+    return local
+
+
+def shard_localize(idx, vocabs, pads, world, rank):
+    """Index matrix (N, F) of the global batch -> int32 local rows of ``rank``'s shards: g // world when
+    g % world == rank and g is not the field's padding_idx, else the sink row ceil(vocab / world).
+    Out-of-range ids raise IndexError, like the nn.Embedding lookup they stand for."""
+    idx = np.asarray(idx).astype(np.int64)
+    out = np.empty(idx.shape, dtype=np.int32)
+    for f in range(idx.shape[1]):
+        g = idx[:, f]
+        if g.size and (g.min() < 0 or g.max() >= vocabs[f]):
+            raise IndexError("index out of range in self")
+        sink = -(-vocabs[f] // world)
+        own = (g % world == rank)
+        if pads is not None and pads[f] is not None and pads[f] >= 0:
+            own &= g != pads[f]
+        out[:, f] = np.where(own, g // world, sink)
+    return out
+
+
+def sharded_embedding_gather(tables, idx, world, pads=None):
+    """Sum over ranks of the gathers of their shards at the localised indices == embedding_gather(tables, idx) (with
+    padding rows zero).  Exactly one term of every sum is non-zero, so the float sum is exact."""
+    vocabs = [t.shape[0] for t in tables]
+    total = None
+    for r in range(world):
+        loc = shard_localize(idx, vocabs, pads, world, r)
+        part = embedding_gather([shard_rows(t, world, r) for t in tables], loc)
+        total = part if total is None else total + part
+    return total
+
+
+# ---------------------------------------------------------------------------------------------------
+# In-batch negative sampler of the HIP path (csrc/data.hip): the reference draws randperm(B-1)[:K] per row
+# (utils/match.py:136-145) and pins only shape / no-self / distinctness / seed sensitivity (its tests); the kernel's
+# stream (Floyd's subset algorithm over a counter hash) is restated here so that the device result is checked bit for bit.
+# ---------------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _sample_hash(seed, ctr, idx):
+    z = (idx * 0x9E3779B97F4A7C15 + seed + ctr * 0xD1B54A32D192ED03) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    z = z ^ (z >> 31)
+    return z >> 32
+
+
+def inbatch_sample_rows(seed, ctr, B, cols, row0, K):
+    """(B, K): for global row r = row0 + i, K distinct columns of {0..cols-1} minus {r}."""
+    out = np.empty((B, K), dtype=np.int64)
+    n = cols - 1
+    for i in range(B):
+        own = row0 + i
+        taken = set()
+        for pos, j in enumerate(range(n - K, n)):
+            t = _sample_hash(seed, ctr, own * K + pos) % (j + 1)
+            pick = j if t in taken else t
+            taken.add(pick)
+            out[i, pos] = pick + (1 if pick >= own else 0)
+    return out

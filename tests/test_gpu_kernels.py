@@ -960,3 +960,85 @@ def test_bn_dice_folded_vs_modules(N, C):
     with torch.no_grad():
         close(ops.bn_dice(h0, bn_mine, al_b.detach(), 1e-3), _dice_ref(bn_ref(h0).double(), al_a.detach()).cpu().numpy(),
               rtol=2e-4, atol_scale=5e-6, what="eval")
+
+
+# -- row-sharded tables (csrc/shard.hip) and the rectangular in-batch sampler -----------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_shard_localize_is_the_oracles(world, idx_dtype):
+    from torch_rechub_amd import ops
+    rng = np.random.default_rng(world)
+    vocabs = [1, 3, 10, 17, 64, 1000, 100003]
+    pads = [None, 0, 2, None, 63, None, 5]
+    idx = np.stack([rng.integers(0, v, 777) for v in vocabs], axis=1)
+    desc = torch.tensor(vocabs + [-1 if p is None else p for p in pads] + [-(-v // world) for v in vocabs],
+                        dtype=torch.int64, device=dev())
+    idx_d = torch.from_numpy(idx).to(idx_dtype).to(dev())
+    for rank in range(world):
+        got = ops.shard_localize(idx_d, desc, world, rank)
+        assert got.dtype == torch.int32
+        assert np.array_equal(got.cpu().numpy(), O.shard_localize(idx, vocabs, pads, world, rank))
+    ops.check_errors()
+    bad = idx_d.clone()
+    bad[5, 2] = 10  # == vocab: out of range, as the reference's IndexError
+    ops.shard_localize(bad, desc, world, 0)
+    with pytest.raises(IndexError):
+        ops.check_errors()
+    assert ops.shard_localize(idx_d[:0], desc, world, 0).shape == (0, len(vocabs))  # empty batch: no launch
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_and_scatter_add_up_to_the_full_table_lookup(world):
+    """Every rank's shard, in one process: the masked gathers sum (bit for bit) to the reference lookup, and the
+    gradients the shards receive are the oracle's dense table gradient dealt out row by row, sink row untouched."""
+    from torch_rechub_amd import ops
+    rng = np.random.default_rng(10 + world)
+    vocabs, pads, D, N = [3, 10, 305, 4001], [None, 2, None, 7], 16, 1500
+    tables = [rng.standard_normal((v, D)).astype(np.float32) for v in vocabs]
+    for t, p in zip(tables, pads):
+        if p is not None:
+            t[p] = 0
+    idx = np.stack([rng.integers(0, v, N) for v in vocabs], axis=1)
+    g_out = rng.standard_normal((N, len(vocabs) * D)).astype(np.float32)
+    idx_d, g_d = torch.from_numpy(idx).to(dev()), torch.from_numpy(g_out).to(dev())
+    want = O.embedding_gather(tables, idx).reshape(N, -1)
+    want_grads = O.embedding_backward([t.shape for t in tables], idx, g_out.reshape(N, len(vocabs), D).astype(F64),
+                                      padding_idx=pads)
+    total = torch.zeros(N, len(vocabs) * D, device=dev())
+    for rank in range(world):
+        sinks = [-(-v // world) for v in vocabs]
+        desc = torch.tensor(vocabs + [-1 if p is None else p for p in pads] + sinks, dtype=torch.int64, device=dev())
+        shards = [torch.nn.Parameter(torch.from_numpy(O.shard_rows(t, world, rank)).to(dev())) for t in tables]
+        loc = ops.shard_localize(idx_d, desc, world, rank)
+        call = ops.EmbedCall(shards, sinks, [loc[:, f] for f in range(len(vocabs))], local_grads=True)
+        out, _, _ = ops.fused_embedding(call)
+        total += out.detach()
+        out.backward(g_d)
+        for f, (w, full) in enumerate(zip(shards, want_grads)):
+            got = ops.grad_buffer(w).cpu().numpy()
+            mine = full[rank::world]
+            close(got[:mine.shape[0]], mine, rtol=1e-5, atol_scale=2e-6, what=f"rank {rank} table {f}")
+            assert not got[mine.shape[0]:].any(), "sink / unused rows must not receive gradient"
+    assert np.array_equal(total.cpu().numpy(), want)
+    ops.check_errors()
+
+
+def test_inbatch_sampler_stream_and_rank_slices():
+    """Bit-exact against the oracle's restatement of the kernel's stream; slices drawn with (cols, row0) are the rows of
+    the square problem (ranks of a job draw what one process draws for the global batch)."""
+    from torch_rechub_amd import ops
+    seed, K, C = 1234, 7, 96
+    ops._sample_rng.clear()
+    full = ops.inbatch_sample(C, K, dev(), seed)           # call counter 0
+    again = ops.inbatch_sample(C, K, dev(), seed)          # call counter 1
+    assert np.array_equal(full.cpu().numpy(), O.inbatch_sample_rows(seed, 0, C, C, 0, K))
+    assert np.array_equal(again.cpu().numpy(), O.inbatch_sample_rows(seed, 1, C, C, 0, K))
+    for row0, B in ((0, 32), (32, 32), (64, 32), (5, 50)):
+        ops._sample_rng.clear()
+        part = ops.inbatch_sample(B, K, dev(), seed, cols=C, row0=row0)
+        assert torch.equal(part, full[row0:row0 + B])
+    ops._sample_rng.clear()
+    wide = ops.inbatch_sample(4, 2999, dev(), seed, cols=3000, row0=2996).cpu().numpy()
+    assert np.array_equal(wide, O.inbatch_sample_rows(seed, 0, 4, 3000, 2996, 2999))
+    with pytest.raises(RuntimeError):
+        ops.inbatch_sample(8, 3, dev(), seed, cols=10, row0=5)  # rows 5..12 do not fit 10 columns

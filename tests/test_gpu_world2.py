@@ -2,7 +2,9 @@
 ranks on one device): the complete N > 1 path -- loss / world, dense bucket all-reduce, all-gather of (indices, gradient
 rows), rh_embed_scatter_rows, lazy Adam's touched pass over the gathered indices -- must reproduce ONE process training
 on the concatenated global batches (what nn.DataParallel computes, trainers/ctr_trainer.py:53-55), and leave both
-replicas equal."""
+replicas equal.  The same is required of row-sharded tables (tables="shard": each rank keeps every second row of every
+table; indices all-gathered, rows reduce-scattered), whose reassembled checkpoint must be the single-process one, and
+of the two-tower step with sequence features and cross-rank in-batch negatives."""
 import os
 import socket
 
@@ -37,12 +39,16 @@ def _model():
     return DeepFM(dense + sparse, sparse, {"dims": [], "dropout": 0.0}).to("cuda:0"), dense, sparse
 
 
-def _train(rows_of_step, world):
+def _train(rows_of_step, world, tables="replicate"):
+    from torch_rechub_amd import sharding
     from torch_rechub_amd.trainers import CTRTrainer
     model, dfe, sfe = _model()
     trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64},
-                         device="cuda:0", show_progress=False, lazy_k=4)
+                         device="cuda:0", show_progress=False, lazy_k=4, tables=tables if world > 1 else None)
     assert (trainer.dp is not None) == (world > 1)
+    if world > 1 and tables == "shard":
+        emb = model.embedding.embed_dict["C5"]
+        assert sharding.is_sharded(emb) and emb.weight.shape[0] == -(-305 // world) + 1
     sparse, dense, label = _data()
     model.train()
     losses = []
@@ -53,39 +59,109 @@ def _train(rows_of_step, world):
         losses.append(float(trainer.train_step(x, label[rows].to("cuda:0"))))
     trainer.flush()
     torch.cuda.synchronize()
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    full = sharding.full_state_dict(model) if trainer.tables == "shard" else model.state_dict()
+    sd = {k: v.detach().cpu() for k, v in full.items()}
     if trainer.dp is not None:
         trainer.dp.close()
     return sd, losses
 
 
-def _worker(rank, port, outdir):
+def _worker(rank, port, outdir, train, arg):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         torch.cuda.set_device(0)
-        sd, losses = _train(lambda s: slice(s * 2 * B + rank * B, s * 2 * B + (rank + 1) * B), world=2)
+        sd, losses = train(lambda s: slice(s * 2 * B + rank * B, s * 2 * B + (rank + 1) * B), 2, arg)
         torch.save({"sd": sd, "losses": losses}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_reproduce_one_process_on_the_global_batch(tmp_path):
+def _two_ranks(tmp_path, train, arg):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
-    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    mp.spawn(_worker, args=(port, str(tmp_path), train, arg), nprocs=2, join=True)
+    return torch.load(os.path.join(tmp_path, "rank0.pt")), torch.load(os.path.join(tmp_path, "rank1.pt"))
+
+
+@pytest.mark.parametrize("tables", ["replicate", "shard"])
+def test_two_ranks_reproduce_one_process_on_the_global_batch(tmp_path, tables):
+    r0, r1 = _two_ranks(tmp_path, _train, tables)
     single, losses = _train(lambda s: slice(s * 2 * B, (s + 1) * 2 * B), world=1)
+    assert set(single) == set(r0["sd"]) and all(single[k].shape == r0["sd"][k].shape for k in single)
     # the mean of the two per-rank losses is the global-batch loss
     np.testing.assert_allclose((np.array(r0["losses"]) + np.array(r1["losses"])) / 2, losses, rtol=2e-5, atol=1e-6)
     travel = 1e-2 * STEPS
     for k, want in single.items():
         a, b, w = r0["sd"][k].numpy(), r1["sd"][k].numpy(), want.numpy()
         # replicas: same data, same arithmetic; only the order of the atomic row sums differs
+        bad = np.abs(a - b) > 2e-5 + 1e-4 * np.abs(w)
+        assert bad.mean() <= 5e-3 and np.abs(a - b).max() <= 0.25 * travel, f"replicas diverged in {k}"
+        bad = np.abs(a - w) > 3e-4 + 1e-3 * np.abs(w)
+        assert bad.mean() <= 5e-3, f"{k}: {bad.sum()} / {bad.size} elements differ from single-process training"
+        assert np.abs(a - w).max() <= 0.25 * travel + 3e-4, k
+
+
+# -- two towers: sequence features (replicated: gradient rows of the history lookups are exchanged; sharded: pooled
+#    partial sums are reduce-scattered) and in-batch negatives drawn over the items of BOTH ranks ---------------------
+N_USER, N_ITEM, N_CATE, HIST = 50, 400, 12, 8
+
+
+def _match_data(seed=23):
+    g = torch.Generator().manual_seed(seed)
+    n = STEPS * 2 * B
+    hist = torch.randint(1, N_ITEM, (n, HIST), generator=g)
+    hist[torch.rand(n, HIST, generator=g) < 0.3] = 0  # padding
+    return {"user_id": torch.randint(0, N_USER, (n,), generator=g), "hist_item_id": hist,
+            "item_id": torch.randint(1, N_ITEM, (n,), generator=g), "cate_id": torch.randint(0, N_CATE, (n,), generator=g)}
+
+
+def _train_match(rows_of_step, world, arg):
+    from torch_rechub_amd import sharding
+    from torch_rechub_amd.basic.features import SequenceFeature, SparseFeature
+    from torch_rechub_amd.models.matching import DSSM
+    from torch_rechub_amd.trainers import MatchTrainer
+    from torch_rechub_amd import ops
+    tables, pooling = arg
+    ops._sample_rng.clear()  # the sampler's call counter starts at 0, as in the freshly spawned ranks
+    torch.manual_seed(9)
+    user = [SparseFeature("user_id", N_USER, 16),
+            SequenceFeature("hist_item_id", N_ITEM, 16, pooling=pooling, shared_with="item_id")]
+    item = [SparseFeature("item_id", N_ITEM, 16, padding_idx=0), SparseFeature("cate_id", N_CATE, 16)]
+    # no hidden layers: BatchNorm statistics are per replica by design
+    model = DSSM(user, item, {"dims": []}, {"dims": []}).to("cuda:0")
+    trainer = MatchTrainer(model, mode=0, in_batch_neg=True, in_batch_neg_ratio=5, sampler_seed=77,
+                           global_negatives=True, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4,
+                                                                    "lazy_small_rows": 16},
+                           device="cuda:0", show_progress=False, lazy_k=4, tables=tables if world > 1 else None)
+    data = _match_data()
+    model.train()
+    losses = []
+    for s in range(STEPS):
+        rows = rows_of_step(s)
+        x = {k: v[rows].to("cuda:0") for k, v in data.items()}
+        losses.append(float(trainer.train_step(x, torch.zeros(x["user_id"].shape[0], device="cuda:0"))))
+    trainer.flush()
+    torch.cuda.synchronize()
+    full = sharding.full_state_dict(model) if trainer.tables == "shard" else model.state_dict()
+    sd = {k: v.detach().cpu() for k, v in full.items()}
+    if trainer.dp is not None:
+        trainer.dp.close()
+    return sd, losses
+
+
+@pytest.mark.parametrize("tables,pooling", [("replicate", "mean"), ("shard", "mean"), ("shard", "sum")])
+def test_two_tower_ranks_with_global_negatives_reproduce_one_process(tmp_path, tables, pooling):
+    r0, r1 = _two_ranks(tmp_path, _train_match, (tables, pooling))
+    single, losses = _train_match(lambda s: slice(s * 2 * B, (s + 1) * 2 * B), 1, (tables, pooling))
+    np.testing.assert_allclose((np.array(r0["losses"]) + np.array(r1["losses"])) / 2, losses, rtol=2e-5, atol=1e-6)
+    travel = 1e-2 * STEPS
+    for k, want in single.items():
+        a, b, w = r0["sd"][k].numpy(), r1["sd"][k].numpy(), want.numpy()
+        assert a.shape == w.shape, k
         bad = np.abs(a - b) > 2e-5 + 1e-4 * np.abs(w)
         assert bad.mean() <= 5e-3 and np.abs(a - b).max() <= 0.25 * travel, f"replicas diverged in {k}"
         bad = np.abs(a - w) > 3e-4 + 1e-3 * np.abs(w)

@@ -81,6 +81,8 @@ SIGNATURES = {
     "rh_batch_gather": [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],
     "rh_inbatch_sample": [c_ptr, c_int, c_int, c_ptr, c_ptr],
+    "rh_inbatch_sample_rows": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_shard_localize": [c_ptr, c_int, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
 }
 _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctypes.c_int64}
 # functions whose int return value is a result, not a status

@@ -19,7 +19,7 @@ Tables stay ``nn.Embedding`` modules inside ``embed_dict`` (checkpoint ABI:
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, sharding
 from .activation import Dice, activation_layer
 from .features import DenseFeature, SequenceFeature, SparseFeature
 
@@ -129,9 +129,17 @@ class EmbeddingLayer(nn.Module):
         dense = [x[f.name].float() for f in dense_feas]
         return ops.EmbedCall(weights, pads, idx, dense, **kw)
 
+    def is_sharded(self, features):
+        """True when a table behind ``features`` is row-sharded over the ranks (sharding.shard_tables)."""
+        return any(sharding.is_sharded(self.table_of(f)) for f in features
+                   if isinstance(f, (SparseFeature, SequenceFeature)))
+
     def can_fuse(self, x, features):
-        """True when the whole list is one fused launch: plain sparse, one dim, 1-D dense values."""
+        """True when the whole list is one fused launch: plain sparse, one dim, 1-D dense values, replicated tables
+        (a sharded lookup is gather -> reduce-scatter: FM / LR cannot ride in the gather kernel)."""
         dims = set()
+        if self.is_sharded(features):
+            return False
         for fea in features:
             if isinstance(fea, SparseFeature):
                 dims.add(fea.embed_dim)
@@ -162,18 +170,21 @@ class EmbeddingLayer(nn.Module):
             out, _, _ = ops.fused_embedding(call)
             return out if squeeze_dim else out.view(call.B, call.F, call.D)
 
-        # general path: sequence features and/or mixed widths -> per-group launches, reference order
+        # general path: sequence features, mixed widths, row-sharded tables -> per-group launches, reference order
         pieces = [None] * len(table_feas)
         groups = {}
         for i, fea in enumerate(table_feas):
             if isinstance(fea, SparseFeature):
-                groups.setdefault(fea.embed_dim, []).append(i)
-        for dim, members in groups.items():
+                groups.setdefault((fea.embed_dim, sharding.is_sharded(self.table_of(fea))), []).append(i)
+        for (dim, sharded), members in groups.items():
             if not _fusable_dim(dim):
                 raise RuntimeError(f"torch_rechub_amd: embed_dim={dim} has no HIP gather kernel yet "
                                    "(supported: 4, 8, 16, 32, 64, 128); refusing to fall back to a CPU/eager path")
-            call = self.make_call(x, [table_feas[i] for i in members])
-            out, _, _ = ops.fused_embedding(call)
+            feas = [table_feas[i] for i in members]
+            if sharded:
+                out = sharding.lookup([self.table_of(f) for f in feas], [_as_index(x[f.name]) for f in feas])
+            else:
+                out, _, _ = ops.fused_embedding(self.make_call(x, feas))
             for k, i in enumerate(members):
                 pieces[i] = out[:, k * dim:(k + 1) * dim].unsqueeze(1)
         for i, fea in enumerate(table_feas):
@@ -181,7 +192,14 @@ class EmbeddingLayer(nn.Module):
                 if not _fusable_dim(fea.embed_dim):
                     raise RuntimeError(f"torch_rechub_amd: sequence embed_dim={fea.embed_dim} has no HIP kernel yet")
                 table = self.table_of(fea)
-                pooled = ops.seq_pool(table.weight, _as_index(x[fea.name]), fea.pooling, table.padding_idx)
+                idx = _as_index(x[fea.name])
+                if not sharding.is_sharded(table):
+                    pooled = ops.seq_pool(table.weight, idx, fea.pooling, table.padding_idx)
+                elif fea.pooling == "concat":  # (B, L, D): L lookups of one table per sample
+                    L = idx.shape[1]
+                    pooled = sharding.lookup([table] * L, [idx[:, j] for j in range(L)]).view(-1, L, fea.embed_dim)
+                else:
+                    pooled = sharding.pooled_lookup(table, idx, fea.pooling)
                 pieces[i] = pooled.unsqueeze(1)
         sparse_emb = torch.cat(pieces, dim=1)
         if not squeeze_dim:

@@ -49,40 +49,53 @@ static __device__ __forceinline__ uint32_t sample_hash(uint64_t seed, uint64_t c
   return (uint32_t)(z >> 32);
 }
 
-__global__ void inbatch_sample_kernel(const int64_t* __restrict__ rng, int B, int K, int words_per_row,
-                                      int64_t* __restrict__ out) {
+// Rectangular form (cross-rank negatives): the rows are rows [row0, row0 + B) of a (cols x cols) global problem, row r
+// draws from the columns {0..cols-1} \ {r}; the RNG is keyed by the GLOBAL row, so the ranks of a job draw what one
+// process would draw for the same rows.
+__global__ void inbatch_sample_kernel(const int64_t* __restrict__ rng, int B, int cols, int row0, int K,
+                                      int words_per_row, int64_t* __restrict__ out) {
   extern __shared__ uint32_t bitmap[];  // [rows per block][words_per_row]
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* mine = bitmap + (size_t)threadIdx.x * words_per_row;
   for (int w = 0; w < words_per_row; ++w) mine[w] = 0u;
   if (row >= B) return;
   const uint64_t seed = (uint64_t)rng[0], ctr = (uint64_t)rng[1];
-  const int N = B - 1;  // candidates: every column but the row's own
+  const int N = cols - 1;  // candidates: every column but the row's own
+  const uint32_t own = (uint32_t)(row0 + row);
   int pos = 0;
   for (int j = N - K; j < N; ++j) {
-    const uint32_t t = sample_hash(seed, ctr, (uint64_t)row * (uint64_t)K + (uint64_t)pos) % (uint32_t)(j + 1);
+    const uint32_t t = sample_hash(seed, ctr, (uint64_t)own * (uint64_t)K + (uint64_t)pos) % (uint32_t)(j + 1);
     const bool taken = (mine[t >> 5] >> (t & 31)) & 1u;
     const uint32_t pick = taken ? (uint32_t)j : t;
     mine[pick >> 5] |= 1u << (pick & 31);
-    out[(int64_t)row * K + pos] = (int64_t)pick + (pick >= (uint32_t)row ? 1 : 0);
+    out[(int64_t)row * K + pos] = (int64_t)pick + (pick >= own ? 1 : 0);
     ++pos;
   }
 }
 
 }  // namespace
 
-extern "C" int rh_inbatch_sample(const int64_t* rng, int B, int K, int64_t* out, void* stream) {
+extern "C" int rh_inbatch_sample_rows(const int64_t* rng, int B, int cols, int row0, int K, int64_t* out,
+                                      void* stream) {
   RH_REQUIRE(rng && out, RH_E_BADARG, "rh_inbatch_sample: null pointer");
-  RH_REQUIRE(B >= 2 && K >= 1 && K <= B - 1, RH_E_BADARG, "rh_inbatch_sample: need 1 <= K <= B-1 (B=%d K=%d)", B, K);
-  const int words = (B + 31) / 32;
+  RH_REQUIRE(B >= 1 && cols >= 2 && row0 >= 0 && row0 + B <= cols, RH_E_BADARG,
+             "rh_inbatch_sample: rows [%d, %d) outside the %d columns", row0, row0 + B, cols);
+  RH_REQUIRE(K >= 1 && K <= cols - 1, RH_E_BADARG, "rh_inbatch_sample: need 1 <= K <= columns-1 (columns=%d K=%d)",
+             cols, K);
+  const int words = (cols + 31) / 32;
   int rows = 64;
   while (rows > 1 && (size_t)rows * words * 4 > 48 * 1024) rows /= 2;
-  RH_REQUIRE((size_t)rows * words * 4 <= 64 * 1024, RH_E_UNSUPPORTED, "rh_inbatch_sample: batch %d too large", B);
+  RH_REQUIRE((size_t)rows * words * 4 <= 64 * 1024, RH_E_UNSUPPORTED, "rh_inbatch_sample: %d columns too many", cols);
   const unsigned grid = (unsigned)((B + rows - 1) / rows);
   hipLaunchKernelGGL(inbatch_sample_kernel, dim3(grid), dim3(rows), (size_t)rows * words * 4,
-                     reinterpret_cast<hipStream_t>(stream), rng, B, K, words, out);
+                     reinterpret_cast<hipStream_t>(stream), rng, B, cols, row0, K, words, out);
   RH_LAUNCH_CHECK("rh_inbatch_sample");
   return 0;
+}
+
+extern "C" int rh_inbatch_sample(const int64_t* rng, int B, int K, int64_t* out, void* stream) {
+  RH_REQUIRE(B >= 2, RH_E_BADARG, "rh_inbatch_sample: need 1 <= K <= B-1 (B=%d K=%d)", B, K);
+  return rh_inbatch_sample_rows(rng, B, B, 0, K, out, stream);
 }
 
 extern "C" int rh_batch_gather(const int64_t* perm, const int64_t* pos, int64_t N, int B, const int64_t* sparse,

@@ -193,7 +193,10 @@ class DenseGradBucket(object):
 class DataParallelContext(object):
     """Replica synchronisation for one model on this rank."""
 
-    def __init__(self, model, group=None, broadcast=True, force=False):
+    def __init__(self, model, group=None, broadcast=True, force=False, shard_tables=False, shard_min_rows=0):
+        """``shard_tables``: keep ONE row-shard of every table (>= shard_min_rows rows) on this rank instead of a
+        replica (sharding.py): their rows travel inside the forward / backward (all-gather of indices, reduce-scatter
+        of rows), so they take no part in the gradient-row exchange below."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (launch with torchrun)")
         self.deferred_mode = False  # True: the backward only records (call, rows); exchange_deferred() runs later
@@ -207,12 +210,16 @@ class DataParallelContext(object):
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
                     dist.broadcast(t, src=0, group=group)
+        self.sharded = []
+        if shard_tables:
+            from . import sharding
+            self.sharded = sharding.shard_tables(model, group, min_rows=shard_min_rows)
         tables = {id(p) for p in table_parameters(model)}
         dense = [p for p in model.parameters() if id(p) not in tables]
         self.bucket = DenseGradBucket(dense, group)
         self.bucket.force = force
         self._hook = ops.add_pre_embed_backward_hook(self.bucket.flush)
-        ops.set_sparse_exchange(self.sparse_exchange)
+        ops.set_sparse_exchange(self.sparse_exchange, self.gather_rows)
 
     def sparse_exchange(self, call, rows):
         """all-gather (indices, gradient rows) of the local batch from every rank."""
@@ -222,6 +229,10 @@ class DataParallelContext(object):
         idx_all = all_gather_cat(pack_indices(call.idx), self.group)
         rows_all = all_gather_cat(rows, self.group)
         return idx_all, rows_all
+
+    def gather_rows(self, t):
+        """Rows of every rank, rank order (sequence-feature backward: its indices and gradient rows)."""
+        return all_gather_cat(t, self.group)
 
     def exchange_deferred(self, deferred):
         """Run the recorded exchanges into STATIC gather buffers (addresses must not change between graph replays)."""

@@ -26,18 +26,16 @@ class DeepFM(torch.nn.Module):
         self.embedding = EmbeddingLayer(deep_features + fm_features)
         self.mlp = MLP(self.deep_dims, **mlp_params)
 
-    def _deep_shares_fm_gather(self, x):
+    def _same_sparse_lists(self):
         deep_sparse = [f for f in self.deep_features if isinstance(f, SparseFeature)]
-        if len(deep_sparse) != len(self.fm_features) or any(a is not b for a, b in zip(deep_sparse, self.fm_features)):
-            return False
-        return self.embedding.can_fuse(x, self.deep_features)
+        return len(deep_sparse) == len(self.fm_features) and all(a is b for a, b in zip(deep_sparse, self.fm_features))
 
     def forward(self, x):
         emb = self.embedding
+        dense = [f for f in self.deep_features if not isinstance(f, SparseFeature)]
         if emb.can_fuse(x, self.fm_features):
             w, b = self.linear.fc.weight, self.linear.fc.bias
-            if self._deep_shares_fm_gather(x):
-                dense = [f for f in self.deep_features if not isinstance(f, SparseFeature)]
+            if self._same_sparse_lists() and emb.can_fuse(x, self.deep_features):
                 call = emb.make_call(x, self.fm_features, dense, want_fm=True, want_lr=True)
                 input_deep, y_fm, y_linear = ops.fused_embedding(call, w, b)
             else:
@@ -45,8 +43,12 @@ class DeepFM(torch.nn.Module):
                 _, y_fm, y_linear = ops.fused_embedding(call, w, b)
                 input_deep = emb(x, self.deep_features, squeeze_dim=True)
         else:
-            input_deep = emb(x, self.deep_features, squeeze_dim=True)
             input_fm = emb(x, self.fm_features, squeeze_dim=False)
+            if self._same_sparse_lists() and all(x[f.name].dim() == 1 for f in dense):
+                # one lookup serves both lists (row-sharded tables: one exchange instead of two); dense values last (Q1)
+                input_deep = torch.cat([input_fm.flatten(start_dim=1)] + emb._dense_columns(x, dense), dim=1)
+            else:
+                input_deep = emb(x, self.deep_features, squeeze_dim=True)
             y_linear = self.linear(input_fm.flatten(start_dim=1))
             y_fm = self.fm(input_fm)
         return self.mlp.sigmoid_head(input_deep, y_linear, y_fm)

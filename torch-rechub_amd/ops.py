@@ -159,7 +159,8 @@ class EmbedCall(object):
     _dcache = _DescCache()
 
     def __init__(self, weights, pads, idx, dense=(), want_fm=False, want_lr=False, slots=None, width=None,
-                 field_split=0, samples_per_block=0):
+                 field_split=0, samples_per_block=0, local_grads=False):
+        self.local_grads = bool(local_grads)  # True: never hand the gradient rows to the data-parallel exchange
         self.weights = list(weights)
         self.idx = list(idx)
         self.dense = list(dense)
@@ -254,13 +255,17 @@ def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D, training=None):
 
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
 _sparse_exchange = None
+_row_gather = None
 
 
-def set_sparse_exchange(fn):
+def set_sparse_exchange(fn, row_gather=None):
     """fn(call, rows_local (B,F,D)) -> (idx_all (W*B,F) int, rows_all (W*B,F,D)), or None when fn keeps the rows and
-    runs the exchange + scatter itself after the backward.  set_sparse_exchange(None) disables the exchange."""
-    global _sparse_exchange
+    runs the exchange + scatter itself after the backward.  row_gather(t) -> the rows of ``t`` from every rank in rank
+    order (used by the sequence-feature backward, which scatters the gathered batch in line).
+    set_sparse_exchange(None) disables both."""
+    global _sparse_exchange, _row_gather
     _sparse_exchange = fn
+    _row_gather = row_gather if fn is not None else None
 
 
 _pre_backward_hooks = []
@@ -320,7 +325,8 @@ class _EmbedFused(torch.autograd.Function):
         want_wgrad = g_lr is not None and lr_w is not None and ctx.needs_input_grad[1]
         nchunks = _lib.call("rh_embed_bwd_nchunks", B, call.samples_per_block)
         partial = torch.empty((nchunks, F * D), dtype=torch.float32, device=dev) if want_wgrad else None
-        exchange = _sparse_exchange if any_table else None
+        # local_grads: a lookup over row-sharded tables already holds the gradient rows of the global batch
+        exchange = _sparse_exchange if (any_table and not call.local_grads) else None
         if any_table or want_wgrad:
             if exchange is None:
                 fdesc = call.fdesc(True)
@@ -413,7 +419,8 @@ _POOL_MODES = {"sum": 0, "mean": 1, "concat": 2}
 class _SeqPoolFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, weight, idx, mode, sentinel, padding_idx):
+    def forward(ctx, weight, idx, mode, sentinel, padding_idx, local_grads=False):
+        ctx.local_grads = local_grads
         require_hip(weight, idx)
         if idx.dim() != 2 or idx.dtype not in (torch.int64, torch.int32):
             raise ValueError("sequence feature values must be an integer (B, L) tensor")
@@ -438,9 +445,12 @@ class _SeqPoolFn(torch.autograd.Function):
         weight = ctx.weight
         mode, sentinel, pad = ctx.meta
         if weight.requires_grad:
+            g = g.contiguous()
+            if _row_gather is not None and not ctx.local_grads:
+                # replicated table under data parallelism: every replica applies the gradient rows of the global batch
+                idx, g = _row_gather(idx.contiguous()), _row_gather(g)
             B, L = idx.shape
             V, D = weight.shape
-            g = g.contiguous()
             buf = _prepare_grad(weight)
             _lib.call("rh_seq_pool_bwd", _p(buf), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
                       idx.stride(1), B, L, D, mode, sentinel, pad, _p(g), g.stride(0), 1.0,
@@ -450,15 +460,16 @@ class _SeqPoolFn(torch.autograd.Function):
                 flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
                 idesc = EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device)
                 _log_touch([weight], [pad], idesc, 1 if idx.dtype == torch.int64 else 0, B * L, 1, D, [flat])
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
-def seq_pool(weight, idx, pooling, padding_idx):
-    """Gather + masked pooling of one sequence feature (mask sentinel = padding_idx, or -1 when unset)."""
+def seq_pool(weight, idx, pooling, padding_idx, local_grads=False):
+    """Gather + masked pooling of one sequence feature (mask sentinel = padding_idx, or -1 when unset).
+    ``local_grads``: the caller already feeds the gradient of the global batch (row-sharded tables)."""
     if pooling not in _POOL_MODES:
         raise ValueError("Sequence pooling method supports only pooling in %s, got %s." % (["sum", "mean"], pooling))
     sentinel = -1 if padding_idx is None else int(padding_idx)
-    return _SeqPoolFn.apply(weight, idx, _POOL_MODES[pooling], sentinel, padding_idx)
+    return _SeqPoolFn.apply(weight, idx, _POOL_MODES[pooling], sentinel, padding_idx, local_grads)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1037,8 +1048,11 @@ def cross_mix_epilogue(x0, xl, uv, gate, bias):
 _sample_rng = {}
 
 
-def inbatch_sample(batch_size, k, device, seed=None):
-    """(B, K) int64: per row K distinct in-batch negatives (never the row itself), uniformly at random; hipGraph-safe."""
+def inbatch_sample(batch_size, k, device, seed=None, cols=None, row0=0):
+    """(B, K) int64: per row K distinct in-batch negatives (never the row itself), uniformly at random; hipGraph-safe.
+
+    ``cols`` / ``row0``: the rows are rows [row0, row0 + B) of a (cols x cols) problem (cross-rank negatives): row r
+    draws from {0..cols-1} minus {row0 + r}, with the random stream of global row row0 + r."""
     key = (str(device), seed)
     st = _sample_rng.get(key)
     if st is None:
@@ -1046,6 +1060,24 @@ def inbatch_sample(batch_size, k, device, seed=None):
         st = torch.tensor([s & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(device)
         _sample_rng[key] = st
     out = torch.empty((batch_size, k), dtype=torch.int64, device=device)
-    _lib.call("rh_inbatch_sample", _p(st), batch_size, k, _p(out), _stream())
+    if cols is None:
+        _lib.call("rh_inbatch_sample", _p(st), batch_size, k, _p(out), _stream())
+    else:
+        _lib.call("rh_inbatch_sample_rows", _p(st), batch_size, int(cols), int(row0), k, _p(out), _stream())
     _lib.call("rh_batch_advance", ctypes.c_void_p(st.data_ptr() + 8), 1, 0, _stream())
+    return out
+
+
+def shard_localize(idx, desc, world, rank):
+    """int32 (N, F): the index matrix ``idx`` (N, F) of a global batch rewritten for this rank's table shards
+    (``rh_shard_localize``; desc = device int64 [vocab | pad | sink] per field, see sharding.RowShard)."""
+    require_hip(idx, desc)
+    if idx.dim() != 2 or not idx.is_contiguous() or idx.dtype not in (torch.int64, torch.int32):
+        raise ValueError("shard_localize: indices must be a contiguous (N, F) int64 / int32 matrix")
+    N, F = int(idx.shape[0]), int(idx.shape[1])
+    if desc.numel() != 3 * F or desc.dtype != torch.int64:
+        raise ValueError("shard_localize: descriptor must hold 3 * F int64 entries")
+    out = torch.empty((N, F), dtype=torch.int32, device=idx.device)
+    _lib.call("rh_shard_localize", _p(idx), 1 if idx.dtype == torch.int64 else 0, N, F, _p(desc), int(world),
+              int(rank), _p(out), _p(err_flag(idx.device)), _stream())
     return out

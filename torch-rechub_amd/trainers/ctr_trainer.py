@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import tqdm
 
-from .. import graphs, ops
+from .. import graphs, ops, sharding
 from ..basic.callback import EarlyStopper
 from ..basic.loss_func import RegularizationLoss
 from ..distributed import DataParallelContext, DenseGradBucket, table_parameters
@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=64):
+                 table_update=None, lazy_k=64, tables=None, shard_min_rows=0):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
@@ -42,7 +42,21 @@ class CTRTrainer(object):
         self.rank = dist.get_rank() if self.world > 1 else 0
         # RECHUB_FORCE_DP=1 runs the full data-parallel machinery (RCCL calls included) on a world of one
         force_dp = os.environ.get("RECHUB_FORCE_DP", "0") == "1" and dist.is_available() and dist.is_initialized()
-        self.dp = DataParallelContext(self.model, force=force_dp) if (self.world > 1 or force_dp) else None
+        # tables: "replicate" = one replica per rank, gradient rows exchanged (DataParallel semantics, the default);
+        # "shard" = one row-shard per rank (sharding.py): table memory, optimizer state and sweep traffic / world.
+        # Either way the step computes the reference's global-batch update.
+        if tables is None:
+            tables = sharding.placement_from_env()
+        if tables not in ("replicate", "shard"):
+            raise ValueError("tables must be 'replicate' or 'shard'")
+        if tables == "shard" and not (self.world > 1 or force_dp):
+            raise RuntimeError("tables='shard' needs an initialised process group with more than one rank "
+                               "(or RECHUB_FORCE_DP=1 for a one-rank dry run)")
+        self.tables = tables
+        self.dp = None
+        if self.world > 1 or force_dp:
+            self.dp = DataParallelContext(self.model, force=force_dp, shard_tables=(tables == "shard"),
+                                          shard_min_rows=shard_min_rows)
         if optimizer_params is None:
             optimizer_params = {"lr": 1e-3, "weight_decay": 1e-5}
         tables = table_parameters(self.model)
@@ -332,8 +346,10 @@ class CTRTrainer(object):
                         print(f"validation: best auc: {self.early_stopper.best_auc}")
                     self.model.load_state_dict(self.early_stopper.best_weights)
                     break
+        # row-sharded tables are reassembled (a collective): the file has the reference's layout whatever the placement
+        weights = sharding.full_state_dict(self.model) if self.tables == "shard" else self.model.state_dict()
         if self.rank == 0:
-            torch.save(self.model.state_dict(), os.path.join(self.model_path, "model.pth"))
+            torch.save(weights, os.path.join(self.model_path, "model.pth"))
         for logger in self._iter_loggers():
             logger.finish()
 

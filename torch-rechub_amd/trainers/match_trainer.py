@@ -4,14 +4,15 @@ Same constructor and training modes {0: point-wise BCE, 1: pair-wise BPR, 2: lis
 ``in_batch_neg=True`` the step is: user/item towers -> (B, B) scores (library GEMM) -> batched in-batch negative
 sampling -> gather [positive, negatives] -> cross entropy / BPR (match_trainer.py:118-138).  Everything else — optimizer
 (TableAdam, lazy-exact), gradient bucket, RCCL data parallelism, hipGraph step — is inherited from CTRTrainer; in-batch
-negatives are taken from the local batch of each rank (the reference's in-batch branch is single-device, :119).
+negatives are taken from the local batch of each rank (the reference's in-batch branch is single-device, :119), or, with
+``global_negatives=True``, from the items of all ranks: the step one process would take on the global batch.
 """
 import os
 
 import torch
 import tqdm
 
-from .. import ops
+from .. import ops, sharding
 from ..basic.loss_func import BPRLoss
 from ..utils.match import gather_inbatch_logits, inbatch_negative_sampling
 from .ctr_trainer import CTRTrainer
@@ -22,7 +23,7 @@ class MatchTrainer(CTRTrainer):
     def __init__(self, model, mode=0, in_batch_neg=False, in_batch_neg_ratio=None, hard_negative=False,
                  sampler_seed=None, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
-                 model_path="./", model_logger=None, **kw):
+                 model_path="./", model_logger=None, global_negatives=False, **kw):
         if in_batch_neg and not (hasattr(model, "user_tower") and hasattr(model, "item_tower")):
             raise ValueError(f"Model {type(model).__name__} does not support in-batch negative sampling. "
                              "Only two-tower models with user_tower() and item_tower() methods are supported, "
@@ -37,6 +38,10 @@ class MatchTrainer(CTRTrainer):
         self.in_batch_neg = in_batch_neg
         self.in_batch_neg_ratio = in_batch_neg_ratio
         self.hard_negative = hard_negative
+        # global_negatives: with more than one rank, score the local users against the items of EVERY rank (one
+        # all-gather of the (B, d) item embeddings; its backward is a reduce-scatter) -- the in-batch step of one
+        # process on the global batch.  Off: each rank samples inside its own batch.
+        self.global_negatives = bool(global_negatives)
         self._sampler_generator = None
         if sampler_seed is not None:
             self._sampler_generator = torch.Generator(device=self.device)
@@ -71,10 +76,15 @@ class MatchTrainer(CTRTrainer):
             if user_embedding.dim() != 2 or item_embedding.dim() != 2:
                 raise ValueError(f"In-batch negative sampling requires 2D embeddings, got shapes "
                                  f"{user_embedding.shape} and {item_embedding.shape}")
+            row0 = 0
+            if self.global_negatives and self.dp is not None:
+                row0 = self.dp.rank * item_embedding.size(0)
+                item_embedding = sharding.gather_rows(item_embedding, self.dp.group)
             scores = torch.matmul(user_embedding, item_embedding.t())
             neg_indices = inbatch_negative_sampling(scores, neg_ratio=self.in_batch_neg_ratio,
-                                                    hard_negative=self.hard_negative, generator=self._sampler_generator)
-            logits = gather_inbatch_logits(scores, neg_indices)
+                                                    hard_negative=self.hard_negative, generator=self._sampler_generator,
+                                                    row_offset=row0)
+            logits = gather_inbatch_logits(scores, neg_indices, row_offset=row0)
             if self.mode == 1:
                 loss = self.criterion(logits[:, 0], logits[:, 1:], in_batch_neg=True)
             else:

@@ -12,47 +12,55 @@ SURVEY 3.5).  Here both modes are ONE batched device op over the (B, B) score ma
 """
 import torch
 
-_DIAG = {}
+_OWN = {}
 
 
-def _diag_mask(n, device):
-    """Cached (n, n) boolean identity: built once, outside any hipGraph (an in-graph torch.eye re-creates it from a
-    memset node on every replay)."""
-    key = (n, str(device))
-    m = _DIAG.get(key)
+def _own_mask(rows, cols, row_offset, device):
+    """Cached (rows, cols) boolean mask of each row's own column (row_offset + i): built once, outside any hipGraph
+    (an in-graph torch.eye re-creates it from a memset node on every replay)."""
+    key = (rows, cols, row_offset, str(device))
+    m = _OWN.get(key)
     if m is None:
         if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("in-batch sampler: run one eager step before capturing a hipGraph")
-        m = torch.eye(n, dtype=torch.bool, device=device)
-        _DIAG[key] = m
+        m = torch.zeros((rows, cols), dtype=torch.bool, device=device)
+        m[torch.arange(rows, device=device), torch.arange(rows, device=device) + row_offset] = True
+        _OWN[key] = m
     return m
 
 
-def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, generator=None):
+def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, generator=None, row_offset=0):
+    """``scores`` (B, B), or (B, C) with ``row_offset``: the rows are rows [row_offset, row_offset + B) of a C x C global
+    batch whose item embeddings were gathered from all ranks (cross-rank negatives); row i's positive is column
+    row_offset + i and its negatives come from the other C - 1 columns."""
     if scores.dim() != 2:
         raise ValueError(f"inbatch_negative_sampling expects 2D scores, got shape {tuple(scores.shape)}")
-    batch_size = scores.size(0)
-    if batch_size <= 1:
+    batch_size, n_cols = scores.size(0), scores.size(1)
+    if n_cols <= 1:
         raise ValueError("In-batch negative sampling requires batch_size > 1")
-    max_neg = batch_size - 1
+    if row_offset < 0 or row_offset + batch_size > n_cols:
+        raise ValueError(f"rows [{row_offset}, {row_offset + batch_size}) do not fit the {n_cols} score columns")
+    max_neg = n_cols - 1
     if neg_ratio is None or neg_ratio <= 0 or neg_ratio > max_neg:
         neg_ratio = max_neg
     device = scores.device
-    diag = _diag_mask(batch_size, device)
+    own = _own_mask(batch_size, n_cols, row_offset, device)
     if hard_negative:
-        keys = scores.detach().masked_fill(diag, float("-inf"))
+        keys = scores.detach().masked_fill(own, float("-inf"))
         return torch.topk(keys, k=neg_ratio, dim=1).indices
-    if scores.is_cuda and batch_size <= 65536:
+    if scores.is_cuda and n_cols <= 65536:
         # HIP sampler (Floyd's algorithm per row, counter-based RNG): one launch, replayable from a hipGraph
         from .. import ops
         seed = None if generator is None else generator.initial_seed()
-        return ops.inbatch_sample(batch_size, neg_ratio, device, seed)
-    keys = torch.rand((batch_size, batch_size), device=device, generator=generator).masked_fill(diag, -1.0)
+        if n_cols == batch_size:
+            return ops.inbatch_sample(batch_size, neg_ratio, device, seed)
+        return ops.inbatch_sample(batch_size, neg_ratio, device, seed, cols=n_cols, row0=row_offset)
+    keys = torch.rand(tuple(scores.shape), device=device, generator=generator).masked_fill(own, -1.0)
     return torch.topk(keys, k=neg_ratio, dim=1).indices
 
 
-def gather_inbatch_logits(scores, neg_indices):
-    """(B, 1+K) logits: column 0 = scores[i, i] (the positive), then scores[i, neg_indices[i, j]]."""
-    positive_logits = torch.diagonal(scores).reshape(-1, 1)
+def gather_inbatch_logits(scores, neg_indices, row_offset=0):
+    """(B, 1+K) logits: column 0 = scores[i, row_offset + i] (the positive), then scores[i, neg_indices[i, j]]."""
+    positive_logits = torch.diagonal(scores, offset=row_offset).reshape(-1, 1)
     negative_logits = torch.gather(scores, 1, neg_indices)
     return torch.cat([positive_logits, negative_logits], dim=1)
