@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
     ap.add_argument("--lazy-k", type=int, default=64)
+    ap.add_argument("--tables", default="replicate", choices=["replicate", "shard"],
+                    help="replicate: one replica of every table per rank (DataParallel semantics, the headline "
+                         "configuration); shard: one row-shard per rank (needs N > 1 or --force-dp)")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives, split graphs) even on one GPU")
     return ap.parse_args()
@@ -183,7 +186,7 @@ def main():
         model = DeepFM(dense_feas + sparse_feas, sparse_feas, {"dims": [256, 128], "dropout": 0.2, "activation": "relu"})
     use_graph = args.graph in ("1", "auto")  # N > 1: two graphs per step with the RCCL exchange between them
     trainer = CTRTrainer(model, device=str(device), show_progress=False, use_graph=use_graph,
-                         table_update=args.table_adam, lazy_k=args.lazy_k)
+                         table_update=args.table_adam, lazy_k=args.lazy_k, tables=args.tables)
     sparse, dense, label = build_dataset(args.rows, vocabs, device, seed=2022 + rank, dist_kind=args.dist)
     loader = DeviceDataLoader(sparse, [f.name for f in sparse_feas], dense, [f.name for f in dense_feas], label,
                               args.batch, shuffle=True)
@@ -244,7 +247,7 @@ def main():
     gsweep = None
     if rank == 0:
         names = ["rh_embed_fwd", "rh_embed_bwd", "rh_adam_dense", "rh_adam_lazy_touched", "rh_adam_lazy_sweep",
-                 "rh_batch_gather", "rh_embed_scatter_rows"]
+                 "rh_batch_gather", "rh_embed_scatter_rows", "rh_shard_localize"]
         timer = KernelTimer(names)
         timer.install()
         n_prof = max(5, min(args.steps, 30))
@@ -354,6 +357,7 @@ def main():
                                  trainer.optimizer, "overlap_sweep", False) else "in line, ") + "flushed "
                              "inside the timed region" if args.table_adam == "lazy" else "dense pass per step"),
                 "parallelism": f"dp{world}" if (world > 1 or args.force_dp) else "single", "hipgraph": graph_ok,
+                "tables": args.tables if (world > 1 or args.force_dp) else "single copy",
                 "vocab_scale": args.vocab_scale,
             },
             "roofline": roofline,

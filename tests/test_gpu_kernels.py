@@ -1042,3 +1042,38 @@ def test_inbatch_sampler_stream_and_rank_slices():
     assert np.array_equal(wide, O.inbatch_sample_rows(seed, 0, 4, 3000, 2996, 2999))
     with pytest.raises(RuntimeError):
         ops.inbatch_sample(8, 3, dev(), seed, cols=10, row0=5)  # rows 5..12 do not fit 10 columns
+
+
+@pytest.mark.parametrize("B,F,D,ND", [(257, 26, 16, 13), (64, 3, 8, 0), (1, 5, 32, 2), (0, 4, 16, 1)])
+def test_fused_rows_is_the_fused_gather_stage_on_rows_in_place(B, F, D, ND):
+    """ops.fused_rows (what a row-sharded lookup feeds): flattened rows + dense values, FM and LR of layers.py:112-120,
+    :313-319, :185-189 and their gradients, against the float64 oracle / torch autograd on the same rows."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + F)
+    emb = (torch.randn(B, F * D, generator=g) * 0.5).to(dev()).requires_grad_(True)
+    dense = torch.rand(B, max(ND, 1), generator=g).to(dev())
+    w = (torch.randn(1, F * D, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(dev()).requires_grad_(True)
+    out, fm, lr = ops.fused_rows(emb, F, [dense[:, j] for j in range(ND)], w, b, want_fm=True)
+    x = emb.detach().cpu().numpy().astype(F64).reshape(B, F, D)
+    assert np.array_equal(out[:, :F * D].detach().cpu().numpy(), emb.detach().cpu().numpy())
+    assert np.array_equal(out[:, F * D:].detach().cpu().numpy(), dense[:, :ND].cpu().numpy())
+    close(fm, O.fm_forward(x), what="fm")
+    close(lr, O.lr_forward(x.reshape(B, F * D), w.detach().cpu().numpy().astype(F64), b.detach().cpu().numpy().astype(F64)),
+          what="lr")
+    G1 = torch.randn(out.shape, generator=g).to(dev())
+    G2, G3 = torch.randn(B, 1, generator=g).to(dev()), torch.randn(B, 1, generator=g).to(dev())
+    ((out * G1).sum() + (fm * G2).sum() + (lr * G3).sum()).backward()
+    got = [emb.grad.clone(), w.grad.clone(), b.grad.clone()]
+    e2 = emb.detach().double().requires_grad_(True)
+    w2, b2 = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    x3 = e2.view(B, F, D)
+    fm2 = 0.5 * (x3.sum(1)**2 - (x3**2).sum(1)).sum(1, keepdim=True)
+    lr2 = e2 @ w2.t() + b2
+    ((e2 * G1[:, :F * D].double()).sum() + (fm2 * G2.double()).sum() + (lr2 * G3.double()).sum()).backward()
+    close(got[0], e2.grad.cpu().numpy(), what="row gradients")
+    close(got[1], w2.grad.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="LR weight gradient")
+    close(got[2], b2.grad.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="LR bias gradient")
+    plain, none_fm, none_lr = ops.fused_rows(emb.detach(), F)
+    assert none_fm is None and none_lr is None and torch.equal(plain, emb.detach())
+    ops.check_errors()

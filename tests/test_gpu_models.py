@@ -248,12 +248,14 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, "single", "split"])
-def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, monkeypatch, use_graph):
+@pytest.mark.parametrize("use_graph,tables", [(False, "replicate"), ("single", "replicate"), ("split", "replicate"),
+                                              (False, "shard"), ("single", "shard")])
+def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, monkeypatch, use_graph, tables):
     """RECHUB_FORCE_DP: dense all-reduce on the side stream + all-gather of (indices, gradient rows) + row scatter
     (eager, captured as one hipGraph with the RCCL launches inside, or as the two-graph split step) on a world of one
-    must reproduce the single-GPU fused path."""
-    from torch_rechub_amd import ops
+    must reproduce the single-GPU fused path.  tables="shard": the row-sharded lookup (all-gather of indices,
+    rh_shard_localize, gather over the shard, reduce-scatter; all-gather of the gradient) over RCCL, eager and captured."""
+    from torch_rechub_amd import ops, sharding
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
     N, B = 64 * 12, 64
@@ -273,16 +275,18 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
     monkeypatch.setenv("RECHUB_FORCE_DP", "1")
     monkeypatch.setenv("RECHUB_DP_GRAPH", use_graph or "single")
     tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
-                    use_graph=bool(use_graph))
+                    use_graph=bool(use_graph), tables=tables)
     assert tb.dp is not None and ops._sparse_exchange is not None
+    assert all(sharding.is_sharded(m) for m in mb.embedding.embed_dict.values()) == (tables == "shard")
     try:
         lb = tb.train_one_epoch(mk())
         if use_graph:
             assert tb._graph is not None and tb.dp_graph == use_graph and (tb._graph_b is None) == (use_graph == "single")
+        sd_b = sharding.full_state_dict(mb) if tables == "shard" else mb.state_dict()
     finally:
         tb.dp.close()
     assert abs(la - lb) < 1e-5
-    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+    for (k, a), (_, b) in zip(ma.state_dict().items(), sd_b.items()):
         if k.endswith("num_batches_tracked"):
             assert int(a) == int(b)
             continue

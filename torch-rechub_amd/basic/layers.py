@@ -149,6 +149,25 @@ class EmbeddingLayer(nn.Module):
                 return False
         return len(dims) == 1 and _fusable_dim(next(iter(dims)))
 
+    def can_fuse_sharded(self, x, features):
+        """True when the list is ONE row-sharded lookup: plain sparse features of one width whose tables are all
+        sharded, 1-D dense values (appended by ops.fused_rows)."""
+        dims = set()
+        for fea in features:
+            if isinstance(fea, SparseFeature):
+                if not sharding.is_sharded(self.table_of(fea)):
+                    return False
+                dims.add(fea.embed_dim)
+            elif isinstance(fea, SequenceFeature):
+                return False
+            elif x[fea.name].dim() != 1:
+                return False
+        return len(dims) == 1 and _fusable_dim(next(iter(dims)))
+
+    def sharded_rows(self, x, sparse_feas):
+        """(B, F*D) rows of row-sharded tables for the local batch (index all-gather, shard gather, reduce-scatter)."""
+        return sharding.lookup([self.table_of(f) for f in sparse_feas], [_as_index(x[f.name]) for f in sparse_feas])
+
     def forward(self, x, features, squeeze_dim=False):
         table_feas = [f for f in features if isinstance(f, (SparseFeature, SequenceFeature))]
         dense_feas = [f for f in features if not isinstance(f, (SparseFeature, SequenceFeature))]
@@ -169,6 +188,11 @@ class EmbeddingLayer(nn.Module):
             call = self.make_call(x, sparse, dense_feas if squeeze_dim else ())
             out, _, _ = ops.fused_embedding(call)
             return out if squeeze_dim else out.view(call.B, call.F, call.D)
+        if self.can_fuse_sharded(x, features):
+            rows = self.sharded_rows(x, table_feas)
+            if squeeze_dim and dense_feas:  # dense values appended by one launch over the received rows (Q1)
+                rows, _, _ = ops.fused_rows(rows, len(table_feas), [x[f.name].float() for f in dense_feas])
+            return rows if squeeze_dim else rows.view(rows.shape[0], len(table_feas), -1)
 
         # general path: sequence features, mixed widths, row-sharded tables -> per-group launches, reference order
         pieces = [None] * len(table_feas)

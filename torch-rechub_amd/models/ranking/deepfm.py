@@ -33,22 +33,24 @@ class DeepFM(torch.nn.Module):
     def forward(self, x):
         emb = self.embedding
         dense = [f for f in self.deep_features if not isinstance(f, SparseFeature)]
+        w, b = self.linear.fc.weight, self.linear.fc.bias
         if emb.can_fuse(x, self.fm_features):
-            w, b = self.linear.fc.weight, self.linear.fc.bias
-            if self._same_sparse_lists() and emb.can_fuse(x, self.deep_features):
-                call = emb.make_call(x, self.fm_features, dense, want_fm=True, want_lr=True)
-                input_deep, y_fm, y_linear = ops.fused_embedding(call, w, b)
-            else:
-                call = emb.make_call(x, self.fm_features, (), want_fm=True, want_lr=True)
-                _, y_fm, y_linear = ops.fused_embedding(call, w, b)
-                input_deep = emb(x, self.deep_features, squeeze_dim=True)
+            # replicated tables: the gather kernel emits the MLP input, the FM scalar and the LR scalar
+            shared = self._same_sparse_lists() and emb.can_fuse(x, self.deep_features)
+            call = emb.make_call(x, self.fm_features, dense if shared else (), want_fm=True, want_lr=True)
+            input_deep, y_fm, y_linear = ops.fused_embedding(call, w, b)
+        elif emb.can_fuse_sharded(x, self.fm_features):
+            # row-sharded tables: ONE exchange for both feature lists, then the same fused stage over the received rows
+            shared = self._same_sparse_lists() and emb.can_fuse_sharded(x, self.deep_features)
+            rows = emb.sharded_rows(x, self.fm_features)
+            input_deep, y_fm, y_linear = ops.fused_rows(rows, len(self.fm_features),
+                                                        [x[f.name].float() for f in dense] if shared else (), w, b,
+                                                        want_fm=True)
         else:
+            shared = False
             input_fm = emb(x, self.fm_features, squeeze_dim=False)
-            if self._same_sparse_lists() and all(x[f.name].dim() == 1 for f in dense):
-                # one lookup serves both lists (row-sharded tables: one exchange instead of two); dense values last (Q1)
-                input_deep = torch.cat([input_fm.flatten(start_dim=1)] + emb._dense_columns(x, dense), dim=1)
-            else:
-                input_deep = emb(x, self.deep_features, squeeze_dim=True)
             y_linear = self.linear(input_fm.flatten(start_dim=1))
             y_fm = self.fm(input_fm)
+        if not shared:
+            input_deep = emb(x, self.deep_features, squeeze_dim=True)
         return self.mlp.sigmoid_head(input_deep, y_linear, y_fm)

@@ -367,6 +367,98 @@ def fused_embedding(call, lr_w=None, lr_b=None):
     return _EmbedFused.apply(call, lr_w, lr_b, *call.weights)
 
 
+_row_ids = {}
+
+
+def _row_index(B, F, device):
+    """int32 (B, F) with entry b * F + f: the lookup (b, f) of a (B, F*D) row block read as a (B*F, D) table."""
+    key = (B, F, str(device))
+    t = _row_ids.get(key)
+    if t is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("torch_rechub_amd: run the step eagerly once before capturing a hipGraph")
+        t = torch.arange(B * F, dtype=torch.int32, device=device).view(B, F)
+        _row_ids[key] = t
+    return t
+
+
+class _RowsFused(torch.autograd.Function):
+    """The fused gather's second half on rows that are already in HBM: ``emb`` (B, F*D) -- the result of a row-sharded
+    lookup (sharding.lookup) -- goes through the SAME kernels as a (B*F, D) table indexed by b*F + f, so that one launch
+    emits the flattened MLP input (sparse block + dense values, Q1), the FM scalar and the LR scalar, and one launch
+    computes the gradient of all three with respect to every row (``sink = 1``: per-lookup gradient rows, the form the
+    row exchange carries) plus the per-block LR weight partials.  Keep ``emb`` at a fixed address from step to step
+    (sharding.lookup does): the descriptor tables are cached by address."""
+
+    @staticmethod
+    def forward(ctx, emb, F, dense, lr_w, lr_b, want_fm):
+        require_hip(emb, *dense)
+        if emb.dim() != 2 or emb.dtype != torch.float32 or not emb.is_contiguous() or emb.shape[1] % F:
+            raise ValueError("fused_rows: rows must be a contiguous float32 (B, F*D) matrix")
+        B, D = int(emb.shape[0]), int(emb.shape[1]) // F
+        dev = emb.device
+        want_lr = lr_w is not None
+        if want_lr:
+            if lr_w.numel() != F * D or not lr_w.is_contiguous() or lr_w.dtype != torch.float32:
+                raise ValueError("fused LR weight must be contiguous float32 with F*D elements")
+            require_hip(lr_w, lr_b)
+        for t in dense:
+            if t.dim() != 1 or t.shape[0] != B or t.dtype != torch.float32:
+                raise ValueError("fused_rows: dense values must be float32 (B,)")
+        ids = _row_index(B, F, dev)
+        fdesc = EmbedCall._fcache.get(tuple([emb.data_ptr()] * F + [0] * F + [B * F] * F + [-1] * F), dev)
+        idesc = EmbedCall._icache.get(tuple([ids.data_ptr() + 4 * f for f in range(F)] + [F] * F + list(range(F))), dev)
+        ddesc = None
+        if dense:
+            ddesc = EmbedCall._dcache.get(tuple([t.data_ptr() for t in dense] + [t.stride(0) for t in dense]), dev)
+        out = torch.empty((B, F * D + len(dense)), dtype=torch.float32, device=dev)
+        fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_fm else None
+        lr = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_lr else None
+        s_sum = torch.empty((B, D), dtype=torch.float32, device=dev) if want_fm else None
+        _lib.call("rh_embed_fwd", _p(fdesc), _p(idesc), 0, B, F, D, _p(ddesc), len(dense), F * D, _p(out), out.stride(0),
+                  _p(lr_w), _p(lr_b if want_lr else None), _p(lr), _p(fm), _p(s_sum), 0, _p(err_flag(dev)), _stream())
+        ctx.meta = (B, F, D, fdesc, idesc, lr_b is not None)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(out, s_sum, lr_w)
+        return out, fm, lr
+
+    @staticmethod
+    def backward(ctx, g_out, g_fm, g_lr):
+        out, s_sum, lr_w = ctx.saved_tensors
+        B, F, D, fdesc, idesc, has_b = ctx.meta
+        dev = out.device
+        for hook in list(_pre_backward_hooks):
+            hook()
+        if g_out is not None and (g_out.stride(1) != 1 or g_out.stride(0) < out.shape[1]):
+            g_out = g_out.contiguous()
+        g_fm = None if g_fm is None else g_fm.reshape(-1).contiguous()
+        g_lr = None if g_lr is None else g_lr.reshape(-1).contiguous()
+        want_wgrad = g_lr is not None and lr_w is not None and ctx.needs_input_grad[3]
+        want_b = g_lr is not None and has_b and ctx.needs_input_grad[4]
+        nchunks = _lib.call("rh_embed_bwd_nchunks", B, 0)
+        partial = torch.empty((nchunks, F * D), dtype=torch.float32, device=dev) if want_wgrad else None
+        rows = torch.empty((B, F * D), dtype=torch.float32, device=dev)
+        g_w = torch.empty_like(lr_w) if want_wgrad else None
+        g_b = torch.empty((1,), dtype=torch.float32, device=dev) if want_b else None
+        if B == 0:
+            g_w = None if g_w is None else g_w.zero_()
+            g_b = None if g_b is None else g_b.zero_()
+            return rows, None, None, g_w, g_b, None
+        _lib.call("rh_embed_bwd", _p(fdesc), _p(idesc), 0, B, F, D, _p(g_out), 0 if g_out is None else g_out.stride(0),
+                  _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr), _p(lr_w), _p(partial), 1.0, 1, _p(rows), 0,
+                  _p(err_flag(dev)), _stream())
+        if want_wgrad or want_b:
+            glc = g_lr.contiguous() if want_b else None
+            _lib.call("rh_colsum", _p(partial), nchunks if want_wgrad else 0, F * D, _p(g_w), _p(glc),
+                      glc.numel() if want_b else 0, _p(g_b), _stream())
+        return rows, None, None, g_w, g_b, None
+
+
+def fused_rows(emb, n_fields, dense=(), lr_w=None, lr_b=None, want_fm=False):
+    """(out (B, F*D + n_dense), fm (B,1)|None, lr (B,1)|None) from rows already gathered into ``emb`` (B, F*D)."""
+    return _RowsFused.apply(emb, int(n_fields), tuple(dense), lr_w, lr_b, bool(want_fm))
+
+
 def scatter_rows(call, idx_all, rows_all):
     """Scatter-add gradient rows (N,F,D) for packed indices idx_all (N,F) into the tables' grad buffers."""
     require_hip(idx_all, rows_all)
@@ -1068,7 +1160,7 @@ def inbatch_sample(batch_size, k, device, seed=None, cols=None, row0=0):
     return out
 
 
-def shard_localize(idx, desc, world, rank):
+def shard_localize(idx, desc, world, rank, out=None):
     """int32 (N, F): the index matrix ``idx`` (N, F) of a global batch rewritten for this rank's table shards
     (``rh_shard_localize``; desc = device int64 [vocab | pad | sink] per field, see sharding.RowShard)."""
     require_hip(idx, desc)
@@ -1077,7 +1169,10 @@ def shard_localize(idx, desc, world, rank):
     N, F = int(idx.shape[0]), int(idx.shape[1])
     if desc.numel() != 3 * F or desc.dtype != torch.int64:
         raise ValueError("shard_localize: descriptor must hold 3 * F int64 entries")
-    out = torch.empty((N, F), dtype=torch.int32, device=idx.device)
+    if out is None:
+        out = torch.empty((N, F), dtype=torch.int32, device=idx.device)
+    elif out.shape != (N, F) or out.dtype != torch.int32 or not out.is_contiguous():
+        raise ValueError("shard_localize: out must be a contiguous int32 (N, F) tensor")
     _lib.call("rh_shard_localize", _p(idx), 1 if idx.dtype == torch.int64 else 0, N, F, _p(desc), int(world),
               int(rank), _p(out), _p(err_flag(idx.device)), _stream())
     return out

@@ -151,13 +151,17 @@ def load_full_state_dict(model, sd):
 
 
 # -- differentiable collectives over the rows of a batch ------------------------------------------------------------
-def _reduce_scatter_sum(x_all, group):
+def _reduce_scatter_sum(x_all, group, out=None):
     world = dist.get_world_size(group)
     B = x_all.shape[0] // max(world, _EMULATE_WORLD if world == 1 else 1)
-    if world == 1:
-        return x_all[:B].clone() if x_all.shape[0] != B else x_all
-    out = torch.empty((B,) + tuple(x_all.shape[1:]), dtype=x_all.dtype, device=x_all.device)
+    if out is None:
+        out = torch.empty((B,) + tuple(x_all.shape[1:]), dtype=x_all.dtype, device=x_all.device)
+    elif out.shape != (B,) + tuple(x_all.shape[1:]) or not out.is_contiguous():
+        raise ValueError("reduce-scatter: bad output buffer")
     x_all = x_all.contiguous()
+    if world == 1 and x_all.shape[0] != B:  # RECHUB_EMULATE_WORLD (timing only): the first block stands for the sum
+        out.copy_(x_all[:B])
+        return out
     try:
         dist.reduce_scatter_tensor(out, x_all, op=dist.ReduceOp.SUM, group=group)
     except (RuntimeError, NotImplementedError):  # gloo has no reduce-scatter: all-reduce, keep the own slice
@@ -172,13 +176,15 @@ class _ScatterRows(torch.autograd.Function):
     """(W*B, C) per-rank partial rows of the GLOBAL batch -> (B, C): the sum over ranks of this rank's row block."""
 
     @staticmethod
-    def forward(ctx, x_all, group):
+    def forward(ctx, x_all, group, box):
         ctx.group = group
-        return _reduce_scatter_sum(x_all, group)
+        # a persistent output buffer travels in a box, not as a tensor argument: the tensor object handed back to
+        # autograd is a fresh alias of it every step (the cached object never acquires a grad_fn)
+        return _reduce_scatter_sum(x_all, group, None if box is None else box[0].detach())
 
     @staticmethod
     def backward(ctx, g):
-        return all_gather_cat(g, ctx.group), None
+        return all_gather_cat(g, ctx.group), None, None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -194,8 +200,9 @@ class _GatherRows(torch.autograd.Function):
         return _reduce_scatter_sum(g_all, ctx.group), None
 
 
-def scatter_rows_sum(x_all, group=None):
-    return _ScatterRows.apply(x_all, group)
+def scatter_rows_sum(x_all, group=None, out=None):
+    """``out``: write into this (B, C) buffer (a fixed address from step to step; it is returned)."""
+    return _ScatterRows.apply(x_all, group, None if out is None else (out,))
 
 
 def gather_rows(x, group=None):
@@ -204,6 +211,38 @@ def gather_rows(x, group=None):
 
 # -- lookups -------------------------------------------------------------------------------------------------------
 _desc_cache = ops._DescCache()
+
+
+class _StaticBuffers(object):
+    """(gathered indices, localised indices) per lookup site, keyed by (tables, index buffer address, shape).
+
+    The fused gather finds its index columns through a descriptor table keyed by ADDRESS (ops.EmbedCall.idesc); with
+    the batch in the loader's static buffers, reusing one localised-index buffer per site keeps that address -- and so
+    the descriptor -- the same from step to step: no per-step descriptor upload, and a hipGraph capture finds every
+    descriptor already on the device.  Entries used while capturing are pinned (the graph replays into them)."""
+
+    def __init__(self, cap=64):
+        from collections import OrderedDict
+        self.cap, self.d, self.pinned = cap, OrderedDict(), {}
+
+    def get(self, key, make):
+        b = self.pinned.get(key)
+        if b is not None:
+            return b
+        b = self.d.get(key)
+        if b is None:
+            b = make()
+            self.d[key] = b
+            if len(self.d) > self.cap:
+                self.d.popitem(last=False)
+        else:
+            self.d.move_to_end(key)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.pinned[key] = b
+        return b
+
+
+_buffers = _StaticBuffers()
 
 
 def _localize(embs, idx, group):
@@ -215,8 +254,19 @@ def _localize(embs, idx, group):
             raise ValueError("one lookup spans tables sharded over different process groups")
     key = tuple([e._rh_shard.vocab for e in embs] + [e._rh_shard.pad for e in embs] + [e._rh_shard.sink for e in embs])
     desc = _desc_cache.get(key, idx.device)
-    idx_all = all_gather_cat(idx, group)
-    return ops.shard_localize(idx_all, desc, sh0.world, sh0.rank)
+    n_all = idx.shape[0] * max(dist.get_world_size(group), sh0.world)
+
+    width = sum(e._rh_shard.dim for e in embs)
+
+    def make():
+        return (torch.empty((n_all, idx.shape[1]), dtype=idx.dtype, device=idx.device),
+                torch.empty((n_all, idx.shape[1]), dtype=torch.int32, device=idx.device),
+                torch.empty((idx.shape[0], width), dtype=torch.float32, device=idx.device))
+
+    site = (tuple(id(e) for e in embs), idx.data_ptr(), tuple(idx.shape), tuple(idx.stride()), idx.dtype, sh0.rank)
+    idx_all, loc, rows = _buffers.get(site, make)
+    all_gather_cat(idx, group, out=idx_all)
+    return ops.shard_localize(idx_all, desc, sh0.world, sh0.rank, out=loc), rows
 
 
 def lookup(embs, idx_cols):
@@ -224,15 +274,14 @@ def lookup(embs, idx_cols):
 
     ``embs[f]`` is the (sharded) ``nn.Embedding`` of field f; entries may repeat (shared tables, history positions)."""
     group = embs[0]._rh_shard.group
-    idx = pack_indices(list(idx_cols))
-    if not idx.is_contiguous():
-        idx = idx.contiguous()
-    loc = _localize(embs, idx, group)
+    loc, rows = _localize(embs, pack_indices(list(idx_cols)), group)
     F = len(embs)
     call = ops.EmbedCall([e.weight for e in embs], [e._rh_shard.sink for e in embs], [loc[:, f] for f in range(F)],
                          local_grads=True)
     out_all, _, _ = ops.fused_embedding(call)
-    return scatter_rows_sum(out_all, group)
+    # the received rows land at a fixed address per lookup site: ops.fused_rows (FM / LR / dense append over them)
+    # caches its descriptor tables by address
+    return scatter_rows_sum(out_all, group, out=rows)
 
 
 def pooled_lookup(emb, idx, pooling):
@@ -241,7 +290,7 @@ def pooled_lookup(emb, idx, pooling):
     the mean divides by the count of non-sentinel positions + 1e-16, taken from the local indices."""
     sh = emb._rh_shard
     B, L = idx.shape
-    loc = _localize([emb], idx.reshape(B * L, 1).contiguous(), sh.group).view(-1, L)
+    loc = _localize([emb], idx.reshape(B * L, 1).contiguous(), sh.group)[0].view(-1, L)
     part = ops.seq_pool(emb.weight, loc, "sum", sh.sink, local_grads=True)
     total = scatter_rows_sum(part, sh.group)
     if pooling == "sum":
