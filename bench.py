@@ -56,9 +56,11 @@ def parse():
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
     ap.add_argument("--lazy-k", type=int, default=64)
-    ap.add_argument("--tables", default="replicate", choices=["replicate", "shard"],
-                    help="replicate: one replica of every table per rank (DataParallel semantics, the headline "
-                         "configuration); shard: one row-shard per rank (needs N > 1 or --force-dp)")
+    ap.add_argument("--tables", default="auto", choices=["auto", "replicate", "shard"],
+                    help="N > 1 placement of the embedding tables; both compute the reference's global-batch update. "
+                         "replicate: one replica per rank, gradient rows all-gathered (nn.DataParallel's layout); "
+                         "shard: one row-shard per rank, indices all-gathered and rows reduce-scattered (table memory, "
+                         "optimizer state and sweep traffic / N); auto = shard when N > 1")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives, split graphs) even on one GPU")
     return ap.parse_args()
@@ -184,9 +186,15 @@ def main():
     sparse_feas = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=EMBED_DIM) for i, v in enumerate(vocabs)]
     with torch.device(device):  # tables are created directly in HBM (2 GiB; never staged through the host)
         model = DeepFM(dense_feas + sparse_feas, sparse_feas, {"dims": [256, 128], "dropout": 0.2, "activation": "relu"})
+    parallel = world > 1 or args.force_dp
+    tables = args.tables
+    if tables == "auto":
+        tables = "shard" if world > 1 else "replicate"
+    if not parallel:
+        tables = None  # one GPU, one copy
     use_graph = args.graph in ("1", "auto")  # N > 1: two graphs per step with the RCCL exchange between them
     trainer = CTRTrainer(model, device=str(device), show_progress=False, use_graph=use_graph,
-                         table_update=args.table_adam, lazy_k=args.lazy_k, tables=args.tables)
+                         table_update=args.table_adam, lazy_k=args.lazy_k, tables=tables)
     sparse, dense, label = build_dataset(args.rows, vocabs, device, seed=2022 + rank, dist_kind=args.dist)
     loader = DeviceDataLoader(sparse, [f.name for f in sparse_feas], dense, [f.name for f in dense_feas], label,
                               args.batch, shuffle=True)
@@ -286,7 +294,8 @@ def main():
                           "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
         # the north-star kernel over batch sizes (same tables, same stream, HIP events): its bandwidth regime starts
         # where the launch is no longer three dependent memory round trips long
-        gsweep = gather_sweep(model, sparse_feas, dense_feas, vocabs, device)
+        if tables != "shard":  # (a shard holds 1/N of the rows under local ids: the study belongs to the full tables)
+            gsweep = gather_sweep(model, sparse_feas, dense_feas, vocabs, device)
     elif world > 1:
         for _ in range(max(5, min(args.steps, 30))):  # keep the collectives of the profiling pass matched
             eager_step()
@@ -357,7 +366,9 @@ def main():
                                  trainer.optimizer, "overlap_sweep", False) else "in line, ") + "flushed "
                              "inside the timed region" if args.table_adam == "lazy" else "dense pass per step"),
                 "parallelism": f"dp{world}" if (world > 1 or args.force_dp) else "single", "hipgraph": graph_ok,
-                "tables": args.tables if (world > 1 or args.force_dp) else "single copy",
+                "tables": {"shard": f"row-sharded over {world} ranks (row g on rank g % {world})",
+                           "replicate": "one replica per rank, gradient rows exchanged",
+                           None: "single copy"}[tables],
                 "vocab_scale": args.vocab_scale,
             },
             "roofline": roofline,

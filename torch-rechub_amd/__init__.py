@@ -12,6 +12,7 @@ Layout (mirrors only what the hot path needs from the reference package):
   utils/data.py    DataGenerator / TorchDataset + the HBM-resident DeviceDataLoader
   optim.py     FusedDenseAdam (torch.optim.Adam semantics, tables stepped by one HIP launch)
   distributed.py   one-process-per-GPU data parallel over RCCL (dense all-reduce + sparse row exchange)
+  sharding.py      row-sharded tables (one shard per rank) + differentiable row collectives (cross-rank negatives)
 """
 __version__ = "0.1.0"
 
