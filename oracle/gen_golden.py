@@ -208,6 +208,26 @@ def build_model(rh, cfg):
         model = DIN(feats, hist, tgt, mlp_params={"dims": [32, 16], "dropout": 0.0},
                     attention_mlp_params={"dims": [16, 8], "use_softmax": cfg.endswith("softmax")})
         return model, {"features": feats, "history_features": hist, "target_features": tgt}
+    if cfg in ("bst", "dien"):  # sequence models over the same (history, target) feature pairs as DIN
+        feats = [SparseFeature("user_id", vocab_size=30, embed_dim=D)]
+        tgt = [SparseFeature("target_item", vocab_size=50, embed_dim=D, padding_idx=0),
+               SparseFeature("target_cate", vocab_size=12, embed_dim=D, padding_idx=0)]
+
+        def sequences(prefix):
+            return [SequenceFeature(prefix + "item", vocab_size=50, embed_dim=D, pooling="concat",
+                                    shared_with="target_item", padding_idx=0),
+                    SequenceFeature(prefix + "cate", vocab_size=12, embed_dim=D, pooling="concat",
+                                    shared_with="target_cate", padding_idx=0)]
+
+        hist = sequences("hist_")
+        if cfg == "bst":
+            from torch_rechub.models.ranking import BST
+            model = BST(feats, hist, tgt, mlp_params=mlp, nhead=2, dropout=0.0, num_layers=1, max_seq_len=8)
+            return model, {"features": feats, "history_features": hist, "target_features": tgt}
+        from torch_rechub.models.ranking import DIEN
+        neg = sequences("neg_hist_")
+        model = DIEN(feats, hist, neg, tgt, mlp_params={"dims": [32, 16], "dropout": 0.0}, alpha=0.2)
+        return model, {"features": feats, "history_features": hist, "neg_history_features": neg, "target_features": tgt}
     dense = [DenseFeature(f"I{i + 1}") for i in range(13)]
     vocabs = [3, 4, 10, 27, 105, 305, 583, 40, 1460, 24, 18, 15, 633] * 2
     if cfg in ("dcnv2_full_stacked", "fibinet", "fibinet_each"):
@@ -290,13 +310,19 @@ def gen_model(rh, cfg):
         for k, v in bx.items():
             out[f"x{bi}.{k}"] = npy(v)
         out[f"y{bi}"] = npy(by)
+    with_aux = cfg == "dien"  # forward returns (prediction, weighted auxiliary loss): CTRTrainer(loss_mode=False)
     model.eval()
     with torch.no_grad():
-        out["pred_eval"] = npy(model(x))
+        out["pred_eval"] = npy(model(x)[0] if with_aux else model(x))
     model.train()
     sd_backup = {k: v.clone() for k, v in model.state_dict().items()}
     pred = model(x)
-    loss = torch.nn.BCELoss()(pred, y.float())
+    if with_aux:
+        pred, aux = pred
+        out["aux_train"] = np.array(aux.item())
+        loss = torch.nn.BCELoss()(pred, y.float()) + aux
+    else:
+        loss = torch.nn.BCELoss()(pred, y.float())
     model.zero_grad()
     loss.backward()
     out["pred_train"] = npy(pred)
@@ -316,7 +342,8 @@ def gen_model(rh, cfg):
             out["user_emb"], out["item_emb"] = npy(model.user_tower(x)), npy(model.item_tower(x))
             model.train()
     else:
-        trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": wd}, n_epoch=1, device="cpu")
+        trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": wd}, n_epoch=1, device="cpu",
+                             loss_mode=not with_aux)
     mean_loss = trainer.train_one_epoch(batches)
     out["train.lr"], out["train.wd"], out["train.mean_loss"] = np.array(1e-2), np.array(wd), np.array(mean_loss)
     for n, t in model.state_dict().items():
@@ -325,8 +352,100 @@ def gen_model(rh, cfg):
     print(f"model_{cfg}.npz", len(out), "arrays, loss", loss.item(), "mean train loss", mean_loss)
 
 
+MTL_CONFIGS = ["shared_bottom", "esmm", "mmoe", "mmoe_uwl", "ple", "aitm"]
+
+
+def build_mtl(rh, cfg):
+    """Multi-task models at fixture size; returns (model, feature groups, task types)."""
+    from torch_rechub.basic.features import DenseFeature, SparseFeature
+    from torch_rechub.models.multi_task import AITM, ESMM, MMOE, PLE, SharedBottom
+    D = 16
+    dense = [DenseFeature(f"I{i + 1}") for i in range(4)]
+    sparse = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=D) for i, v in enumerate([3, 10, 27, 105, 305, 40, 24, 18])]
+    feats = dense + sparse
+    tower = {"dims": [8], "dropout": 0.0, "activation": "relu"}
+    body = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
+    if cfg == "shared_bottom":
+        types = ["classification", "regression"]
+        return SharedBottom(feats, types, body, [dict(tower), dict(tower)]), {"features": feats}, types
+    if cfg == "esmm":
+        types = ["classification"] * 3  # columns: cvr, ctr, ctcvr (the trainer skips the first loss)
+        return ESMM(sparse[:3], sparse[3:], dict(body), dict(body)), {"user_features": sparse[:3],
+                                                                       "item_features": sparse[3:]}, types
+    types = ["classification", "classification"]
+    if cfg in ("mmoe", "mmoe_uwl"):
+        return MMOE(feats, types, 3, body, [dict(tower), dict(tower)]), {"features": feats}, types
+    if cfg == "ple":
+        return PLE(feats, types, 2, 2, 1, body, [dict(tower), dict(tower)]), {"features": feats}, types
+    if cfg == "aitm":
+        return AITM(feats, 2, body, [dict(tower), dict(tower)]), {"features": feats}, types
+    raise ValueError(cfg)
+
+
+def gen_mtl(rh, cfg):
+    """Predictions, per-task losses, every gradient and the 3-step trajectory of the reference MTLTrainer
+    (trainers/mtl_trainer.py:112-165: mean of the task losses; ESMM: ctr + ctcvr; "uwl": learned loss weights)."""
+    from torch_rechub.trainers import MTLTrainer
+    torch.manual_seed(SEED)
+    g = torch.Generator().manual_seed(SEED + 2)
+    model, groups, types = build_mtl(rh, cfg)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Embedding):
+            torch.nn.init.normal_(m.weight, 0, 0.1, generator=g)
+    B = 48
+    batches = []
+    for _ in range(3):
+        x, _ = make_batch(groups, B, g)
+        ys = torch.stack([(torch.rand(B, generator=g) < 0.3).float() if t == "classification" else
+                          torch.randn(B, generator=g) for t in types], dim=1)
+        batches.append((x, ys))
+    out = {"spec": np.array(json.dumps({k: [spec_of(f) for f in v] for k, v in groups.items()})), "cfg": np.array(cfg),
+           "task_types": np.array(json.dumps(types))}
+    adaptive = {"method": "uwl"} if cfg.endswith("_uwl") else None
+    trainer = MTLTrainer(model, task_types=types, optimizer_params={"lr": 1e-2, "weight_decay": 1e-3},
+                         adaptive_params=adaptive, n_epoch=1, device="cpu")
+    for n, t in model.state_dict().items():  # after the trainer: "uwl" registers its weights on the model
+        out["sd0." + n] = npy(t)
+    for bi, (bx, by) in enumerate(batches):
+        for k, v in bx.items():
+            out[f"x{bi}.{k}"] = npy(v)
+        out[f"y{bi}"] = npy(by)
+    x, ys = batches[0]
+    model.eval()
+    with torch.no_grad():
+        out["pred_eval"] = npy(model(x))
+    model.train()
+    backup = {k: v.clone() for k, v in model.state_dict().items()}
+    pred = model(x)
+    losses = [trainer.loss_fns[i](pred[:, i], ys[:, i].float()) for i in range(len(types))]
+    if cfg == "esmm":
+        loss = sum(losses[1:])
+    elif adaptive:
+        loss = 0
+        for li, wi in zip(losses, trainer.loss_weight):
+            wi = torch.clamp(wi, min=0)
+            loss = loss + 2 * li * torch.exp(-wi) + wi
+    else:
+        loss = sum(losses) / len(types)
+    model.zero_grad()
+    loss.backward()
+    out["pred_train"], out["loss"] = npy(pred), np.array(loss.item())
+    out["task_losses"] = np.array([l.item() for l in losses])
+    for n, p in model.named_parameters():
+        out["grad." + n] = npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    model.load_state_dict(backup)
+    model.zero_grad()
+    per_task = trainer.train_one_epoch(batches)
+    out["train.lr"], out["train.wd"] = np.array(1e-2), np.array(1e-3)
+    out["train.task_losses"] = np.array(per_task)
+    for n, t in model.state_dict().items():
+        out["sd3." + n] = npy(t)
+    np.savez_compressed(os.path.join(OUT, f"model_{cfg}.npz"), **out)
+    print(f"model_{cfg}.npz", len(out), "arrays, loss", loss.item(), "train task losses", per_task)
+
+
 CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-           "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention"]
+           "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
@@ -337,3 +456,6 @@ if __name__ == "__main__":
     for cfg in CONFIGS:
         if not only or cfg in only:
             gen_model(rh, cfg)
+    for cfg in MTL_CONFIGS:
+        if not only or cfg in only:
+            gen_mtl(rh, cfg)

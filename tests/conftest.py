@@ -25,7 +25,8 @@ def layers_golden():
 
 
 MODEL_CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-                 "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention"]
+                 "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
+AUX_LOSS_CONFIGS = {"dien"}  # forward returns (prediction, weighted auxiliary loss): CTRTrainer(loss_mode=False)
 
 
 def features_from_spec(spec_json):
@@ -63,6 +64,14 @@ def build_amd_model(cfg, groups):
         tower = {"dims": [32, 16], "activation": "prelu"}
         return DSSM(groups["user_features"], groups["item_features"], user_params=dict(tower), item_params=dict(tower),
                     temperature=0.02)
+    if cfg == "bst":
+        from torch_rechub_amd.models.ranking import BST
+        return BST(groups["features"], groups["history_features"], groups["target_features"], mlp_params=mlp, nhead=2,
+                   dropout=0.0, num_layers=1, max_seq_len=8)
+    if cfg == "dien":
+        from torch_rechub_amd.models.ranking import DIEN
+        return DIEN(groups["features"], groups["history_features"], groups["neg_history_features"],
+                    groups["target_features"], mlp_params={"dims": [32, 16], "dropout": 0.0}, alpha=0.2)
     if cfg.startswith("din"):
         return DIN(groups["features"], groups["history_features"], groups["target_features"],
                    mlp_params={"dims": [32, 16], "dropout": 0.0},
@@ -92,6 +101,28 @@ def build_amd_model(cfg, groups):
         from torch_rechub_amd.models.ranking import FiBiNet
         return FiBiNet(groups["features"], mlp, reduction_ratio=3,
                        bilinear_type="field_interaction" if cfg == "fibinet" else "field_each")
+    raise ValueError(cfg)
+
+
+MTL_CONFIGS = ["shared_bottom", "esmm", "mmoe", "mmoe_uwl", "ple", "aitm"]
+
+
+def build_mtl_model(cfg, groups, task_types):
+    """Same constructor calls as oracle/gen_golden.py::build_mtl, on the torch_rechub_amd classes."""
+    from torch_rechub_amd.models.multi_task import AITM, ESMM, MMOE, PLE, SharedBottom
+    tower = {"dims": [8], "dropout": 0.0, "activation": "relu"}
+    body = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
+    towers = [dict(tower), dict(tower)]
+    if cfg == "shared_bottom":
+        return SharedBottom(groups["features"], task_types, body, towers)
+    if cfg == "esmm":
+        return ESMM(groups["user_features"], groups["item_features"], dict(body), dict(body))
+    if cfg in ("mmoe", "mmoe_uwl"):
+        return MMOE(groups["features"], task_types, 3, body, towers)
+    if cfg == "ple":
+        return PLE(groups["features"], task_types, 2, 2, 1, body, towers)
+    if cfg == "aitm":
+        return AITM(groups["features"], 2, body, towers)
     raise ValueError(cfg)
 
 

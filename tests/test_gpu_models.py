@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import MODEL_CONFIGS, build_amd_model, features_from_spec, golden_batch, golden_state, load_golden
+from conftest import AUX_LOSS_CONFIGS, MODEL_CONFIGS, MTL_CONFIGS, build_amd_model, build_mtl_model, features_from_spec, golden_batch, golden_state, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -45,15 +45,21 @@ def test_forward_loss_and_gradients_match_reference(cfg):
     gold, model = load_model(cfg)
     x, y = golden_batch(gold, 0)
     xd, yd = to_dev(x), y.to(dev()).float()
+    aux = cfg in AUX_LOSS_CONFIGS
+    # recurrent / attention stacks on the libraries (MIOpen GRU, SDPA) reorder more sums than the MLP-only models
+    rtol, atol = (1e-4, 1e-5) if cfg in ("bst", "dien") else (1e-5, 2e-6)
     model.eval()
     with torch.no_grad():
-        pe = model(xd)
-    np.testing.assert_allclose(pe.cpu().numpy(), gold["pred_eval"], rtol=1e-5, atol=2e-6)
+        pe = model(xd)[0] if aux else model(xd)
+    np.testing.assert_allclose(pe.cpu().numpy(), gold["pred_eval"], rtol=rtol, atol=atol)
     model.train()
     pred = model(xd)
-    np.testing.assert_allclose(pred.detach().cpu().numpy(), gold["pred_train"], rtol=1e-5, atol=2e-6)
-    loss = torch.nn.BCELoss()(pred, yd)
-    assert abs(loss.item() - float(gold["loss"])) < 2e-6
+    if aux:
+        pred, aux_loss = pred
+        assert abs(aux_loss.item() - float(gold["aux_train"])) < 1e-5
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), gold["pred_train"], rtol=rtol, atol=atol)
+    loss = torch.nn.BCELoss()(pred, yd) + (aux_loss if aux else 0.0)
+    assert abs(loss.item() - float(gold["loss"])) < (2e-5 if cfg in ("bst", "dien") else 2e-6)
     loss.backward()
     ops.check_errors()
     # atol is tied to the largest gradient of the model: a Linear bias in front of BatchNorm has an exactly-zero
@@ -71,7 +77,8 @@ def test_forward_loss_and_gradients_match_reference(cfg):
         if n in noise:
             assert np.abs(got).max() <= 1e-5 * max(gmax, 1e-3) + 1e-6 and np.abs(ref).max() <= 1e-5 * max(gmax, 1e-3) + 1e-6, n
             continue
-        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * gmax, err_msg=f"{cfg}: grad of {n}")
+        np.testing.assert_allclose(got, ref, rtol=1e-4 if cfg not in ("bst", "dien") else 1e-3,
+                                   atol=(2e-6 if cfg not in ("bst", "dien") else 2e-5) * gmax, err_msg=f"{cfg}: grad of {n}")
 
 
 @pytest.mark.parametrize("mode", ["dense", "lazy"])
@@ -91,7 +98,7 @@ def test_three_step_training_matches_reference_trainer(cfg, mode):
                                table_update=mode, lazy_k=2)
     else:
         trainer = CTRTrainer(model, optimizer_params=params, n_epoch=1, device="cuda:0", show_progress=False,
-                             table_update=mode, lazy_k=2)
+                             table_update=mode, lazy_k=2, loss_mode=cfg not in AUX_LOSS_CONFIGS)
     mean_loss = trainer.train_one_epoch(batches)
     assert abs(mean_loss - float(gold["train.mean_loss"])) < 5e-5
     ref = golden_state(gold, "sd3.")
@@ -112,7 +119,14 @@ def test_three_step_training_matches_reference_trainer(cfg, mode):
             # the batch mean of (W x + b) carries the noise-driven drift of the bias b above one-for-one
             assert np.abs(got - v.numpy()).max() <= 0.5 * lr * steps, k
             continue
-        assert_trajectory_close(got, v.numpy(), lr * steps, f"{cfg}: {k} after 3 steps")
+        want = v.numpy()
+        if k.endswith("self_attn.in_proj_bias"):
+            # the KEY bias shifts every score of a softmax row by the same q . b: its gradient is zero mathematically and
+            # rounding noise in practice, which Adam turns into +-lr steps; only the query / value thirds are defined
+            d = got.shape[0] // 3
+            assert np.abs(got[d:2 * d] - want[d:2 * d]).max() <= 2.1 * lr * steps, k
+            got, want = np.delete(got, np.s_[d:2 * d]), np.delete(want, np.s_[d:2 * d])
+        assert_trajectory_close(got, want, lr * steps, f"{cfg}: {k} after 3 steps")
     # rows never touched by the three batches still moved (dense Adam + coupled L2)
     name = next(k for k in ref if "embed_dict" in k)
     before = gold["sd0." + name]
@@ -349,3 +363,89 @@ def test_checkpoint_written_on_gpu_loads_into_the_reference_layout():
     x, _ = batches[0]
     with torch.no_grad():
         np.testing.assert_allclose(model(to_dev(x)).cpu().numpy(), port(x).numpy(), rtol=1e-5, atol=2e-6)
+
+
+# -- multi-task models + MTLTrainer against the reference's own trainer ---------------------------------
+def load_mtl(cfg):
+    import json
+    gold = load_golden(f"model_{cfg}.npz")
+    types = json.loads(str(gold["task_types"]))
+    model = build_mtl_model(cfg, features_from_spec(gold["spec"]), types)
+    return gold, model, types
+
+
+def _mtl_trainer(cfg, model, types, gold, **kw):
+    from torch_rechub_amd.trainers import MTLTrainer
+    params = {"lr": float(gold["train.lr"]), "weight_decay": float(gold["train.wd"])}
+    params.update(kw.pop("extra", {}))
+    trainer = MTLTrainer(model, task_types=types, optimizer_params=params, n_epoch=1, device="cuda:0",
+                         adaptive_params={"method": "uwl"} if cfg.endswith("_uwl") else None, show_progress=False, **kw)
+    model.load_state_dict(golden_state(gold, "sd0."))  # after the trainer: "uwl" adds its weights to the model
+    return trainer
+
+
+@pytest.mark.parametrize("cfg", MTL_CONFIGS)
+def test_multi_task_forward_losses_and_gradients_match_reference(cfg):
+    from torch_rechub_amd import ops
+    gold, model, types = load_mtl(cfg)
+    trainer = _mtl_trainer(cfg, model, types, gold)
+    x, ys = golden_batch(gold, 0)
+    xd, yd = to_dev(x), ys.to(dev()).float()
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(xd).cpu().numpy(), gold["pred_eval"], rtol=1e-5, atol=2e-6)
+    model.train()
+    np.testing.assert_allclose(model(xd).detach().cpu().numpy(), gold["pred_train"], rtol=1e-5, atol=2e-6)
+    # the trainer's own loss (mean of the task losses / ESMM's ctr + ctcvr / uncertainty weighting) and its per-task log
+    model.load_state_dict(golden_state(gold, "sd0."))  # undo the BatchNorm running-stat update of the probe forward
+    trainer._task_loss.zero_()
+    loss = trainer._compute_loss(xd, yd)
+    assert abs(loss.item() - float(gold["loss"])) < 5e-6
+    np.testing.assert_allclose(trainer._task_loss.cpu().numpy(), gold["task_losses"], rtol=1e-5, atol=2e-6)
+    trainer._zero_grad()
+    loss.backward()
+    ops.check_errors()
+    gmax = max(float(np.abs(gold["grad." + n]).max()) for n, _ in model.named_parameters())
+    noise = set()
+    for mn, m in model.named_modules():
+        if isinstance(m, torch.nn.Sequential):
+            mods = list(m)
+            noise |= {f"{mn}.{i}.bias" for i in range(len(mods) - 1)
+                      if isinstance(mods[i], torch.nn.Linear) and isinstance(mods[i + 1], torch.nn.BatchNorm1d)}
+    for n, p in model.named_parameters():
+        ref = gold["grad." + n]
+        if "embed_dict" in n:
+            got = ops.grad_buffer(p).cpu().numpy()
+        else:
+            got = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        if n in noise:
+            assert np.abs(got).max() <= 1e-5 * max(gmax, 1e-3) + 1e-6, n
+            continue
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * gmax, err_msg=f"{cfg}: grad of {n}")
+
+
+@pytest.mark.parametrize("mode", ["dense", "lazy"])
+@pytest.mark.parametrize("cfg", MTL_CONFIGS)
+def test_multi_task_three_steps_match_reference_mtl_trainer(cfg, mode):
+    gold, model, types = load_mtl(cfg)
+    extra = {"lazy_small_rows": 8} if mode == "lazy" else {}
+    trainer = _mtl_trainer(cfg, model, types, gold, table_update=mode, lazy_k=2, extra=extra)
+    nb = sum(1 for k in gold.files if k.startswith("y") and k[1:].isdigit())
+    per_task = trainer.train_one_epoch([golden_batch(gold, i) for i in range(nb)])
+    np.testing.assert_allclose(per_task, gold["train.task_losses"], rtol=1e-4, atol=5e-5)
+    ref = golden_state(gold, "sd3.")
+    mine = model.state_dict()
+    gmax = max(float(np.abs(gold[k]).max()) for k in gold.files if k.startswith("grad."))
+    lr, steps = float(gold["train.lr"]), 3
+    for k, v in ref.items():
+        got = mine[k].detach().cpu().numpy()
+        if k.endswith("num_batches_tracked"):
+            assert int(got) == int(v)
+            continue
+        if "grad." + k in gold.files and float(np.abs(gold["grad." + k]).max()) < 1e-5 * gmax:
+            assert np.abs(got - v.numpy()).max() <= 2.1 * lr * steps, k  # noise-driven (bias in front of BatchNorm)
+            continue
+        if k.endswith("running_mean"):
+            assert np.abs(got - v.numpy()).max() <= 0.5 * lr * steps, k
+            continue
+        assert_trajectory_close(got, v.numpy(), lr * steps, f"{cfg}: {k} after 3 steps")

@@ -5,7 +5,7 @@ import pytest
 import torch
 from torch import nn
 
-from conftest import MODEL_CONFIGS, build_amd_model, features_from_spec, golden_batch, golden_state, load_golden
+from conftest import MODEL_CONFIGS, MTL_CONFIGS, build_amd_model, build_mtl_model, features_from_spec, golden_batch, golden_state, load_golden
 
 
 @pytest.mark.parametrize("cfg", MODEL_CONFIGS)
@@ -203,3 +203,34 @@ def test_match_trainer_rejects_models_without_towers():
     from torch_rechub_amd.trainers import MatchTrainer
     with pytest.raises(ValueError, match="does not support in-batch negative sampling"):
         MatchTrainer(nn.Linear(2, 1), in_batch_neg=True, device="cuda:0")
+
+
+@pytest.mark.parametrize("cfg", MTL_CONFIGS)
+def test_multi_task_state_dict_keys_and_shapes_match_reference(cfg):
+    """Checkpoint ABI of the multi-task mirrors (models/multi_task/*.py): same keys, order and shapes as the reference
+    model the fixture was dumped from ("uwl": the trainer registers the loss weights under "loss weight")."""
+    import json
+    gold = load_golden(f"model_{cfg}.npz")
+    types = json.loads(str(gold["task_types"]))
+    model = build_mtl_model(cfg, features_from_spec(gold["spec"]), types)
+    if cfg.endswith("_uwl"):
+        model.add_module("loss weight", torch.nn.ParameterList(torch.nn.Parameter(torch.zeros(1)) for _ in types))
+    want = golden_state(gold, "sd0.")
+    have = model.state_dict()
+    assert list(have.keys()) == list(want.keys())
+    for k in want:
+        assert tuple(have[k].shape) == tuple(want[k].shape), k
+
+
+def test_mtl_trainer_argument_checks():
+    from torch_rechub_amd.trainers import MTLTrainer
+    from torch_rechub_amd.utils.data import get_loss_func, get_metric_func
+    assert isinstance(get_loss_func("classification"), torch.nn.BCELoss)
+    assert isinstance(get_loss_func("regression"), torch.nn.MSELoss)
+    assert get_metric_func("classification").__name__ == "roc_auc_score"
+    with pytest.raises(ValueError):
+        get_loss_func("ranking")
+    with pytest.raises(NotImplementedError):
+        MTLTrainer(torch.nn.Linear(2, 2), ["classification"] * 2, adaptive_params={"method": "gradnorm"}, device="cuda:0")
+    with pytest.raises(RuntimeError):  # the HIP hot path has no CPU mode
+        MTLTrainer(torch.nn.Linear(2, 2), ["classification"] * 2, device="cpu")

@@ -26,10 +26,11 @@ from . import ops
 
 
 def table_parameters(model):
-    """Parameters that belong to nn.Embedding modules (deduplicated, model.parameters() order)."""
+    """Parameters that belong to nn.Embedding modules (deduplicated, model.parameters() order).  A module flagged
+    ``_rh_dense`` (a small table read as a slice, e.g. BST's positional table) counts as a dense parameter."""
     ids = set()
     for m in model.modules():
-        if isinstance(m, (nn.Embedding, nn.EmbeddingBag)):
+        if isinstance(m, (nn.Embedding, nn.EmbeddingBag)) and not getattr(m, "_rh_dense", False):
             ids.update(id(p) for p in m.parameters())
     return [p for p in model.parameters() if id(p) in ids]
 

@@ -5,9 +5,11 @@ from importlib import import_module
 _EXPORTS = {
     "afm": ("AFM",),
     "autoint": ("AutoInt",),
+    "bst": ("BST",),
     "dcn": ("DCN",),
     "dcn_v2": ("DCNv2",),
     "deepfm": ("DeepFM",),
+    "dien": ("DIEN", "AUGRU", "AUGRU_Cell"),
     "din": ("DIN", "ActivationUnit"),
     "edcn": ("EDCN",),
     "fibinet": ("FiBiNet",),

@@ -100,7 +100,8 @@ def shard_tables(model, group=None, min_rows=0):
         raise RuntimeError("row-sharded tables need an initialised process group (launch with torchrun)")
     out, seen = [], set()
     for m in model.modules():
-        if isinstance(m, nn.Embedding) and id(m) not in seen and m.weight.shape[0] >= min_rows:
+        if (isinstance(m, nn.Embedding) and id(m) not in seen and m.weight.shape[0] >= min_rows and
+                not getattr(m, "_rh_dense", False)):
             seen.add(id(m))
             shard_table(m, group)
             out.append(m)

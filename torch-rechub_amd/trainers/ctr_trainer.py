@@ -312,6 +312,7 @@ class CTRTrainer(object):
                     run.zero_()
         self.flush()
         ops.check_errors(self.device)
+        self._epoch_batches = batch_count
         return epoch.item() / batch_count if batch_count > 0 else 0
 
     def flush(self):

@@ -17,6 +17,25 @@ from torch.utils.data import DataLoader, Dataset, random_split
 from .. import _lib, ops
 
 
+def get_loss_func(task_type="classification"):
+    """Default criterion of a task (reference utils/data.py:104-110): BCELoss on probabilities / MSELoss."""
+    if task_type == "classification":
+        return torch.nn.BCELoss()
+    if task_type == "regression":
+        return torch.nn.MSELoss()
+    raise ValueError("task_type must be classification or regression")
+
+
+def get_metric_func(task_type="classification"):
+    """Default validation metric of a task (reference utils/data.py:113-119): ROC AUC / mean squared error."""
+    from sklearn.metrics import mean_squared_error, roc_auc_score
+    if task_type == "classification":
+        return roc_auc_score
+    if task_type == "regression":
+        return mean_squared_error
+    raise ValueError("task_type must be classification or regression")
+
+
 class TorchDataset(Dataset):
 
     def __init__(self, x, y):
