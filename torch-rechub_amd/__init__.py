@@ -7,8 +7,9 @@ Layout (mirrors only what the hot path needs from the reference package):
   csrc/        hand-written HIP kernels + the C ABI (include/rechub_hip.h) -> librechub_hip.so
   _lib.py      ctypes binding; ops.py: autograd functions over raw pointers + the current HIP stream
   basic/       features, initializers, activation, layers, loss_func, callback   (reference basic/*)
-  models/ranking/  DeepFM, WideDeep, DCN, DCNv2, DIN                           (reference models/ranking/*)
-  trainers/    CTRTrainer                                                      (reference trainers/ctr_trainer.py)
+  models/ranking/  DeepFM, WideDeep, DCN, DCNv2, DIN, DIEN, BST, AFM, AutoInt, EDCN, FiBiNet   (reference models/ranking/*)
+  models/matching/ DSSM; models/multi_task/ SharedBottom, ESMM, MMOE, PLE, AITM
+  trainers/    CTRTrainer, MatchTrainer, MTLTrainer                            (reference trainers/*.py)
   utils/data.py    DataGenerator / TorchDataset + the HBM-resident DeviceDataLoader
   optim.py     FusedDenseAdam (torch.optim.Adam semantics, tables stepped by one HIP launch)
   distributed.py   one-process-per-GPU data parallel over RCCL (dense all-reduce + sparse row exchange)
