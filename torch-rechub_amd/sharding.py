@@ -256,17 +256,22 @@ def _localize(embs, idx, group):
     key = tuple([e._rh_shard.vocab for e in embs] + [e._rh_shard.pad for e in embs] + [e._rh_shard.sink for e in embs])
     desc = _desc_cache.get(key, idx.device)
     n_all = idx.shape[0] * max(dist.get_world_size(group), sh0.world)
-
     width = sum(e._rh_shard.dim for e in embs)
+    # ids travel as int32 when every vocabulary allows it (the loader holds int64, as the reference's encoders emit):
+    # half the bytes of the one exchange that grows with the number of ranks on the forward's critical path
+    narrow = idx.dtype == torch.int64 and max(e._rh_shard.vocab for e in embs) < 2**31
+    wire = torch.int32 if narrow else idx.dtype
 
     def make():
-        return (torch.empty((n_all, idx.shape[1]), dtype=idx.dtype, device=idx.device),
+        return (torch.empty((n_all, idx.shape[1]), dtype=wire, device=idx.device),
                 torch.empty((n_all, idx.shape[1]), dtype=torch.int32, device=idx.device),
                 torch.empty((idx.shape[0], width), dtype=torch.float32, device=idx.device))
 
     site = (tuple(id(e) for e in embs), idx.data_ptr(), tuple(idx.shape), tuple(idx.stride()), idx.dtype, sh0.rank)
     idx_all, loc, rows = _buffers.get(site, make)
-    all_gather_cat(idx, group, out=idx_all)
+    # saturating: an id beyond int32 must stay out of range (-> RH_FLAG_INDEX_OOB), not wrap onto a valid row
+    send = idx.clamp(min=-1, max=2**31 - 1).to(torch.int32) if narrow else idx
+    all_gather_cat(send, group, out=idx_all)
     return ops.shard_localize(idx_all, desc, sh0.world, sh0.rank, out=loc), rows
 
 
