@@ -43,12 +43,18 @@ def _train(rows_of_step, world, tables="replicate"):
     from torch_rechub_amd import sharding
     from torch_rechub_amd.trainers import CTRTrainer
     model, dfe, sfe = _model()
+    # "shard>=300": only the tables with at least 300 rows are sharded, the small ones stay replicated (their
+    # gradient rows go through the all-gather exchange): both mechanisms inside one lookup list
+    min_rows = 300 if tables == "shard>=300" else 0
+    placement = "shard" if tables.startswith("shard") else tables
     trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64},
-                         device="cuda:0", show_progress=False, lazy_k=4, tables=tables if world > 1 else None)
+                         device="cuda:0", show_progress=False, lazy_k=4, tables=placement if world > 1 else None,
+                         shard_min_rows=min_rows)
     assert (trainer.dp is not None) == (world > 1)
-    if world > 1 and tables == "shard":
+    if world > 1 and placement == "shard":
         emb = model.embedding.embed_dict["C5"]
         assert sharding.is_sharded(emb) and emb.weight.shape[0] == -(-305 // world) + 1
+        assert sharding.is_sharded(model.embedding.embed_dict["C0"]) == (min_rows == 0)
     sparse, dense, label = _data()
     model.train()
     losses = []
@@ -87,7 +93,7 @@ def _two_ranks(tmp_path, train, arg):
     return torch.load(os.path.join(tmp_path, "rank0.pt")), torch.load(os.path.join(tmp_path, "rank1.pt"))
 
 
-@pytest.mark.parametrize("tables", ["replicate", "shard"])
+@pytest.mark.parametrize("tables", ["replicate", "shard", "shard>=300"])
 def test_two_ranks_reproduce_one_process_on_the_global_batch(tmp_path, tables):
     r0, r1 = _two_ranks(tmp_path, _train, tables)
     single, losses = _train(lambda s: slice(s * 2 * B, (s + 1) * 2 * B), world=1)
