@@ -385,3 +385,58 @@ def inbatch_sample_rows(seed, ctr, B, cols, row0, K):
             taken.add(pick)
             out[i, pos] = pick + (1 if pick >= own else 0)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# AUGRU  models/ranking/dien.py:17-66 (AUGRU_Cell.forward :30-36, the step loop of AUGRU.forward :60-66)
+# ---------------------------------------------------------------------------------------------------
+def augru_forward(xw, attn, U):
+    """h_all (B, T, D).  xw (B, T, 3D) = x_t [Wu|Wr|Wh] + [bu|br|bh]; attn (B, T); U (D, 3D) = [Uu|Ur|Uh]; h_0 = 0.
+    Per step (dien.py:32-36): u = sig(xw_u + h Uu), r = sig(xw_r + h Ur), c = tanh(xw_h + r * (h Uh)),
+    h' = (1 - a u) h + a u c."""
+    B, T, D3 = xw.shape
+    D = D3 // 3
+    h = np.zeros((B, D), dtype=xw.dtype)
+    out = np.empty((B, T, D), dtype=xw.dtype)
+    for t in range(T):
+        hu = h @ U
+        u = sigmoid(xw[:, t, :D] + hu[:, :D])
+        r = sigmoid(xw[:, t, D:2 * D] + hu[:, D:2 * D])
+        c = np.tanh(xw[:, t, 2 * D:] + r * hu[:, 2 * D:])
+        g = attn[:, t:t + 1] * u
+        h = (1 - g) * h + g * c
+        out[:, t] = h
+    return out
+
+
+def augru_backward(xw, attn, U, g_hall):
+    """Hand-derived backward through time: returns (d_xw (B,T,3D), d_attn (B,T), d_U (D,3D)) for upstream g_hall (B,T,D)."""
+    B, T, D3 = xw.shape
+    D = D3 // 3
+    h_all = augru_forward(xw, attn, U)
+    d_xw = np.zeros_like(xw)
+    d_attn = np.zeros_like(attn)
+    d_U = np.zeros_like(U)
+    dh = np.zeros((B, D), dtype=xw.dtype)
+    for t in range(T - 1, -1, -1):
+        dh = dh + g_hall[:, t]
+        hp = h_all[:, t - 1] if t > 0 else np.zeros((B, D), dtype=xw.dtype)
+        hu = hp @ U
+        u = sigmoid(xw[:, t, :D] + hu[:, :D])
+        r = sigmoid(xw[:, t, D:2 * D] + hu[:, D:2 * D])
+        q = hu[:, 2 * D:]
+        c = np.tanh(xw[:, t, 2 * D:] + r * q)
+        a = attn[:, t:t + 1]
+        g = a * u
+        dg = dh * (c - hp)
+        dc = dh * g
+        d_attn[:, t] = (dg * u).sum(1)
+        dpu = dg * a * u * (1 - u)
+        dpc = dc * (1 - c * c)
+        dpr = dpc * q * r * (1 - r)
+        dq = dpc * r
+        d_xw[:, t] = np.concatenate([dpu, dpr, dpc], axis=1)
+        d_hu = np.concatenate([dpu, dpr, dq], axis=1)
+        d_U += hp.T @ d_hu
+        dh = dh * (1 - g) + d_hu @ U.T
+    return d_xw, d_attn, d_U

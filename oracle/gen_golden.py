@@ -352,6 +352,35 @@ def gen_model(rh, cfg):
     print(f"model_{cfg}.npz", len(out), "arrays, loss", loss.item(), "mean train loss", mean_loss)
 
 
+def gen_augru(rh):
+    """AUGRU of the UNMODIFIED reference (models/ranking/dien.py:38-66) on a ragged batch: states of every step, the
+    final state, and the gradients of a random linear functional of them with respect to inputs and parameters."""
+    from torch_rechub.models.ranking.dien import AUGRU
+    torch.manual_seed(SEED + 7)
+    g = torch.Generator().manual_seed(SEED + 8)
+    out = {}
+    for D, B, T in ((16, 37, 9), (8, 5, 4)):
+        net = AUGRU(D)
+        for p in net.parameters():
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.4)
+        x = (torch.randn(B, T, D, generator=g) * 0.8).requires_grad_(True)
+        item = torch.randn(B, D, generator=g).requires_grad_(True)
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        mask = torch.arange(T)[None, :] < lens[:, None]
+        outs, h = net(x, item, mask)
+        G, Gh = torch.randn(B, T, D, generator=g), torch.randn(B, D, generator=g)
+        ((outs * G).sum() + (h * Gh).sum()).backward()
+        tag = f"d{D}."
+        out[tag + "x"], out[tag + "item"], out[tag + "mask"] = npy(x), npy(item), npy(mask)
+        out[tag + "outs"], out[tag + "h"], out[tag + "G"], out[tag + "Gh"] = npy(outs), npy(h), npy(G), npy(Gh)
+        out[tag + "gx"], out[tag + "gitem"] = npy(x.grad), npy(item.grad)
+        for n, p in net.named_parameters():
+            out[tag + "p." + n], out[tag + "g." + n] = npy(p), npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, "augru.npz"), **out)
+    print("augru.npz", len(out), "arrays")
+
+
 MTL_CONFIGS = ["shared_bottom", "esmm", "mmoe", "mmoe_uwl", "ple", "aitm"]
 
 
@@ -453,6 +482,8 @@ if __name__ == "__main__":
     only = sys.argv[1:]  # optional: regenerate just the named fixtures ("layers" or model configs)
     if not only or "layers" in only:
         gen_layers(rh)
+    if not only or "augru" in only:
+        gen_augru(rh)
     for cfg in CONFIGS:
         if not only or cfg in only:
             gen_model(rh, cfg)

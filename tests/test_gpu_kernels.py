@@ -1077,3 +1077,31 @@ def test_fused_rows_is_the_fused_gather_stage_on_rows_in_place(B, F, D, ND):
     plain, none_fm, none_lr = ops.fused_rows(emb.detach(), F)
     assert none_fm is None and none_lr is None and torch.equal(plain, emb.detach())
     ops.check_errors()
+
+
+@pytest.mark.parametrize("B,T,D", [(37, 9, 16), (130, 5, 8), (64, 1, 4), (5, 12, 32), (300, 100, 16)])
+def test_augru_recurrence_forward_and_backward_through_time(B, T, D):
+    """ops.augru (csrc/augru.hip) against the float64 oracle, which tests/test_oracle_golden.py pins to the reference's
+    AUGRU (dien.py:30-66): every state; gradients of xw, the attention weights and U for a random upstream gradient on
+    every state.  Tolerance: fp32 recurrence of T dependent steps vs float64, rtol 2e-4 on gradients."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + D)
+    xw = (torch.randn(B, T, 3 * D, generator=g) * 0.8)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    attn = torch.rand(B, T, generator=g) * (torch.arange(T)[None, :] < lens[:, None])  # 0 on padded steps
+    U = torch.randn(D, 3 * D, generator=g) * (0.5 / D**0.5)
+    G = torch.randn(B, T, D, generator=g)
+    xd, ad, ud = (t.to(dev()).requires_grad_(True) for t in (xw, attn, U))
+    h_all = ops.augru(xd, ad, ud)
+    want = O.augru_forward(xw.numpy().astype(F64), attn.numpy().astype(F64), U.numpy().astype(F64))
+    close(h_all, want, rtol=2e-5, atol_scale=2e-6, what="states")
+    h_all.backward(G.to(dev()))
+    d_xw, d_attn, d_U = O.augru_backward(xw.numpy().astype(F64), attn.numpy().astype(F64), U.numpy().astype(F64),
+                                         G.numpy().astype(F64))
+    close(xd.grad, d_xw, rtol=2e-4, atol_scale=2e-6, what="d xw")
+    close(ad.grad, d_attn, rtol=2e-4, atol_scale=2e-6, what="d attn")
+    close(ud.grad, d_U, rtol=2e-4, atol_scale=5e-6, what="d U")
+    # a padded step leaves the state where it was
+    hs = h_all.detach().cpu()
+    stay = (attn[:, 1:] == 0)
+    assert torch.equal(hs[:, 1:][stay], hs[:, :-1][stay])

@@ -82,13 +82,16 @@ SIGNATURES = {
     "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],
     "rh_inbatch_sample": [c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_inbatch_sample_rows": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_augru_max_dim": [],
+    "rh_augru_fwd": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_augru_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_shard_localize": [c_ptr, c_int, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
 }
 _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctypes.c_int64}
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
                     "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles",
-                    "rh_head_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks"}
+                    "rh_head_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks", "rh_augru_max_dim"}
 
 ABI_VERSION = 1
 _lib = None

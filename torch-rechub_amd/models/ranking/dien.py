@@ -15,13 +15,15 @@ boolean-mask indexing):
   the pair count (0 when there is none) instead of indexing the valid rows out.
 * AUGRU (dien.py:38-66): attention = softmax of (x Wa) . target over the valid steps; a padded step has weight 0 and
   leaves the state untouched, rows without history keep the zero state.  The three input projections of all steps are
-  ONE product, the three state projections one product per step.
+  ONE product; the recurrence itself and its backward through time are one HIP launch each (``ops.augru``,
+  csrc/augru.hip: one lane per sample, state in registers) for embed_dim 4 / 8 / 16 / 32, a per-step product otherwise.
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
 from torch.nn import Parameter, init
 
+from ... import ops
 from ...basic.layers import MLP, EmbeddingLayer
 
 
@@ -83,6 +85,9 @@ class AUGRU(nn.Module):
         W, b = self.augru_cell.input_weights()
         xw = (x.reshape(B * T, D) @ W + b).view(B, T, 3 * D)
         U = self.augru_cell.state_weights()
+        if ops.augru_ok(xw, D):  # the whole recurrence (and its backward through time) as one HIP launch
+            outs = ops.augru(xw, attn, U)
+            return outs, outs[:, -1]
         h = x.new_zeros(B, D)
         outs = []
         for t in range(T):

@@ -1137,6 +1137,52 @@ def cross_mix_epilogue(x0, xl, uv, gate, bias):
 
 
 # --------------------------------------------------------------------------------------------
+class _AugruFn(torch.autograd.Function):
+    """h_all (B, T, D) = AUGRU recurrence over xw (B, T, 3D), attn (B, T), U (D, 3D) (csrc/augru.hip)."""
+
+    @staticmethod
+    def forward(ctx, xw, attn, U):
+        require_hip(xw, attn, U)
+        B, T, D3 = xw.shape
+        D = D3 // 3
+        xw, attn, U = xw.contiguous(), attn.contiguous(), U.contiguous()
+        h_all = torch.empty((B, T, D), dtype=torch.float32, device=xw.device)
+        _lib.call("rh_augru_fwd", _p(xw), _p(attn), _p(U), B, T, D, _p(h_all), _stream())
+        ctx.save_for_backward(xw, attn, U, h_all)
+        return h_all
+
+    @staticmethod
+    def backward(ctx, g):
+        xw, attn, U, h_all = ctx.saved_tensors
+        B, T, D3 = xw.shape
+        D = D3 // 3
+        g = g.contiguous()
+        d_xw = torch.empty_like(xw)
+        d_huh = torch.empty((B, T, D), dtype=torch.float32, device=xw.device)
+        d_attn = torch.empty((B, T), dtype=torch.float32, device=xw.device)
+        _lib.call("rh_augru_bwd", _p(xw), _p(attn), _p(U), _p(h_all), _p(g), B, T, D, _p(d_xw), _p(d_huh), _p(d_attn),
+                  _stream())
+        d_U = None
+        if ctx.needs_input_grad[2]:
+            # dU = sum_t h_{t-1}^T [d pre_u | d pre_r | d (h Uh)]: one product over all (sample, step) pairs
+            h_prev = torch.cat([h_all.new_zeros(B, 1, D), h_all[:, :-1]], dim=1).reshape(B * T, D)
+            d_hu = torch.cat([d_xw[:, :, :2 * D], d_huh], dim=2).reshape(B * T, D3)
+            d_U = h_prev.t() @ d_hu
+        return d_xw, d_attn, d_U
+
+
+def augru_ok(xw, D):
+    return (xw.is_cuda and xw.dtype == torch.float32 and xw.dim() == 3 and xw.shape[1] >= 1 and
+            D in (4, 8, 16, 32) and xw.shape[2] == 3 * D)
+
+
+def augru(xw, attn, U):
+    """States h_1 .. h_T (B, T, D) of the attentional-update GRU (reference dien.py:30-36, 60-66) in one launch each
+    way; ``xw`` holds the input halves of the three gates for every step, ``U`` = [Uu | Ur | Uh]."""
+    return _AugruFn.apply(xw, attn, U)
+
+
+# --------------------------------------------------------------------------------------------
 _sample_rng = {}
 
 
