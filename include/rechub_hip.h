@@ -384,7 +384,7 @@ int rh_inbatch_sample_rows(const int64_t* rng, int B, int cols, int row0, int K,
  * backward: g_hall (B, T, D) = upstream gradient of every h_t (may be null: zeros);
  *           d_xw (B, T, 3D) = gradient of xw;  d_huh (B, T, D) = gradient of (h_{t-1} Uh) (so that
  *           dU = [h_0 .. h_{T-1}]^T [d_xw_u | d_xw_r | d_huh] is one GEMM by the caller);  d_attn (B, T).
- * D in {4, 8, 16, 32} (rh_augru_max_dim()); one lane per sample, state in registers, U in LDS. */
+ * D in {4, 8, 16, 32} (rh_augru_max_dim()); D / 4 lanes per sample, state in registers, U in LDS. */
 int rh_augru_max_dim(void);
 int rh_augru_fwd(const float* xw, const float* attn, const float* U, int B, int T, int D, float* h_all, void* stream);
 int rh_augru_bwd(const float* xw, const float* attn, const float* U, const float* h_all, const float* g_hall, int B,

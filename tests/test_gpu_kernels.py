@@ -1083,7 +1083,8 @@ def test_fused_rows_is_the_fused_gather_stage_on_rows_in_place(B, F, D, ND):
 def test_augru_recurrence_forward_and_backward_through_time(B, T, D):
     """ops.augru (csrc/augru.hip) against the float64 oracle, which tests/test_oracle_golden.py pins to the reference's
     AUGRU (dien.py:30-66): every state; gradients of xw, the attention weights and U for a random upstream gradient on
-    every state.  Tolerance: fp32 recurrence of T dependent steps vs float64, rtol 2e-4 on gradients."""
+    every state.  Tolerance: fp32 recurrence of up to 100 dependent steps with the hardware exponent / reciprocal
+    (v_exp_f32, v_rcp_f32: 1 ulp each) vs float64 -- states rtol 1e-4 + 1e-5 * max, gradients rtol 5e-4 + 1e-5 * max."""
     from torch_rechub_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + T * 10 + D)
     xw = (torch.randn(B, T, 3 * D, generator=g) * 0.8)
@@ -1094,13 +1095,13 @@ def test_augru_recurrence_forward_and_backward_through_time(B, T, D):
     xd, ad, ud = (t.to(dev()).requires_grad_(True) for t in (xw, attn, U))
     h_all = ops.augru(xd, ad, ud)
     want = O.augru_forward(xw.numpy().astype(F64), attn.numpy().astype(F64), U.numpy().astype(F64))
-    close(h_all, want, rtol=2e-5, atol_scale=2e-6, what="states")
+    close(h_all, want, rtol=1e-4, atol_scale=1e-5, what="states")
     h_all.backward(G.to(dev()))
     d_xw, d_attn, d_U = O.augru_backward(xw.numpy().astype(F64), attn.numpy().astype(F64), U.numpy().astype(F64),
                                          G.numpy().astype(F64))
-    close(xd.grad, d_xw, rtol=2e-4, atol_scale=2e-6, what="d xw")
-    close(ad.grad, d_attn, rtol=2e-4, atol_scale=2e-6, what="d attn")
-    close(ud.grad, d_U, rtol=2e-4, atol_scale=5e-6, what="d U")
+    close(xd.grad, d_xw, rtol=5e-4, atol_scale=1e-5, what="d xw")
+    close(ad.grad, d_attn, rtol=5e-4, atol_scale=1e-5, what="d attn")
+    close(ud.grad, d_U, rtol=5e-4, atol_scale=1e-5, what="d U")
     # a padded step leaves the state where it was
     hs = h_all.detach().cpu()
     stay = (attn[:, 1:] == 0)
