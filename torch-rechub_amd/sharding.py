@@ -267,7 +267,10 @@ def _localize(embs, idx, group):
                 torch.empty((n_all, idx.shape[1]), dtype=torch.int32, device=idx.device),
                 torch.empty((idx.shape[0], width), dtype=torch.float32, device=idx.device))
 
-    site = (tuple(id(e) for e in embs), idx.data_ptr(), tuple(idx.shape), tuple(idx.stride()), idx.dtype, sh0.rank)
+    # (object ids can be recycled after a model is freed: the placement tuple `key` and the width make a stale entry
+    # with other shapes impossible)
+    site = (tuple(id(e) for e in embs), key, width, n_all, idx.data_ptr(), tuple(idx.shape), tuple(idx.stride()),
+            idx.dtype, str(idx.device), sh0.rank)
     idx_all, loc, rows = _buffers.get(site, make)
     # saturating: an id beyond int32 must stay out of range (-> RH_FLAG_INDEX_OOB), not wrap onto a valid row
     send = idx.clamp(min=-1, max=2**31 - 1).to(torch.int32) if narrow else idx
