@@ -373,22 +373,27 @@ int rh_inbatch_sample(const int64_t* rng, int B, int K, int64_t* out, void* stre
  * replaces: torch_rechub/utils/match.py:136-145 on the single-device branch of match_trainer.py:118-138 */
 int rh_inbatch_sample_rows(const int64_t* rng, int B, int cols, int row0, int K, int64_t* out, void* stream);
 
-/* ---- AUGRU recurrence (DIEN's interest-evolving layer) ------------------------------------------------------------
+/* ---- gated recurrences of DIEN: AUGRU (interest evolving) and GRU (interest extractor) ------------------------------
  * replaces: the per-step Python loop of AUGRU.forward over AUGRU_Cell.forward, torch_rechub/models/ranking/dien.py:30-36,
- *           60-66 (6 matmuls + ~12 elementwise kernels per step and as many again under autograd).
- * xw   (B, T, 3D): x_t [Wu | Wr | Wh] + [bu | br | bh] for every step (one GEMM by the caller)
- * attn (B, T):     the step's attention weight a_t (0 on padded steps)
- * U    (D, 3D):    [Uu | Ur | Uh]
- * forward, h_0 = 0:  u = sigmoid(xw_u + h Uu), r = sigmoid(xw_r + h Ur), c = tanh(xw_h + r * (h Uh)),
+ *           60-66 (6 matmuls + ~12 elementwise kernels per step and as many again under autograd); and the
+ *           nn.GRU(batch_first=True) of the interest extractor, dien.py:101,138-143.
+ * xw   (B, T, 3D): input halves of the three gates for every step, x_t [Wu | Wr | Wh] + [bu | br | bh] (one GEMM by
+ *                  the caller)
+ * attn (B, T) or null: the step's attention weight a_t (0 on padded steps); null = 1 everywhere
+ * U    (D, 3D):    [Uu | Ur | Uh];   state_bias (3D) or null: added to h U (nn.GRU's bias_hh)
+ * forward, h_0 = 0:  s = h U + state_bias;  u = sigmoid(xw_u + s_u), r = sigmoid(xw_r + s_r), c = tanh(xw_h + r * s_h),
  *                    h_t = (1 - a_t u) h_{t-1} + a_t u c;   h_all (B, T, D) receives every h_t.
+ *   nn.GRU is this with a = 1, u = 1 - z (negate the z rows of weight_ih / weight_hh / both biases) and r, n as r, c.
  * backward: g_hall (B, T, D) = upstream gradient of every h_t (may be null: zeros);
- *           d_xw (B, T, 3D) = gradient of xw;  d_huh (B, T, D) = gradient of (h_{t-1} Uh) (so that
- *           dU = [h_0 .. h_{T-1}]^T [d_xw_u | d_xw_r | d_huh] is one GEMM by the caller);  d_attn (B, T).
+ *           d_xw (B, T, 3D) = gradient of xw;  d_huh (B, T, D) = gradient of s_h (so that
+ *           dU = [h_0 .. h_{T-1}]^T [d_xw_u | d_xw_r | d_huh] is one GEMM by the caller and d state_bias its column sum);
+ *           d_attn (B, T) (may be null when attn is).
  * D in {4, 8, 16, 32} (rh_augru_max_dim()); D / 4 lanes per sample, state in registers, U in LDS. */
 int rh_augru_max_dim(void);
-int rh_augru_fwd(const float* xw, const float* attn, const float* U, int B, int T, int D, float* h_all, void* stream);
-int rh_augru_bwd(const float* xw, const float* attn, const float* U, const float* h_all, const float* g_hall, int B,
-                 int T, int D, float* d_xw, float* d_huh, float* d_attn, void* stream);
+int rh_augru_fwd(const float* xw, const float* attn, const float* U, const float* state_bias, int B, int T, int D,
+                 float* h_all, void* stream);
+int rh_augru_bwd(const float* xw, const float* attn, const float* U, const float* state_bias, const float* h_all,
+                 const float* g_hall, int B, int T, int D, float* d_xw, float* d_huh, float* d_attn, void* stream);
 
 /* ---- row-sharded tables (one shard per rank) -----------------------------------------------------------------------
  * Global row g of a table lives on rank g % world as local row g / world.  rh_shard_localize rewrites an index matrix

@@ -390,16 +390,21 @@ def inbatch_sample_rows(seed, ctr, B, cols, row0, K):
 # ---------------------------------------------------------------------------------------------------
 # AUGRU  models/ranking/dien.py:17-66 (AUGRU_Cell.forward :30-36, the step loop of AUGRU.forward :60-66)
 # ---------------------------------------------------------------------------------------------------
-def augru_forward(xw, attn, U):
+def augru_forward(xw, attn, U, state_bias=None):
     """h_all (B, T, D).  xw (B, T, 3D) = x_t [Wu|Wr|Wh] + [bu|br|bh]; attn (B, T); U (D, 3D) = [Uu|Ur|Uh]; h_0 = 0.
     Per step (dien.py:32-36): u = sig(xw_u + h Uu), r = sig(xw_r + h Ur), c = tanh(xw_h + r * (h Uh)),
-    h' = (1 - a u) h + a u c."""
+    h' = (1 - a u) h + a u c.  ``state_bias`` (3D) is added to h U, ``attn`` None means a = 1: with those two the same
+    recurrence is torch.nn.GRU's cell (update gate 1 - z), which DIEN's interest extractor uses (dien.py:101)."""
     B, T, D3 = xw.shape
     D = D3 // 3
+    if attn is None:
+        attn = np.ones((B, T), dtype=xw.dtype)
+    if state_bias is None:
+        state_bias = np.zeros(D3, dtype=xw.dtype)
     h = np.zeros((B, D), dtype=xw.dtype)
     out = np.empty((B, T, D), dtype=xw.dtype)
     for t in range(T):
-        hu = h @ U
+        hu = h @ U + state_bias
         u = sigmoid(xw[:, t, :D] + hu[:, :D])
         r = sigmoid(xw[:, t, D:2 * D] + hu[:, D:2 * D])
         c = np.tanh(xw[:, t, 2 * D:] + r * hu[:, 2 * D:])
@@ -409,11 +414,18 @@ def augru_forward(xw, attn, U):
     return out
 
 
-def augru_backward(xw, attn, U, g_hall):
-    """Hand-derived backward through time: returns (d_xw (B,T,3D), d_attn (B,T), d_U (D,3D)) for upstream g_hall (B,T,D)."""
+def augru_backward(xw, attn, U, g_hall, state_bias=None):
+    """Hand-derived backward through time: returns (d_xw (B,T,3D), d_attn (B,T), d_U (D,3D)[, d_state_bias (3D)]) for
+    upstream g_hall (B,T,D)."""
     B, T, D3 = xw.shape
     D = D3 // 3
-    h_all = augru_forward(xw, attn, U)
+    with_bias = state_bias is not None
+    if attn is None:
+        attn = np.ones((B, T), dtype=xw.dtype)
+    if state_bias is None:
+        state_bias = np.zeros(D3, dtype=xw.dtype)
+    d_b = np.zeros(D3, dtype=xw.dtype)
+    h_all = augru_forward(xw, attn, U, state_bias)
     d_xw = np.zeros_like(xw)
     d_attn = np.zeros_like(attn)
     d_U = np.zeros_like(U)
@@ -421,7 +433,7 @@ def augru_backward(xw, attn, U, g_hall):
     for t in range(T - 1, -1, -1):
         dh = dh + g_hall[:, t]
         hp = h_all[:, t - 1] if t > 0 else np.zeros((B, D), dtype=xw.dtype)
-        hu = hp @ U
+        hu = hp @ U + state_bias
         u = sigmoid(xw[:, t, :D] + hu[:, :D])
         r = sigmoid(xw[:, t, D:2 * D] + hu[:, D:2 * D])
         q = hu[:, 2 * D:]
@@ -438,5 +450,6 @@ def augru_backward(xw, attn, U, g_hall):
         d_xw[:, t] = np.concatenate([dpu, dpr, dpc], axis=1)
         d_hu = np.concatenate([dpu, dpr, dq], axis=1)
         d_U += hp.T @ d_hu
+        d_b += d_hu.sum(0)
         dh = dh * (1 - g) + d_hu @ U.T
-    return d_xw, d_attn, d_U
+    return (d_xw, d_attn, d_U, d_b) if with_bias else (d_xw, d_attn, d_U)

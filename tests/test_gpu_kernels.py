@@ -1106,3 +1106,36 @@ def test_augru_recurrence_forward_and_backward_through_time(B, T, D):
     hs = h_all.detach().cpu()
     stay = (attn[:, 1:] == 0)
     assert torch.equal(hs[:, 1:][stay], hs[:, :-1][stay])
+
+
+@pytest.mark.parametrize("B,T,H", [(70, 7, 16), (9, 30, 8), (33, 3, 32), (4, 5, 4)])
+def test_gru_on_the_recurrence_kernel_is_torch_nn_gru(B, T, H):
+    """ops.gru (nn.GRU's r, z, n cell expressed on csrc/augru.hip: update gate 1 - z, weight 1, bias_hh on the state
+    product) against the float64 oracle of the same mapping -- which reproduces torch.nn.GRU to 1e-15 on CPU -- and
+    against the module's own (library) forward on the device: outputs, input gradient and all four parameter gradients."""
+    from torch_rechub_amd import ops
+    torch.manual_seed(B + T + H)
+    gru = torch.nn.GRU(H, H, batch_first=True).to(dev())
+    x = torch.randn(B, T, H, device=dev(), requires_grad=True)
+    G = torch.randn(B, T, H, device=dev())
+    assert ops.gru_ok(gru, x)
+    out = ops.gru(gru, x)
+    (out * G).sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in gru.parameters()]
+    x.grad = None
+    gru.zero_grad()
+    ref, _ = gru(x)
+    (ref * G).sum().backward()
+    want = [x.grad.clone()] + [p.grad.clone() for p in gru.parameters()]
+    close(out, ref.detach().cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="outputs vs library GRU")
+    for a, b, name in zip(got, want, ["x", "weight_ih", "weight_hh", "bias_ih", "bias_hh"]):
+        close(a, b.cpu().numpy(), rtol=5e-4, atol_scale=2e-5, what=f"grad {name} vs library GRU")
+
+    def gates(m):
+        return np.concatenate([-m[H:2 * H], m[:H], m[2 * H:]], axis=0)
+
+    w_ih, w_hh, b_ih, b_hh = (p.detach().cpu().numpy().astype(F64) for p in gru.parameters())
+    xw = x.detach().cpu().numpy().astype(F64) @ gates(w_ih).T + gates(b_ih)
+    close(out, O.augru_forward(xw, None, gates(w_hh).T, gates(b_hh)), rtol=1e-4, atol_scale=1e-5, what="outputs vs oracle")
+    assert not ops.gru_ok(torch.nn.GRU(H, H, batch_first=True, num_layers=2).to(dev()), x)
+    assert not ops.gru_ok(torch.nn.GRU(H, 12, batch_first=True).to(dev()), x)

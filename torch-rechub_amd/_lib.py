@@ -83,8 +83,8 @@ SIGNATURES = {
     "rh_inbatch_sample": [c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_inbatch_sample_rows": [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_augru_max_dim": [],
-    "rh_augru_fwd": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
-    "rh_augru_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_augru_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_augru_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_shard_localize": [c_ptr, c_int, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
 }
 _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctypes.c_int64}

@@ -35,7 +35,9 @@ static __device__ __forceinline__ int per_step() {
 // results live (230 VGPRs at D = 8 in a first version, scratch spills from D = 16 on).
 template <int D>
 static __device__ __forceinline__ float4 column_block(const float* Us, int col, const float (&h)[D]) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  // row D of the LDS copy holds the state-side bias (zeros when there is none)
+  const float4 b4 = *reinterpret_cast<const float4*>(&Us[col + D * 3 * D]);
+  float a0 = b4.x, a1 = b4.y, a2 = b4.z, a3 = b4.w;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     const float4 w = *reinterpret_cast<const float4*>(&Us[col + k * 3 * D]);
@@ -59,12 +61,13 @@ static __device__ __forceinline__ void load_row(const float* p, float (&h)[D]) {
 
 template <int D>
 __global__ __launch_bounds__(RH_WAVE) void augru_fwd_kernel(const float* __restrict__ xw, const float* __restrict__ attn,
-                                                            const float* __restrict__ U, int B, int T,
-                                                            float* __restrict__ h_all) {
+                                                            const float* __restrict__ U, const float* __restrict__ ub,
+                                                            int B, int T, float* __restrict__ h_all) {
   constexpr int G = D / 4;            // lanes per sample
   constexpr int SPW = RH_WAVE / G;    // samples per wavefront
-  __shared__ __attribute__((aligned(16))) float Us[D * 3 * D];
+  __shared__ __attribute__((aligned(16))) float Us[(D + 1) * 3 * D];
   for (int i = threadIdx.x; i < D * 3 * D; i += RH_WAVE) Us[i] = U[i];
+  for (int i = threadIdx.x; i < 3 * D; i += RH_WAVE) Us[D * 3 * D + i] = ub != nullptr ? ub[i] : 0.f;
   __syncthreads();
   const int lane = threadIdx.x;
   const int q = lane % G;
@@ -73,20 +76,20 @@ __global__ __launch_bounds__(RH_WAVE) void augru_fwd_kernel(const float* __restr
   const bool live = b < B;
   if (!live) b = B - 1;  // keep the group converged for the shuffles; nothing is stored
   const float* xb = xw + b * T * 3 * D + 4 * q;
-  const float* ab = attn + b * T;
+  const float* ab = attn != nullptr ? attn + b * T : nullptr;  // null: every weight is 1 (a plain GRU update)
   float* hb = h_all + b * T * D + 4 * q;
   float h[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) h[d] = 0.f;
   float4 own = f4_zero();
   float4 xu = gload<float4>(xb), xr = gload<float4>(xb + D), xh = gload<float4>(xb + 2 * D);
-  float a = ab[0];
+  float a = ab != nullptr ? ab[0] : 1.f;
   for (int t = 0; t < T; ++t) {
     // the next step's inputs are requested before this step's arithmetic: a step is latency, not bandwidth
     const int tn = t + 1 < T ? t + 1 : t;
     const float4 nxu = gload<float4>(xb + (int64_t)tn * 3 * D), nxr = gload<float4>(xb + (int64_t)tn * 3 * D + D),
                  nxh = gload<float4>(xb + (int64_t)tn * 3 * D + 2 * D);
-    const float na = ab[tn];
+    const float na = ab != nullptr ? ab[tn] : 1.f;
     const int off = per_step() + 4 * q;
     const float4 su = column_block<D>(Us, off, h), sr = column_block<D>(Us, off + D, h),
                  sh = column_block<D>(Us, off + 2 * D, h);
@@ -117,14 +120,16 @@ __global__ __launch_bounds__(RH_WAVE) void augru_fwd_kernel(const float* __restr
 
 template <int D>
 __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restrict__ xw, const float* __restrict__ attn,
-                                                            const float* __restrict__ U, const float* __restrict__ h_all,
+                                                            const float* __restrict__ U, const float* __restrict__ ub,
+                                                            const float* __restrict__ h_all,
                                                             const float* __restrict__ g_hall, int B, int T,
                                                             float* __restrict__ d_xw, float* __restrict__ d_huh,
                                                             float* __restrict__ d_attn) {
   constexpr int G = D / 4;
   constexpr int SPW = RH_WAVE / G;
-  __shared__ __attribute__((aligned(16))) float Us[D * 3 * D];
+  __shared__ __attribute__((aligned(16))) float Us[(D + 1) * 3 * D];
   for (int i = threadIdx.x; i < D * 3 * D; i += RH_WAVE) Us[i] = U[i];
+  for (int i = threadIdx.x; i < 3 * D; i += RH_WAVE) Us[D * 3 * D + i] = ub != nullptr ? ub[i] : 0.f;
   __syncthreads();
   const int lane = threadIdx.x;
   const int q = lane % G;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
   const bool live = b < B;
   if (!live) b = B - 1;
   const float* xb = xw + b * T * 3 * D + 4 * q;
-  const float* ab = attn + b * T;
+  const float* ab = attn != nullptr ? attn + b * T : nullptr;
   const float* hb = h_all + b * T * D;
   const float* gb = g_hall != nullptr ? g_hall + b * T * D + 4 * q : nullptr;
   float4 dh = f4_zero();  // gradient of the OWN four state elements
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
     if (gb != nullptr) dh = f4_add(dh, gload<float4>(gb + (int64_t)t * D));
     const float4 xu = gload<float4>(xb + (int64_t)t * 3 * D), xr = gload<float4>(xb + (int64_t)t * 3 * D + D),
                  xh = gload<float4>(xb + (int64_t)t * 3 * D + 2 * D);
-    const float a = ab[t];
+    const float a = ab != nullptr ? ab[t] : 1.f;
     const int off = per_step() + 4 * q;
     const float4 su = column_block<D>(Us, off, hp), sr = column_block<D>(Us, off + D, hp),
                  sh = column_block<D>(Us, off + 2 * D, hp);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
       gstore<float4>(dx + D, make_float4(o_r[0], o_r[1], o_r[2], o_r[3]));
       gstore<float4>(dx + 2 * D, make_float4(o_c[0], o_c[1], o_c[2], o_c[3]));
       gstore<float4>(d_huh + (b * T + t) * D + 4 * q, make_float4(o_q[0], o_q[1], o_q[2], o_q[3]));
-      if (q == 0) d_attn[b * T + t] = da;
+      if (q == 0 && d_attn != nullptr) d_attn[b * T + t] = da;
     }
     // dh_{t-1}[k] += sum_j v[j] U[k][j], v = [d pre_u | d pre_r | d (h Uh)]: this lane holds 12 of the 3D entries of v,
     // so it forms its share of the sum for EVERY k, and the shares are added across the group (xor butterfly)
@@ -220,39 +225,41 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
 
 extern "C" int rh_augru_max_dim(void) { return 32; }
 
-extern "C" int rh_augru_fwd(const float* xw, const float* attn, const float* U, int B, int T, int D, float* h_all,
-                            void* stream) {
+extern "C" int rh_augru_fwd(const float* xw, const float* attn, const float* U, const float* state_bias, int B, int T,
+                            int D, float* h_all, void* stream) {
   RH_REQUIRE(B >= 0 && T >= 1, RH_E_BADARG, "rh_augru_fwd: bad shape B=%d T=%d", B, T);
   RH_REQUIRE(D == 4 || D == 8 || D == 16 || D == 32, RH_E_UNSUPPORTED, "rh_augru_fwd: D=%d (4, 8, 16, 32)", D);
   if (B == 0) return 0;
-  RH_REQUIRE(xw && attn && U && h_all, RH_E_BADARG, "rh_augru_fwd: null pointer");
+  RH_REQUIRE(xw && U && h_all, RH_E_BADARG, "rh_augru_fwd: null pointer");
   const int spw = RH_WAVE / (D / 4);  // samples per wavefront (= per workgroup)
   const dim3 grid((unsigned)((B + spw - 1) / spw)), block(RH_WAVE);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (D) {
-    case 4: hipLaunchKernelGGL(augru_fwd_kernel<4>, grid, block, 0, s, xw, attn, U, B, T, h_all); break;
-    case 8: hipLaunchKernelGGL(augru_fwd_kernel<8>, grid, block, 0, s, xw, attn, U, B, T, h_all); break;
-    case 16: hipLaunchKernelGGL(augru_fwd_kernel<16>, grid, block, 0, s, xw, attn, U, B, T, h_all); break;
-    default: hipLaunchKernelGGL(augru_fwd_kernel<32>, grid, block, 0, s, xw, attn, U, B, T, h_all); break;
+    case 4: hipLaunchKernelGGL(augru_fwd_kernel<4>, grid, block, 0, s, xw, attn, U, state_bias, B, T, h_all); break;
+    case 8: hipLaunchKernelGGL(augru_fwd_kernel<8>, grid, block, 0, s, xw, attn, U, state_bias, B, T, h_all); break;
+    case 16: hipLaunchKernelGGL(augru_fwd_kernel<16>, grid, block, 0, s, xw, attn, U, state_bias, B, T, h_all); break;
+    default: hipLaunchKernelGGL(augru_fwd_kernel<32>, grid, block, 0, s, xw, attn, U, state_bias, B, T, h_all); break;
   }
   RH_LAUNCH_CHECK("rh_augru_fwd");
   return 0;
 }
 
-extern "C" int rh_augru_bwd(const float* xw, const float* attn, const float* U, const float* h_all, const float* g_hall,
-                            int B, int T, int D, float* d_xw, float* d_huh, float* d_attn, void* stream) {
+extern "C" int rh_augru_bwd(const float* xw, const float* attn, const float* U, const float* state_bias,
+                            const float* h_all, const float* g_hall, int B, int T, int D, float* d_xw, float* d_huh,
+                            float* d_attn, void* stream) {
   RH_REQUIRE(B >= 0 && T >= 1, RH_E_BADARG, "rh_augru_bwd: bad shape B=%d T=%d", B, T);
   RH_REQUIRE(D == 4 || D == 8 || D == 16 || D == 32, RH_E_UNSUPPORTED, "rh_augru_bwd: D=%d (4, 8, 16, 32)", D);
   if (B == 0) return 0;
-  RH_REQUIRE(xw && attn && U && h_all && d_xw && d_huh && d_attn, RH_E_BADARG, "rh_augru_bwd: null pointer");
+  RH_REQUIRE(xw && U && h_all && d_xw && d_huh, RH_E_BADARG, "rh_augru_bwd: null pointer");
+  RH_REQUIRE(attn == nullptr || d_attn != nullptr, RH_E_BADARG, "rh_augru_bwd: attn without d_attn");
   const int spw = RH_WAVE / (D / 4);  // samples per wavefront (= per workgroup)
   const dim3 grid((unsigned)((B + spw - 1) / spw)), block(RH_WAVE);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (D) {
-    case 4: hipLaunchKernelGGL(augru_bwd_kernel<4>, grid, block, 0, s, xw, attn, U, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
-    case 8: hipLaunchKernelGGL(augru_bwd_kernel<8>, grid, block, 0, s, xw, attn, U, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
-    case 16: hipLaunchKernelGGL(augru_bwd_kernel<16>, grid, block, 0, s, xw, attn, U, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
-    default: hipLaunchKernelGGL(augru_bwd_kernel<32>, grid, block, 0, s, xw, attn, U, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
+    case 4: hipLaunchKernelGGL(augru_bwd_kernel<4>, grid, block, 0, s, xw, attn, U, state_bias, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
+    case 8: hipLaunchKernelGGL(augru_bwd_kernel<8>, grid, block, 0, s, xw, attn, U, state_bias, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
+    case 16: hipLaunchKernelGGL(augru_bwd_kernel<16>, grid, block, 0, s, xw, attn, U, state_bias, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
+    default: hipLaunchKernelGGL(augru_bwd_kernel<32>, grid, block, 0, s, xw, attn, U, state_bias, h_all, g_hall, B, T, d_xw, d_huh, d_attn); break;
   }
   RH_LAUNCH_CHECK("rh_augru_bwd");
   return 0;

@@ -34,7 +34,9 @@ class SegmentedGraph(object):
         g = torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()  # one private pool: later segments read earlier ones' tensors
-        g.capture_begin(pool=self._pool)
+        # thread-local error mode: with a process group alive, RCCL's watchdog thread polls events of earlier eager
+        # collectives; under the default global mode such a call from another thread invalidates a running capture
+        g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
         self.segments.append([g, None])
 
     def capture(self, fn):

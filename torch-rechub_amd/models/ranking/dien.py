@@ -10,7 +10,9 @@ boolean-mask indexing):
 
 * interest extractor: the reference packs the first ``len`` steps of every row (``len`` = number of non-padding ids,
   dien.py:134-143).  A GRU is causal, so running it over the padded block and zeroing the steps >= len gives the same
-  outputs; rows without history come out zero either way.
+  outputs; rows without history come out zero either way.  The ``nn.GRU`` module keeps its parameters (checkpoint
+  ABI); its cell runs on the recurrence kernel of csrc/augru.hip (update gate 1 - z, weight 1, bias_hh on the state
+  product: ``ops.gru``).
 * auxiliary loss (dien.py:106-121): mean BCE over the valid (step, step + 1) pairs, written as a weighted sum divided by
   the pair count (0 when there is none) instead of indexing the valid rows out.
 * AUGRU (dien.py:38-66): attention = softmax of (x Wa) . target over the valid steps; a padded step has weight 0 and
@@ -139,7 +141,10 @@ class DIEN(nn.Module):
             seq = history[:, i]
             mask = self.embedding.input_mask(x, fea).squeeze(1).bool()  # (B, T)
             packed = (steps < mask.sum(dim=1, keepdim=True)).unsqueeze(-1)  # the steps pack_padded_sequence keeps
-            interests = self.interest_extractor_layers[i](seq)[0] * packed
+            extractor = self.interest_extractor_layers[i]
+            # the GRU through the same recurrence kernel as the AUGRU when the width allows; the library's otherwise
+            states = ops.gru(extractor, seq) if ops.gru_ok(extractor, seq) else extractor(seq)[0]
+            interests = states * packed
             aux = aux + self.auxiliary(interests, seq, negatives[:, i], mask)
             _, h = self.interest_evolving_layers[i](interests, target[:, i], mask)
             evolved.append(h * mask.any(dim=1, keepdim=True))

@@ -1138,37 +1138,43 @@ def cross_mix_epilogue(x0, xl, uv, gate, bias):
 
 # --------------------------------------------------------------------------------------------
 class _AugruFn(torch.autograd.Function):
-    """h_all (B, T, D) = AUGRU recurrence over xw (B, T, 3D), attn (B, T), U (D, 3D) (csrc/augru.hip)."""
+    """h_all (B, T, D) = gated recurrence over xw (B, T, 3D), attn (B, T) | None, U (D, 3D), state_bias (3D) | None
+    (csrc/augru.hip)."""
 
     @staticmethod
-    def forward(ctx, xw, attn, U):
-        require_hip(xw, attn, U)
+    def forward(ctx, xw, attn, U, ub):
+        require_hip(xw, U)
         B, T, D3 = xw.shape
         D = D3 // 3
-        xw, attn, U = xw.contiguous(), attn.contiguous(), U.contiguous()
+        xw, U = xw.contiguous(), U.contiguous()
+        attn = None if attn is None else attn.contiguous()
+        ub = None if ub is None else ub.contiguous()
         h_all = torch.empty((B, T, D), dtype=torch.float32, device=xw.device)
-        _lib.call("rh_augru_fwd", _p(xw), _p(attn), _p(U), B, T, D, _p(h_all), _stream())
-        ctx.save_for_backward(xw, attn, U, h_all)
+        _lib.call("rh_augru_fwd", _p(xw), _p(attn), _p(U), _p(ub), B, T, D, _p(h_all), _stream())
+        ctx.save_for_backward(xw, attn, U, ub, h_all)
         return h_all
 
     @staticmethod
     def backward(ctx, g):
-        xw, attn, U, h_all = ctx.saved_tensors
+        xw, attn, U, ub, h_all = ctx.saved_tensors
         B, T, D3 = xw.shape
         D = D3 // 3
         g = g.contiguous()
         d_xw = torch.empty_like(xw)
         d_huh = torch.empty((B, T, D), dtype=torch.float32, device=xw.device)
-        d_attn = torch.empty((B, T), dtype=torch.float32, device=xw.device)
-        _lib.call("rh_augru_bwd", _p(xw), _p(attn), _p(U), _p(h_all), _p(g), B, T, D, _p(d_xw), _p(d_huh), _p(d_attn),
-                  _stream())
-        d_U = None
-        if ctx.needs_input_grad[2]:
-            # dU = sum_t h_{t-1}^T [d pre_u | d pre_r | d (h Uh)]: one product over all (sample, step) pairs
-            h_prev = torch.cat([h_all.new_zeros(B, 1, D), h_all[:, :-1]], dim=1).reshape(B * T, D)
-            d_hu = torch.cat([d_xw[:, :, :2 * D], d_huh], dim=2).reshape(B * T, D3)
-            d_U = h_prev.t() @ d_hu
-        return d_xw, d_attn, d_U
+        d_attn = None if attn is None else torch.empty((B, T), dtype=torch.float32, device=xw.device)
+        _lib.call("rh_augru_bwd", _p(xw), _p(attn), _p(U), _p(ub), _p(h_all), _p(g), B, T, D, _p(d_xw), _p(d_huh),
+                  _p(d_attn), _stream())
+        d_U = d_ub = None
+        if ctx.needs_input_grad[2] or (ub is not None and ctx.needs_input_grad[3]):
+            # gradient of s = h_{t-1} U + state_bias: [d pre_u | d pre_r | d s_h] for every (sample, step)
+            d_s = torch.cat([d_xw[:, :, :2 * D], d_huh], dim=2).reshape(B * T, D3)
+            if ctx.needs_input_grad[2]:
+                h_prev = torch.cat([h_all.new_zeros(B, 1, D), h_all[:, :-1]], dim=1).reshape(B * T, D)
+                d_U = h_prev.t() @ d_s
+            if ub is not None and ctx.needs_input_grad[3]:
+                d_ub = d_s.sum(dim=0)
+        return d_xw, d_attn, d_U, d_ub
 
 
 def augru_ok(xw, D):
@@ -1176,10 +1182,31 @@ def augru_ok(xw, D):
             D in (4, 8, 16, 32) and xw.shape[2] == 3 * D)
 
 
-def augru(xw, attn, U):
+def augru(xw, attn, U, state_bias=None):
     """States h_1 .. h_T (B, T, D) of the attentional-update GRU (reference dien.py:30-36, 60-66) in one launch each
     way; ``xw`` holds the input halves of the three gates for every step, ``U`` = [Uu | Ur | Uh]."""
-    return _AugruFn.apply(xw, attn, U)
+    return _AugruFn.apply(xw, attn, U, state_bias)
+
+
+def gru_ok(gru, x):
+    return (isinstance(gru, torch.nn.GRU) and gru.num_layers == 1 and not gru.bidirectional and gru.batch_first and
+            gru.bias and gru.input_size == x.shape[-1] and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and
+            x.shape[1] >= 1 and gru.hidden_size in (4, 8, 16, 32))
+
+
+def gru(gru_mod, x):
+    """Outputs (B, T, H) of a one-layer ``nn.GRU(batch_first=True)`` from the zero state, through the same recurrence
+    kernel: PyTorch's cell is r, z, n with h' = (1 - z) n + z h, i.e. the kernel's update gate is 1 - z = sigmoid of
+    the NEGATED z pre-activation, its weight a = 1, and bias_hh rides on the state product."""
+    H = gru_mod.hidden_size
+    w_ih, w_hh, b_ih, b_hh = gru_mod.weight_ih_l0, gru_mod.weight_hh_l0, gru_mod.bias_ih_l0, gru_mod.bias_hh_l0
+
+    def gates(m):  # rows (r, z, n) of a (3H, ...) parameter -> kernel order (1 - z, r, n)
+        return torch.cat([-m[H:2 * H], m[:H], m[2 * H:]], dim=0)
+
+    B, T, _ = x.shape
+    xw = (x.reshape(B * T, -1) @ gates(w_ih).t() + gates(b_ih)).view(B, T, 3 * H)
+    return _AugruFn.apply(xw, None, gates(w_hh).t(), gates(b_hh))
 
 
 # --------------------------------------------------------------------------------------------

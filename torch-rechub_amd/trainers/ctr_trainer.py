@@ -246,13 +246,13 @@ class CTRTrainer(object):
                 self.optimizer._join_sweep()  # plain captures cannot hold the eager side-stream sweep:
                 self.optimizer.overlap_sweep = False  # from here on the window sweep runs in line
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 x, y = loader.load_next()
                 self._graph_loss, self._deferred_static = self._phase_a(x, y)
             self._graph.replay()  # capture does not execute: run A for real, exchange, then capture + run B
             gathered = self._phase_x(self._deferred_static)
             self._graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
+            with torch.cuda.graph(self._graph_b, pool=self._graph.pool(), capture_error_mode="thread_local"):
                 self._phase_b(gathered)
             self._graph_b.replay()
             return total + self._graph_loss, self.GRAPH_WARMUP + 1
