@@ -449,3 +449,106 @@ def test_multi_task_three_steps_match_reference_mtl_trainer(cfg, mode):
             assert np.abs(got - v.numpy()).max() <= 0.5 * lr * steps, k
             continue
         assert_trajectory_close(got, v.numpy(), lr * steps, f"{cfg}: {k} after 3 steps")
+
+
+# -- the HBM-resident loader with sequence columns and multi-task labels: hipGraph training for DIN / DIEN / MMOE ------
+def _rows_for(groups, N, seed, L=7):
+    """Random dataset rows for every feature of ``groups`` + the loader's column description."""
+    g = torch.Generator().manual_seed(seed)
+    cols, names, dense, dnames, seen = [], [], [], [], set()
+    for feas in groups.values():
+        for f in feas:
+            if f.name in seen:
+                continue
+            seen.add(f.name)
+            kind = type(f).__name__
+            if kind == "DenseFeature":
+                dense.append(torch.rand(N, generator=g))
+                dnames.append(f.name)
+            elif kind == "SparseFeature":
+                cols.append(torch.randint(1 if f.padding_idx == 0 else 0, f.vocab_size, (N, 1), generator=g))
+                names.append(f.name)
+            else:
+                idx = torch.randint(1, f.vocab_size, (N, L), generator=g)
+                lens = torch.randint(1, L + 1, (N,), generator=g)
+                idx[torch.arange(L)[None, :] >= lens[:, None]] = 0
+                cols.append(idx)
+                names.append((f.name, L))
+    return torch.cat(cols, dim=1).contiguous(), names, (torch.stack(dense, 1) if dense else None), dnames
+
+
+def _host_batches(sparse, names, dense, dnames, label, B):
+    out, N = [], sparse.shape[0]
+    for i in range(N // B):
+        sl, x, at = slice(i * B, (i + 1) * B), {}, 0
+        for entry in names:
+            name, w = (entry, 1) if isinstance(entry, str) else entry
+            x[name] = sparse[sl, at] if w == 1 else sparse[sl, at:at + w]
+            at += w
+        for j, n in enumerate(dnames):
+            x[n] = dense[sl, j]
+        out.append((x, label[sl]))
+    return out
+
+
+def _same_training(ma, mb, la, lb):
+    assert np.allclose(la, lb, atol=2e-5), (la, lb)
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        if k.endswith("num_batches_tracked"):
+            assert int(a) == int(b)
+            continue
+        if k.endswith("running_mean") or (k.endswith(".bias") and "mlp" in k):
+            continue  # biases in front of BatchNorm: rounding-noise gradients, Adam makes their path arbitrary
+        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 8, k, atol=2e-5, rtol=2e-4)
+
+
+@pytest.mark.parametrize("cfg", ["din", "dien"])
+def test_sequence_models_train_from_the_device_loader_under_hipgraph(cfg):
+    """(name, L) columns of the HBM-resident dataset become contiguous (B, L) index buffers; the captured step (batch
+    assembly, gathers, attention / recurrences, optimizer) must train like eager steps over host batches."""
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    gold = load_golden(f"model_{cfg}.npz")
+    N, B = 64 * 8, 64
+    models = []
+    for _ in range(2):
+        m = build_amd_model(cfg, features_from_spec(gold["spec"]))
+        m.load_state_dict(golden_state(gold, "sd0."))
+        models.append(m.to(dev()))
+    groups = features_from_spec(gold["spec"])
+    sparse, names, dense, dnames = _rows_for(groups, N, seed=3)
+    label = (torch.rand(N, generator=torch.Generator().manual_seed(4)) < 0.3).float()
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False,
+              loss_mode=cfg not in AUX_LOSS_CONFIGS)
+    ta, tb = CTRTrainer(models[0], **kw), CTRTrainer(models[1], use_graph=True, **kw)
+    dl = DeviceDataLoader(sparse.to(dev()), names, None if dense is None else dense.to(dev()), dnames, label.to(dev()), B,
+                          shuffle=False)
+    x, _ = dl.load_next()
+    assert x["hist_item"].shape == (B, 7) and x["hist_item"].is_contiguous()
+    assert torch.equal(x["hist_item"].cpu(), sparse[:B, 1:8]) and torch.equal(x["user_id"].cpu(), sparse[:B, 0])
+    la = ta.train_one_epoch(_host_batches(sparse, names, dense, dnames, label, B))
+    lb = tb.train_one_epoch(dl)
+    assert tb._graph is not None
+    _same_training(models[0], models[1], la, lb)
+
+
+def test_multi_task_training_from_the_device_loader_under_hipgraph():
+    """(N, n_task) labels ride behind the dense block through the batch-assembly kernel; MTLTrainer's captured step."""
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    gold, _, types = load_mtl("mmoe")
+    N, B = 64 * 8, 64
+    groups = features_from_spec(gold["spec"])
+    sparse, names, dense, dnames = _rows_for(groups, N, seed=5)
+    ys = (torch.rand(N, 2, generator=torch.Generator().manual_seed(6)) < 0.3).float()
+    models, trainers = [], []
+    for graph in (False, True):
+        m = build_mtl_model("mmoe", features_from_spec(gold["spec"]), types)
+        trainers.append(_mtl_trainer("mmoe", m, types, gold, use_graph=graph))
+        models.append(m)
+    dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, ys.to(dev()), B, shuffle=False)
+    x, y = dl.load_next()
+    assert y.shape == (B, 2) and torch.equal(y.cpu(), ys[:B]) and torch.equal(x["I1"].cpu(), dense[:B, 0])
+    la = trainers[0].train_one_epoch(_host_batches(sparse, names, dense, dnames, ys, B))
+    lb = trainers[1].train_one_epoch(dl)
+    assert trainers[1]._graph is not None
+    _same_training(models[0], models[1], la, lb)

@@ -117,9 +117,12 @@ class DeviceBatch(dict):
 class DeviceDataLoader(object):
     """HBM-resident columnar dataset + on-device shuffled batch assembly.
 
-    sparse : (N, F) int64 on the device, columns named ``sparse_names``
+    sparse : (N, F) int64 on the device, columns named ``sparse_names``.  An entry of ``sparse_names`` may be a
+             ``(name, L)`` pair: the next L columns are one padded sequence feature (what ``generate_seq_feature`` /
+             ``pad_sequences`` produce per row, utils/data.py:122-214); the batch then carries it as a contiguous
+             (B, L) index matrix.
     dense  : (N, ND) float32 on the device (or None), columns named ``dense_names``
-    label  : (N,) float32 on the device
+    label  : (N,) float32 on the device, or (N, n_task) for the multi-task trainer (``ys[:, i]`` = task i)
     Iterating yields ``(DeviceBatch, y)`` whose tensors are the same static buffers every step.  With
     ``drop_last=False`` (reference DataLoader default) the tail batch is smaller and uses its own buffers.
     """
@@ -131,10 +134,27 @@ class DeviceDataLoader(object):
             raise ValueError("sparse must be a contiguous int64 (N, F) matrix")
         if dense is not None and (dense.dtype != torch.float32 or dense.dim() != 2 or not dense.is_contiguous()):
             raise ValueError("dense must be a contiguous float32 (N, ND) matrix")
-        self.sparse, self.dense, self.label = sparse, dense, label.float().contiguous()
         self.sparse_names, self.dense_names = list(sparse_names), list(dense_names or [])
         self.N, self.F = sparse.shape
         self.ND = 0 if dense is None else dense.shape[1]
+        # column layout of the sparse block: (name, first column, width); width > 1 = a padded sequence feature
+        self.columns, at = [], 0
+        for entry in self.sparse_names:
+            name, width = (entry, 1) if isinstance(entry, str) else (entry[0], int(entry[1]))
+            self.columns.append((name, at, width))
+            at += width
+        if at != self.F:
+            raise ValueError(f"sparse has {self.F} columns, sparse_names describe {at}")
+        label = label.float()
+        self.n_label = 1 if label.dim() == 1 else int(label.shape[1])
+        if label.dim() == 2:
+            # multi-task labels ride behind the dense block: one gather moves features and every task's label
+            dense = label.contiguous() if dense is None else torch.cat([dense, label], dim=1).contiguous()
+            label = None
+        elif label.dim() != 1:
+            raise ValueError("label must be (N,) or (N, n_task)")
+        self.sparse, self.dense, self.label = sparse, dense, None if label is None else label.contiguous()
+        self.NDL = 0 if dense is None else dense.shape[1]  # dense columns + label columns riding with them
         self.batch_size = int(batch_size)
         self.shuffle, self.drop_last = shuffle, drop_last
         self.generator = generator
@@ -224,15 +244,20 @@ class DeviceDataLoader(object):
         if b is None:
             dev = self.sparse.device
             sp = torch.empty((B, self.F), dtype=torch.int64, device=dev)
-            de = torch.empty((B, self.ND), dtype=torch.float32, device=dev) if self.ND else None
-            y = torch.empty((B,), dtype=torch.float32, device=dev)
+            de = torch.empty((B, self.NDL), dtype=torch.float32, device=dev) if self.NDL else None
+            y = torch.empty((B,), dtype=torch.float32, device=dev) if self.label is not None else de[:, self.ND:]
             x = DeviceBatch()
-            for j, n in enumerate(self.sparse_names):
-                x[n] = sp[:, j]
+            seqs = []
+            for name, at, width in self.columns:
+                if width == 1:
+                    x[name] = sp[:, at]
+                else:  # a sequence feature gets its own contiguous (B, L) buffer (the kernels' descriptors are by address)
+                    x[name] = torch.empty((B, width), dtype=torch.int64, device=dev)
+                    seqs.append((x[name], sp[:, at:at + width]))
             for j, n in enumerate(self.dense_names):
                 x[n] = de[:, j]
-            x.sparse, x.sparse_names, x.dense, x.dense_names = sp, self.sparse_names, de, self.dense_names
-            b = (x, y, sp, de)
+            x.sparse, x.sparse_names, x.dense, x.dense_names = sp, [c[0] for c in self.columns], de, self.dense_names
+            b = (x, y, sp, de, seqs)
             self._bufs[B] = b
         return b
 
@@ -245,11 +270,14 @@ class DeviceDataLoader(object):
     def load_next(self, B=None):
         """Assemble the batch at the current position into the static buffers and advance (2 launches)."""
         B = self.batch_size if B is None else B
-        x, y, sp, de = self._buffers(B)
+        x, y, sp, de, seqs = self._buffers(B)
         s = ops._stream()
         _lib.call("rh_batch_gather", ops._p(self.perm), ops._p(self.pos), self.N, B, ops._p(self.sparse), self.F,
-                  ops._p(self.dense), self.ND, ops._p(self.label), ops._p(sp), ops._p(de), ops._p(y), s)
+                  ops._p(self.dense), self.NDL, ops._p(self.label), ops._p(sp), ops._p(de),
+                  ops._p(y if self.label is not None else None), s)
         _lib.call("rh_batch_advance", ops._p(self.pos), B, self.N, s)
+        for dst, src in seqs:
+            dst.copy_(src)
         return x, y
 
     def __iter__(self):
