@@ -2,6 +2,7 @@
 """Train-step throughput of the secondary BASELINE.json configs on ONE GPU (eager + hipGraph):
   dcn / dcnv2 : configs[2] shape (Criteo tables, 13 dense + 26 sparse, 3 cross layers)          [C3 runs it data-parallel]
   din         : configs[3] shape (2 history fields x L=100 + 2 targets + user_id, D=16, attention MLP [256,128] Dice)
+  dien / bst  : the same tables and histories through DIEN (GRU + AUGRU recurrences, auxiliary loss) / BST (1 encoder layer)
   dssm        : configs[4] shape (100 M-item + 10 M-user tables, history L=50 mean-pooled, towers [256,128,64] prelu,
                 in-batch negatives)
     python tools/model_bench.py --models dcn,dcnv2,din,dssm --steps 30
@@ -34,15 +35,24 @@ def build(name, dev, B, scale):
         x = {f.name: torch.randint(0, v, (B,), device=dev, generator=g) for f, v in zip(sparse, vocabs)}
         x.update({f.name: torch.rand(B, device=dev, generator=g) for f in dense})
         trainer = CTRTrainer(model, device=str(dev), show_progress=False)
-    elif name == "din":
+    elif name in ("din", "dien", "bst"):
         nu, ni, nc, L = int(200000 * scale) + 10, int(63001 * scale) + 10, 801, 100
         feats = [SparseFeature("user_id", nu, 16)]
         hist = [SequenceFeature("hist_item", ni, 16, pooling="concat", shared_with="target_item", padding_idx=0),
                 SequenceFeature("hist_cate", nc, 16, pooling="concat", shared_with="target_cate", padding_idx=0)]
         tgt = [SparseFeature("target_item", ni, 16, padding_idx=0), SparseFeature("target_cate", nc, 16, padding_idx=0)]
         with torch.device(dev):
-            model = DIN(feats, hist, tgt, mlp_params={"dims": [256, 128], "dropout": 0.2},
-                        attention_mlp_params={"dims": [256, 128]})
+            if name == "din":
+                model = DIN(feats, hist, tgt, mlp_params={"dims": [256, 128], "dropout": 0.2},
+                            attention_mlp_params={"dims": [256, 128]})
+            elif name == "dien":  # same tables and history shape; negative histories for the auxiliary loss
+                from torch_rechub_amd.models.ranking import DIEN
+                neg = [SequenceFeature("neg_hist_item", ni, 16, pooling="concat", shared_with="target_item", padding_idx=0),
+                       SequenceFeature("neg_hist_cate", nc, 16, pooling="concat", shared_with="target_cate", padding_idx=0)]
+                model = DIEN(feats, hist, neg, tgt, mlp_params={"dims": [256, 128], "dropout": 0.2})
+            else:
+                from torch_rechub_amd.models.ranking import BST
+                model = BST(feats, hist, tgt, mlp_params=mlp, nhead=4, dropout=0.2, num_layers=1, max_seq_len=L + 1)
         lens = torch.randint(1, L + 1, (B,), device=dev, generator=g)
         pad = torch.arange(L, device=dev)[None, :] >= lens[:, None]
         x = {"user_id": torch.randint(0, nu, (B,), device=dev, generator=g),
@@ -50,7 +60,10 @@ def build(name, dev, B, scale):
              "target_cate": torch.randint(1, nc, (B,), device=dev, generator=g),
              "hist_item": torch.randint(1, ni, (B, L), device=dev, generator=g).masked_fill(pad, 0),
              "hist_cate": torch.randint(1, nc, (B, L), device=dev, generator=g).masked_fill(pad, 0)}
-        trainer = CTRTrainer(model, device=str(dev), show_progress=False)
+        if name == "dien":
+            x["neg_hist_item"] = torch.randint(1, ni, (B, L), device=dev, generator=g).masked_fill(pad, 0)
+            x["neg_hist_cate"] = torch.randint(1, nc, (B, L), device=dev, generator=g).masked_fill(pad, 0)
+        trainer = CTRTrainer(model, device=str(dev), show_progress=False, loss_mode=name != "dien")
     elif name == "dssm":
         nu, ni, L = int(10_000_000 * scale) + 10, int(100_000_000 * scale) + 10, 50
         user = [SparseFeature("user_id", nu, 16),

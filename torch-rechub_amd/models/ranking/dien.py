@@ -72,8 +72,17 @@ class AUGRU(nn.Module):
         self.augru_cell = AUGRU_Cell(embed_dim)
         self.Wa = _xavier(embed_dim, embed_dim)
 
+    @staticmethod
+    def _project(x2d, W, b=None):
+        """x2d W (+ b) over all B*T rows; on the device through ops.linear, whose weight / bias gradient is the
+        split-batch MFMA kernel (the reduction over B*T rows is what a library GEMM is slow at)."""
+        if x2d.is_cuda:
+            return ops.linear(x2d, W.t(), None if b is None else b.reshape(-1))
+        return x2d @ W if b is None else x2d @ W + b
+
     def attention(self, x, item, mask=None):
-        scores = ((x @ self.Wa) * item.unsqueeze(1)).sum(-1)  # (B, T)
+        B, T, D = x.shape
+        scores = (self._project(x.reshape(B * T, D), self.Wa).view(B, T, D) * item.unsqueeze(1)).sum(-1)  # (B, T)
         if mask is None:
             return torch.softmax(scores, dim=1)
         some = mask.any(dim=1, keepdim=True)
@@ -85,7 +94,7 @@ class AUGRU(nn.Module):
         B, T, D = x.shape
         attn = self.attention(x, item, mask)
         W, b = self.augru_cell.input_weights()
-        xw = (x.reshape(B * T, D) @ W + b).view(B, T, 3 * D)
+        xw = self._project(x.reshape(B * T, D), W, b).view(B, T, 3 * D)
         U = self.augru_cell.state_weights()
         if ops.augru_ok(xw, D):  # the whole recurrence (and its backward through time) as one HIP launch
             outs = ops.augru(xw, attn, U)

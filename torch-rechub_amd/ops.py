@@ -1167,13 +1167,13 @@ class _AugruFn(torch.autograd.Function):
                   _p(d_attn), _stream())
         d_U = d_ub = None
         if ctx.needs_input_grad[2] or (ub is not None and ctx.needs_input_grad[3]):
-            # gradient of s = h_{t-1} U + state_bias: [d pre_u | d pre_r | d s_h] for every (sample, step)
+            # gradient of s = h_{t-1} U + state_bias: [d pre_u | d pre_r | d s_h] for every (sample, step); dU^T =
+            # d_s^T h_prev sums over B*T rows -- the split-batch MFMA weight-gradient kernel's shape (a library GEMM
+            # with K = B*T = 409600 took 580 us here), which also returns the column sums = d state_bias
             d_s = torch.cat([d_xw[:, :, :2 * D], d_huh], dim=2).reshape(B * T, D3)
-            if ctx.needs_input_grad[2]:
-                h_prev = torch.cat([h_all.new_zeros(B, 1, D), h_all[:, :-1]], dim=1).reshape(B * T, D)
-                d_U = h_prev.t() @ d_s
-            if ub is not None and ctx.needs_input_grad[3]:
-                d_ub = d_s.sum(dim=0)
+            h_prev = torch.cat([h_all.new_zeros(B, 1, D), h_all[:, :-1]], dim=1).reshape(B * T, D)
+            d_Ut, d_ub = linear_wgrad(d_s, h_prev, want_bias=ub is not None)
+            d_U = d_Ut.t()
         return d_xw, d_attn, d_U, d_ub
 
 
@@ -1205,7 +1205,7 @@ def gru(gru_mod, x):
         return torch.cat([-m[H:2 * H], m[:H], m[2 * H:]], dim=0)
 
     B, T, _ = x.shape
-    xw = (x.reshape(B * T, -1) @ gates(w_ih).t() + gates(b_ih)).view(B, T, 3 * H)
+    xw = linear(x.reshape(B * T, -1), gates(w_ih), gates(b_ih)).view(B, T, 3 * H)
     return _AugruFn.apply(xw, None, gates(w_hh).t(), gates(b_hh))
 
 
