@@ -181,26 +181,56 @@ def main():
     from torch_rechub_amd.utils.data import DeviceDataLoader
 
     vocabs = [max(3, int(v * args.vocab_scale)) for v in CRITEO_VOCABS]
-    torch.manual_seed(2022)  # identical initial replica on every rank (and broadcast from rank 0 anyway)
     dense_feas = [DenseFeature(f"I{i + 1}") for i in range(N_DENSE)]
     sparse_feas = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=EMBED_DIM) for i, v in enumerate(vocabs)]
-    with torch.device(device):  # tables are created directly in HBM (2 GiB; never staged through the host)
-        model = DeepFM(dense_feas + sparse_feas, sparse_feas, {"dims": [256, 128], "dropout": 0.2, "activation": "relu"})
     parallel = world > 1 or args.force_dp
     tables = args.tables
+    test_fallback = os.environ.get("RECHUB_BENCH_TEST_FALLBACK") == "1"  # exercise the fallback below on one GPU
     if tables == "auto":
-        tables = "shard" if world > 1 else "replicate"
+        tables = "shard" if (world > 1 or (test_fallback and args.force_dp)) else "replicate"
     if not parallel:
         tables = None  # one GPU, one copy
-    use_graph = args.graph in ("1", "auto")  # N > 1: two graphs per step with the RCCL exchange between them
-    trainer = CTRTrainer(model, device=str(device), show_progress=False, use_graph=use_graph,
-                         table_update=args.table_adam, lazy_k=args.lazy_k, tables=tables)
+    use_graph = args.graph in ("1", "auto")  # N > 1: the RCCL collectives are captured with the rest of the step
     sparse, dense, label = build_dataset(args.rows, vocabs, device, seed=2022 + rank, dist_kind=args.dist)
-    loader = DeviceDataLoader(sparse, [f.name for f in sparse_feas], dense, [f.name for f in dense_feas], label,
+
+    def build(placement):
+        for f in sparse_feas:  # Feature objects cache their nn.Embedding (Q2): a rebuild must start from fresh tables
+            if hasattr(f, "embed"):
+                del f.embed
+        torch.manual_seed(2022)  # identical initial replica on every rank (and broadcast from rank 0 anyway)
+        with torch.device(device):  # tables are created directly in HBM (2 GiB; never staged through the host)
+            m = DeepFM(dense_feas + sparse_feas, sparse_feas, {"dims": [256, 128], "dropout": 0.2, "activation": "relu"})
+        t = CTRTrainer(m, device=str(device), show_progress=False, use_graph=use_graph, table_update=args.table_adam,
+                       lazy_k=args.lazy_k, tables=placement)
+        ld = DeviceDataLoader(sparse, [f.name for f in sparse_feas], dense, [f.name for f in dense_feas], label,
                               args.batch, shuffle=True)
-    loader.reshuffle()
-    model.train()
-    trainer.optimizer.sync_hyper()
+        ld.reshuffle()
+        m.train()
+        t.optimizer.sync_hyper()
+        return m, t, ld
+
+    model, trainer, loader = build(tables)
+    if tables == "shard" and args.tables == "auto":
+        # the row-sharded exchange has been validated with two ranks on one GPU and on a one-rank RCCL group, never on
+        # this node's N GPUs: one eager step decides, on every rank alike, whether this job keeps it
+        ok = torch.ones(1, device=device)
+        try:
+            trainer.train_step(*loader.load_next())
+            torch.cuda.synchronize()
+            if test_fallback:
+                raise RuntimeError("RECHUB_BENCH_TEST_FALLBACK")
+        except Exception as e:  # noqa: BLE001
+            ok.zero_()
+            print(f"[bench] rank {rank}: row-sharded step failed ({type(e).__name__}: {e})", file=sys.stderr)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            if rank == 0:
+                print("[bench] falling back to replicated tables", file=sys.stderr)
+            trainer.dp.close()
+            del model, trainer, loader
+            torch.cuda.empty_cache()
+            tables = "replicate"
+            model, trainer, loader = build(tables)
     B = args.batch
 
     graph_ok = False
