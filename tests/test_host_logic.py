@@ -62,6 +62,17 @@ def test_ops_refuse_cpu_tensors_loudly():
         ops.fm(torch.zeros(2, 3, 4))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.cross_network(torch.zeros(2, 8), torch.zeros(1, 8), torch.zeros(1, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.augru(torch.zeros(2, 3, 12), torch.ones(2, 3), torch.zeros(4, 12))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.fused_rows(torch.zeros(2, 8), 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.shard_localize(torch.zeros(2, 1, dtype=torch.int64), torch.tensor([4, -1, 2]), 2, 0)
+    for cfg in ("dien", "bst", "din"):  # sequence models: nothing of them runs on CPU tensors either
+        g = load_golden(f"model_{cfg}.npz")
+        m = build_amd_model(cfg, features_from_spec(g["spec"]))
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m(golden_batch(g, 0)[0])
 
 
 def test_trainer_refuses_cpu_device():

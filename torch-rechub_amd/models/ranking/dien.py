@@ -74,11 +74,9 @@ class AUGRU(nn.Module):
 
     @staticmethod
     def _project(x2d, W, b=None):
-        """x2d W (+ b) over all B*T rows; on the device through ops.linear, whose weight / bias gradient is the
-        split-batch MFMA kernel (the reduction over B*T rows is what a library GEMM is slow at)."""
-        if x2d.is_cuda:
-            return ops.linear(x2d, W.t(), None if b is None else b.reshape(-1))
-        return x2d @ W if b is None else x2d @ W + b
+        """x2d W (+ b) over all B*T rows through ops.linear, whose weight / bias gradient is the split-batch MFMA kernel
+        (the reduction over B*T rows is what a library GEMM is slow at)."""
+        return ops.linear(x2d, W.t(), None if b is None else b.reshape(-1))
 
     def attention(self, x, item, mask=None):
         B, T, D = x.shape
