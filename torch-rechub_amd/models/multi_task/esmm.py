@@ -10,20 +10,23 @@ from torch import nn
 from ...basic.layers import MLP, EmbeddingLayer
 
 
+def _uniform_width(features):
+    """Input width the reference assumes for a feature list: len(list) x embed_dim of its first member (esmm.py:27)."""
+    return len(features) * features[0].embed_dim
+
+
 class ESMM(nn.Module):
 
     def __init__(self, user_features, item_features, cvr_params, ctr_params):
         super().__init__()
         self.user_features, self.item_features = user_features, item_features
         self.embedding = EmbeddingLayer(user_features + item_features)
-        self.tower_dims = (len(user_features) * user_features[0].embed_dim +
-                           len(item_features) * item_features[0].embed_dim)
-        self.tower_cvr = MLP(self.tower_dims, **cvr_params)
-        self.tower_ctr = MLP(self.tower_dims, **ctr_params)
+        self.tower_dims = _uniform_width(user_features) + _uniform_width(item_features)
+        for name, params in (("tower_cvr", cvr_params), ("tower_ctr", ctr_params)):  # registration order = key order
+            setattr(self, name, MLP(self.tower_dims, **params))
 
     def forward(self, x):
-        both = self.embedding(x, self.user_features + self.item_features, squeeze_dim=False)  # user fields, then item
-        tower_in = both.flatten(start_dim=1)
-        cvr = torch.sigmoid(self.tower_cvr(tower_in))
-        ctr = torch.sigmoid(self.tower_ctr(tower_in))
-        return torch.cat([cvr, ctr, ctr * cvr], dim=1)
+        fields = self.embedding(x, self.user_features + self.item_features, squeeze_dim=False)  # user fields, then item
+        tower_in = fields.flatten(start_dim=1)
+        p_cvr, p_ctr = (torch.sigmoid(tower(tower_in)) for tower in (self.tower_cvr, self.tower_ctr))
+        return torch.cat([p_cvr, p_ctr, p_ctr * p_cvr], dim=1)
