@@ -50,6 +50,27 @@ static __device__ __forceinline__ float4 column_block(const float* Us, int col, 
   return make_float4(a0, a1, a2, a3);
 }
 
+// Exchanges inside an aligned group of 4 lanes as DPP quad permutes (a VALU move) instead of ds_bpermute (a trip through
+// the LDS crossbar): used when 4 lanes share a sample (D = 16), where a step does 16 (forward) / 34 (backward) of them.
+template <int CTRL>
+static __device__ __forceinline__ float quad_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;  // lanes (1,0,3,2) / (2,3,0,1)
+
+// sum over the G lanes of a sample's group; every lane gets the total
+template <int G>
+static __device__ __forceinline__ float group_sum(float v) {
+  if constexpr (G == 4) {
+    v += quad_perm<kQuadXor1>(v);
+    v += quad_perm<kQuadXor2>(v);
+  } else {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, RH_WAVE);
+  }
+  return v;
+}
+
 template <int D>
 static __device__ __forceinline__ void load_row(const float* p, float (&h)[D]) {
 #pragma unroll
@@ -107,12 +128,23 @@ __global__ __launch_bounds__(RH_WAVE) void augru_fwd_kernel(const float* __restr
     own = make_float4(hv[0], hv[1], hv[2], hv[3]);
     if (live) gstore<float4>(hb + (int64_t)t * D, own);
     // every lane of the group needs the whole new state for the next state product
+    if constexpr (G == 4) {
+      const float o[4] = {own.x, own.y, own.z, own.w};
 #pragma unroll
-    for (int p = 0; p < G; ++p) {
-      h[4 * p + 0] = __shfl(own.x, head + p, RH_WAVE);
-      h[4 * p + 1] = __shfl(own.y, head + p, RH_WAVE);
-      h[4 * p + 2] = __shfl(own.z, head + p, RH_WAVE);
-      h[4 * p + 3] = __shfl(own.w, head + p, RH_WAVE);
+      for (int e = 0; e < 4; ++e) {
+        h[0 + e] = quad_perm<0x00>(o[e]);
+        h[4 + e] = quad_perm<0x55>(o[e]);
+        h[8 + e] = quad_perm<0xAA>(o[e]);
+        h[12 + e] = quad_perm<0xFF>(o[e]);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < G; ++p) {
+        h[4 * p + 0] = __shfl(own.x, head + p, RH_WAVE);
+        h[4 * p + 1] = __shfl(own.y, head + p, RH_WAVE);
+        h[4 * p + 2] = __shfl(own.z, head + p, RH_WAVE);
+        h[4 * p + 3] = __shfl(own.w, head + p, RH_WAVE);
+      }
     }
     xu = nxu, xr = nxr, xh = nxh, a = na;
   }
@@ -179,8 +211,7 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
       o_r[e] = o_c[e] * shs[e] * r * (1.f - r);
       o_q[e] = o_c[e] * r;
     }
-#pragma unroll
-    for (int m = 1; m < G; m <<= 1) da += __shfl_xor(da, m, RH_WAVE);
+    da = group_sum<G>(da);
     if (live) {
       float* dx = d_xw + (b * T + t) * 3 * D + 4 * q;
       gstore<float4>(dx, make_float4(o_u[0], o_u[1], o_u[2], o_u[3]));
@@ -205,10 +236,7 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
       part[k] = s;
     }
 #pragma unroll
-    for (int m = 1; m < G; m <<= 1) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) part[k] += __shfl_xor(part[k], m, RH_WAVE);
-    }
+    for (int k = 0; k < D; ++k) part[k] = group_sum<G>(part[k]);
     float nd[4] = {keep[0], keep[1], keep[2], keep[3]};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
