@@ -14,7 +14,6 @@ as one accumulated buffer per table that needs its own kernels and is not built 
 """
 import os
 
-import numpy as np
 import torch
 import tqdm
 from torch import nn
