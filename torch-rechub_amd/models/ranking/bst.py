@@ -33,7 +33,8 @@ class BST(nn.Module):
         self.pos_embedding._rh_dense = True  # max_seq_len rows read as one slice: a dense parameter, not a lookup table
         layer = nn.TransformerEncoderLayer(d_model=self.item_dim, nhead=nhead, dropout=dropout, activation=nn.LeakyReLU(),
                                            batch_first=True)
-        self.transformer_layers = nn.TransformerEncoder(layer, num_layers=num_layers)
+        # (a LeakyReLU feed-forward never takes the nested-tensor fast path; saying so avoids the constructor's warning)
+        self.transformer_layers = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
         self.mlp = MLP(self.all_dims, **mlp_params)
 
     def _padding_steps(self, x):
