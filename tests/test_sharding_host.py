@@ -108,6 +108,25 @@ def _worker(rank, world, port, outdir):
         want = O.shard_rows(bumped["a.weight"].numpy(), world, rank)
         got = model["a"].weight.detach().numpy()
         assert np.array_equal(got[:len(range(rank, 11, world))], want[:len(range(rank, 11, world))])
+        # the data-parallel context in sharded mode: replicas made equal first, then dealt out; only the dense
+        # parameters go into the all-reduce bucket; a flagged small table (BST's positions) stays a dense parameter
+        from torch_rechub_amd import ops
+        from torch_rechub_amd.distributed import DataParallelContext, table_parameters
+        net = nn.ModuleDict({"emb": nn.Embedding(9, 4), "pos": nn.Embedding(5, 4), "fc": nn.Linear(4, 2)})
+        net["pos"]._rh_dense = True
+        if rank == 1:
+            with torch.no_grad():
+                net["emb"].weight.add_(1.0)
+        ctx = DataParallelContext(net, shard_tables=True)
+        assert [m is net["emb"] for m in ctx.sharded] == [True]
+        assert net["emb"].weight.shape == (-(-9 // world) + 1, 4) and net["pos"].weight.shape == (5, 4)
+        assert [tuple(p.shape) for p in table_parameters(net)] == [tuple(net["emb"].weight.shape)]
+        assert {id(p) for p in ctx.bucket.params} == {id(net["pos"].weight), id(net["fc"].weight), id(net["fc"].bias)}
+        assert ops._sparse_exchange is not None
+        rows = sharding.full_table(net["emb"])
+        torch.save(rows, os.path.join(outdir, f"emb{rank}.pt"))  # rank 0's values everywhere (broadcast before dealing)
+        ctx.close()
+        assert ops._sparse_exchange is None
         # differentiable collectives: scatter_rows_sum (forward reduce-scatter, backward all-gather) and gather_rows
         B, C = 3, 5
         g = torch.Generator().manual_seed(40 + rank)
@@ -129,6 +148,8 @@ def _worker(rank, world, port, outdir):
 def test_shard_roundtrip_and_row_collectives_over_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    tables = [torch.load(os.path.join(tmp_path, f"emb{r}.pt")) for r in range(world)]
+    assert all(t.shape == (9, 4) and torch.equal(t, tables[0]) for t in tables)
     B, C = 3, 5
     xs, ws, x2, w2 = [], [], [], []
     for r in range(world):
