@@ -173,18 +173,33 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
   const float* hb = h_all + b * T * D;
   const float* gb = g_hall != nullptr ? g_hall + b * T * D + 4 * q : nullptr;
   float4 dh = f4_zero();  // gradient of the OWN four state elements
+  // As in the forward, the inputs of the next step to be processed (t - 1) are requested before this step's arithmetic:
+  // h_{t-2} (whole row: the state product needs all of it), the upstream gradient, the input halves and the weight.
+  float hp[D];
+  if (T > 1) {
+    load_row<D>(hb + (int64_t)(T - 2) * D, hp);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) hp[d] = 0.f;
+  }
+  float4 gv = gb != nullptr ? gload<float4>(gb + (int64_t)(T - 1) * D) : f4_zero();
+  float4 xu = gload<float4>(xb + (int64_t)(T - 1) * 3 * D), xr = gload<float4>(xb + (int64_t)(T - 1) * 3 * D + D),
+         xh = gload<float4>(xb + (int64_t)(T - 1) * 3 * D + 2 * D);
+  float a = ab != nullptr ? ab[T - 1] : 1.f;
   for (int t = T - 1; t >= 0; --t) {
-    float hp[D];  // h_{t-1}, whole (the state product needs all of it)
-    if (t > 0) {
-      load_row<D>(hb + (int64_t)(t - 1) * D, hp);
+    const int tn = t > 0 ? t - 1 : 0;  // the step after this one (clamped: the last prefetch is discarded)
+    float nhp[D];
+    if (tn > 0) {
+      load_row<D>(hb + (int64_t)(tn - 1) * D, nhp);
     } else {
 #pragma unroll
-      for (int d = 0; d < D; ++d) hp[d] = 0.f;
+      for (int d = 0; d < D; ++d) nhp[d] = 0.f;
     }
-    if (gb != nullptr) dh = f4_add(dh, gload<float4>(gb + (int64_t)t * D));
-    const float4 xu = gload<float4>(xb + (int64_t)t * 3 * D), xr = gload<float4>(xb + (int64_t)t * 3 * D + D),
-                 xh = gload<float4>(xb + (int64_t)t * 3 * D + 2 * D);
-    const float a = ab != nullptr ? ab[t] : 1.f;
+    const float4 ngv = gb != nullptr ? gload<float4>(gb + (int64_t)tn * D) : f4_zero();
+    const float4 nxu = gload<float4>(xb + (int64_t)tn * 3 * D), nxr = gload<float4>(xb + (int64_t)tn * 3 * D + D),
+                 nxh = gload<float4>(xb + (int64_t)tn * 3 * D + 2 * D);
+    const float na = ab != nullptr ? ab[tn] : 1.f;
+    dh = f4_add(dh, gv);
     const int off = per_step() + 4 * q;
     const float4 su = column_block<D>(Us, off, hp), sr = column_block<D>(Us, off + D, hp),
                  sh = column_block<D>(Us, off + 2 * D, hp);
@@ -246,6 +261,9 @@ __global__ __launch_bounds__(RH_WAVE) void augru_bwd_kernel(const float* __restr
       nd[e] += mine;
     }
     dh = make_float4(nd[0], nd[1], nd[2], nd[3]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) hp[d] = nhp[d];
+    gv = ngv, xu = nxu, xr = nxr, xh = nxh, a = na;
   }
 }
 
