@@ -245,3 +245,31 @@ def test_mtl_trainer_argument_checks():
         MTLTrainer(torch.nn.Linear(2, 2), ["classification"] * 2, adaptive_params={"method": "gradnorm"}, device="cuda:0")
     with pytest.raises(RuntimeError):  # the HIP hot path has no CPU mode
         MTLTrainer(torch.nn.Linear(2, 2), ["classification"] * 2, device="cpu")
+
+
+def test_early_stopper_patience_rule_and_best_weight_snapshot():
+    """Reference rule (basic/callback.py:17-33): a strictly better AUC resets the counter and deep-copies the weights;
+    otherwise the counter advances and the call turns True on the patience-th evaluation in a row without improvement."""
+    from torch_rechub_amd.basic.callback import EarlyStopper
+    es = EarlyStopper(patience=3)
+    w = {"a": torch.zeros(2)}
+    assert es.stop_training(0.60, w) is False and es.best_auc == 0.60
+    w["a"].add_(1)  # the snapshot must not follow later in-place updates
+    assert torch.equal(es.best_weights["a"], torch.zeros(2))
+    assert [es.stop_training(v, w) for v in (0.60, 0.59)] == [False, False]  # equal is not an improvement
+    assert es.trial_counter == 2
+    assert es.stop_training(0.61, w) is False and es.trial_counter == 0 and torch.equal(es.best_weights["a"], torch.ones(2))
+    assert [es.stop_training(0.5, w) for _ in range(3)] == [False, False, True]
+    assert EarlyStopper(patience=1).stop_training(0.0, w) is True  # AUC 0 never beats the initial best of 0
+
+
+def test_bpr_loss_values():
+    """-log(sigmoid(pos - neg)).mean() for 1-D negatives and for (B, K) in-batch negatives (basic/loss_func.py:95-107)."""
+    from torch_rechub_amd.basic.loss_func import BPRLoss
+    pos = torch.tensor([[1.0], [0.5], [-0.2]])
+    neg = torch.tensor([0.3, 0.9, -0.1])
+    want = -torch.log(torch.sigmoid(pos.view(-1) - neg)).mean()
+    assert torch.allclose(BPRLoss()(pos, neg), want)
+    negs = torch.tensor([[0.3, 0.1], [0.9, 0.2], [-0.1, 0.0]])
+    want = -torch.log(torch.sigmoid(pos.view(-1, 1) - negs)).mean()
+    assert torch.allclose(BPRLoss()(pos, negs, in_batch_neg=True), want)
