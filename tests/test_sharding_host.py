@@ -167,3 +167,58 @@ def test_shard_roundtrip_and_row_collectives_over_gloo(tmp_path, world):
         # rows of rank r appear in every rank's gathered copy: the gradients add up
         want = sum(w2[q][r * B:(r + 1) * B] for q in range(world))
         np.testing.assert_allclose(got[r]["gx"].numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+
+
+# -- cross-rank in-batch negatives on CPU tensors: two ranks == one process on the global batch -----------------------
+def _towers():
+    torch.manual_seed(21)
+    return nn.Linear(6, 4), nn.Linear(5, 4)
+
+
+def _negatives_loss(user, item, rows, world, rank, gather):
+    """The in-batch step of MatchTrainer._compute_loss (mode 0, hard negatives: deterministic) on plain tensors."""
+    import torch.nn.functional as F
+    from torch_rechub_amd.utils.match import gather_inbatch_logits, inbatch_negative_sampling
+    u, v = F.normalize(user, dim=1), F.normalize(item, dim=1)
+    row0 = 0
+    if gather is not None:
+        row0 = rank * rows
+        v = gather(v)
+    scores = u @ v.t()
+    neg = inbatch_negative_sampling(scores, neg_ratio=3, hard_negative=True, row_offset=row0)
+    logits = gather_inbatch_logits(scores, neg, row_offset=row0)
+    return F.cross_entropy(logits, torch.zeros(logits.shape[0], dtype=torch.long))
+
+
+def _neg_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch_rechub_amd import sharding
+        fu, fi = _towers()
+        g = torch.Generator().manual_seed(50)
+        xu, xi = torch.randn(world * 8, 6, generator=g), torch.randn(world * 8, 5, generator=g)
+        sl = slice(rank * 8, (rank + 1) * 8)
+        loss = _negatives_loss(fu(xu[sl]), fi(xi[sl]), 8, world, rank, sharding.gather_rows)
+        (loss / world).backward()  # the trainer's scaling: gradients are summed over ranks
+        grads = [p.grad.clone() for p in list(fu.parameters()) + list(fi.parameters())]
+        for t in grads:
+            dist.all_reduce(t)
+        torch.save({"loss": loss.detach(), "grads": grads}, os.path.join(outdir, f"n{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cross_rank_negatives_equal_one_process_on_the_global_batch(tmp_path):
+    world = 2
+    mp.spawn(_neg_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"n{r}.pt")) for r in range(world)]
+    fu, fi = _towers()
+    g = torch.Generator().manual_seed(50)
+    xu, xi = torch.randn(world * 8, 6, generator=g), torch.randn(world * 8, 5, generator=g)
+    loss = _negatives_loss(fu(xu), fi(xi), world * 8, 1, 0, None)
+    loss.backward()
+    np.testing.assert_allclose(sum(float(r["loss"]) for r in got) / world, float(loss), rtol=1e-6)
+    for a, b, p in zip(got[0]["grads"], got[1]["grads"], list(fu.parameters()) + list(fi.parameters())):
+        assert torch.equal(a, b)  # all-reduced: both ranks hold the same sum
+        np.testing.assert_allclose(a.numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-7)
