@@ -218,7 +218,7 @@ def test_cross_rank_negatives_equal_one_process_on_the_global_batch(tmp_path):
     xu, xi = torch.randn(world * 8, 6, generator=g), torch.randn(world * 8, 5, generator=g)
     loss = _negatives_loss(fu(xu), fi(xi), world * 8, 1, 0, None)
     loss.backward()
-    np.testing.assert_allclose(sum(float(r["loss"]) for r in got) / world, float(loss), rtol=1e-6)
+    np.testing.assert_allclose(sum(float(r["loss"]) for r in got) / world, float(loss.detach()), rtol=1e-6)
     for a, b, p in zip(got[0]["grads"], got[1]["grads"], list(fu.parameters()) + list(fi.parameters())):
         assert torch.equal(a, b)  # all-reduced: both ranks hold the same sum
         np.testing.assert_allclose(a.numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-7)
