@@ -1139,3 +1139,39 @@ def test_gru_on_the_recurrence_kernel_is_torch_nn_gru(B, T, H):
     close(out, O.augru_forward(xw, None, gates(w_hh).T, gates(b_hh)), rtol=1e-4, atol_scale=1e-5, what="outputs vs oracle")
     assert not ops.gru_ok(torch.nn.GRU(H, H, batch_first=True, num_layers=2).to(dev()), x)
     assert not ops.gru_ok(torch.nn.GRU(H, 12, batch_first=True).to(dev()), x)
+
+
+def test_sharded_history_lookup_many_positions_of_one_table():
+    """A concat-pooled history on a row-sharded table = L lookups of ONE table per sample (F = L = 100 'fields' sharing a
+    shard): per-rank gathers sum bit-exactly to the reference lookup, the shard's gradient is the oracle's shared-table
+    gradient dealt out row by row, padding positions and the sink row receive nothing."""
+    from torch_rechub_amd import ops
+    world, vocab, D, L, N = 2, 5003, 16, 100, 300
+    rng = np.random.default_rng(77)
+    table = rng.standard_normal((vocab, D)).astype(np.float32)
+    table[0] = 0  # padding_idx = 0
+    idx = rng.integers(1, vocab, (N, L))
+    lens = rng.integers(1, L + 1, N)
+    idx[np.arange(L)[None, :] >= lens[:, None]] = 0
+    g_out = rng.standard_normal((N, L * D)).astype(np.float32)
+    idx_d, g_d = torch.from_numpy(idx).to(dev()), torch.from_numpy(g_out).to(dev())
+    want = O.embedding_gather([table] * L, idx).reshape(N, -1)
+    shared = np.zeros((vocab, D), dtype=F64)
+    O.embedding_backward([(vocab, D)] * L, idx, g_out.reshape(N, L, D).astype(F64), padding_idx=[0] * L,
+                         out=[shared] * L)
+    sink = -(-vocab // world)
+    desc = torch.tensor([vocab] * L + [0] * L + [sink] * L, dtype=torch.int64, device=dev())
+    total = torch.zeros(N, L * D, device=dev())
+    for rank in range(world):
+        shard = torch.nn.Parameter(torch.from_numpy(O.shard_rows(table, world, rank)).to(dev()))
+        loc = ops.shard_localize(idx_d, desc, world, rank)
+        call = ops.EmbedCall([shard] * L, [sink] * L, [loc[:, j] for j in range(L)], local_grads=True)
+        out, _, _ = ops.fused_embedding(call)
+        total += out.detach()
+        out.backward(g_d)
+        got = ops.grad_buffer(shard).cpu().numpy()
+        mine = shared[rank::world]
+        close(got[:mine.shape[0]], mine, rtol=1e-5, atol_scale=2e-6, what=f"rank {rank} shard gradient")
+        assert not got[mine.shape[0]:].any()
+    assert np.array_equal(total.cpu().numpy(), want)
+    ops.check_errors()

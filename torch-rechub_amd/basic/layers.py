@@ -219,12 +219,9 @@ class EmbeddingLayer(nn.Module):
                 idx = _as_index(x[fea.name])
                 if not sharding.is_sharded(table):
                     pooled = ops.seq_pool(table.weight, idx, fea.pooling, table.padding_idx)
-                elif fea.pooling == "concat":
-                    # (B, L, D) would be L lookups of one sharded table per sample through sharding.lookup; that
-                    # combination has no parity test on a GPU yet, so it is refused rather than shipped unverified
-                    raise RuntimeError("torch_rechub_amd: concat-pooled sequence features on row-sharded tables are not "
-                                       "validated yet; keep this model's tables replicated (tables='replicate', or "
-                                       "shard_min_rows above the history table's size)")
+                elif fea.pooling == "concat":  # (B, L, D): L lookups of one table per sample through the same exchange
+                    L = idx.shape[1]
+                    pooled = sharding.lookup([table] * L, [idx[:, j] for j in range(L)]).view(-1, L, fea.embed_dim)
                 else:
                     pooled = sharding.pooled_lookup(table, idx, fea.pooling)
                 pieces[i] = pooled.unsqueeze(1)
