@@ -5,15 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: DeepFM (tutorials/00 wiring: MLP on 13 dense + 26x16 sparse, FM + LR on the
-sparse block), 26 sparse fields with the Criteo cardinalities (33 762 577 rows, D=16, fp32, 2.01 GiB of tables),
-synthetic rows resident in HBM, B=4096 per GPU, the reference trainer's defaults (Adam lr 1e-3, coupled
-weight_decay 1e-5, dropout 0.2) — i.e. a DENSE-exact optimizer step over every table row, as torch.optim.Adam does in
-the reference.  A step = batch assembly + forward + BCE + backward + optimizer step.  Weak scaling:
-per-GPU batch fixed, one process per GPU, RCCL all-reduce (dense grads) + all-gather (embedding gradient rows).
+Workload (default, --model deepfm) = BASELINE.json configs[1]: DeepFM (tutorials/00 wiring: MLP on 13 dense + 26x16
+sparse, FM + LR on the sparse block), 26 sparse fields with the Criteo cardinalities (33 762 577 rows, D=16, fp32,
+2.01 GiB of tables), synthetic rows resident in HBM, B=4096 per GPU, the reference trainer's defaults (Adam lr 1e-3,
+coupled weight_decay 1e-5, dropout 0.2) — i.e. a DENSE-exact optimizer step over every table row, as torch.optim.Adam
+does in the reference.  A step = batch assembly + forward + BCE + backward + optimizer step.  Weak scaling:
+per-GPU batch fixed, one process per GPU over RCCL.  --model dcnv2 | din | dssm time configs[2..4] on the same harness.
 
-One JSON line on rank 0; `roofline` is measured live with HIP events around the kernels of the step (same stream),
-`cpu_baseline` is oracle/cpu_port.py (the reference's op chain on eager torch CPU) timed on the host cores.
+Timed region: EXACTLY --steps steps of the STEADY STATE of the blocked-lazy exact optimizer (at least lazy_k + 8 replayed
+steps since the last flush, so every window sweep replays lazy_k steps and the lag distribution of the table rows is
+the same at the start and at the end of the region: no deferred work enters or leaves it).  The end-of-epoch flush (all
+rows brought to the last step) is timed separately (`flush_ms`) and checked afterwards (`min(last) == t`).
+
+One JSON line on rank 0; `roofline` / `kernels` are measured live with HIP events around the kernels of the step (same
+stream, same steady-state regime), `cpu_baseline` is oracle/cpu_port.py (the reference's op chain + its DataLoader
+contract on eager torch CPU) timed on the host cores.
 """
 import argparse
 import json
@@ -34,11 +40,12 @@ N_DENSE = 13
 EMBED_DIM = 16
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a float4 copy
 
-# algorithmic bytes: F=26, D=16, fp32, int64 indices
+# algorithmic bytes: F=26, D=16, fp32, int64 indices as the loader holds them
 FWD_BYTES_PER_SAMPLE = 26 * 8 + 26 * 16 * 4 + 26 * 16 * 4 + 8  # 3544
 BWD_BYTES_PER_SAMPLE = 26 * 8 + 26 * 16 * 4 + 26 * 16 * 4 + 4 + 26 * 16 * 4  # 5204
 ADAM_BYTES_PER_ELEM = 28  # read p,g,m,v + write p,m,v
 GATHER_BYTES_PER_SAMPLE = 2 * (26 * 8 + N_DENSE * 4 + 4)
+EPOCH_ROWS = 45_000_000  # BASELINE.json configs[1]: one epoch of the Criteo-shape dataset
 
 
 def parse():
@@ -46,27 +53,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="deepfm", choices=["deepfm", "dcnv2", "din", "dssm"],
+                    help="deepfm = BASELINE.json configs[1] (the headline); dcnv2 / din / dssm = configs[2] / [3] / [4]")
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch size")
-    ap.add_argument("--rows", type=int, default=45_000_000, help="synthetic dataset rows resident per GPU")
+    ap.add_argument("--rows", type=int, default=0, help="synthetic dataset rows resident per GPU (0 = per model)")
     ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"], help="replay the step from a hipGraph")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"], help="index distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline steps")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU baseline work (both legs together)")
     ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink every table")
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
     ap.add_argument("--lazy-k", type=int, default=64)
-    ap.add_argument("--tables", default="auto", choices=["auto", "replicate", "shard"],
+    ap.add_argument("--tables", default="auto", choices=["auto", "replicate", "shard", "both"],
                     help="N > 1 placement of the embedding tables; both compute the reference's global-batch update. "
-                         "replicate: one replica per rank, gradient rows all-gathered (nn.DataParallel's layout); "
-                         "shard: one row-shard per rank, indices all-gathered and rows reduce-scattered (table memory, "
-                         "optimizer state and sweep traffic / N); auto = shard when N > 1")
+                         "replicate: one replica per rank, gradient rows all-gathered (nn.DataParallel's layout, SURVEY "
+                         "8e); shard: one row-shard per rank, indices all-gathered and rows reduce-scattered (table "
+                         "memory, optimizer state and sweep traffic / N).  auto / both (N > 1): time BOTH, report each "
+                         "under `scaling_modes`, headline = the faster")
     ap.add_argument("--force-dp", action="store_true",
-                    help="run the data-parallel machinery (RCCL collectives, split graphs) even on one GPU")
+                    help="run the data-parallel machinery (RCCL collectives) even on one GPU")
+    ap.add_argument("--no-kernel-sweep", action="store_true", help="skip the gather-kernel batch sweep")
     return ap.parse_args()
 
 
-def build_dataset(rows, vocabs, device, seed, dist_kind):
+def criteo_columns(rows, vocabs, device, seed, dist_kind):
     g = torch.Generator(device=device).manual_seed(seed)
     sparse = torch.empty((rows, len(vocabs)), dtype=torch.int64, device=device)
     for j, v in enumerate(vocabs):
@@ -80,6 +91,116 @@ def build_dataset(rows, vocabs, device, seed, dist_kind):
     dense = torch.rand((rows, N_DENSE), generator=g, device=device, dtype=torch.float32)
     label = (torch.rand(rows, generator=g, device=device) < 0.25).float()
     return sparse, dense, label
+
+
+def padded_history(rows, L, vocab, g, device):
+    lens = torch.randint(1, L + 1, (rows,), device=device, generator=g)
+    h = torch.randint(1, vocab, (rows, L), device=device, generator=g)
+    return h.masked_fill_(torch.arange(L, device=device)[None, :] >= lens[:, None], 0)
+
+
+class Workload(object):
+    """Feature lists, synthetic HBM-resident dataset and the model / trainer factory of one --model."""
+
+    def __init__(self, args, device, rank):
+        from torch_rechub_amd.basic.features import DenseFeature, SequenceFeature, SparseFeature
+        self.args, self.device, self.name = args, device, args.model
+        scale = args.vocab_scale
+        g = torch.Generator(device=device).manual_seed(2022 + rank)
+        self.match = False
+        if self.name in ("deepfm", "dcnv2"):
+            self.vocabs = [max(3, int(v * scale)) for v in CRITEO_VOCABS]
+            self.dense_feas = [DenseFeature(f"I{i + 1}") for i in range(N_DENSE)]
+            self.sparse_feas = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=EMBED_DIM)
+                                for i, v in enumerate(self.vocabs)]
+            rows = args.rows or 45_000_000
+            self.sparse, self.dense, self.label = criteo_columns(rows, self.vocabs, device, 2022 + rank, args.dist)
+            self.sparse_names = [f.name for f in self.sparse_feas]
+            self.dense_names = [f.name for f in self.dense_feas]
+            self.table_feas = self.sparse_feas
+            self.desc = ("BASELINE.json configs[1]: DeepFM Criteo-shape synthetic, 26 sparse fields (33.76M rows total, "
+                         "D=16) + 13 dense, MLP 429-256-128-1, fp32, dataset resident in HBM") if self.name == "deepfm" \
+                else ("BASELINE.json configs[2]: DCN-v2 (CrossNetMix: 3 layers, rank 32, 4 experts; parallel DNN "
+                      "429-256-128) on the same Criteo-shape synthetic data, fp32, dataset resident in HBM")
+        elif self.name == "din":
+            nu, ni, nc, L = int(200000 * scale) + 10, int(63001 * scale) + 10, 801, 100
+            rows = args.rows or 1_000_000
+            self.L = L
+            self.feats = [SparseFeature("user_id", nu, 16)]
+            self.hist = [SequenceFeature("hist_item", ni, 16, pooling="concat", shared_with="target_item", padding_idx=0),
+                         SequenceFeature("hist_cate", nc, 16, pooling="concat", shared_with="target_cate", padding_idx=0)]
+            self.tgt = [SparseFeature("target_item", ni, 16, padding_idx=0),
+                        SparseFeature("target_cate", nc, 16, padding_idx=0)]
+            self.sparse = torch.cat([torch.randint(0, nu, (rows, 1), device=device, generator=g),
+                                     torch.randint(1, ni, (rows, 1), device=device, generator=g),
+                                     torch.randint(1, nc, (rows, 1), device=device, generator=g),
+                                     padded_history(rows, L, ni, g, device), padded_history(rows, L, nc, g, device)],
+                                    dim=1).contiguous()
+            self.sparse_names = ["user_id", "target_item", "target_cate", ("hist_item", L), ("hist_cate", L)]
+            self.dense, self.dense_names = None, []
+            self.label = (torch.rand(rows, device=device, generator=g) < 0.25).float()
+            self.table_feas = self.feats + self.tgt
+            self.desc = ("BASELINE.json configs[3]: DIN on Amazon-Electronics-shape synthetic (2 history fields x L<=100 "
+                         "post-padded, 2 targets + user_id, D=16, attention MLP [256,128] Dice, MLP [256,128]), fp32")
+        else:  # dssm
+            nu, ni, L = int(10_000_000 * scale) + 10, int(100_000_000 * scale) + 10, 50
+            rows = args.rows or 2_000_000
+            self.L = L
+            self.user = [SparseFeature("user_id", nu, 16),
+                         SequenceFeature("hist_item", ni, 16, pooling="mean", shared_with="item_id", padding_idx=0)]
+            self.item = [SparseFeature("item_id", ni, 16, padding_idx=0), SparseFeature("cate_id", 1000, 16)]
+            self.sparse = torch.cat([torch.randint(0, nu, (rows, 1), device=device, generator=g),
+                                     torch.randint(1, ni, (rows, 1), device=device, generator=g),
+                                     torch.randint(0, 1000, (rows, 1), device=device, generator=g),
+                                     padded_history(rows, L, ni, g, device)], dim=1).contiguous()
+            self.sparse_names = ["user_id", "item_id", "cate_id", ("hist_item", L)]
+            self.dense, self.dense_names = None, []
+            self.label = torch.zeros(rows, device=device)
+            self.table_feas = [self.user[0]] + self.item
+            self.match = True
+            self.desc = ("BASELINE.json configs[4]: DSSM two-tower, in-batch negatives (20 per row), 100M-item + "
+                         "10M-user tables (D=16) resident in HBM, history L<=50 mean-pooled, towers [256,128,64] prelu")
+        self.rows = rows
+
+    def build(self, placement, use_graph):
+        """(model, trainer, loader); every call starts from fresh tables (Feature objects cache their nn.Embedding, Q2)."""
+        from torch_rechub_amd.trainers import CTRTrainer, MatchTrainer
+        from torch_rechub_amd.utils.data import DeviceDataLoader
+        a, device = self.args, self.device
+        feas = {"deepfm": lambda: self.sparse_feas, "dcnv2": lambda: self.sparse_feas,
+                "din": lambda: self.feats + self.hist + self.tgt, "dssm": lambda: self.user + self.item}[self.name]()
+        for f in feas:
+            if hasattr(f, "embed"):
+                del f.embed
+        torch.manual_seed(2022)  # identical initial replica on every rank (and broadcast from rank 0 anyway)
+        mlp = {"dims": [256, 128], "dropout": 0.2, "activation": "relu"}
+        with torch.device(device):  # tables are created directly in HBM (never staged through the host)
+            if self.name == "deepfm":
+                from torch_rechub_amd.models.ranking import DeepFM
+                m = DeepFM(self.dense_feas + self.sparse_feas, self.sparse_feas, mlp)
+            elif self.name == "dcnv2":
+                from torch_rechub_amd.models.ranking import DCNv2
+                m = DCNv2(self.dense_feas + self.sparse_feas, 3, mlp)
+            elif self.name == "din":
+                from torch_rechub_amd.models.ranking import DIN
+                m = DIN(self.feats, self.hist, self.tgt, mlp_params={"dims": [256, 128], "dropout": 0.2},
+                        attention_mlp_params={"dims": [256, 128]})
+            else:
+                from torch_rechub_amd.models.matching import DSSM
+                tower = {"dims": [256, 128, 64], "activation": "prelu"}
+                m = DSSM(self.user, self.item, user_params=dict(tower), item_params=dict(tower), temperature=0.02)
+        kw = dict(device=str(device), show_progress=False, use_graph=use_graph, table_update=a.table_adam,
+                  lazy_k=a.lazy_k, tables=placement)
+        if self.match:
+            t = MatchTrainer(m, mode=0, in_batch_neg=True, in_batch_neg_ratio=20, **kw)
+        else:
+            t = CTRTrainer(m, **kw)
+        ld = DeviceDataLoader(self.sparse, self.sparse_names, self.dense, self.dense_names, self.label, a.batch,
+                              shuffle=True)
+        ld.reshuffle()
+        m.train()
+        t.optimizer.sync_hyper()
+        return m, t, ld
 
 
 class KernelTimer(object):
@@ -110,9 +231,9 @@ class KernelTimer(object):
         _lib.call = timed
 
     def _modules(self):
-        from torch_rechub_amd import ops, optim
+        from torch_rechub_amd import ops, optim, sharding
         from torch_rechub_amd.utils import data
-        return [ops, optim, data]
+        return [m for m in (ops, optim, data, sharding) if hasattr(m, "_lib")]
 
     def remove(self):
         from torch_rechub_amd import _lib
@@ -124,115 +245,147 @@ class KernelTimer(object):
         torch.cuda.synchronize()
         return {n: (sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None) for n, ev in self.events.items()}
 
+    def calls(self):
+        return {n: len(ev) for n, ev in self.events.items()}
 
-def gather_sweep(model, sparse_feas, dense_feas, vocabs, device, batches=(4096, 16384, 65536), iters=50):
-    """rh_embed_fwd (gather + FM + LR + dense concat) alone at several batch sizes: avg launch time and achieved GB/s."""
+
+class CommTimer(object):
+    """HIP-event timing of the collectives a step issues (eager profiling pass only): every torch.distributed collective
+    is bracketed by events on the stream it is ISSUED on (main stream = exposed; the dense all-reduce runs on the
+    bucket's side stream = overlapped), and the main stream's wait for the side stream (DenseGradBucket.join) is
+    bracketed too (exposed tail of the overlapped all-reduce)."""
+
+    FNS = ["all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor", "all_gather", "broadcast"]
+
+    def __init__(self, bucket):
+        self.bucket, self.ev, self._orig = bucket, [], {}
+
+    def _wrap(self, name, fn):
+        timer = self
+
+        def timed(*a, **k):
+            cur = torch.cuda.current_stream()
+            side = timer.bucket is not None and timer.bucket.side is not None and \
+                cur.cuda_stream == timer.bucket.side.cuda_stream
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            if side:  # async all-reduce on the side stream: its bracket is closed when the main stream joins
+                if timer.side_open is None:
+                    timer.side_open = e0
+                return out
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            timer.ev.append(("main_stream", e0, e1))
+            return out
+
+        return timed
+
+    def install(self):
+        self.side_open = None
+        for n in self.FNS:
+            if hasattr(dist, n):
+                self._orig[n] = getattr(dist, n)
+                setattr(dist, n, self._wrap(n, self._orig[n]))
+        if self.bucket is not None:
+            self._join = self.bucket.join
+            timer = self
+
+            def join():
+                if timer.side_open is not None and timer.bucket.side is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    with torch.cuda.stream(timer.bucket.side):
+                        e1.record()  # after every collective queued on the side stream so far
+                    timer.ev.append(("side_stream", timer.side_open, e1))
+                    timer.side_open = None
+                j0, j1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                j0.record()
+                timer._join()
+                j1.record()
+                timer.ev.append(("join_wait", j0, j1))
+
+            self.bucket.join = join
+
+    def remove(self):
+        for n, fn in self._orig.items():
+            setattr(dist, n, fn)
+        if self.bucket is not None and hasattr(self, "_join"):
+            self.bucket.join = self._join
+
+    def per_step_us(self, steps):
+        torch.cuda.synchronize()
+        out = {"main_stream": 0.0, "side_stream": 0.0, "join_wait": 0.0}
+        for kind, e0, e1 in self.ev:
+            try:
+                out[kind] += e0.elapsed_time(e1) * 1e3
+            except RuntimeError:
+                pass
+        return {k: round(v / max(steps, 1), 2) for k, v in out.items()}
+
+
+def gather_sweep(model, wl, device, batches=(4096, 16384, 65536), iters=40):
+    """rh_embed_fwd (gather + FM + LR + dense concat) and rh_embed_bwd (gradient rows -> scatter-add + LR weight partials)
+    alone at several batch sizes, on the real tables, packed (B, F) index layout as the loader hands it over: avg launch
+    time (HIP events) and achieved GB/s against the algorithmic bytes of SURVEY 8(d)."""
     from torch_rechub_amd import ops
     out = {}
     g = torch.Generator(device=device).manual_seed(7)
     w, b = model.linear.fc.weight, model.linear.fc.bias
-    with torch.no_grad():
-        for B in batches:
-            # the batch layout the device loader hands over: one packed (B, F) index matrix and one (B, n_dense) matrix
-            idx = torch.stack([torch.randint(0, v, (B,), device=device, generator=g) for v in vocabs], 1).contiguous()
-            den = torch.rand(B, len(dense_feas), device=device, generator=g)
-            x = {f.name: idx[:, j] for j, f in enumerate(sparse_feas)}
-            x.update({f.name: den[:, j] for j, f in enumerate(dense_feas)})
-            call = model.embedding.make_call(x, sparse_feas, dense_feas, want_fm=True, want_lr=True)
-            for _ in range(5):
-                ops.fused_embedding(call, w, b)
-            timer = KernelTimer(["rh_embed_fwd"])
-            timer.install()
-            for _ in range(iters):
-                ops.fused_embedding(call, w, b)
-            ms = timer.mean_ms()["rh_embed_fwd"]
-            timer.remove()
-            gbs = FWD_BYTES_PER_SAMPLE * B / (ms * 1e-3) / 1e9
-            out[str(B)] = {"avg_ms": round(ms, 5), "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    for B in batches:
+        idx = torch.stack([torch.randint(0, v, (B,), device=device, generator=g) for v in wl.vocabs], 1).contiguous()
+        den = torch.rand(B, len(wl.dense_feas), device=device, generator=g)
+        x = {f.name: idx[:, j] for j, f in enumerate(wl.sparse_feas)}
+        x.update({f.name: den[:, j] for j, f in enumerate(wl.dense_feas)})
+        call = model.embedding.make_call(x, wl.sparse_feas, wl.dense_feas, want_fm=True, want_lr=True)
+        g_out = torch.randn(B, call.width, device=device, generator=g)
+        g_fm = torch.randn(B, 1, device=device, generator=g)
+        g_lr = torch.randn(B, 1, device=device, generator=g)
+
+        def once():
+            o, fm, lr = ops.fused_embedding(call, w, b)
+            torch.autograd.backward([o, fm, lr], [g_out, g_fm, g_lr])
+            w.grad = b.grad = None
+
+        for _ in range(3):
+            once()
+        timer = KernelTimer(["rh_embed_fwd", "rh_embed_bwd"])
+        timer.install()
+        for _ in range(iters):
+            once()
+        ms = timer.mean_ms()
+        timer.remove()
+        ent = {}
+        for k, nbytes in (("rh_embed_fwd", FWD_BYTES_PER_SAMPLE), ("rh_embed_bwd", BWD_BYTES_PER_SAMPLE)):
+            gbs = nbytes * B / (ms[k] * 1e-3) / 1e9
+            ent[k] = {"avg_ms": round(ms[k], 5), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        # r01-compatible top-level fields = the forward
+        ent.update({"avg_ms": ent["rh_embed_fwd"]["avg_ms"], "achieved_GBps": ent["rh_embed_fwd"]["achieved_GBps"],
+                    "frac_of_hbm_peak": ent["rh_embed_fwd"]["frac"], "frac": ent["rh_embed_fwd"]["frac"]})
+        out[str(B)] = ent
     return out
 
 
-def main():
-    args = parse()
-    # stdout carries exactly ONE line, the result JSON: RCCL / the runtime print banners on fd 1 (seen: "RCCL version :
-    # ..." after the collectives), so everything else is sent to stderr for the lifetime of the process.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_dp:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    if args.force_dp:
-        os.environ["RECHUB_FORCE_DP"] = "1"
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    device = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(device)
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
-    from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
-    from torch_rechub_amd.models.ranking import DeepFM
-    from torch_rechub_amd.trainers import CTRTrainer
-    from torch_rechub_amd.utils.data import DeviceDataLoader
 
-    vocabs = [max(3, int(v * args.vocab_scale)) for v in CRITEO_VOCABS]
-    dense_feas = [DenseFeature(f"I{i + 1}") for i in range(N_DENSE)]
-    sparse_feas = [SparseFeature(f"C{i + 1}", vocab_size=v, embed_dim=EMBED_DIM) for i, v in enumerate(vocabs)]
-    parallel = world > 1 or args.force_dp
-    tables = args.tables
-    test_fallback = os.environ.get("RECHUB_BENCH_TEST_FALLBACK") == "1"  # exercise the fallback below on one GPU
-    if tables == "auto":
-        tables = "shard" if (world > 1 or (test_fallback and args.force_dp)) else "replicate"
-    if not parallel:
-        tables = None  # one GPU, one copy
-    use_graph = args.graph in ("1", "auto")  # N > 1: the RCCL collectives are captured with the rest of the step
-    sparse, dense, label = build_dataset(args.rows, vocabs, device, seed=2022 + rank, dist_kind=args.dist)
-
-    def build(placement):
-        for f in sparse_feas:  # Feature objects cache their nn.Embedding (Q2): a rebuild must start from fresh tables
-            if hasattr(f, "embed"):
-                del f.embed
-        torch.manual_seed(2022)  # identical initial replica on every rank (and broadcast from rank 0 anyway)
-        with torch.device(device):  # tables are created directly in HBM (2 GiB; never staged through the host)
-            m = DeepFM(dense_feas + sparse_feas, sparse_feas, {"dims": [256, 128], "dropout": 0.2, "activation": "relu"})
-        t = CTRTrainer(m, device=str(device), show_progress=False, use_graph=use_graph, table_update=args.table_adam,
-                       lazy_k=args.lazy_k, tables=placement)
-        ld = DeviceDataLoader(sparse, [f.name for f in sparse_feas], dense, [f.name for f in dense_feas], label,
-                              args.batch, shuffle=True)
-        ld.reshuffle()
-        m.train()
-        t.optimizer.sync_hyper()
-        return m, t, ld
-
-    model, trainer, loader = build(tables)
-    if tables == "shard" and args.tables == "auto":
-        # the row-sharded exchange has been validated with two ranks on one GPU and on a one-rank RCCL group, never on
-        # this node's N GPUs: one eager step decides, on every rank alike, whether this job keeps it
-        ok = torch.ones(1, device=device)
-        try:
-            trainer.train_step(*loader.load_next())
-            torch.cuda.synchronize()
-            if test_fallback:
-                raise RuntimeError("RECHUB_BENCH_TEST_FALLBACK")
-        except Exception as e:  # noqa: BLE001
-            ok.zero_()
-            print(f"[bench] rank {rank}: row-sharded step failed ({type(e).__name__}: {e})", file=sys.stderr)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            if rank == 0:
-                print("[bench] falling back to replicated tables", file=sys.stderr)
-            trainer.dp.close()
-            del model, trainer, loader
-            torch.cuda.empty_cache()
-            tables = "replicate"
-            model, trainer, loader = build(tables)
+def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
+    """Build, warm up into the steady state, time exactly --steps steps; optionally the per-kernel eager pass; then the
+    flush (timed separately) and the no-row-behind check.  Returns a dict."""
+    from torch_rechub_amd import ops
+    model, trainer, loader = wl.build(placement, use_graph)
     B = args.batch
-
+    opt = trainer.optimizer
+    lazy = getattr(opt, "lazy_k", 0) > 1
+    res = {"tables": placement}
     graph_ok = False
 
     def eager_step():
@@ -263,149 +416,299 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # warm-up INTO the steady state: after a flush the first lazy_k window sweeps replay 1, 2, ... steps only
+    warm = max(args.warmup, (args.lazy_k + 8) if lazy else 0)
+    for _ in range(warm):
         step()
-    trainer.flush()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    trainer.flush()  # lazy mode: every table row is brought to the last step INSIDE the timed region (weights final)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    from torch_rechub_amd import ops
-    ops.check_errors(device)
+    res.update(dt=dt, warmup_effective=warm, hipgraph=graph_ok, ms_per_step=1e3 * dt / args.steps,
+               value=world * B * args.steps / dt)
 
-    # ---- per-kernel HIP-event timing of the same step (eager launches, same stream, after the headline loop) ----
-    kernels = {}
-    gsweep = None
-    if rank == 0:
+    # ---- per-kernel HIP-event timing, eager launches of the same step in the SAME regime (no flush in between) ----
+    n_prof = max(8, min(args.steps, 30))
+    if profile:
         names = ["rh_embed_fwd", "rh_embed_bwd", "rh_adam_dense", "rh_adam_lazy_touched", "rh_adam_lazy_sweep",
-                 "rh_batch_gather", "rh_embed_scatter_rows", "rh_shard_localize"]
+                 "rh_batch_gather", "rh_embed_scatter_rows", "rh_shard_localize", "rh_seq_pool_fwd", "rh_seq_pool_bwd"]
         timer = KernelTimer(names)
+        comm = CommTimer(trainer.bucket) if trainer.dp is not None else None
+        overlap = getattr(opt, "overlap_sweep", None)
+        if overlap:
+            opt.overlap_sweep = False  # time the sweep alone, not under the forward / backward it hides behind
         timer.install()
-        n_prof = max(5, min(args.steps, 30))
-        overlap = getattr(trainer.optimizer, "overlap_sweep", None)
-        if overlap is not None:
-            trainer.optimizer.overlap_sweep = False  # time the sweep alone, not under the forward / backward it hides behind
+        if comm is not None:
+            try:
+                comm.install()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] comm timer not installed: {e}", file=sys.stderr)
+                comm = None
         for _ in range(n_prof):
             eager_step()
-        ms = timer.mean_ms()
+        res["kernel_ms"] = timer.mean_ms()
+        res["kernel_calls_per_step"] = {n: round(c / n_prof, 2) for n, c in timer.calls().items() if c}
         timer.remove()
-        if overlap is not None:
-            trainer.optimizer.flush()
-            trainer.optimizer.overlap_sweep = overlap
-        total_elems = sum(p.numel() for p in trainer.optimizer._tables)
-        # lazy sweep: bytes one launch must move = its 1/K window of every table (read + write p, m, v; 4 B/row of
-        # `last` both ways) + the K=1 (small) tables in full incl. their gradient.  The other 1 - 1/K of the dense
-        # pass's traffic is replaced by replay arithmetic, which is what bounds this kernel (VALU).
-        opt = trainer.optimizer
-        sweep_bytes = 0
-        for p_ in opt._tables:
-            rows, d_ = p_.shape
-            k_ = 1 if (opt.lazy_k <= 1 or rows <= opt.lazy_small_rows) else opt.lazy_k
-            win = -(-rows // k_)
-            sweep_bytes += win * (d_ * 4 * (7 if k_ == 1 else 6) + 8)
-        alg = {"rh_embed_fwd": FWD_BYTES_PER_SAMPLE * B, "rh_embed_bwd": BWD_BYTES_PER_SAMPLE * B,
-               "rh_adam_dense": ADAM_BYTES_PER_ELEM * total_elems, "rh_adam_lazy_sweep": sweep_bytes,
-               "rh_batch_gather": GATHER_BYTES_PER_SAMPLE * B}
+        if comm is not None:
+            comm.remove()
+            res["comm_us_per_step"] = comm.per_step_us(n_prof)
+            res["comm_us_per_step"]["note"] = ("eager pass, HIP events on the issuing stream: main_stream = exposed "
+                                               "collectives (row / index exchange), side_stream = dense all-reduce under "
+                                               "the embedding backward, join_wait = its exposed tail")
+        if overlap:
+            opt.overlap_sweep = overlap
+    elif world > 1:
+        for _ in range(n_prof):  # keep the collectives of the profiling pass matched on every rank
+            eager_step()
+
+    # ---- the end-of-epoch flush, timed on its own, then: no row may be behind the step counter ----
+    torch.cuda.synchronize()
+    f0 = time.perf_counter()
+    trainer.flush()
+    torch.cuda.synchronize()
+    res["flush_ms"] = round(1e3 * (time.perf_counter() - f0), 4)
+    if lazy and opt._tables:
+        t_now = int(opt._t_step.item())
+        behind = min(int(last.min().item()) for last in opt._t_last)
+        res["rows_behind_after_flush"] = t_now - behind
+        if behind != t_now:
+            raise RuntimeError(f"flush left rows behind: step counter {t_now}, min(last) {behind}")
+    ops.check_errors(device)
+    res["total_elems"] = sum(p.numel() for p in opt._tables) if hasattr(opt, "_tables") else 0
+    # lazy sweep: bytes one launch must move = its 1/K window of every table (read + write p, m, v; 4 B/row of `last`
+    # both ways) + the K=1 (small) tables in full incl. their gradient.  The other 1 - 1/K of the dense pass's traffic
+    # is replaced by replay arithmetic, which is what bounds this kernel (VALU).
+    sweep_bytes = 0
+    for p_ in (opt._tables if hasattr(opt, "_tables") else []):
+        rows, d_ = p_.shape
+        k_ = 1 if (opt.lazy_k <= 1 or rows <= opt.lazy_small_rows) else opt.lazy_k
+        win = -(-rows // k_)
+        sweep_bytes += win * (d_ * 4 * (7 if k_ == 1 else 6) + 8)
+    res["sweep_bytes"] = sweep_bytes
+    res["overlap_sweep"] = bool(getattr(opt, "overlap_sweep", False))
+    # the north-star kernels over batch sizes (same tables, same stream, HIP events): their bandwidth regime starts
+    # where the launch is no longer three dependent memory round trips long.  Last: it leaves junk gradient rows behind.
+    if profile and wl.name == "deepfm" and trainer.dp is None and not args.no_kernel_sweep:
+        try:
+            res["gsweep"] = gather_sweep(model, wl, device)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] gather sweep failed: {type(e).__name__}: {e}", file=sys.stderr)
+        if hasattr(opt, "_touch_log"):
+            del opt._touch_log[:]
+    if trainer.dp is not None:
+        trainer.dp.close()
+    return res
+
+
+def main():
+    args = parse()
+    # stdout carries exactly ONE line, the result JSON: RCCL / the runtime print banners on fd 1 (seen: "RCCL version :
+    # ..." after the collectives), so everything else is sent to stderr for the lifetime of the process.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if args.force_dp:
+        os.environ["RECHUB_FORCE_DP"] = "1"
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    parallel = world > 1 or args.force_dp
+    use_graph = args.graph in ("1", "auto")  # N > 1: the RCCL collectives are captured with the rest of the step
+    wl = Workload(args, device, rank)
+    B = args.batch
+
+    if not parallel:
+        modes = [None]  # one GPU, one copy
+    elif args.tables in ("auto", "both"):
+        modes = ["replicate", "shard"]
+    else:
+        modes = [args.tables]
+    results = {}
+    for i, placement in enumerate(modes):
+        ok = torch.ones(1, device=device)
+        r = None
+        try:
+            r = run_mode(args, wl, placement, use_graph, world, rank, device, profile=(rank == 0))
+        except Exception as e:  # noqa: BLE001
+            if len(modes) == 1:
+                raise
+            ok.zero_()
+            print(f"[bench] rank {rank}: tables={placement} failed ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 1 and r is not None:
+            results[placement] = r
+        torch.cuda.empty_cache()  # this mode's model is gone (run_mode returned): room for the next one
+    if not results:
+        raise RuntimeError("no table placement completed")
+    best = max(results, key=lambda k: results[k]["value"])
+    head = results[best]
+
+    kernels, gsweep = {}, head.get("gsweep")
+    if rank == 0:
+        ms = head.get("kernel_ms", {})
+        total_elems, sweep_bytes = head["total_elems"], head["sweep_bytes"]
+        alg = {"rh_adam_dense": ADAM_BYTES_PER_ELEM * total_elems, "rh_adam_lazy_sweep": sweep_bytes}
+        if wl.name in ("deepfm", "dcnv2") and best != "shard":
+            alg.update({"rh_embed_fwd": FWD_BYTES_PER_SAMPLE * B, "rh_embed_bwd": BWD_BYTES_PER_SAMPLE * B,
+                        "rh_batch_gather": GATHER_BYTES_PER_SAMPLE * B})
         for n, t_ms in ms.items():
             if t_ms is None:
                 continue
+            calls = head.get("kernel_calls_per_step", {}).get(n)
             if n not in alg:
-                kernels[n] = {"avg_ms": round(t_ms, 5)}
+                kernels[n] = {"avg_ms": round(t_ms, 5), "calls_per_step": calls}
                 continue
             gbs = alg[n] / (t_ms * 1e-3) / 1e9
-            kernels[n] = {"avg_ms": round(t_ms, 5), "algorithmic_bytes": alg[n], "achieved_GBps": round(gbs, 1),
-                          "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        # the north-star kernel over batch sizes (same tables, same stream, HIP events): its bandwidth regime starts
-        # where the launch is no longer three dependent memory round trips long
-        if tables != "shard":  # (a shard holds 1/N of the rows under local ids: the study belongs to the full tables)
-            gsweep = gather_sweep(model, sparse_feas, dense_feas, vocabs, device)
-    elif world > 1:
-        for _ in range(max(5, min(args.steps, 30))):  # keep the collectives of the profiling pass matched
-            eager_step()
+            kernels[n] = {"avg_ms": round(t_ms, 5), "calls_per_step": calls, "algorithmic_bytes": alg[n],
+                          "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        ms_per_step = 1e3 * dt / args.steps
-        value = world * B * args.steps / dt
         timed = {n: k for n, k in kernels.items() if "achieved_GBps" in k}
-        dominant = max(timed, key=lambda n: timed[n]["avg_ms"]) if timed else None
+        dominant = max(timed, key=lambda n: timed[n]["avg_ms"] * (timed[n]["calls_per_step"] or 1)) if timed else None
         roofline = None
         if dominant:
             k = kernels[dominant]
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": k["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": None,
-                        "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"]}
+                        "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
+                        "regime": f"steady state, >= {head['warmup_effective']} steps since the last flush; compare with "
+                                  "the kernel's average in profiles/r02_bench_kernel_stats.txt"}
             pmc_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
-            if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0:
+            if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0 and best is None:
                 # measured with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel in this
                 # configuration (2*FETCH + WRITE, gfx950 correction, calibrated on rh_adam_dense): profiles/r01_pmc_traffic.md
                 roofline["traffic"] = pmc_traffic
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
             if dominant == "rh_adam_lazy_sweep":
-                # the kernel's own bound: one replay iteration = 16 packed f32 ops (4 cycles / wavefront) + 4 sqrt + 4 rcp
-                # (8 cycles each, measured) + 2 scalar-ish VALU ops = 136 cycles per 256 element-steps on each of the
-                # 1024 SIMDs at 2.4 GHz (csrc/optim.hip)
+                # The kernel's own bound is the replay arithmetic.  In the steady state every table element advances
+                # lazy_k steps per lazy_k launches, so one launch replays AT MOST total_elems element-steps (the rows the
+                # batch touched are replayed by rh_adam_lazy_touched instead): an upper bound on the work, hence on frac.
+                # One replay iteration = 16 packed f32 ops (4 cycles / wavefront) + 4 sqrt + 4 rcp (8 cycles each,
+                # measured) + 2 VALU ops = 136 cycles per 256 element-steps on each of 1024 SIMDs at 2.4 GHz.
                 valu_peak = 1024 * 2.4e9 / 136 * 256
                 es = total_elems / (k["avg_ms"] * 1e-3)
-                roofline["valu"] = {"achieved": round(es / 1e9, 1), "peak": round(valu_peak / 1e9, 1),
-                                    "unit": "G element-steps/s", "frac": round(es / valu_peak, 4)}
+                frac = es / valu_peak
+                roofline["valu"] = {"achieved_upper_bound": round(es / 1e9, 1), "peak": round(valu_peak / 1e9, 1),
+                                    "unit": "G element-steps/s", "frac_upper_bound": round(frac, 4) if frac <= 1 else None,
+                                    "element_steps_per_launch_upper_bound": total_elems}
                 roofline["note"] = ("blocked-lazy exact Adam: this launch moves 1/K of the dense pass's bytes and replays "
-                                    "the rest in registers (VALU-bound: %.0f M element-steps per launch, %.1f G "
-                                    "element-steps/s); the dense pass it replaces is rh_adam_dense at 64-75 %% of HBM "
-                                    "peak, see profiles/" % (total_elems / 1e6, total_elems / (k["avg_ms"] * 1e-3) / 1e9))
+                                    "the rest in registers (VALU-bound); the HBM fraction is low BY CONSTRUCTION; the "
+                                    "dense pass it replaces (rh_adam_dense) runs at 64-75 % of HBM peak, see profiles/")
+        north = None
+        if "rh_embed_fwd" in timed and "rh_embed_bwd" in timed:
+            f_, b_ = timed["rh_embed_fwd"], timed["rh_embed_bwd"]
+            both_ms = f_["avg_ms"] + b_["avg_ms"]
+            both_gbs = (f_["algorithmic_bytes"] + b_["algorithmic_bytes"]) / (both_ms * 1e-3) / 1e9
+            north = {"kernels": ["rh_embed_fwd", "rh_embed_bwd"], "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "in_step": {"batch": B, "fwd_ms": f_["avg_ms"], "bwd_ms": b_["avg_ms"],
+                                 "fwd_frac": f_["frac_of_hbm_peak"], "bwd_frac": b_["frac_of_hbm_peak"],
+                                 "achieved": round(both_gbs, 1), "frac": round(both_gbs / HBM_PEAK_GBS, 4),
+                                 "batch_assembly_ms": (timed.get("rh_batch_gather") or {}).get("avg_ms")},
+                     "algorithmic_bytes_per_sample": {"fwd": FWD_BYTES_PER_SAMPLE, "bwd": BWD_BYTES_PER_SAMPLE}}
+            if gsweep:
+                big = gsweep[max(gsweep, key=int)]
+                north["at_batch_%s" % max(gsweep, key=int)] = {"fwd_frac": big["rh_embed_fwd"]["frac"],
+                                                              "bwd_frac": big["rh_embed_bwd"]["frac"]}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.cpu_port import time_cpu_baseline
+        if world == 1 and not args.no_cpu_baseline and wl.name == "deepfm":
+            from oracle.cpu_port import time_cpu_baseline, time_cpu_end_to_end
+            cpu = {"unit": "samples/s", "kind": "port", "cores": os.cpu_count(), "cpu_model": cpu_model_string()}
             try:
-                r = time_cpu_baseline(vocabs, N_DENSE, B, budget_s=args.cpu_budget)
-                cpu = {"value": round(r["samples_per_s"], 1), "unit": "samples/s", "cores": r["cores"], "kind": "port",
-                       "sample": f"{r['steps']} model-step-only train steps (fwd+bwd+dense Adam) of the reference op chain "
-                                 f"on eager torch CPU (oracle/cpu_port.py), same DeepFM shape and vocab, B={B}, "
-                                 f"{r['ms_per_step']:.0f} ms/step, pre-collated batches (no DataLoader)"}
+                r = time_cpu_end_to_end(wl.vocabs, N_DENSE, B, budget_s=args.cpu_budget / 2)
+                cpu["end_to_end"] = {"value": round(r["samples_per_s"], 1), "steps": r["steps"],
+                                     "ms_per_step": round(r["ms_per_step"], 1), "loader_ms_per_step": round(r["loader_ms_per_step"], 1),
+                                     "rows": r["rows"]}
+                cpu["value"], cpu["cores"] = cpu["end_to_end"]["value"], r["cores"]
+                cpu["sample"] = (f"{r['steps']} steps of the reference's CTRTrainer.train_one_epoch loop "
+                                 f"(trainers/ctr_trainer.py:77-108) restated on eager torch CPU (oracle/cpu_port.py): "
+                                 f"DataGenerator-style loader (TorchDataset + random_split 0.7/0.1/0.2 + "
+                                 f"DataLoader(shuffle=True, num_workers=0), x = dict of numpy, {r['rows']} rows) -> "
+                                 f"DeepFM op chain -> BCELoss -> dense Adam over all 33.76M rows, B={B}")
             except (MemoryError, RuntimeError) as e:
-                cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-                       "sample": f"failed: {type(e).__name__}: {e}"}
+                cpu["end_to_end"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+                cpu["value"] = None
+            try:
+                r = time_cpu_baseline(wl.vocabs, N_DENSE, B, budget_s=args.cpu_budget / 2)
+                cpu["model_step"] = {"value": round(r["samples_per_s"], 1), "steps": r["steps"],
+                                     "ms_per_step": round(r["ms_per_step"], 1),
+                                     "sample": "model-step-only (fwd+bwd+dense Adam), pre-collated batches, no DataLoader"}
+                cpu["cores"] = r["cores"]
+            except (MemoryError, RuntimeError) as e:
+                cpu["model_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        opt_desc = "dense pass per step"
+        if args.table_adam == "lazy":
+            opt_desc = (f"blocked-lazy exact replay, K={args.lazy_k}, window sweep "
+                        + ("of step t on a side stream under step t+1's forward/backward" if head["overlap_sweep"]
+                           else "in line")
+                        + f"; timed region = steady state ({head['warmup_effective']} untimed steps since the last flush: "
+                        "the rows' lag distribution is the same at its start and end, no deferred work crosses it); the "
+                        "end-of-epoch flush is timed separately (flush_ms) and verified (rows_behind_after_flush = 0)")
+        steps_per_epoch = EPOCH_ROWS // (B * world)
         line = {
-            "metric": "CTR train samples/sec, DeepFM Criteo-shape synthetic",
-            "value": round(value, 1),
+            "metric": "CTR train samples/sec, DeepFM Criteo-shape synthetic" if wl.name == "deepfm" else
+                      f"CTR train samples/sec, {wl.name} (secondary config)",
+            "value": round(head["value"], 1),
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": round(head["ms_per_step"], 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[1]: DeepFM Criteo-shape synthetic, 26 sparse fields (33.76M rows total, "
-                            "D=16) + 13 dense, MLP 429-256-128-1, fp32, dataset resident in HBM",
-                "rows_per_gpu": args.rows, "batch_per_gpu": B, "global_batch": B * world, "index_dist": args.dist,
+                "workload": wl.desc,
+                "model": wl.name, "rows_per_gpu": wl.rows, "batch_per_gpu": B, "global_batch": B * world,
+                "index_dist": args.dist, "warmup_effective": head["warmup_effective"],
                 "optimizer": "Adam lr=1e-3 weight_decay=1e-5, dense-exact semantics (every table row moves every step, as "
-                             "torch.optim.Adam); execution: " + (f"blocked-lazy exact replay, K={args.lazy_k}, window sweep "
-                             + ("of step t on a side stream under step t+1's forward/backward, " if getattr(
-                                 trainer.optimizer, "overlap_sweep", False) else "in line, ") + "flushed "
-                             "inside the timed region" if args.table_adam == "lazy" else "dense pass per step"),
-                "parallelism": f"dp{world}" if (world > 1 or args.force_dp) else "single", "hipgraph": graph_ok,
+                             "torch.optim.Adam); execution: " + opt_desc,
+                "parallelism": f"dp{world}" if parallel else "single", "hipgraph": head["hipgraph"],
                 "tables": {"shard": f"row-sharded over {world} ranks (row g on rank g % {world})",
                            "replicate": "one replica per rank, gradient rows exchanged",
-                           None: "single copy"}[tables],
+                           None: "single copy"}[best],
                 "vocab_scale": args.vocab_scale,
             },
+            "flush_ms": head["flush_ms"],
+            "rows_behind_after_flush": head.get("rows_behind_after_flush"),
+            "epoch_amortised": {"steps_per_epoch": steps_per_epoch,
+                                "value": round(world * B * steps_per_epoch /
+                                               (steps_per_epoch * head["ms_per_step"] * 1e-3 + head["flush_ms"] * 1e-3), 1),
+                                "note": "one 45M-row epoch = steps_per_epoch steady-state steps + ONE flush"},
             "roofline": roofline,
+            "roofline_north_star": north,
             "kernels": kernels,
             "gather_kernel_sweep": gsweep,
             "cpu_baseline": cpu,
         }
+        if parallel:
+            line["scaling_modes"] = {
+                k: {"value": round(v["value"], 1), "ms_per_step": round(v["ms_per_step"], 4), "hipgraph": v["hipgraph"],
+                    "flush_ms": v["flush_ms"], "comm_us_per_step": v.get("comm_us_per_step")}
+                for k, v in results.items()}
+            line["scaling_modes"]["headline"] = best
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()

@@ -12,12 +12,18 @@ It restates the reference's op chain one-for-one, so that its cost profile is th
   * CrossNetwork loop (layers.py:412-420);
   * step = BCELoss on probabilities, model.zero_grad(), backward (dense embedding gradients), torch.optim.Adam over
     every parameter incl. all table rows (trainers/ctr_trainer.py:59-61, 87-99), loss.item() twice per step.
+  * end-to-end leg: the reference's input contract -- ``TorchDataset.__getitem__`` builds one dict PER SAMPLE,
+    ``DataGenerator.generate_dataloader`` does ``random_split`` + ``DataLoader(shuffle=True, num_workers=0)``
+    (utils/data.py:14-25, 61-83), the loop moves every column to the device and calls ``y.float()``
+    (trainers/ctr_trainer.py:83-85) -- SURVEY 8(d) "the reference CPU CTRTrainer".
 Pinned by tests/test_oracle_golden.py::test_cpu_port_* against the reference's golden vectors.
 """
 import time
 
+import numpy as np
 import torch
 from torch import nn
+from torch.utils.data import DataLoader, Dataset, random_split
 
 
 class PortMLP(nn.Module):
@@ -142,3 +148,71 @@ def time_cpu_baseline(vocabs, n_dense, batch_size, budget_s=20.0, min_steps=3, m
     dt = time.perf_counter() - t_start
     return dict(samples_per_s=steps * batch_size / dt, steps=steps, ms_per_step=1e3 * dt / steps,
                 cores=torch.get_num_threads(), build_s=build_s)
+
+
+class PortDataset(Dataset):
+    """TorchDataset (utils/data.py:14-25): x = dict of column arrays, one python dict per sample."""
+
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+    def __getitem__(self, index):
+        return {k: v[index] for k, v in self.x.items()}, self.y[index]
+
+    def __len__(self):
+        return len(self.y)
+
+
+def port_dataloaders(x, y, split_ratio, batch_size):
+    """DataGenerator.generate_dataloader with split_ratio (utils/data.py:61-83)."""
+    ds = PortDataset(x, y)
+    n = len(ds)
+    n_train, n_val = int(n * split_ratio[0]), int(n * split_ratio[1])
+    train, val, test = random_split(ds, (n_train, n_val, n - n_train - n_val))
+    return (DataLoader(train, batch_size=batch_size, shuffle=True, num_workers=0),
+            DataLoader(val, batch_size=batch_size, shuffle=False, num_workers=0),
+            DataLoader(test, batch_size=batch_size, shuffle=False, num_workers=0))
+
+
+def time_cpu_end_to_end(vocabs, n_dense, batch_size, rows=200_000, budget_s=12.0, min_steps=2, max_steps=50, seed=2022,
+                        threads=None):
+    """Times the reference's train_one_epoch loop END TO END (loader included) on a ``rows``-row slice given as a dict
+    of numpy columns (int64 sparse as its LabelEncoder emits, float32 dense, int64 labels; tutorial-00 usage).
+
+    Returns dict(samples_per_s, steps, ms_per_step, loader_ms_per_step, cores, rows)."""
+    if threads:
+        torch.set_num_threads(threads)
+    rng = np.random.default_rng(seed)
+    names = {f"C{i + 1}": int(v) for i, v in enumerate(vocabs)}
+    dense_names = [f"I{i + 1}" for i in range(n_dense)]
+    x = {n: rng.integers(0, v, rows, dtype=np.int64) for n, v in names.items()}
+    x.update({n: rng.random(rows, dtype=np.float32) for n in dense_names})
+    y = (rng.random(rows) < 0.25).astype(np.int64)
+    torch.manual_seed(seed)
+    train_dl, _, _ = port_dataloaders(x, y, [0.7, 0.1], batch_size)
+    model = PortDeepFM(names, dense_names)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)  # trainer default, ctr_trainer.py:60
+    crit = nn.BCELoss()
+    device = torch.device("cpu")
+    it = iter(train_dl)
+    xb, yb = next(it)
+    train_step(model, opt, crit, {k: v.to(device) for k, v in xb.items()}, yb.to(device))  # warm-up: Adam state
+    steps, loader_s, t_start = 0, 0.0, time.perf_counter()
+    while steps < max_steps:
+        t0 = time.perf_counter()
+        try:
+            xb, yb = next(it)
+        except StopIteration:
+            it = iter(train_dl)
+            xb, yb = next(it)
+        xb = {k: v.to(device) for k, v in xb.items()}  # ctr_trainer.py:84
+        yb = yb.to(device)
+        loader_s += time.perf_counter() - t0
+        train_step(model, opt, crit, xb, yb)
+        steps += 1
+        if steps >= min_steps and time.perf_counter() - t_start > budget_s:
+            break
+    dt = time.perf_counter() - t_start
+    return dict(samples_per_s=steps * batch_size / dt, steps=steps, ms_per_step=1e3 * dt / steps,
+                loader_ms_per_step=1e3 * loader_s / steps, cores=torch.get_num_threads(), rows=rows)

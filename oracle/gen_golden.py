@@ -473,6 +473,20 @@ def gen_mtl(rh, cfg):
     print(f"model_{cfg}.npz", len(out), "arrays, loss", loss.item(), "train task losses", per_task)
 
 
+def gen_inbatch(rh):
+    """Random in-batch negatives of the UNMODIFIED reference (utils/match.py:104-145) on CPU for fixed generator seeds:
+    the index stream torch_rechub_amd's ``stream="reference"`` mode must reproduce bit for bit."""
+    from torch_rechub.utils.match import inbatch_negative_sampling
+    out = {}
+    for B, k, seed in [(4, 2, 0), (4, 2, 1), (6, 3, 2022), (9, None, 7), (33, 5, 3)]:
+        g = torch.Generator().manual_seed(seed)
+        first = inbatch_negative_sampling(torch.zeros((B, B)), neg_ratio=k, generator=g)
+        second = inbatch_negative_sampling(torch.zeros((B, B)), neg_ratio=k, generator=g)  # generator state carries on
+        out[f"B{B}_k{k}_seed{seed}.0"], out[f"B{B}_k{k}_seed{seed}.1"] = npy(first), npy(second)
+    np.savez_compressed(os.path.join(OUT, "inbatch_random.npz"), **out)
+    print("inbatch_random.npz", len(out), "arrays")
+
+
 CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
            "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
 
@@ -484,6 +498,8 @@ if __name__ == "__main__":
         gen_layers(rh)
     if not only or "augru" in only:
         gen_augru(rh)
+    if not only or "inbatch" in only:
+        gen_inbatch(rh)
     for cfg in CONFIGS:
         if not only or cfg in only:
             gen_model(rh, cfg)

@@ -1044,6 +1044,36 @@ def test_inbatch_sampler_stream_and_rank_slices():
         ops.inbatch_sample(8, 3, dev(), seed, cols=10, row0=5)  # rows 5..12 do not fit 10 columns
 
 
+def test_inbatch_fast_stream_is_uniform_over_k_subsets_chi_square():
+    """The DOCUMENTED deviation of stream="fast" from the reference (utils/match.py:141-145): other indices for the same
+    seed, same law.  Each row must draw K distinct columns, never its own, and every other column equally often:
+    chi-square over 4000 draws per row (14 degrees of freedom; 60 is beyond the 1 - 1e-7 quantile)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.utils.match import inbatch_negative_sampling
+    B, K, calls = 16, 3, 4000
+    ops._sample_rng.clear()
+    counts = torch.zeros(B, B, dtype=torch.int64, device=dev())
+    ones = torch.ones(B, K, dtype=torch.int64, device=dev())
+    scores = torch.zeros(B, B, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(99)
+    for _ in range(calls):
+        idx = inbatch_negative_sampling(scores, neg_ratio=K, generator=g)  # GPU default: the fast stream
+        counts.scatter_add_(1, idx, ones)
+    c = counts.cpu().numpy().astype(F64)
+    assert np.all(np.diag(c) == 0) and np.all(c.sum(1) == calls * K) and c.max() <= calls  # distinct, never own
+    expect = calls * K / (B - 1)
+    off = ~np.eye(B, dtype=bool)
+    chi2 = (((c - expect)**2 / expect) * off).sum(1)
+    assert chi2.max() < 60.0, chi2
+    # the opt-in reference stream on the device: valid draws, reproducible from the generator state
+    a = inbatch_negative_sampling(scores, neg_ratio=K, generator=torch.Generator(device=dev()).manual_seed(5),
+                                  stream="reference")
+    b = inbatch_negative_sampling(scores, neg_ratio=K, generator=torch.Generator(device=dev()).manual_seed(5),
+                                  stream="reference")
+    assert torch.equal(a, b) and not (a == torch.arange(B, device=dev()).unsqueeze(1)).any()
+    assert all(len(set(r)) == K for r in a.cpu().tolist())
+
+
 @pytest.mark.parametrize("B,F,D,ND", [(257, 26, 16, 13), (64, 3, 8, 0), (1, 5, 32, 2), (0, 4, 16, 1)])
 def test_fused_rows_is_the_fused_gather_stage_on_rows_in_place(B, F, D, ND):
     """ops.fused_rows (what a row-sharded lookup feeds): flattened rows + dense values, FM and LR of layers.py:112-120,

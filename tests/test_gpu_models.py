@@ -208,6 +208,134 @@ def test_device_loader_training_equals_host_loader_training(use_graph):
         assert abs(la2 - lb2) < 1e-5
 
 
+def _collision_free_columns(vocabs, widths, n_batches, B, seed):
+    """(n_batches * B, sum(widths)) indices in which no table row occurs twice inside one batch (fields listed in
+    ``vocabs`` with ``widths`` columns each; columns of one field share its table): the scatter-add then has no
+    order-dependent fp32 sums, so two trainings are comparable BIT FOR BIT."""
+    g = torch.Generator().manual_seed(seed)
+    blocks = []
+    for _ in range(n_batches):
+        cols = []
+        for v, w in zip(vocabs, widths):
+            assert v - 1 >= B * w
+            cols.append((torch.randperm(v - 1, generator=g)[:B * w] + 1).view(B, w))  # row 0 is left to padding
+        blocks.append(torch.cat(cols, 1))
+    return torch.cat(blocks, 0).contiguous()
+
+
+def _assert_no_row_behind(trainer):
+    opt = trainer.optimizer
+    t = int(opt._t_step.item())
+    assert t > 0
+    for last in opt._t_last:
+        assert bool((last == t).all()), f"rows behind step {t}: min last = {int(last.min())}"
+    return t
+
+
+def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer():
+    """Round-1 bug: TableAdam.flush() was driven by a host flag that hipGraph replays never set, so from the second
+    epoch on state_dict() / checkpoints held table rows up to K-1 steps behind the dense-Adam semantics of the reference
+    (trainers/ctr_trainer.py:99: every row stepped; :138: state_dict saved).  Two epochs from the HBM-resident loader
+    under use_graph=True with K = 4 and every table lazy (lazy_small_rows = 8): the tables and both Adam moments must
+    be BIT-EQUAL to a table_update="dense" twin, and every row's `last` must equal the step counter."""
+    from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
+    from torch_rechub_amd.models.ranking import DeepFM
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    vocabs, B, nb = [65, 100, 300, 1000, 5000, 20000], 64, 12
+    sparse = _collision_free_columns(vocabs, [1] * len(vocabs), nb, B, seed=11)
+    g = torch.Generator().manual_seed(12)
+    dense = torch.rand(nb * B, 3, generator=g)
+    label = (torch.rand(nb * B, generator=g) < 0.3).float()
+
+    def build():
+        torch.manual_seed(7)
+        dfe = [DenseFeature(f"I{i}") for i in range(3)]
+        sfe = [SparseFeature(f"C{i}", v, 16) for i, v in enumerate(vocabs)]
+        m = DeepFM(dfe + sfe, sfe, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"})
+        with torch.no_grad():
+            for e in m.embedding.embed_dict.values():
+                e.weight.normal_(0, 0.05)
+        return m, [f.name for f in sfe], [f.name for f in dfe]
+
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, device="cuda:0", show_progress=False, use_graph=True)
+    ma, names, dnames = build()
+    mb, _, _ = build()
+    mb.load_state_dict(ma.state_dict())
+    ta = CTRTrainer(ma, table_update="lazy", lazy_k=4, lazy_small_rows=8, **kw)
+    tb = CTRTrainer(mb, table_update="dense", **kw)
+    assert ta.optimizer.lazy_k == 4 and ta.optimizer.lazy_small_rows == 8
+    losses = []
+    for t in (ta, tb):
+        dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        losses.append([t.train_one_epoch(dl) for _ in range(2)])  # epoch 2 = graph replays only
+        assert t._graph is not None
+    assert losses[0] == losses[1]
+    steps = _assert_no_row_behind(ta)
+    assert steps == 2 * nb
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    oa, ob = ta.optimizer, tb.optimizer
+    for pa, pb in zip(oa._tables, ob._tables):
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+    # a second flush after more replays: optimizer.state_dict() flushes too
+    dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+    for _ in range(5):
+        ta._graphed_step(dl)
+    ta.optimizer.state_dict()
+    assert _assert_no_row_behind(ta) == steps + 5
+
+
+def test_graph_mode_flush_leaves_no_row_behind_match_trainer():
+    """Same property through MatchTrainer (in-batch negatives, history feature mean-pooled from the item table)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.features import SequenceFeature, SparseFeature
+    from torch_rechub_amd.models.matching import DSSM
+    from torch_rechub_amd.trainers import MatchTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    B, nb, L = 32, 10, 3
+    n_user, n_item = 400, 600
+    sparse = _collision_free_columns([n_user, n_item], [1, 1 + L], nb, B, seed=21)  # user | item, hist x L
+    label = torch.zeros(nb * B)
+
+    def build():
+        torch.manual_seed(3)
+        uf = [SparseFeature("user_id", n_user, 16),
+              SequenceFeature("hist_item_id", n_item, 16, pooling="mean", shared_with="item_id", padding_idx=0)]
+        itf = [SparseFeature("item_id", n_item, 16, padding_idx=0)]
+        m = DSSM(uf, itf, user_params={"dims": [32, 16], "activation": "prelu"},
+                 item_params={"dims": [32, 16], "activation": "prelu"}, temperature=0.05)
+        with torch.no_grad():
+            for e in m.embedding.embed_dict.values():
+                e.weight.normal_(0, 0.05)
+                if e.padding_idx is not None:
+                    e.weight[e.padding_idx].zero_()
+        return m
+
+    kw = dict(mode=0, in_batch_neg=True, in_batch_neg_ratio=5, sampler_seed=4, device="cuda:0", show_progress=False,
+              optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, use_graph=True)
+    ma, mb = build(), build()
+    mb.load_state_dict(ma.state_dict())
+    results = []
+    for m, extra in ((ma, dict(table_update="lazy", lazy_k=4, lazy_small_rows=8)), (mb, dict(table_update="dense"))):
+        ops._sample_rng.clear()  # both twins draw the same negatives: same seed, call counter from 0
+        t = MatchTrainer(m, **extra, **kw)
+        dl = DeviceDataLoader(sparse.to(dev()), ["user_id", "item_id", ("hist_item_id", L)], None, [], label.to(dev()), B,
+                              shuffle=False)
+        results.append((t, [t.train_one_epoch(dl) for _ in range(2)]))
+        assert t._graph is not None
+    (ta, la), (tb, lb) = results
+    assert la == lb
+    assert _assert_no_row_behind(ta) == 2 * nb
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for pa, pb in zip(ta.optimizer._tables, tb.optimizer._tables):
+        assert torch.equal(ta.optimizer.state[pa]["exp_avg_sq"], tb.optimizer.state[pb]["exp_avg_sq"])
+
+
 def test_fit_evaluate_predict_and_checkpoint_roundtrip(tmp_path):
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DataGenerator

@@ -210,6 +210,46 @@ def test_inbatch_sampling_known_answers_cpu():
         inbatch_negative_sampling(torch.zeros(3))
 
 
+def test_inbatch_random_stream_is_the_references_bit_for_bit():
+    """stream="reference" (what CPU tensors always use): same indices as the unmodified reference for the same generator
+    state, also on the second call (the generator carries on) -- tests/golden/inbatch_random.npz was written by
+    oracle/gen_golden.py::gen_inbatch from /root/reference/torch_rechub/utils/match.py:104-145."""
+    from torch_rechub_amd.utils.match import inbatch_negative_sampling
+    gold = load_golden("inbatch_random.npz")
+    seen = 0
+    for key in gold.files:
+        if not key.endswith(".0"):
+            continue
+        name = key[:-2]
+        B, k, seed = (name.split("_")[0][1:], name.split("_")[1][1:], name.split("_")[2][4:])
+        B, k, seed = int(B), (None if k == "None" else int(k)), int(seed)
+        g = torch.Generator().manual_seed(seed)
+        for call in (0, 1):
+            got = inbatch_negative_sampling(torch.zeros(B, B), neg_ratio=k, generator=g)
+            assert torch.equal(got, torch.from_numpy(gold[f"{name}.{call}"])), (name, call)
+        seen += 1
+    assert seen == 5
+    # rank slices of a global problem: two "ranks" seeded alike draw what one process draws for the 6 x 6 batch
+    whole = inbatch_negative_sampling(torch.zeros(6, 6), neg_ratio=3, generator=torch.Generator().manual_seed(5))
+    for r in range(2):
+        part = inbatch_negative_sampling(torch.zeros(3, 6), neg_ratio=3, generator=torch.Generator().manual_seed(5),
+                                         row_offset=3 * r)
+        assert torch.equal(part, whole[3 * r:3 * r + 3])
+
+
+def test_inbatch_random_stream_against_the_live_reference():
+    from oracle.ref_import import available, import_reference
+    if not available():
+        pytest.skip("reference checkout not present (GPU box)")
+    import_reference()
+    from torch_rechub.utils.match import inbatch_negative_sampling as ref_fn
+    from torch_rechub_amd.utils.match import inbatch_negative_sampling
+    for B, k, seed in [(5, 2, 11), (17, 16, 12), (40, 7, 13)]:
+        a = ref_fn(torch.zeros(B, B), neg_ratio=k, generator=torch.Generator().manual_seed(seed))
+        b = inbatch_negative_sampling(torch.zeros(B, B), neg_ratio=k, generator=torch.Generator().manual_seed(seed))
+        assert torch.equal(a, b)
+
+
 def test_match_trainer_rejects_models_without_towers():
     from torch_rechub_amd.trainers import MatchTrainer
     with pytest.raises(ValueError, match="does not support in-batch negative sampling"):

@@ -22,7 +22,15 @@ class RegularizationLoss(nn.Module):
     def active(self):
         return max(self.embedding_l1, self.embedding_l2, self.dense_l1, self.dense_l2) > 0
 
-    def forward(self, model):
+    def embedding_term(self, model):
+        """Only the nn.Embedding part of the penalty (python 0.0 when it is off).  The data-parallel trainers add
+        (1 - 1/world) of it back after scaling the loss by 1/world: a table's regulariser gradient is a local dense
+        term that takes no part in the row exchange, so it must not be divided by the world size."""
+        if max(self.embedding_l1, self.embedding_l2) <= 0:
+            return 0.0
+        return self.forward(model, _only_tables=True)
+
+    def forward(self, model, _only_tables=False):
         total = 0.0
         if not self.active():
             return total
@@ -34,6 +42,8 @@ class RegularizationLoss(nn.Module):
                 tables.update(id(p) for p in m.parameters())
         for p in model.parameters():
             if not p.requires_grad or id(p) in skip:
+                continue
+            if _only_tables and id(p) not in tables:
                 continue
             l1, l2 = (self.embedding_l1, self.embedding_l2) if id(p) in tables else (self.dense_l1, self.dense_l2)
             if l1 > 0:

@@ -69,7 +69,9 @@ class TableAdam(torch.optim.Adam):
         if self.lazy_k >= self.RING:
             raise ValueError(f"lazy_k must be < {self.RING}")
         self.lazy_small_rows = int(lazy_small_rows)
-        self._lazy_dirty = False
+        # step number (device counter _t_step) every row was last known to be at: flush() compares it with the counter
+        # ITSELF, not with a host-side flag -- hipGraph replays advance the tables without running any host code
+        self._flushed_at = 0
         if tables or (others and others[0].is_cuda):
             dev = (tables or others)[0].device
             self._t_m = [torch.zeros_like(p) for p in tables]
@@ -130,6 +132,13 @@ class TableAdam(torch.optim.Adam):
         self._s_desc = torch.tensor(rows, dtype=torch.int64).to(dev)
         self._s_numel = (ctypes.c_int64 * len(bucket.params))(*[p.numel() for p in bucket.params])
         for p, m, v in zip(bucket.params, self._s_m, self._s_v):
+            old = self.state.get(p)
+            if old and "exp_avg" in old:  # load_state_dict() ran before the first step (resume): keep the moments
+                m.copy_(old["exp_avg"])
+                v.copy_(old["exp_avg_sq"])
+                if not self._tables:  # with tables the step counter was restored from them
+                    self._t_step.fill_(int(float(old["step"])))
+                    self._t_hyper_host = None
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m, "exp_avg_sq": v}
 
     def _groups_agree(self):
@@ -151,14 +160,23 @@ class TableAdam(torch.optim.Adam):
             self._t_hyper[:5].copy_(torch.tensor(host, dtype=torch.float64))
             self._t_hyper_host = host
 
+    MAX_TENSORS = 128  # kMaxTensors of csrc/optim.hip: tensors per multi-tensor launch
+
     def _desc(self):
+        """[(device descriptor, n tensors, host numel array)] -- one entry per launch of <= MAX_TENSORS tables."""
         grads = [ops.grad_buffer(p) for p in self._tables]
         key = tuple([p.data_ptr() for p in self._tables] + [g.data_ptr() for g in grads])
         if key != self._t_desc_key:
-            rows = ([p.data_ptr() for p in self._tables] + [g.data_ptr() for g in grads] +
-                    [m.data_ptr() for m in self._t_m] + [v.data_ptr() for v in self._t_v] +
-                    [p.numel() for p in self._tables])
-            self._t_desc = torch.tensor(rows, dtype=torch.int64).to(self._tables[0].device)
+            out = []
+            for c0 in range(0, len(self._tables), self.MAX_TENSORS):
+                sl = slice(c0, c0 + self.MAX_TENSORS)
+                tabs = self._tables[sl]
+                rows = ([p.data_ptr() for p in tabs] + [g.data_ptr() for g in grads[sl]] +
+                        [m.data_ptr() for m in self._t_m[sl]] + [v.data_ptr() for v in self._t_v[sl]] +
+                        [p.numel() for p in tabs])
+                out.append((torch.tensor(rows, dtype=torch.int64).to(tabs[0].device), len(tabs),
+                            (ctypes.c_int64 * len(tabs))(*[p.numel() for p in tabs])))
+            self._t_desc = out
             self._t_desc_key = key
         return self._t_desc
 
@@ -169,26 +187,27 @@ class TableAdam(torch.optim.Adam):
         key = tuple([p.data_ptr() for p in self._tables] + [g.data_ptr() for g in grads])
         if self._lazy_groups is not None and self._lazy_key == key:
             return self._lazy_groups
-        groups = {}
+        by_dim = {}
         for i, p in enumerate(self._tables):
-            groups.setdefault(int(p.shape[1]), []).append(i)
-        out = {}
-        for D, members in groups.items():
+            by_dim.setdefault(int(p.shape[1]), []).append(i)
+        chunks = [(D, m[c0:c0 + self.MAX_TENSORS]) for D, m in by_dim.items() for c0 in range(0, len(m), self.MAX_TENSORS)]
+        out = []
+        for D, members in chunks:
             rows = [int(self._tables[i].shape[0]) for i in members]
             ks = [1 if r <= self.lazy_small_rows else self.lazy_k for r in rows]
             win = [-(-r // k) for r, k in zip(rows, ks)]
             desc = ([self._tables[i].data_ptr() for i in members] + [grads[i].data_ptr() for i in members] +
                     [self._t_m[i].data_ptr() for i in members] + [self._t_v[i].data_ptr() for i in members] +
                     [self._t_last[i].data_ptr() for i in members] + rows + ks + win)
-            out[D] = dict(members=members, local={id(self._tables[i]): j for j, i in enumerate(members)},
+            out.append(dict(D=D, members=members, local={id(self._tables[i]): j for j, i in enumerate(members)},
                           ldesc=torch.tensor(desc, dtype=torch.int64).to(self._tables[0].device),
-                          h_rows=(ctypes.c_int64 * len(rows))(*rows), h_win=(ctypes.c_int64 * len(rows))(*win))
+                          h_rows=(ctypes.c_int64 * len(rows))(*rows), h_win=(ctypes.c_int64 * len(rows))(*win)))
         self._lazy_groups, self._lazy_key = out, key
         self._ft_cache = {}
         return out
 
     def _field_table(self, rec, grp):
-        ids = tuple(id(w) for w in rec["weights"]) + tuple(rec["pads"])
+        ids = (id(grp),) + tuple(id(w) for w in rec["weights"]) + tuple(rec["pads"])
         ft = self._ft_cache.get(ids)
         if ft is None:
             tab = [grp["local"].get(id(w), -1) for w in rec["weights"]]
@@ -198,8 +217,9 @@ class TableAdam(torch.optim.Adam):
         return ft
 
     def _touch(self, rec, groups, stream, refresh=False):
-        grp = groups.get(rec["D"])
-        if grp is not None:
+        for grp in groups:
+            if grp["D"] != rec["D"] or not any(id(w) in grp["local"] for w in rec["weights"]):
+                continue
             _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
                       ops._p(self._t_ring), self.RING, 64, 1 if refresh else 0,
@@ -237,9 +257,9 @@ class TableAdam(torch.optim.Adam):
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
 
     def _sweep(self, mode, stream, t_value=-1):
-        for D, grp in self._lazy_setup().items():
+        for grp in self._lazy_setup():
             _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
-                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), D,
+                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
                       ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, mode, t_value, stream)
 
     def _fork_sweep(self):
@@ -275,7 +295,6 @@ class TableAdam(torch.optim.Adam):
             self._sweep_pending = True
         else:
             self._sweep(SWEEP_WINDOW, stream)
-        self._lazy_dirty = True
 
     def _finish_sweep(self):
         """A sweep that was not forked (no training-mode gather since the last step, or a plain hipGraph capture)
@@ -286,13 +305,20 @@ class TableAdam(torch.optim.Adam):
 
     def flush(self):
         """Bring every table row up to the current step (no-op in dense mode).  Must run before the weights are read
-        by anything but the training step: evaluation, state_dict, checkpointing."""
+        by anything but the training step: evaluation, state_dict, checkpointing.
+
+        Whether rows are behind is decided from the DEVICE step counter (one scalar read-back, i.e. a stream sync --
+        every caller is an epoch / evaluation / checkpoint boundary): steps replayed from a hipGraph run no host code,
+        so a host-side dirty flag would miss them (round-1 bug: stale rows in state_dict() after graph replays)."""
         if self.lazy_k > 1 and self._tables:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("TableAdam.flush() inside a hipGraph capture")
             self._join_sweep()
             self._sweep_pending = False  # subsumed: the flush visits every row
-            if self._lazy_dirty:
+            t = int(self._t_step.item())
+            if t != self._flushed_at:
                 self._sweep(SWEEP_FLUSH, ops._stream())
-                self._lazy_dirty = False
+                self._flushed_at = t
 
     def step_tables(self):
         """One Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
@@ -321,9 +347,9 @@ class TableAdam(torch.optim.Adam):
         if self.lazy_k > 1:
             self._lazy_step(stream)
         else:
-            desc = self._desc()
-            _lib.call("rh_adam_dense", ops._p(desc), len(self._tables), ctypes.cast(self._t_numel, ctypes.c_void_p),
-                      ops._p(self._t_hyper), 1, stream)
+            for desc, n, numel in self._desc():
+                _lib.call("rh_adam_dense", ops._p(desc), n, ctypes.cast(numel, ctypes.c_void_p),
+                          ops._p(self._t_hyper), 1, stream)
         for p in self._tables:
             p._rh_dirty = False  # the kernels zeroed every non-zero gradient row
             if p.grad is None:
@@ -388,7 +414,7 @@ class TableAdam(torch.optim.Adam):
             self._t_hyper_host = None
             if self.lazy_k > 1:  # a checkpoint is a flushed state: every row is at step t
                 self._join_sweep()
-                self._sweep_pending, self._lazy_dirty, self._host_step = False, False, t
+                self._sweep_pending, self._flushed_at, self._host_step = False, t, t
                 for last in self._t_last:
                     last.fill_(t)
         if self._bucket is not None:

@@ -24,7 +24,9 @@ Everything runs on the caller's stream, so a hipGraph capture of the step contai
 two-tower trainer (match_trainer.py:118-138 is single-device; here every rank scores its users against the items of
 all ranks).
 
-Batch sizes must be equal on all ranks (``DeviceDataLoader`` guarantees it); lookups are collective calls.
+Batch sizes and batch counts must be equal on all ranks: lookups are collective calls.  The trainers check it on
+every rank before an epoch / a sharded evaluation (``CTRTrainer._check_equal_batches``) and
+``DeviceDataLoader.from_parquet`` truncates every rank to the minimum row count.
 """
 import os
 
@@ -246,8 +248,24 @@ class _StaticBuffers(object):
 _buffers = _StaticBuffers()
 
 
-def _localize(embs, idx, group):
-    """all-gather the (B, F) index matrix and rewrite it for the local shards -> int32 (W*B, F)."""
+def _is_static(t):
+    """True when ``t`` lives in a buffer that keeps its address AND its role from step to step: a DeviceDataLoader
+    batch buffer (tagged ``_rh_static``, or a view of one), or anything seen while a hipGraph is being captured (the
+    replays read the same addresses by construction)."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return True
+    base = t._base if t._base is not None else t
+    return bool(getattr(t, "_rh_static", False) or getattr(base, "_rh_static", False))
+
+
+def _localize(embs, idx, group, static=False):
+    """all-gather the (B, F) index matrix and rewrite it for the local shards -> int32 (W*B, F).
+
+    ``static``: the index matrix is a loader-owned buffer, so the per-site buffers (gathered ids, localised ids,
+    received rows) are cached by its address (descriptor tables upload once, the step is hipGraph-capturable).  For an
+    ordinary temporary (a host DataLoader batch moved to the device, ``.long()`` casts) the address can be recycled
+    by the allocator within ONE forward, so two lookups would share -- and overwrite -- each other's buffers: those
+    get fresh buffers per call."""
     sh0 = embs[0]._rh_shard
     for e in embs:
         s = e._rh_shard
@@ -271,7 +289,7 @@ def _localize(embs, idx, group):
     # with other shapes impossible)
     site = (tuple(id(e) for e in embs), key, width, n_all, idx.data_ptr(), tuple(idx.shape), tuple(idx.stride()),
             idx.dtype, str(idx.device), sh0.rank)
-    idx_all, loc, rows = _buffers.get(site, make)
+    idx_all, loc, rows = _buffers.get(site, make) if static else make()
     # saturating: an id beyond int32 must stay out of range (-> RH_FLAG_INDEX_OOB), not wrap onto a valid row
     send = idx.clamp(min=-1, max=2**31 - 1).to(torch.int32) if narrow else idx
     all_gather_cat(send, group, out=idx_all)
@@ -283,7 +301,8 @@ def lookup(embs, idx_cols):
 
     ``embs[f]`` is the (sharded) ``nn.Embedding`` of field f; entries may repeat (shared tables, history positions)."""
     group = embs[0]._rh_shard.group
-    loc, rows = _localize(embs, pack_indices(list(idx_cols)), group)
+    idx_cols = list(idx_cols)
+    loc, rows = _localize(embs, pack_indices(idx_cols), group, static=all(_is_static(c) for c in idx_cols))
     F = len(embs)
     call = ops.EmbedCall([e.weight for e in embs], [e._rh_shard.sink for e in embs], [loc[:, f] for f in range(F)],
                          local_grads=True)
@@ -299,7 +318,7 @@ def pooled_lookup(emb, idx, pooling):
     the mean divides by the count of non-sentinel positions + 1e-16, taken from the local indices."""
     sh = emb._rh_shard
     B, L = idx.shape
-    loc = _localize([emb], idx.reshape(B * L, 1).contiguous(), sh.group)[0].view(-1, L)
+    loc = _localize([emb], idx.reshape(B * L, 1).contiguous(), sh.group, static=_is_static(idx))[0].view(-1, L)
     part = ops.seq_pool(emb.weight, loc, "sum", sh.sink, local_grads=True)
     total = scatter_rows_sum(part, sh.group)
     if pooling == "sum":

@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=64, tables=None, shard_min_rows=0):
+                 table_update=None, lazy_k=64, tables=None, shard_min_rows=0, lazy_small_rows=4096):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
@@ -73,7 +73,8 @@ class CTRTrainer(object):
         self.table_update = table_update
         if optimizer_fn is torch.optim.Adam and not optimizer_params.get("amsgrad", False):
             self.optimizer = TableAdam(self.model.parameters(), table_params=tables,
-                                       lazy_k=(lazy_k if table_update == "lazy" else 0), **optimizer_params)
+                                       lazy_k=(lazy_k if table_update == "lazy" else 0),
+                                       lazy_small_rows=lazy_small_rows, **optimizer_params)
         else:
             self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         table_ids = {id(p) for p in tables}
@@ -133,12 +134,20 @@ class CTRTrainer(object):
             return ops.bce_mean(y_pred, y)
         return self.criterion(y_pred, y)
 
+    def _scale_for_world(self, loss):
+        """Gradients of the data loss and of the dense regulariser are SUMMED over the ranks (row exchange / dense
+        all-reduce), so the loss is scaled by 1/world: the global-batch mean, as DataParallel.  The embedding
+        regulariser's gradient is a LOCAL dense term on each replica / shard and keeps its full strength."""
+        if self.world <= 1:
+            return loss
+        emb_reg = self.reg_loss_fn.embedding_term(self.model)
+        return loss / self.world + (1.0 - 1.0 / self.world) * emb_reg
+
     def train_step(self, x_dict, y):
         """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
         loss = self._compute_loss(x_dict, y)
         report = loss.detach()
-        if self.world > 1:
-            loss = loss / self.world  # gradients are SUMMED over ranks: global-batch mean, as DataParallel
+        loss = self._scale_for_world(loss)
         self._zero_grad()
         loss.backward()
         fast = isinstance(self.optimizer, TableAdam)
@@ -164,8 +173,7 @@ class CTRTrainer(object):
         self.bucket.defer = True
         loss = self._compute_loss(x_dict, y)
         report = loss.detach()
-        if self.world > 1:
-            loss = loss / self.world
+        loss = self._scale_for_world(loss)
         self._zero_grad()
         loss.backward()
         if not self._bucket_attached:
@@ -263,8 +271,36 @@ class CTRTrainer(object):
             self._graph_b.replay()
         return self._graph_loss, 1
 
+    def _check_equal_batches(self, data_loader, what):
+        """Every rank must run the same number of equally sized batches: each step (and, with row-sharded tables,
+        each evaluation batch) is a collective.  Raises on EVERY rank alike when they disagree."""
+        if self.world <= 1 or not hasattr(data_loader, "__len__"):
+            return
+        n = len(data_loader)
+        bs = int(getattr(data_loader, "batch_size", 0) or 0)
+        rows = getattr(data_loader, "N", None)
+        if rows is None and hasattr(data_loader, "dataset") and hasattr(data_loader.dataset, "__len__"):
+            rows = len(data_loader.dataset)
+        mine = torch.tensor([n, -n, bs, -bs, int(rows or 0), -int(rows or 0)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(mine, op=dist.ReduceOp.MIN)
+        lo_n, hi_n, lo_b, hi_b, lo_r, hi_r = (int(v) for v in mine.tolist())
+        if lo_n != -hi_n or lo_b != -hi_b or lo_r != -hi_r:
+            raise RuntimeError(f"{what}: the ranks disagree on the loader (batches {lo_n}..{-hi_n}, batch size "
+                               f"{lo_b}..{-hi_b}, rows {lo_r}..{-hi_r}); every step is a collective -- give each rank "
+                               "the same number of rows (DeviceDataLoader.from_parquet truncates to the minimum)")
+
+    def _global_metric(self, value):
+        """Mean of a per-rank validation metric over the ranks: every rank then takes the same early-stopping decision
+        and restores the same epoch (a per-rank decision would leave some ranks inside the next collective)."""
+        if self.world <= 1:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item()) / self.world
+
     def train_one_epoch(self, data_loader, log_interval=10):
         self.model.train()
+        self._check_equal_batches(data_loader, "train_one_epoch")
         device_loader = isinstance(data_loader, DeviceDataLoader)
         if isinstance(self.optimizer, TableAdam):
             self.optimizer.sync_hyper()
@@ -337,7 +373,7 @@ class CTRTrainer(object):
                     print("Current lr : {}".format(self.optimizer.state_dict()["param_groups"][0]["lr"]))
                 self.scheduler.step()
             if val_dataloader:
-                auc = self.evaluate(self.model, val_dataloader)
+                auc = self._global_metric(self.evaluate(self.model, val_dataloader))
                 if self.rank == 0:
                     print("epoch:", epoch_i, "validation: auc:", auc)
                 for logger in self._iter_loggers():
@@ -366,6 +402,8 @@ class CTRTrainer(object):
 
     def evaluate(self, model, data_loader):
         self.flush()
+        if self.tables == "shard":
+            self._check_equal_batches(data_loader, "evaluate (row-sharded tables: each batch is a collective)")
         model.eval()
         targets, predicts = [], []
         with torch.no_grad():

@@ -23,7 +23,7 @@ class MatchTrainer(CTRTrainer):
     def __init__(self, model, mode=0, in_batch_neg=False, in_batch_neg_ratio=None, hard_negative=False,
                  sampler_seed=None, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
-                 model_path="./", model_logger=None, global_negatives=False, **kw):
+                 model_path="./", model_logger=None, global_negatives=False, sampler_stream="fast", **kw):
         if in_batch_neg and not (hasattr(model, "user_tower") and hasattr(model, "item_tower")):
             raise ValueError(f"Model {type(model).__name__} does not support in-batch negative sampling. "
                              "Only two-tower models with user_tower() and item_tower() methods are supported, "
@@ -42,6 +42,13 @@ class MatchTrainer(CTRTrainer):
         # all-gather of the (B, d) item embeddings; its backward is a reduce-scatter) -- the in-batch step of one
         # process on the global batch.  Off: each rank samples inside its own batch.
         self.global_negatives = bool(global_negatives)
+        # "fast": one HIP launch, own counter-based stream (distribution-preserving, hipGraph-replayable);
+        # "reference": the reference's randperm-per-row draw, bit-identical indices for the same sampler_seed
+        if sampler_stream not in ("fast", "reference"):
+            raise ValueError("sampler_stream must be 'fast' or 'reference'")
+        self.sampler_stream = sampler_stream
+        if sampler_stream == "reference" and in_batch_neg and not hard_negative:
+            self.use_graph = False  # B randperm launches + host control flow per step
         self._sampler_generator = None
         if sampler_seed is not None:
             self._sampler_generator = torch.Generator(device=self.device)
@@ -83,7 +90,7 @@ class MatchTrainer(CTRTrainer):
             scores = torch.matmul(user_embedding, item_embedding.t())
             neg_indices = inbatch_negative_sampling(scores, neg_ratio=self.in_batch_neg_ratio,
                                                     hard_negative=self.hard_negative, generator=self._sampler_generator,
-                                                    row_offset=row0)
+                                                    row_offset=row0, stream=self.sampler_stream)
             logits = gather_inbatch_logits(scores, neg_indices, row_offset=row0)
             if self.mode == 1:
                 loss = self.criterion(logits[:, 0], logits[:, 1:], in_batch_neg=True)

@@ -101,7 +101,8 @@ class MTLTrainer(CTRTrainer):
                 if epoch_i % self.scheduler.step_size == 0 and self.rank == 0:
                     print("Current lr : {}".format(self.optimizer.state_dict()["param_groups"][0]["lr"]))
                 self.scheduler.step()
-            scores = self.evaluate(self.model, val_dataloader)
+            # mean over the ranks: one early-stopping decision and one restored epoch for the whole job
+            scores = [self._global_metric(v) for v in self.evaluate(self.model, val_dataloader)]
             if self.rank == 0:
                 print("epoch:", epoch_i, "validation scores: ", scores)
             for i, score in enumerate(scores):
@@ -129,6 +130,8 @@ class MTLTrainer(CTRTrainer):
 
     def evaluate(self, model, data_loader):
         self.flush()
+        if self.tables == "shard":
+            self._check_equal_batches(data_loader, "evaluate (row-sharded tables: each batch is a collective)")
         model.eval()
         targets, predicts = [], []
         with torch.no_grad():

@@ -187,11 +187,22 @@ class DeviceDataLoader(object):
             world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
             rank = dist.get_rank() if world > 1 else 0
         mine = partition_files(file_paths, world, rank or 0)
-        if not mine:
-            raise ValueError(f"rank {rank} of {world} received no Parquet file ({len(file_paths)} files in total)")
         sparse_names, dense_names = list(sparse_names), list(dense_names or [])
         n_rows = sum(pq.ParquetFile(p).metadata.num_rows for p in mine)
         dev = torch.device(device)
+        if world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == world:
+            # every training step is a collective: all ranks must run the same number of equally sized batches.  Each
+            # rank keeps the first min_r(rows_r) rows of its run of files (the tail of the longer runs is dropped, as a
+            # drop_last over ranks), and a rank without files makes EVERY rank raise instead of leaving its peers
+            # blocked in the first collective.
+            t = torch.tensor([n_rows], dtype=torch.int64, device=dev if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_rows = int(t.item())
+            if n_rows == 0:
+                raise ValueError(f"a rank of {world} received no Parquet rows ({len(file_paths)} files in total): "
+                                 "give the job at least one non-empty file per rank")
+        elif not mine:
+            raise ValueError(f"rank {rank} of {world} received no Parquet file ({len(file_paths)} files in total)")
         F, ND = len(sparse_names), len(dense_names)
         sparse = torch.empty((n_rows, F), dtype=torch.int64, device=dev)
         dense = torch.empty((n_rows, ND), dtype=torch.float32, device=dev) if ND else None
@@ -203,9 +214,13 @@ class DeviceDataLoader(object):
         scanner = pads.dataset(list(mine), format="parquet").scanner(columns=columns, batch_size=int(chunk_rows))
         at = 0
         for i, rb in enumerate(scanner.to_batches()):
-            n = rb.num_rows
-            if n == 0:
+            n = min(rb.num_rows, n_rows - at)  # n_rows may have been truncated to the minimum over the ranks
+            if n <= 0:
+                if at >= n_rows:
+                    break
                 continue
+            if n < rb.num_rows:
+                rb = rb.slice(0, n)
             k = i & 1
             if done[k] is not None:
                 done[k].synchronize()  # the copy that last used this staging block has finished
@@ -244,6 +259,7 @@ class DeviceDataLoader(object):
         if b is None:
             dev = self.sparse.device
             sp = torch.empty((B, self.F), dtype=torch.int64, device=dev)
+            sp._rh_static = True  # same address, same role every step: per-site caches may key on it (sharding.py)
             de = torch.empty((B, self.NDL), dtype=torch.float32, device=dev) if self.NDL else None
             y = torch.empty((B,), dtype=torch.float32, device=dev) if self.label is not None else de[:, self.ND:]
             x = DeviceBatch()
@@ -253,6 +269,7 @@ class DeviceDataLoader(object):
                     x[name] = sp[:, at]
                 else:  # a sequence feature gets its own contiguous (B, L) buffer (the kernels' descriptors are by address)
                     x[name] = torch.empty((B, width), dtype=torch.int64, device=dev)
+                    x[name]._rh_static = True
                     seqs.append((x[name], sp[:, at:at + width]))
             for j, n in enumerate(self.dense_names):
                 x[n] = de[:, j]

@@ -4,13 +4,33 @@ The reference loops ``for i in range(batch_size)`` in Python, launching a randpe
 SURVEY 3.5).  Here both modes are ONE batched device op over the (B, B) score matrix:
   * hard negatives: top-k of the scores with the diagonal masked to -inf (same indices as the reference: its
     known-answer test [[1,2,3],[4,5,6],[7,8,0]] -> [2,2,1] holds);
-  * random negatives: a uniformly random k-subset of the other B-1 columns per row — on the GPU one HIP launch
-    (``rh_inbatch_sample``: Floyd's algorithm per row, counter-based RNG, hipGraph-replayable), on CPU tensors top-k of
-    i.i.d. uniform keys.  Same distribution of the SET as ``candidates[randperm(B-1)[:k]]`` (the loss does not depend on
-    the order); the exact indices depend on how an RNG stream is consumed, which the reference does not pin: its tests
-    check shape, no self index and seed sensitivity.
+  * random negatives, two streams:
+    - ``stream="reference"`` (always used for CPU tensors; opt-in on the GPU, ``MatchTrainer(sampler_stream=
+      "reference")``): the reference's own draw, ``candidates[randperm(B-1, generator=g)[:k]]`` row after row
+      (match.py:141-145) -- the SAME indices as the reference for the same ``torch.Generator`` state on the same
+      device type, bit for bit (pinned on CPU by tests/golden/inbatch_random.npz, generated from the unmodified
+      reference).  B launches + host control flow: not hipGraph-capturable; for parity runs.
+    - ``stream="fast"`` (GPU default): ONE HIP launch (``rh_inbatch_sample``: Floyd's algorithm per row, counter-based
+      RNG, hipGraph-replayable).  DOCUMENTED DEVIATION: a different random stream, hence different indices for the
+      same seed; what is preserved is the distribution -- every row draws a uniformly random k-subset of the other
+      B-1 columns without replacement (chi-square-tested on the device, tests/test_gpu_kernels.py); the in-batch
+      losses are symmetric in the negatives, so only the set matters.
 """
 import torch
+
+
+def _reference_stream(n_rows, n_cols, row_offset, neg_ratio, device, generator):
+    """The reference's per-row draw (utils/match.py:136-145): row i takes candidates[randperm(C-1)[:k]] with
+    candidates = every column but its own.  ``row_offset``: the rows are rows [row_offset, row_offset + n_rows) of a
+    C x C global problem -- the generator is advanced through EVERY global row, so N ranks seeded alike draw what
+    one process draws for the global batch."""
+    out = torch.empty((n_rows, neg_ratio), dtype=torch.long, device=device)
+    for i in range(n_cols):
+        perm = torch.randperm(n_cols - 1, device=device, generator=generator)
+        if row_offset <= i < row_offset + n_rows:
+            pick = perm[:neg_ratio]
+            out[i - row_offset] = pick + (pick >= i).long()  # candidates = arange(C) without i
+    return out
 
 _OWN = {}
 
@@ -29,7 +49,7 @@ def _own_mask(rows, cols, row_offset, device):
     return m
 
 
-def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, generator=None, row_offset=0):
+def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, generator=None, row_offset=0, stream=None):
     """``scores`` (B, B), or (B, C) with ``row_offset``: the rows are rows [row_offset, row_offset + B) of a C x C global
     batch whose item embeddings were gathered from all ranks (cross-rank negatives); row i's positive is column
     row_offset + i and its negatives come from the other C - 1 columns."""
@@ -48,7 +68,11 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
     if hard_negative:
         keys = scores.detach().masked_fill(own, float("-inf"))
         return torch.topk(keys, k=neg_ratio, dim=1).indices
-    if scores.is_cuda and n_cols <= 65536:
+    if stream not in (None, "fast", "reference"):
+        raise ValueError("stream must be 'fast' or 'reference'")
+    if stream == "reference" or not scores.is_cuda:
+        return _reference_stream(batch_size, n_cols, row_offset, neg_ratio, device, generator)
+    if n_cols <= 65536:
         # HIP sampler (Floyd's algorithm per row, counter-based RNG): one launch, replayable from a hipGraph
         from .. import ops
         seed = None if generator is None else generator.initial_seed()
@@ -56,7 +80,7 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
             return ops.inbatch_sample(batch_size, neg_ratio, device, seed)
         return ops.inbatch_sample(batch_size, neg_ratio, device, seed, cols=n_cols, row0=row_offset)
     keys = torch.rand(tuple(scores.shape), device=device, generator=generator).masked_fill(own, -1.0)
-    return torch.topk(keys, k=neg_ratio, dim=1).indices
+    return torch.topk(keys, k=neg_ratio, dim=1).indices  # > 65536 columns: top-k of i.i.d. uniform keys (same set law)
 
 
 def gather_inbatch_logits(scores, neg_indices, row_offset=0):
