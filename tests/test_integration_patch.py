@@ -1,0 +1,77 @@
+"""INTEGRATION.md section B executed for real: ``torch_rechub_amd.integration.enable()`` against the imported,
+UNMODIFIED reference package (only present in the build container; skipped on the GPU box)."""
+import pytest
+import torch
+
+from oracle.ref_import import available, import_reference
+
+pytestmark = pytest.mark.skipif(not available(), reason="reference checkout not present (GPU box)")
+
+
+@pytest.fixture()
+def patched():
+    import_reference()
+    import torch_rechub.models.ranking  # noqa: F401  (imported BEFORE enable(): the models already hold the layer classes)
+    import torch_rechub.trainers  # noqa: F401
+    from torch_rechub_amd import integration
+    yield integration
+    integration.disable()
+
+
+def _features(mod):
+    dense = [mod.DenseFeature(f"I{i}") for i in range(3)]
+    sparse = [mod.SparseFeature(f"C{i}", vocab_size=v, embed_dim=16) for i, v in enumerate([7, 50, 300])]
+    return dense, sparse
+
+
+def test_layer_level_patch_runs_the_unmodified_reference_deepfm_on_the_hip_layers(patched):
+    import torch_rechub.basic.features as RF
+    import torch_rechub.models.ranking.deepfm as ref_deepfm
+    from torch_rechub_amd.basic import layers as H
+    mlp = {"dims": [32, 16], "dropout": 0.2, "activation": "relu"}
+    torch.manual_seed(0)
+    dense, sparse = _features(RF)
+    before = ref_deepfm.DeepFM(dense + sparse, sparse, dict(mlp))  # the reference as it is
+    ref_cls, ref_src = ref_deepfm.DeepFM, ref_deepfm.DeepFM.forward.__code__
+
+    names = patched.enable(models=False, trainers=False)
+    assert "torch_rechub.basic.layers.EmbeddingLayer" in names and "torch_rechub.basic.features.SparseFeature" in names
+    assert ref_deepfm.DeepFM is ref_cls and ref_deepfm.DeepFM.forward.__code__ is ref_src  # model source untouched
+    assert ref_deepfm.EmbeddingLayer is H.EmbeddingLayer and ref_deepfm.MLP is H.MLP  # ... but bound to the HIP layers
+    dense, sparse = _features(RF)  # RF.SparseFeature is now the mirror class (attribute-compatible)
+    after = ref_deepfm.DeepFM(dense + sparse, sparse, dict(mlp))
+    assert type(after.embedding) is H.EmbeddingLayer and type(after.mlp) is H.MLP and type(after.fm) is H.FM
+    sa, sb = before.state_dict(), after.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    assert all(sa[k].shape == sb[k].shape and sa[k].dtype == sb[k].dtype for k in sa)
+    after.load_state_dict(sa)  # a reference checkpoint loads into the patched model
+    # and it IS the HIP path: CPU tensors are refused, nothing falls back to eager ATen
+    x = {f.name: torch.zeros(4, dtype=torch.long) for f in sparse}
+    x.update({f.name: torch.zeros(4) for f in dense})
+    with pytest.raises(RuntimeError, match="HIP device"):
+        after(x)
+
+    patched.disable()
+    assert ref_deepfm.EmbeddingLayer is not H.EmbeddingLayer
+    import torch_rechub.basic.layers as RL
+    assert ref_deepfm.EmbeddingLayer is RL.EmbeddingLayer
+
+
+def test_model_and_trainer_level_patch(patched):
+    import torch_rechub.basic.features as RF
+    import torch_rechub.models.ranking as RR
+    import torch_rechub.trainers as RT
+    from torch_rechub_amd.models.ranking import DCNv2, DeepFM
+    from torch_rechub_amd.trainers import CTRTrainer
+    dense, sparse = _features(RF)
+    ref_model = RR.DeepFM(dense + sparse, sparse, {"dims": [32, 16]})
+    keys = list(ref_model.state_dict().keys())
+    names = patched.enable()
+    assert RR.DeepFM is DeepFM and RR.DCNv2 is DCNv2 and RT.CTRTrainer is CTRTrainer
+    assert {"torch_rechub.models.ranking.DeepFM", "torch_rechub.trainers.CTRTrainer"} <= set(names)
+    dense, sparse = _features(RF)
+    m = RR.DeepFM(dense + sparse, sparse, {"dims": [32, 16]})
+    assert list(m.state_dict().keys()) == keys
+    with pytest.raises(RuntimeError, match="HIP"):  # the patched trainer drives the HIP path only
+        RT.CTRTrainer(m, device="cpu")
+    assert patched.enable() == []  # idempotent

@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=64, tables=None, shard_min_rows=0, lazy_small_rows=4096):
+                 table_update=None, lazy_k=64, tables=None, shard_min_rows=0, lazy_small_rows=None):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
@@ -72,9 +72,11 @@ class CTRTrainer(object):
             table_update = "dense"
         self.table_update = table_update
         if optimizer_fn is torch.optim.Adam and not optimizer_params.get("amsgrad", False):
+            optimizer_params = dict(optimizer_params)
+            if lazy_small_rows is not None:  # tables up to this many rows take the dense pass (K = 1) in lazy mode
+                optimizer_params["lazy_small_rows"] = lazy_small_rows
             self.optimizer = TableAdam(self.model.parameters(), table_params=tables,
-                                       lazy_k=(lazy_k if table_update == "lazy" else 0),
-                                       lazy_small_rows=lazy_small_rows, **optimizer_params)
+                                       lazy_k=(lazy_k if table_update == "lazy" else 0), **optimizer_params)
         else:
             self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         table_ids = {id(p) for p in tables}
