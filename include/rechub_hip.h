@@ -55,6 +55,9 @@ const char* rh_last_error(void);
 #define RH_TUNE_SWEEP_GRID 2   /* workgroups of rh_adam_lazy_sweep (0 = default 8192) */
 #define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per sweep workgroup (<= 56 KiB): caps its residency so that kernels on
                                   other streams find free wave slots while it runs */
+#define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
+#define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
+#define RH_TUNE_BWD_PATH 6      /* rh_embed_bwd experiments: 0 auto, 1 global atomics for every table, 3 no sink */
 int rh_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------

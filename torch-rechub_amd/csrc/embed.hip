@@ -56,6 +56,18 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
   bool oob_any = false;
   float* orow = a.out + b * a.out_stride + q * 4;
 
+  // dense values appended after the sparse block (layers.py:120 order).  The first column of every lane rides along
+  // with the gathers (descriptor with the field descriptors, value with the indices): as a tail loop after the
+  // gathers it was two more dependent round trips (measured at B = 65536, 13 dense columns: 49.6 -> 64.7 us).
+  const bool dense0 = a.ND > 0 && lig < a.ND;
+  const float* dp0 = nullptr;
+  int64_t ds0 = 0;
+  float dv0 = 0.f;
+  if (dense0) {
+    dp0 = reinterpret_cast<const float*>(a.ddesc[lig]);
+    ds0 = a.ddesc[a.ND + lig];
+  }
+
   for (int j0 = 0; j0 < nfl; j0 += U) {
     int fcl[U];
     bool ok[U];
@@ -80,6 +92,7 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
     int64_t row[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) row[u] = (int64_t)gload<IdxT>(ip[u] + b * st[u]);
+    if (j0 == 0 && dense0) dv0 = gload<float>(dp0 + b * ds0);
     // phase 2: row gathers (16 B per lane), all in flight together
     float4 v[U];
     float4 w[U];
@@ -102,9 +115,9 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
     }
   }
 
-  // dense values appended after the sparse block (layers.py:120 order)
-  if (a.ND > 0 && live) {
-    for (int j = lig; j < a.ND; j += G) {
+  if (dense0 && live) a.out[b * a.out_stride + a.dense_col + lig] = dv0;
+  if (a.ND > G && live) {  // more dense columns than lanes per sample: the rest in a tail loop
+    for (int j = lig + G; j < a.ND; j += G) {
       const float* dp = reinterpret_cast<const float*>(a.ddesc[j]);
       const int64_t ds = a.ddesc[a.ND + j];
       a.out[b * a.out_stride + a.dense_col + j] = gload<float>(dp + b * ds);
@@ -188,21 +201,58 @@ struct EmbedBwdArgs {
   float* rows_out;
   const float* rows_in;
   int spb;
-  int lds_floats;
   int wide_atomics;
+  int path;  // experiment knob: 0 auto, 1 global atomics for every table, 3 no sink, 4 chunk-fastest block order
+  int nchunks8;  // sample chunks rounded up to a multiple of 8
   int* err;
 };
 
+constexpr int kSweeps = 2;  // phase-B sweeps of the small-table path: covers kSweeps * 4 * (64 / D) rows (32 at D = 16)
+
 // grid = (sample chunks, fields).  SRC 0: compute the gradient row from the upstream gradients,
 // 1: read it from rows_in.  SINK 0: scatter-add into the table gradient, 1: write to rows_out.
+//
+// Small tables (Criteo has vocab 3, 4, 10, 15, 18, 24, 27, 105): every lookup of the batch lands on a few rows, and what
+// is expensive on MI355X is contention, measured at B = 65536 (tools/bwd_field_probe.py):
+//   * device-scope atomics on ONE cache line serialise at ~11 ns per request (a 3-row table: 1 ms; 105 rows: +9 us);
+//   * LDS float atomics (ds_add_f32) retire at ~5 cycles per LANE, conflict-free or not (the 9 tables of <= 512 rows
+//     LDS-aggregated: 126 us; with 16 private copies: 84 us);
+//   * one float4 accumulator per table row in every lane (one-hot FMA) needs 128 registers: occupancy 2, 62-80 us.
+//   * walking the lookups one by one per wavefront (row-split accumulators fed straight from HBM) serialises the
+//     memory latency: 116 us.
+//   * 32 row-split scalar accumulators per lane selected by compare chains: 64 x 32 selects per wavefront, 143 us
+//     (uniform branches around them cost more than the selects).
+// So tables of <= kSweeps * 4 * (64 / D) rows (32 at D = 16) are summed WITHOUT atomics in two phases per block:
+//   A. the usual layout (one lookup per LPR lanes, 4 per lane in flight: full memory parallelism) computes the
+//      gradient rows and parks them in LDS with plain stores, [lookup][D] + the row id;
+//   B. every lane owns ONE (row, float) pair per sweep -- lane (rg, d) of wavefront w owns float d of row
+//      sweep * 4 RG + w * RG + rg (RG = 64 / D) -- and ALL wavefronts walk ALL parked lookups (LDS reads) adding the
+//      float under `row == mine`: O(1) work per lookup, no shuffles, no atomics, no cross-wave hand-off.
+// At the end every lane holds the block's complete sum of its (row, float): 64 lanes = RG whole rows, added to the table
+// gradient with one coalesced atomic instruction (one request per 64-byte line per block and sweep).
 template <int LPR, typename IdxT, int SRC, int SINK>
 __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // small tables: parked gradient rows + row ids
   __shared__ float4 red[RH_BLOCK / RH_WAVE][32];
-  float4* lds4 = reinterpret_cast<float4*>(lds);
   constexpr int LPP = RH_BLOCK / LPR;  // lookups per pass
   constexpr int U = 4;
-  const int f = blockIdx.y;
+  // Block -> (sample chunk, field).  The blocks that read the SAME rows of g_out / emb / s_sum (one chunk, all fields:
+  // adjacent 64-byte pieces of the same 1.7 KB rows) are made neighbours on ONE XCD (block id % 8 = XCD, measured
+  // placement): they run at the same time and share the XCD's L2 lines, instead of each fetching a piece of every
+  // line on its own.  a.path == 4 keeps the plain chunk-fastest order for comparison.
+  int f, chunk;
+  {
+    const int L = blockIdx.x, F_ = a.F;
+    if (a.path == 4) {
+      chunk = L % a.nchunks8;
+      f = L / a.nchunks8;
+    } else {
+      const int xcd = L & 7, within = L >> 3;
+      f = within % F_;
+      chunk = (within / F_) * 8 + xcd;
+    }
+  }
+  if ((int64_t)chunk * a.spb >= (int64_t)a.B) return;  // padding block (chunk count rounded up to the 8 XCDs)
   const int tid = threadIdx.x;
   const int q = tid % LPR;
   const int slot = tid / LPR;
@@ -214,12 +264,16 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
   const int64_t pad = a.fdesc[3 * F + f];
   const int col = (int)a.idesc[2 * F + f] * D;  // column of this field in g_out / emb
   const bool has_tab = gtab != nullptr;  // frozen tables (requires_grad = False) carry no gradient buffer
-  const bool use_lds = (SINK == 0) && has_tab && (vocab * D <= (int64_t)a.lds_floats);
-  const int n4 = (int)(vocab * D / 4);
-  if (use_lds) {
-    for (int i = tid; i < n4; i += RH_BLOCK) lds4[i] = f4_zero();
-    __syncthreads();
-  }
+  constexpr bool kSmallOk = (SINK == 0) && (LPR <= 16);
+  constexpr int RG = kSmallOk ? RH_WAVE / (4 * LPR) : 1;  // row groups of phase B
+  constexpr int NL = LPP * U;                            // lookups per pass
+  constexpr int RPS = (RH_BLOCK / RH_WAVE) * RG;         // rows per phase-B sweep
+  const bool small = kSmallOk && has_tab && a.path != 1 && vocab <= (int64_t)kSweeps * RPS;  // block-uniform
+  float* park = lds;                                                 // [NL][D] gradient rows of the pass
+  int* park_row = reinterpret_cast<int*>(lds + NL * 4 * LPR);       // [NL] row id, -1 = dead lookup
+  float acc[kSweeps];
+#pragma unroll
+  for (int k = 0; k < kSweeps; ++k) acc[k] = 0.f;
   const bool has_gout = (SRC == 0) && a.g_out != nullptr;
   const bool has_lr = (SRC == 0) && a.g_lr != nullptr && a.lr_w != nullptr;
   const bool has_fm = (SRC == 0) && a.g_fm != nullptr;
@@ -228,7 +282,7 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
       has_lr ? gload<float4>(a.lr_w + f * D + q * 4) : f4_zero();
   float4 wacc = f4_zero();
   bool oob_any = false;
-  const int64_t b0 = (int64_t)blockIdx.x * a.spb;
+  const int64_t b0 = (int64_t)chunk * a.spb;
   const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
 
   // trip count is uniform over the block: the full-line atomic path below shuffles across the wavefront
@@ -271,12 +325,11 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
       } else {
         const bool oob = (uint64_t)row[u] >= (uint64_t)vocab;
         oob_any |= (oob && ok[u]);
-        const bool live = ok[u] && has_tab && !oob && row[u] != pad;
-        if (use_lds) {
-          if (live) {
-            const int off = (int)(row[u] * D) + q * 4;
-            RH_LDS_ATOMIC_ADD_F4(lds, off, gr);
-          }
+        const bool live = ok[u] && has_tab && !oob && row[u] != pad && a.path != 3;
+        if (kSmallOk && small) {
+          const int j = u * LPP + slot;
+          *reinterpret_cast<float4*>(park + j * (4 * LPR) + q * 4) = gr;
+          if (q == 0) park_row[j] = live ? (int)row[u] : -1;
         } else if (a.wide_atomics) {
           // Re-lay the wavefront's 256 gradient floats (64/LPR rows x 4*LPR dwords) so that one atomic
           // instruction carries WHOLE rows: 4 requests of 64 contiguous dwords instead of 4 requests that each
@@ -305,15 +358,33 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
         }
       }
     }
-  }
-
-  if (use_lds) {
-    __syncthreads();
-    for (int i = tid; i < n4; i += RH_BLOCK) {
-      const float4 x = lds4[i];
-      if (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f) gatomic_add_f4(gtab + (int64_t)i * 4, x);
+    if (kSmallOk && small) {  // phase B (block-uniform branch)
+      constexpr int DD = 4 * LPR;
+      __syncthreads();
+      const int lane = tid % RH_WAVE, wave = tid / RH_WAVE;
+      const int d = lane % DD;
+      const int myrow = wave * RG + lane / DD;
+#pragma unroll 16
+      for (int j = 0; j < NL; ++j) {
+        const int rb = park_row[j];  // wavefront-uniform (broadcast read)
+        const float val = park[j * DD + d];
+#pragma unroll
+        for (int k = 0; k < kSweeps; ++k) acc[k] += (rb == myrow + k * RPS) ? val : 0.f;
+      }
+      __syncthreads();  // the next pass overwrites the parked rows
     }
   }
+  if (kSmallOk && small) {
+    constexpr int DD = 4 * LPR;
+    const int lane = tid % RH_WAVE, wave = tid / RH_WAVE;
+    const int d = lane % DD;
+#pragma unroll
+    for (int k = 0; k < kSweeps; ++k) {
+      const int r = k * RPS + wave * RG + lane / DD;
+      if (r < (int)vocab && acc[k] != 0.f) gatomic_add_f32(gtab + (int64_t)r * DD + d, acc[k]);
+    }
+  }
+
   if (want_wgrad) {
     // sum over the lookups of this block that share q: inside the wavefront, then across the 4
 #pragma unroll
@@ -325,13 +396,13 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
       float4 sum = red[0][tid];
 #pragma unroll
       for (int wv = 1; wv < RH_BLOCK / RH_WAVE; ++wv) sum = f4_add(sum, red[wv][tid]);
-      gstore<float4>(a.lr_wgrad + ((int64_t)blockIdx.x * F + f) * D + tid * 4, sum);
+      gstore<float4>(a.lr_wgrad + ((int64_t)chunk * F + f) * D + tid * 4, sum);
     }
   }
   if (oob_any && a.err != nullptr) atomicOr(a.err, RH_FLAG_INDEX_OOB);
 }
 
-constexpr int kLdsFloats = 8192;  // 32 KiB per block: tables with vocab*D <= 8192 aggregate in LDS
+int g_bwd_path = 0;        // tuning knob RH_TUNE_BWD_PATH (experiments)
 
 int g_wide_atomics = -1;  // tuning knob RH_TUNE_WIDE_ATOMICS (env RECHUB_WIDE_ATOMICS), default on
 
@@ -346,10 +417,12 @@ int wide_atomics_default() {
 template <int LPR, typename IdxT, int SRC, int SINK>
 int launch_bwd(EmbedBwdArgs a, hipStream_t s) {
   const unsigned gx = (unsigned)((a.B + a.spb - 1) / a.spb);
-  a.lds_floats = (SINK == 0) ? kLdsFloats : 0;
   a.wide_atomics = wide_atomics_default();
-  const size_t shmem = (SINK == 0) ? kLdsFloats * sizeof(float) : 0;
-  hipLaunchKernelGGL((embed_bwd_kernel<LPR, IdxT, SRC, SINK>), dim3(gx, (unsigned)a.F), dim3(RH_BLOCK),
+  a.path = g_bwd_path;
+  // parked gradient rows of one pass (16 KiB) + their row ids
+  const size_t shmem = (SINK == 0) ? (size_t)(RH_BLOCK * 4 * 4 + (RH_BLOCK / LPR) * 4) * sizeof(float) : 0;
+  a.nchunks8 = (int)((gx + 7) / 8 * 8);
+  hipLaunchKernelGGL((embed_bwd_kernel<LPR, IdxT, SRC, SINK>), dim3((unsigned)a.nchunks8 * (unsigned)a.F), dim3(RH_BLOCK),
                      shmem, s, a);
   return 0;
 }
@@ -429,7 +502,7 @@ extern "C" int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_
              "rh_embed_bwd: lr_wgrad needs emb and g_lr");
   if (B == 0) return 0;
   EmbedBwdArgs a{fdesc, idesc, B, F, D, g_out, g_stride, emb, emb_stride, s_sum, g_fm, g_lr, lr_w,
-                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, 0, err_flag};
+                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, 0, 0, err_flag};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (sink == 0)
@@ -446,6 +519,11 @@ extern "C" int rh_set_tuning(int key, int value) {
     g_wide_atomics = value != 0;
     return 0;
   }
+  if (key == RH_TUNE_BWD_PATH) {
+    g_bwd_path = value;
+    return 0;
+  }
+  if (key == RH_TUNE_BWD_SPLIT || key == RH_TUNE_BWD_SLABS) return 0;  // retired knobs (kept so old probes still run)
   if (rh_optim_set_tuning(key, value) == 0) return 0;
   rh_set_error("rh_set_tuning: unknown key %d", key);
   return RH_E_BADARG;
@@ -463,7 +541,7 @@ extern "C" int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc,
   RH_REQUIRE(rows != nullptr, RH_E_BADARG, "rh_embed_scatter_rows: rows is null");
   if (B == 0) return 0;
   EmbedBwdArgs a{fdesc, idesc, B, F, D, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, 0, err_flag};
+                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, 0, 0, err_flag};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = idx_is_i64 ? dispatch_bwd<int64_t, 1, 0>(a, s) : dispatch_bwd<int32_t, 1, 0>(a, s);
   if (rc != 0) return rc;
