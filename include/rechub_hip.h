@@ -261,6 +261,23 @@ int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, con
 /* Column sums of the per-block partial buffers the backward kernels emit (replaces the trailing `.sum(0)` / `.sum()`
  * launches of autograd): out (cols,) = sum over rows of a (rows, cols); optionally vsum (1,) = sum of v (n,). */
 int rh_colsum(const float* a, int rows, int cols, float* out, const float* v, int64_t n, float* vsum, void* stream);
+/* Fused head + loss for the trainer's step (models/ranking/deepfm.py:39-43 + torch.nn.BCELoss trainers/ctr_trainer.py:62,88):
+ * rh_head_loss_fwd = rh_head_fwd that also emits, per block, the sum of the BCE terms of its rows against the labels t
+ *   (loss_partial: rh_head_loss_nblocks(B) floats; the mean is finished by rh_step_scalars);
+ * rh_head_loss_bwd = rh_bce_bwd + rh_head_bwd in one pass: g_y = g_loss[0] / B * (y - t) / max((1 - y) y, 1e-12) is
+ *   formed per row with the arithmetic of rh_bce_bwd (bit-identical to the two separate launches).
+ * rh_step_scalars: the scalar work of one training step in ONE single-block launch (each part optional, null = skip):
+ *   loss[0] = sum(loss_partial[0..n_partial)) / B;  the bias corrections of the next Adam step (== rh_adam_prepare);
+ *   two device counters c = (c + inc) % mod (mod 0 = no wrap): the batch position of the device loader (==
+ *   rh_batch_advance), the call counter of the in-batch sampler. */
+int rh_head_loss_nblocks(int B);
+int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
+                     int K, float* y, const float* t, float* loss_partial, void* stream);
+int rh_head_loss_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* t, const float* g_loss, int B,
+                     int K, float* g_h, float* g_z, float* g_w, float* g_b, float* partial, void* stream);
+int rh_step_scalars(const float* loss_partial, int n_partial, int64_t B, float* loss, double* hyper, int64_t* step,
+                    float* ring, int ring_size, int64_t* c0, int64_t inc0, int64_t mod0, int64_t* c1, int64_t inc1,
+                    int64_t mod1, void* stream);
 int rh_bce_fwd(const float* y, const float* t, int64_t B, float* loss, void* stream);
 int rh_bce_bwd(const float* y, const float* t, const float* g_loss, int64_t B, float* g_y, void* stream);
 

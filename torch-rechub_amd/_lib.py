@@ -64,6 +64,11 @@ SIGNATURES = {
     "rh_head_nblocks": [c_int],
     "rh_head_fwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_head_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_head_loss_nblocks": [c_int],
+    "rh_head_loss_fwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_head_loss_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_step_scalars": [c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                        c_ptr],
     "rh_colsum": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bce_fwd": [c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_bce_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
@@ -91,7 +96,7 @@ _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctyp
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
                     "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles",
-                    "rh_head_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks", "rh_augru_max_dim"}
+                    "rh_head_nblocks", "rh_head_loss_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks", "rh_augru_max_dim"}
 
 ABI_VERSION = 1
 _lib = None

@@ -211,10 +211,13 @@ __device__ __forceinline__ float group_sum16(float v) {
 __global__ __launch_bounds__(RH_BLOCK) void head_fwd_kernel(const float* __restrict__ h, int64_t ldh,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             const float* __restrict__ e0, const float* __restrict__ e1,
-                                                            int B, int K, float* __restrict__ y) {
+                                                            int B, int K, float* __restrict__ y,
+                                                            const float* __restrict__ t, float* __restrict__ loss_partial) {
+  __shared__ float lred[kHeadRows];
   const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
   const int nv = K / 4;
   const float b0 = bias ? bias[0] : 0.f;
+  float lacc = 0.f;  // this lane group's BCE terms (t != null): -(t log y + (1 - t) log(1 - y)), logs clamped at -100
   for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < B; row += (int64_t)gridDim.x * kHeadRows) {
     float acc = 0.f;
     for (int v = sub; v < nv; v += kHeadLanes) {
@@ -231,7 +234,22 @@ __global__ __launch_bounds__(RH_BLOCK) void head_fwd_kernel(const float* __restr
       float z = acc + b0;
       if (e0) z += e0[row];
       if (e1) z += e1[row];
-      y[row] = 1.f / (1.f + __expf(-z));
+      const float yv = 1.f / (1.f + __expf(-z));
+      y[row] = yv;
+      if (t) {
+        const float tv = t[row];
+        lacc -= tv * fmaxf(logf(yv), -100.f) + (1.f - tv) * fmaxf(log1pf(-yv), -100.f);
+      }
+    }
+  }
+  if (loss_partial) {  // fixed order: row groups of the block, then the blocks (rh_step_scalars)
+    if (sub == 0) lred[grp] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < kHeadRows; ++r) v += lred[r];
+      loss_partial[blockIdx.x] = v;
     }
   }
 }
@@ -242,6 +260,8 @@ struct HeadBwdArgs {
   const float* w;
   const float* y;
   const float* g_y;
+  const float* t;       // != null: g_y is not read; g_y[row] = g_loss[0] / B * (y - t) / max((1 - y) y, 1e-12)  (BCELoss)
+  const float* g_loss;  //          (the arithmetic of rh_bce_bwd, so fused == unfused bit for bit)
   int B, K;
   float* g_h;  // (B, K) contiguous
   float* g_z;  // (B,)
@@ -270,9 +290,11 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
   const int tcol = 4 * nv + sub;
   const float tw = has_tail ? a.w[tcol] : 0.f;
   float tacc = 0.f;
+  const float lscale = a.t ? a.g_loss[0] / (float)a.B : 0.f;
   for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < a.B; row += (int64_t)gridDim.x * kHeadRows) {
     const float yv = a.y[row];
-    const float gz = a.g_y[row] * yv * (1.f - yv);
+    const float gy = a.t ? lscale * (yv - a.t[row]) / fmaxf((1.f - yv) * yv, 1e-12f) : a.g_y[row];
+    const float gz = gy * yv * (1.f - yv);
     if (sub == 0) {
       a.g_z[row] = gz;
       gb += gz;
@@ -419,7 +441,73 @@ __global__ __launch_bounds__(RH_BLOCK) void bce_bwd_kernel(const float* __restri
   }
 }
 
+// The scalar work of one training step in ONE launch (was: rh_bce_fwd + rh_adam_prepare + rh_batch_advance):
+//   loss[0] = sum(loss_partial[0 .. n)) / B          (mean BCE from the per-block terms of rh_head_loss_fwd)
+//   Adam bias corrections of step t + 1 (== rh_adam_prepare: step counter, hyper[8..14], the (A, E) ring)
+//   up to two device counters advanced: *c = (*c + inc) % mod (mod == 0: no wrap) -- the loader's batch position, ...
+// Each part is skipped when its pointer is null.
+__global__ __launch_bounds__(RH_BLOCK) void step_scalars_kernel(const float* __restrict__ loss_partial, int n, float inv_b,
+                                                                float* __restrict__ loss, double* hyper, int64_t* step,
+                                                                float* ring, int64_t ring_mask, int64_t* c0, int64_t inc0,
+                                                                int64_t mod0, int64_t* c1, int64_t inc1, int64_t mod1) {
+  __shared__ float red[RH_BLOCK / RH_WAVE];
+  if (loss_partial != nullptr) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += RH_BLOCK) acc += loss_partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_b;
+  }
+  if (threadIdx.x == 0) {
+    if (hyper != nullptr) {
+      const int64_t t = *step + 1;
+      *step = t;
+      const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2];
+      const double bc1 = 1.0 - pow(b1, (double)t);
+      const double bc2 = 1.0 - pow(b2, (double)t);
+      hyper[8] = lr / bc1;
+      hyper[9] = sqrt(bc2);
+      hyper[10] = 1.0 - b1;
+      hyper[11] = 1.0 - b2;
+      hyper[12] = (double)t;
+      const double A = hyper[8] * hyper[9], E = hyper[3] * hyper[9];
+      hyper[13] = A;
+      hyper[14] = E;
+      if (ring != nullptr) {
+        ring[2 * (t & ring_mask) + 0] = (float)A;
+        ring[2 * (t & ring_mask) + 1] = (float)E;
+      }
+    }
+    if (c0 != nullptr) {
+      int64_t p = *c0 + inc0;
+      if (mod0 > 0 && p >= mod0) p %= mod0;
+      *c0 = p;
+    }
+    if (c1 != nullptr) {
+      int64_t p = *c1 + inc1;
+      if (mod1 > 0 && p >= mod1) p %= mod1;
+      *c1 = p;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int rh_step_scalars(const float* loss_partial, int n_partial, int64_t B, float* loss, double* hyper,
+                               int64_t* step, float* ring, int ring_size, int64_t* c0, int64_t inc0, int64_t mod0,
+                               int64_t* c1, int64_t inc1, int64_t mod1, void* stream) {
+  RH_REQUIRE(loss_partial == nullptr || (loss != nullptr && n_partial >= 1 && B >= 1), RH_E_BADARG,
+             "rh_step_scalars: loss_partial needs loss, n_partial >= 1 and B >= 1");
+  RH_REQUIRE(hyper == nullptr || step != nullptr, RH_E_BADARG, "rh_step_scalars: hyper without step");
+  RH_REQUIRE(ring == nullptr || (ring_size > 0 && (ring_size & (ring_size - 1)) == 0), RH_E_BADARG,
+             "rh_step_scalars: ring_size must be a power of two");
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), loss_partial,
+                     n_partial, loss_partial ? 1.f / (float)B : 0.f, loss, hyper, step, ring, (int64_t)(ring_size - 1), c0,
+                     inc0, mod0, c1, inc1, mod1);
+  RH_LAUNCH_CHECK("rh_step_scalars");
+  return 0;
+}
 
 extern "C" int64_t rh_linear_wgrad_workspace(int B, int N, int K) {
   if (B < 1 || N < 1 || K < 1) return 0;
@@ -457,25 +545,60 @@ extern "C" int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int6
 
 extern "C" int rh_head_nblocks(int B) { return head_grid(B); }
 
+int head_fwd_grid(int B) {
+  int grid = (B + kHeadRows - 1) / kHeadRows;
+  if (grid > 256 * 8) grid = 256 * 8;
+  return grid < 1 ? 1 : grid;
+}
+
 extern "C" int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0,
                            const float* e1, int B, int K, float* y, void* stream) {
   RH_REQUIRE(h && w && y, RH_E_BADARG, "rh_head_fwd: null pointer");
   RH_REQUIRE(B >= 0 && K >= 1 && ldh >= K, RH_E_UNSUPPORTED, "rh_head_fwd: bad width K=%d", K);
   if (B == 0) return 0;
-  int grid = (B + kHeadRows - 1) / kHeadRows;
-  if (grid > 256 * 8) grid = 256 * 8;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), h, ldh, w, bias,
-                     e0, e1, B, K, y);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_fwd_grid(B)), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), h,
+                     ldh, w, bias, e0, e1, B, K, y, (const float*)nullptr, (float*)nullptr);
   RH_LAUNCH_CHECK("rh_head_fwd");
   return 0;
 }
 
+extern "C" int rh_head_loss_nblocks(int B) { return head_fwd_grid(B); }
+
+extern "C" int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0,
+                                const float* e1, int B, int K, float* y, const float* t, float* loss_partial,
+                                void* stream) {
+  RH_REQUIRE(h && w && y && t && loss_partial, RH_E_BADARG, "rh_head_loss_fwd: null pointer");
+  RH_REQUIRE(B >= 1 && K >= 1 && ldh >= K, RH_E_UNSUPPORTED, "rh_head_loss_fwd: bad shape B=%d K=%d", B, K);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(head_fwd_grid(B)), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), h,
+                     ldh, w, bias, e0, e1, B, K, y, t, loss_partial);
+  RH_LAUNCH_CHECK("rh_head_loss_fwd");
+  return 0;
+}
+
+static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                         const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
+                         float* partial, void* stream);
+
 extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K,
                            float* g_h, float* g_z, float* g_w, float* g_b, float* partial, void* stream) {
-  RH_REQUIRE(h && w && y && g_y && g_h && g_z && g_w && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
+  RH_REQUIRE(g_y != nullptr, RH_E_BADARG, "rh_head_bwd: null pointer");
+  return head_bwd_impl(h, ldh, w, y, g_y, nullptr, nullptr, B, K, g_h, g_z, g_w, g_b, partial, stream);
+}
+
+extern "C" int rh_head_loss_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* t,
+                                const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
+                                float* partial, void* stream) {
+  RH_REQUIRE(t && g_loss, RH_E_BADARG, "rh_head_loss_bwd: null pointer");
+  return head_bwd_impl(h, ldh, w, y, nullptr, t, g_loss, B, K, g_h, g_z, g_w, g_b, partial, stream);
+}
+
+static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                         const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
+                         float* partial, void* stream) {
+  RH_REQUIRE(h && w && y && g_h && g_z && g_w && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
   RH_REQUIRE(B >= 1 && K >= 1 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
              "rh_head_bwd: K=%d unsupported (1 .. %d)", K, 4 * kHeadLanes * kHeadMaxV4);
-  HeadBwdArgs a{h, ldh, w, y, g_y, B, K, g_h, g_z, partial, g_w, g_b};
+  HeadBwdArgs a{h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, partial, g_w, g_b};
   const int need = K < 4 ? 1 : (K / 4 + kHeadLanes - 1) / kHeadLanes;
   const dim3 grid(head_grid(B)), block(RH_BLOCK);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -837,6 +837,55 @@ def _col(t, B):
     return t.reshape(B).contiguous()
 
 
+class StepFusion(object):
+    """Cross-op state of ONE fused training step, armed by the trainers around ``model(x)`` + criterion.
+
+    The reference's step ends with  y = sigmoid(...);  loss = BCELoss()(y, t);  loss.backward();  optimizer.step()
+    (models/ranking/deepfm.py:43, trainers/ctr_trainer.py:88-99): five tiny launches here (head, BCE forward, BCE
+    backward, Adam bias corrections, loader position) that are pure launch latency at B = 4096.  While a trainer has
+    armed ``target`` (the labels of the batch), the output head also emits the per-block BCE terms, ``bce_mean`` on that
+    very output finishes the mean inside ``rh_step_scalars`` -- the one single-block launch that also does the Adam
+    bias corrections of the coming optimizer step and advances the registered device counters -- and the head's
+    backward forms the BCE gradient inline.  Nothing changes numerically (same per-row arithmetic); any other use of
+    the head's output (another criterion, no trainer) takes the unfused kernels."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.target = None     # (B,) float32 labels the head may score against
+        self.optimizer = None  # optim.TableAdam: its prepare() rides in rh_step_scalars
+        self.counters = []     # [(int64 device tensor of one element, increment, modulus)]
+        self.head = None       # dict(y_ptr, partial, t) of the head launch that computed BCE terms
+        self.g_loss = None     # (1,) gradient of the loss, handed from the fused BCE backward to the head backward
+
+
+fusion = StepFusion()
+
+
+def fusion_begin(target=None, optimizer=None, counters=()):
+    fusion.clear()
+    if target is not None and target.is_cuda and target.dtype == torch.float32 and target.dim() == 1 and \
+            target.is_contiguous():
+        fusion.target = target
+    fusion.optimizer = optimizer
+    fusion.counters = list(counters)
+
+
+def fusion_end():
+    """Disarm; returns the device counters nobody advanced (the caller launches rh_batch_advance for them)."""
+    left = fusion.counters
+    g = fusion.g_loss
+    fusion.clear()
+    fusion.g_loss = g  # the backward of this step has not run yet
+    return left
+
+
+def advance_counters(counters):
+    for t, inc, mod in counters:
+        _lib.call("rh_batch_advance", _p(t), int(inc), int(mod), _stream())
+
+
 class _HeadFn(torch.autograd.Function):
     """y = sigmoid(h w^T + b + e0 + e1): the MLP's Linear(K, 1), the wide / FM terms and the sigmoid in one launch each way."""
 
@@ -848,7 +897,16 @@ class _HeadFn(torch.autograd.Function):
         B, K = h.shape
         c0, c1 = _col(e0, B), _col(e1, B)
         y = torch.empty((B,), dtype=torch.float32, device=h.device)
-        _lib.call("rh_head_fwd", _p(h), h.stride(0), _p(weight), _p(bias), _p(c0), _p(c1), B, K, _p(y), _stream())
+        t = fusion.target
+        ctx.fused_t = None
+        if t is not None and t.numel() == B and t.device == h.device and B > 0 and any(ctx.needs_input_grad):
+            partial = torch.empty((_lib.call("rh_head_loss_nblocks", B),), dtype=torch.float32, device=h.device)
+            _lib.call("rh_head_loss_fwd", _p(h), h.stride(0), _p(weight), _p(bias), _p(c0), _p(c1), B, K, _p(y), _p(t),
+                      _p(partial), _stream())
+            fusion.head = dict(y_ptr=y.data_ptr(), partial=partial, t=t)
+            ctx.fused_t = t
+        else:
+            _lib.call("rh_head_fwd", _p(h), h.stride(0), _p(weight), _p(bias), _p(c0), _p(c1), B, K, _p(y), _stream())
         ctx.save_for_backward(h, weight, y)
         ctx.shapes = (None if e0 is None else e0.shape, None if e1 is None else e1.shape, bias is not None)
         return y
@@ -859,14 +917,21 @@ class _HeadFn(torch.autograd.Function):
         s0, s1, has_bias = ctx.shapes
         B, K = h.shape
         dev = h.device
-        g_y = g_y.contiguous()
         g_h = torch.empty((B, K), dtype=torch.float32, device=dev)
         g_z = torch.empty((B,), dtype=torch.float32, device=dev)
         g_w = torch.empty_like(weight)
         g_b = torch.empty((1,), dtype=torch.float32, device=dev) if has_bias else None
         partial = torch.empty((_lib.call("rh_head_nblocks", B), K + 1), dtype=torch.float32, device=dev)
-        _lib.call("rh_head_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), B, K, _p(g_h), _p(g_z), _p(g_w),
-                  _p(g_b), _p(partial), _stream())
+        g_loss = fusion.g_loss
+        if ctx.fused_t is not None and g_loss is not None and g_loss[1] == y.data_ptr():
+            # the only consumer of y was the fused BCE: its gradient is formed per row inside this launch
+            fusion.g_loss = None
+            _lib.call("rh_head_loss_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(ctx.fused_t), _p(g_loss[0]), B, K,
+                      _p(g_h), _p(g_z), _p(g_w), _p(g_b), _p(partial), _stream())
+        else:
+            g_y = g_y.contiguous()
+            _lib.call("rh_head_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), B, K, _p(g_h), _p(g_z), _p(g_w),
+                      _p(g_b), _p(partial), _stream())
         return (g_h, g_w, g_b, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1))
 
 
@@ -908,8 +973,48 @@ def bce_ok(criterion, y, t):
             y.shape == t.shape and 0 < y.numel() <= (1 << 22) and not t.requires_grad)
 
 
+class _FusedBceFn(torch.autograd.Function):
+    """Mean BCE of a head output whose per-block terms were computed by rh_head_loss_fwd: the forward is the step's
+    ONE scalar launch (rh_step_scalars: mean of the terms + Adam bias corrections + device counters), the backward only
+    hands the loss gradient to the head's backward (which forms dL/dy inline, rh_head_loss_bwd)."""
+
+    @staticmethod
+    def forward(ctx, y, t, partial):
+        loss = torch.empty((1,), dtype=torch.float32, device=y.device)
+        opt = fusion.optimizer
+        hyper = step = ring = None
+        ring_size = 0
+        if opt is not None and opt.can_fuse_prepare():
+            hyper, step, ring, ring_size = opt.fuse_prepare()
+        cs = fusion.counters[:2]
+        fusion.counters = fusion.counters[2:]
+        flat = []
+        for c, inc, mod in cs:
+            flat += [_p(c), int(inc), int(mod)]
+        while len(flat) < 6:
+            flat += [_NULL, 0, 0]
+        _lib.call("rh_step_scalars", _p(partial), partial.numel(), y.numel(), _p(loss), _p(hyper), _p(step), _p(ring),
+                  ring_size, *flat, _stream())
+        ctx.y_ptr = y.data_ptr()
+        ctx.shape = y.shape
+        ctx.dev = y.device
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        fusion.g_loss = (g.contiguous().view(1), ctx.y_ptr)
+        # placeholder: the head's backward does not read it (it recomputes dL/dy from y, t and g)
+        return torch.empty(ctx.shape, dtype=torch.float32, device=ctx.dev), None, None
+
+
 def bce_mean(y, t):
-    """torch.nn.BCELoss()(y, t) (mean reduction, log clamped at -100) in one launch each way."""
+    """torch.nn.BCELoss()(y, t) (mean reduction, log clamped at -100) in one launch each way; when ``y`` is the output
+    of a head that already scored against ``t`` (StepFusion), the mean is finished by the step's scalar launch."""
+    head = fusion.head
+    if head is not None and head["y_ptr"] == y.data_ptr() and head["t"].data_ptr() == t.data_ptr() and \
+            y.grad_fn is not None and y.grad_fn.__class__.__name__ == "_HeadFnBackward":
+        fusion.head = None
+        return _FusedBceFn.apply(y, t, head["partial"])
     return _BceFn.apply(y, t)
 
 

@@ -72,6 +72,7 @@ class TableAdam(torch.optim.Adam):
         # step number (device counter _t_step) every row was last known to be at: flush() compares it with the counter
         # ITSELF, not with a host-side flag -- hipGraph replays advance the tables without running any host code
         self._flushed_at = 0
+        self._prepared = False  # the bias corrections of the coming step were already computed by rh_step_scalars
         if tables or (others and others[0].is_cuda):
             dev = (tables or others)[0].device
             self._t_m = [torch.zeros_like(p) for p in tables]
@@ -320,6 +321,20 @@ class TableAdam(torch.optim.Adam):
                 self._sweep(SWEEP_FLUSH, ops._stream())
                 self._flushed_at = t
 
+    # -- the step's scalar launch (ops.StepFusion): rh_step_scalars may do this optimizer's rh_adam_prepare --------
+    def can_fuse_prepare(self):
+        return (self._tables or self._bucket is not None) and not self._prepared and \
+            not getattr(self, "overlap_sweep", False)
+
+    def fuse_prepare(self):
+        """Arguments of the prepare part of rh_step_scalars; the next step_tables() then skips rh_adam_prepare.  Must
+        be launched AFTER the last gather of the step's forward (the pre-gather refresh reads the previous step's
+        corrections) and before the optimizer kernels -- i.e. where the loss is computed."""
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()  # lr / betas / eps / weight_decay must be on the device BEFORE the corrections are formed
+        self._prepared = True
+        return self._t_hyper, self._t_step, self._t_ring, self.RING
+
     def step_tables(self):
         """One Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
         if not self._tables and self._bucket is None:
@@ -334,8 +349,11 @@ class TableAdam(torch.optim.Adam):
                 seg.cut(self._advance_host_step)  # replays count their steps on the host too (sweep step by value)
             elif not torch.cuda.is_current_stream_capturing():
                 self._host_step += 1
-        _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
-                  stream)
+        if self._prepared:
+            self._prepared = False
+        else:
+            _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
+                      stream)
         if self._bucket is not None:
             b = self._bucket
             if not all(b.packed):

@@ -108,6 +108,7 @@ class CTRTrainer(object):
         self._graph_b = None
         self._graph_loss = None
         self._deferred_static = None
+        self._counters = []  # device counters of the running step (loader position ...): advanced by rh_step_scalars
 
     # -- one optimisation step ----------------------------------------------------------------
     def _zero_grad(self):
@@ -120,6 +121,29 @@ class CTRTrainer(object):
 
     def _prepare_target(self, y):
         return y.float()
+
+    def _load(self, loader, B=None):
+        """Next batch of a DeviceDataLoader; its position counter is advanced by this step's scalar launch."""
+        x, y = loader.load_next(B, advance=False)
+        self._counters.append(loader.counter(loader.batch_size if B is None else B))
+        return x, y
+
+    def _forward_loss(self, x_dict, y):
+        """_compute_loss under an armed ops.StepFusion: head + BCE terms in one launch, the loss mean / Adam bias
+        corrections / device counters in ONE scalar launch (ops.StepFusion).  Anything the fusion did not absorb is
+        launched here."""
+        fuse = (os.environ.get("RECHUB_STEP_FUSION", "1") == "1" and isinstance(self.optimizer, TableAdam) and
+                self.loss_mode and
+                type(self)._compute_loss is CTRTrainer._compute_loss and type(self)._criterion is CTRTrainer._criterion
+                and type(self.criterion) is torch.nn.BCELoss)
+        counters, self._counters = self._counters, []
+        ops.fusion_begin(target=y if fuse else None, optimizer=self.optimizer if fuse else None, counters=counters)
+        try:
+            loss = self._compute_loss(x_dict, y)
+        finally:
+            left = ops.fusion_end()
+        ops.advance_counters(left)
+        return loss
 
     def _compute_loss(self, x_dict, y):
         """model forward + criterion + regularisation (trainers/ctr_trainer.py:86-95); overridden by MatchTrainer."""
@@ -147,7 +171,7 @@ class CTRTrainer(object):
 
     def train_step(self, x_dict, y):
         """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
-        loss = self._compute_loss(x_dict, y)
+        loss = self._forward_loss(x_dict, y)
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
@@ -173,7 +197,7 @@ class CTRTrainer(object):
     def _phase_a(self, x_dict, y):
         self.dp.deferred_mode, self.dp.deferred = True, []
         self.bucket.defer = True
-        loss = self._compute_loss(x_dict, y)
+        loss = self._forward_loss(x_dict, y)
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
@@ -225,7 +249,7 @@ class CTRTrainer(object):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(self.GRAPH_WARMUP):  # allocator, descriptor caches, lazily created optimizer state
-                    x, y = loader.load_next()
+                    x, y = self._load(loader)
                     total += self._split_step(x, y) if split else self.train_step(x, y)
             torch.cuda.current_stream().wait_stream(side)
             # Segmented capture: the optimizer cuts the step where it launches the deferred table sweep eagerly on
@@ -233,7 +257,7 @@ class CTRTrainer(object):
             self._graph = graphs.SegmentedGraph()
 
             def whole_step():
-                x, y = loader.load_next()
+                x, y = self._load(loader)
                 return self._split_step(x, y) if split else self.train_step(x, y)
 
             if not split:
@@ -257,7 +281,7 @@ class CTRTrainer(object):
                 self.optimizer.overlap_sweep = False  # from here on the window sweep runs in line
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                x, y = loader.load_next()
+                x, y = self._load(loader)
                 self._graph_loss, self._deferred_static = self._phase_a(x, y)
             self._graph.replay()  # capture does not execute: run A for real, exchange, then capture + run B
             gathered = self._phase_x(self._deferred_static)
@@ -317,7 +341,7 @@ class CTRTrainer(object):
             since_log = 0
             while batch_count < full:
                 if self._graph is None and full - batch_count <= self.GRAPH_WARMUP:
-                    x, y = data_loader.load_next()
+                    x, y = self._load(data_loader)
                     loss, n = self.train_step(x, y), 1
                 else:
                     loss, n = self._graphed_step(data_loader)
@@ -332,7 +356,7 @@ class CTRTrainer(object):
                     since_log = 0
             it.close()
             if rem and not data_loader.drop_last:
-                x, y = data_loader.load_next(rem)
+                x, y = self._load(data_loader, rem)
                 epoch += self.train_step(x, y)
                 batch_count += 1
         else:

@@ -284,18 +284,26 @@ class DeviceDataLoader(object):
                                            generator=self.generator))
         self.pos.zero_()
 
-    def load_next(self, B=None):
-        """Assemble the batch at the current position into the static buffers and advance (2 launches)."""
+    def load_next(self, B=None, advance=True):
+        """Assemble the batch at the current position into the static buffers and advance the position.
+
+        ``advance=False``: the caller advances the position later in the step (``counter()`` -> ops.StepFusion: the
+        trainers fold it into the step's single scalar launch instead of a launch of its own)."""
         B = self.batch_size if B is None else B
         x, y, sp, de, seqs = self._buffers(B)
         s = ops._stream()
         _lib.call("rh_batch_gather", ops._p(self.perm), ops._p(self.pos), self.N, B, ops._p(self.sparse), self.F,
                   ops._p(self.dense), self.NDL, ops._p(self.label), ops._p(sp), ops._p(de),
                   ops._p(y if self.label is not None else None), s)
-        _lib.call("rh_batch_advance", ops._p(self.pos), B, self.N, s)
+        if advance:
+            _lib.call("rh_batch_advance", ops._p(self.pos), B, self.N, s)
         for dst, src in seqs:
             dst.copy_(src)
         return x, y
+
+    def counter(self, B=None):
+        """(device counter, increment, modulus) of the batch position: pos = (pos + B) % N."""
+        return self.pos, int(self.batch_size if B is None else B), int(self.N)
 
     def __iter__(self):
         self.reshuffle()
