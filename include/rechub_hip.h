@@ -253,6 +253,11 @@ int64_t rh_linear_wgrad_workspace(int B, int N, int K);
 int rh_linear_wgrad_tiles(int N, int K);
 int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* dW, float* db,
                     float* partial, void* stream);
+/* The same without the reduction launch: partial = S slabs (N, K) followed by S slabs (N,), S = rh_linear_wgrad_splits;
+ * the caller sums them (rh_pack_grads folds that into the packing of the step's dense gradients). */
+int rh_linear_wgrad_splits(int B, int N, int K);
+int rh_linear_wgrad_partial(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* partial,
+                            void* stream);
 int rh_head_nblocks(int B);
 int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
                 int K, float* y, void* stream);
@@ -270,6 +275,9 @@ int rh_colsum(const float* a, int rows, int cols, float* out, const float* v, in
  *   loss[0] = sum(loss_partial[0..n_partial)) / B;  the bias corrections of the next Adam step (== rh_adam_prepare);
  *   two device counters c = (c + inc) % mod (mod 0 = no wrap): the batch position of the device loader (==
  *   rh_batch_advance), the call counter of the in-batch sampler. */
+int rh_head_bwd_ex(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                   const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b, float* partial,
+                   int reduce, void* stream);
 int rh_head_loss_nblocks(int B);
 int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
                      int K, float* y, const float* t, float* loss_partial, void* stream);
@@ -331,6 +339,21 @@ int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel, const dou
  * replaces: optimizer.step() for the non-embedding parameters, trainers/ctr_trainer.py:99 */
 int rh_adam_small(const int64_t* sdesc, int T, const int64_t* h_numel, const float* flat_g, const double* hyper,
                   void* stream);
+
+/* Pack the dense gradients of one step into the flat bucket (replaces: torch.cat over the parameter gradients + the
+ * trailing partial-sum launch of every backward kernel; autograd's `.sum(0)` / accumulate kernels in the reference,
+ * trainers/ctr_trainer.py:97-98):  flat[dst_offset + i] = sum_{r < nparts} src[r * stride + i] (+ add[i]),  i < numel,
+ * summed in the fixed order r = 0, 1, ... (deterministic).  nparts == 0 writes zeros.  `items` is a HOST array; its
+ * entries travel by value in the kernel arguments (hipGraph-capturable although the slabs are temporaries). */
+typedef struct RhPackItem {
+  uint64_t src;       /* device pointer to the partial rows (float) */
+  uint64_t add;       /* device pointer to a plain (numel,) term added on top, or 0 */
+  int64_t nparts;     /* rows to sum */
+  int64_t stride;     /* floats between consecutive rows */
+  int64_t numel;      /* elements of the parameter */
+  int64_t dst_offset; /* offset of the parameter inside flat */
+} RhPackItem;
+int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)

@@ -61,6 +61,11 @@ SIGNATURES = {
     "rh_linear_wgrad_workspace": [c_int, c_int, c_int],
     "rh_linear_wgrad_tiles": [c_int, c_int],
     "rh_linear_wgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_linear_wgrad_splits": [c_int, c_int, c_int],
+    "rh_linear_wgrad_partial": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_head_bwd_ex": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                       c_int, c_ptr],
+    "rh_pack_grads": [c_ptr, c_int, c_ptr, c_ptr],
     "rh_head_nblocks": [c_int],
     "rh_head_fwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_head_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -95,11 +100,17 @@ SIGNATURES = {
 _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctypes.c_int64}
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
-                    "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles",
+                    "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles", "rh_linear_wgrad_splits",
                     "rh_head_nblocks", "rh_head_loss_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks", "rh_augru_max_dim"}
 
 ABI_VERSION = 1
 _lib = None
+
+
+class PackItem(ctypes.Structure):
+    """RhPackItem of include/rechub_hip.h (one parameter's gradient sources for rh_pack_grads)."""
+    _fields_ = [("src", ctypes.c_uint64), ("add", ctypes.c_uint64), ("nparts", c_i64), ("stride", c_i64),
+                ("numel", c_i64), ("dst_offset", c_i64)]
 
 
 def load():

@@ -35,9 +35,10 @@ struct WgradArgs {
   int64_t ldx;
   int B, N, K;
   int S, rows_per_split;
-  float* partial;      // (S, tiles, kPartStride)
+  float* partial;      // split s: dW part at partial + s * N * K, db part at partial + S * N * K + s * N
   float* dW;           // (N, K) contiguous
   float* db;           // (N,) or null
+  int direct;          // 1: S == 1 and the block writes dW / db itself
 };
 
 __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
@@ -138,19 +139,22 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
     mine[kTileElems + 32 + c] = bs1;
   }
   __syncthreads();
-  const bool direct = a.S == 1;
-  float* part = a.partial + ((int64_t)s * tiles + tile) * kPartStride;
+  // Partial results of split s in the layout of the outputs themselves -- (N, K) and (N,) slabs, one per split -- so
+  // that summing the splits is a plain slab sum for whoever does it (wgrad_reduce_kernel, or rh_pack_grads fused with
+  // the packing of the step's dense gradients).
+  (void)tile;
+  (void)tiles;
+  float* outW = a.direct ? a.dW : a.partial + (int64_t)s * a.N * a.K;
+  float* outB = a.direct ? a.db : a.partial + (int64_t)a.S * a.N * a.K + (int64_t)s * a.N;
   for (int e = threadIdx.x; e < kPartStride; e += RH_BLOCK) {
     float v = red[e];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) v += red[w * kPartStride + e];
-    if (!direct) {
-      part[e] = v;
-    } else if (e < kTileElems) {
+    if (e < kTileElems) {
       const int n = n0 + e / kTile, k = k0 + e % kTile;
-      if (n < a.N && k < a.K) a.dW[(int64_t)n * a.K + k] = v;
-    } else if (a.db && blockIdx.x == 0 && n0 + e - kTileElems < a.N) {
-      a.db[n0 + e - kTileElems] = v;
+      if (n < a.N && k < a.K) outW[(int64_t)n * a.K + k] = v;
+    } else if (outB && blockIdx.x == 0 && n0 + e - kTileElems < a.N) {
+      outB[n0 + e - kTileElems] = v;
     }
   }
 }
@@ -158,27 +162,23 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
 // Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
 // "last block reduces" election needs a device-scope fence per block, which on this 8-XCD part writes back and
 // invalidates the XCD's whole L2 (measured: ~140 us for 500 blocks) -- a 3 us launch is the cheaper barrier.
-__global__ __launch_bounds__(RH_BLOCK) void wgrad_reduce_kernel(const WgradArgs a, int tiles_k, int tiles) {
-  const int tile = blockIdx.y;
-  const int e = blockIdx.x * RH_BLOCK + threadIdx.x;
-  if (e >= kPartStride) return;
-  const float* p0 = a.partial + (int64_t)tile * kPartStride + e;
-  const int64_t sstride = (int64_t)tiles * kPartStride;
+__global__ __launch_bounds__(RH_BLOCK) void wgrad_reduce_kernel(const WgradArgs a) {
+  const int64_t nk = (int64_t)a.N * a.K;
+  const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+  const bool is_b = i >= nk;
+  if (i >= nk + a.N || (is_b && a.db == nullptr)) return;
+  const int64_t stride = is_b ? a.N : nk;
+  const float* p0 = is_b ? a.partial + (int64_t)a.S * nk + (i - nk) : a.partial + i;
   float v = 0.f;
   int q = 0;
   for (; q + 4 <= a.S; q += 4) {
-    const float t0 = p0[(q + 0) * sstride], t1 = p0[(q + 1) * sstride];
-    const float t2 = p0[(q + 2) * sstride], t3 = p0[(q + 3) * sstride];
+    const float t0 = p0[(q + 0) * stride], t1 = p0[(q + 1) * stride];
+    const float t2 = p0[(q + 2) * stride], t3 = p0[(q + 3) * stride];
     v = (((v + t0) + t1) + t2) + t3;
   }
-  for (; q < a.S; ++q) v += p0[q * sstride];
-  const int n0 = (tile / tiles_k) * kTile, k0 = (tile % tiles_k) * kTile;
-  if (e < kTileElems) {
-    const int n = n0 + e / kTile, k = k0 + e % kTile;
-    if (n < a.N && k < a.K) a.dW[(int64_t)n * a.K + k] = v;
-  } else if (a.db && tile % tiles_k == 0 && n0 + e - kTileElems < a.N) {
-    a.db[n0 + e - kTileElems] = v;
-  }
+  for (; q < a.S; ++q) v += p0[q * stride];
+  if (is_b) a.db[i - nk] = v;
+  else a.dW[i] = v;
 }
 
 void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
@@ -513,19 +513,44 @@ extern "C" int64_t rh_linear_wgrad_workspace(int B, int N, int K) {
   if (B < 1 || N < 1 || K < 1) return 0;
   int tn, tk, S, rps;
   wgrad_plan(B, N, K, &tn, &tk, &S, &rps);
-  return (int64_t)S * tn * tk * kPartStride;
+  return (int64_t)S * ((int64_t)N * K + N);
+}
+
+extern "C" int rh_linear_wgrad_splits(int B, int N, int K) {
+  if (B < 1 || N < 1 || K < 1) return 0;
+  int tn, tk, S, rps;
+  wgrad_plan(B, N, K, &tn, &tk, &S, &rps);
+  return S;
 }
 
 extern "C" int rh_linear_wgrad_tiles(int N, int K) { return ((N + kTile - 1) / kTile) * ((K + kTile - 1) / kTile); }
 
+// reduce != 0: dW / db are produced (second small launch when the batch was split).  reduce == 0: only the per-split
+// slabs are written -- partial holds S x (N, K) then S x (N,) with S = rh_linear_wgrad_splits(B, N, K) -- and the caller
+// sums them (rh_pack_grads); dW / db may be null.
+static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* dW, float* db,
+                      float* partial, int reduce, void* stream);
+
 extern "C" int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K,
                                float* dW, float* db, float* partial, void* stream) {
-  RH_REQUIRE(g && x && dW && partial, RH_E_BADARG, "rh_linear_wgrad: null pointer");
+  RH_REQUIRE(dW != nullptr, RH_E_BADARG, "rh_linear_wgrad: null pointer");
+  return wgrad_impl(g, ldg, x, ldx, B, N, K, dW, db, partial, 1, stream);
+}
+
+extern "C" int rh_linear_wgrad_partial(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K,
+                                       float* partial, void* stream) {
+  return wgrad_impl(g, ldg, x, ldx, B, N, K, nullptr, nullptr, partial, 0, stream);
+}
+
+static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* dW, float* db,
+                      float* partial, int reduce, void* stream) {
+  RH_REQUIRE(g && x && partial, RH_E_BADARG, "rh_linear_wgrad: null pointer");
   RH_REQUIRE(B >= 1 && N >= 1 && K >= 1 && ldg >= N && ldx >= K, RH_E_BADARG,
              "rh_linear_wgrad: bad shape B=%d N=%d K=%d ldg=%lld ldx=%lld", B, N, K, (long long)ldg, (long long)ldx);
-  WgradArgs a{g, ldg, x, ldx, B, N, K, 1, B, partial, dW, db};
+  WgradArgs a{g, ldg, x, ldx, B, N, K, 1, B, partial, dW, db, 0};
   int tn, tk;
   wgrad_plan(B, N, K, &tn, &tk, &a.S, &a.rows_per_split);
+  a.direct = (reduce && a.S == 1) ? 1 : 0;
   static bool attr_set = false;
   const size_t lds = (size_t)kWaves * kPartStride * sizeof(float);
   if (!attr_set) {
@@ -536,9 +561,9 @@ extern "C" int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int6
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
-  if (a.S > 1)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartStride + RH_BLOCK - 1) / RH_BLOCK, tk * tn), dim3(RH_BLOCK), 0, st, a,
-                       tk, tk * tn);
+  if (reduce && a.S > 1)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)N * K + N + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK),
+                       0, st, a);
   RH_LAUNCH_CHECK("rh_linear_wgrad");
   return 0;
 }
@@ -577,7 +602,17 @@ extern "C" int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, con
 
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
-                         float* partial, void* stream);
+                         float* partial, void* stream, int reduce = 1);
+
+// One entry point for every combination: g_y given (t, g_loss null) or the BCE gradient formed inline (g_y null);
+// reduce == 0: g_w / g_b are not produced, the caller sums the rh_head_nblocks(B) x (K + 1) partial rows (rh_pack_grads).
+extern "C" int rh_head_bwd_ex(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                              const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
+                              float* partial, int reduce, void* stream) {
+  RH_REQUIRE((g_y != nullptr) != (t != nullptr && g_loss != nullptr), RH_E_BADARG,
+             "rh_head_bwd_ex: give either g_y or (t, g_loss)");
+  return head_bwd_impl(h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, g_w, g_b, partial, stream, reduce);
+}
 
 extern "C" int rh_head_bwd(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, int B, int K,
                            float* g_h, float* g_z, float* g_w, float* g_b, float* partial, void* stream) {
@@ -594,8 +629,8 @@ extern "C" int rh_head_loss_bwd(const float* h, int64_t ldh, const float* w, con
 
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
-                         float* partial, void* stream) {
-  RH_REQUIRE(h && w && y && g_h && g_z && g_w && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
+                         float* partial, void* stream, int reduce) {
+  RH_REQUIRE(h && w && y && g_h && g_z && (g_w || !reduce) && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
   RH_REQUIRE(B >= 1 && K >= 1 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
              "rh_head_bwd: K=%d unsupported (1 .. %d)", K, 4 * kHeadLanes * kHeadMaxV4);
   HeadBwdArgs a{h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, partial, g_w, g_b};
@@ -607,7 +642,7 @@ static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const floa
   else if (need <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, grid, block, 0, st, a);
   else if (need <= 8) hipLaunchKernelGGL(head_bwd_kernel<8>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(head_bwd_kernel<16>, grid, block, 0, st, a);
-  launch_colsum(partial, (int)grid.x, K + 1, g_w, K, g_b, nullptr, 0, nullptr, st);
+  if (reduce) launch_colsum(partial, (int)grid.x, K + 1, g_w, K, g_b, nullptr, 0, nullptr, st);
   RH_LAUNCH_CHECK("rh_head_bwd");
   return 0;
 }

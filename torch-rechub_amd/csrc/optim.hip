@@ -432,7 +432,91 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_small_kernel(const AdamSmallArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Pack the dense (non-embedding) gradients of one step into the flat bucket the optimizer (and the RCCL all-reduce)
+// reads, summing per-block / per-split partial slabs on the way: ONE launch instead of torch.cat + the trailing
+// reduction launch of every backward kernel (wgrad_reduce x layers, colsum x 2 in the DeepFM step).
+//   dst[off + i] = sum_{r < nparts} src[r * stride + i]  (+ add[i])      i < numel, fixed order r = 0, 1, ...
+// nparts == 0 writes zeros (a parameter without gradient, like DDP).  The items travel BY VALUE in the kernel
+// arguments: the slabs are temporaries whose addresses are only stable inside a captured hipGraph.
+constexpr int kPackItems = 32;
+struct PackArgs {
+  RhPackItem it[kPackItems];
+  int64_t vb_prefix[kPackItems + 1];
+  int n;
+  float* flat;
+};
+constexpr int kPackChunk = RH_BLOCK;  // outputs per virtual block
+
+__global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) {
+  __shared__ float red[RH_BLOCK / RH_WAVE];
+  for (int64_t vb = blockIdx.x; vb < a.vb_prefix[a.n]; vb += gridDim.x) {
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.vb_prefix[mid] <= vb) lo = mid; else hi = mid;
+    }
+    const RhPackItem& it = a.it[lo];
+    const float* src = reinterpret_cast<const float*>(it.src);
+    const float* add = reinterpret_cast<const float*>(it.add);
+    float* dst = a.flat + it.dst_offset;
+    if (it.numel < 64 && it.nparts > 64) {
+      // tall and thin (a bias: hundreds of partial rows of one float): the block strides over the rows
+      __syncthreads();
+      for (int64_t e = 0; e < it.numel; ++e) {
+        float acc = 0.f;
+        for (int64_t r = threadIdx.x; r < it.nparts; r += RH_BLOCK) acc += src[r * it.stride + e];
+        acc = wave_sum(acc);
+        if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) dst[e] = (((red[0] + red[1]) + red[2]) + red[3]) + (add ? add[e] : 0.f);
+        __syncthreads();
+      }
+      continue;
+    }
+    const int64_t i = (vb - a.vb_prefix[lo]) * kPackChunk + threadIdx.x;
+    if (i < it.numel) {
+      float v = 0.f;
+      int64_t r = 0;
+      for (; r + 4 <= it.nparts; r += 4) {
+        const float t0 = src[(r + 0) * it.stride + i], t1 = src[(r + 1) * it.stride + i];
+        const float t2 = src[(r + 2) * it.stride + i], t3 = src[(r + 3) * it.stride + i];
+        v = (((v + t0) + t1) + t2) + t3;
+      }
+      for (; r < it.nparts; ++r) v += src[r * it.stride + i];
+      if (add) v += add[i];
+      dst[i] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream) {
+  RH_REQUIRE(items != nullptr && flat != nullptr && n >= 0, RH_E_BADARG, "rh_pack_grads: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < n; base += kPackItems) {
+    PackArgs a;
+    a.n = n - base < kPackItems ? n - base : kPackItems;
+    a.flat = flat;
+    a.vb_prefix[0] = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const RhPackItem& it = items[base + i];
+      RH_REQUIRE(it.numel >= 0 && it.nparts >= 0 && it.dst_offset >= 0 && (it.nparts == 0 || it.src != 0), RH_E_BADARG,
+                 "rh_pack_grads: bad item %d", base + i);
+      a.it[i] = it;
+      const bool tall = it.numel < 64 && it.nparts > 64;
+      a.vb_prefix[i + 1] = a.vb_prefix[i] + (tall ? 1 : (it.numel + kPackChunk - 1) / kPackChunk);
+    }
+    for (int i = a.n; i < kPackItems; ++i) a.vb_prefix[i + 1] = a.vb_prefix[a.n];
+    if (a.vb_prefix[a.n] == 0) continue;
+    int64_t grid = a.vb_prefix[a.n];
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_grads_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, st, a);
+  }
+  RH_LAUNCH_CHECK("rh_pack_grads");
+  return 0;
+}
 
 extern "C" int rh_optim_set_tuning(int key, int value) {
   if (key == RH_TUNE_SWEEP_GRID) {

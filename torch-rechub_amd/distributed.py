@@ -187,6 +187,35 @@ class DenseGradBucket(object):
             for i, p in enumerate(self.params):
                 p.grad = self.view(i)
 
+    def pack(self, deferred_items):
+        """Single-GPU fast path: ONE launch (rh_pack_grads) fills the flat bucket from whatever each parameter has -- a
+        slab of partial rows registered in ``ops.deferred`` (summed in fixed order), a plain ``.grad`` tensor (copied; added
+        on top of a slab when both exist), or nothing (zeros) -- instead of torch.cat + one reduction launch per slab."""
+        import ctypes
+
+        from . import _lib
+        n = len(self.params)
+        items = (_lib.PackItem * n)()
+        keep = []
+        for i, p in enumerate(self.params):
+            it, rec, g = items[i], deferred_items.get(id(p)), p.grad
+            it.numel, it.dst_offset = self.sizes[i], self.offsets[i]
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.float().contiguous()
+            if g is not None:
+                keep.append(g)
+            if rec is not None:
+                it.src, it.nparts, it.stride = rec["src"], rec["nparts"], rec["stride"]
+                it.add = g.data_ptr() if g is not None else 0
+                keep.append(rec["keep"])
+            elif g is not None:
+                it.src, it.nparts, it.stride, it.add = g.data_ptr(), 1, self.sizes[i], 0
+            else:
+                it.src, it.nparts, it.stride, it.add = 0, 0, 0, 0
+            self.packed[i] = True
+        _lib.call("rh_pack_grads", ctypes.cast(items, ctypes.c_void_p), n, ops._p(self.flat), ops._stream())
+        self._pack_keep = keep  # alive until the launch is enqueued (and, under capture, pooled by the graph)
+
     def close(self):
         self.pending = []
 

@@ -305,6 +305,7 @@ class _EmbedFused(torch.autograd.Function):
                   _p(err_flag(dev)), _stream())
         ctx.call = call
         ctx.has_lr_b = lr_b is not None
+        ctx.lr_params = (lr_w, lr_b)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(out, s_sum, lr_w if call.want_lr else None)
         return out, fm, lr
@@ -350,6 +351,16 @@ class _EmbedFused(torch.autograd.Function):
                 for w in {id(w): w for w in call.weights if w.requires_grad}.values():
                     _publish_grad(w)
         want_b = g_lr is not None and ctx.has_lr_b and ctx.needs_input_grad[2]
+        wp, bp = ctx.lr_params
+        armed = deferred.armed
+        if B > 0 and want_wgrad and armed is not None and id(wp) in armed and (not want_b or id(bp) in armed):
+            # the per-block partial rows (and, for the bias, the per-sample g_lr) go to the step's packing launch
+            g_w = deferred.offer(wp, partial.data_ptr(), nchunks, F * D, F * D, lambda: partial.sum(0).view_as(lr_w), partial)
+            g_b = None
+            if want_b:
+                glc = g_lr.contiguous()
+                g_b = deferred.offer(bp, glc.data_ptr(), glc.numel(), 1, 1, lambda: glc.sum().view(1), glc)
+            return (None, g_w, g_b) + (None,) * len(call.weights)
         g_w = torch.empty_like(lr_w) if want_wgrad else None
         g_b = torch.empty((1,), dtype=torch.float32, device=dev) if want_b else None
         if B == 0:  # empty batch: nothing was launched; the parameter gradients are exact zeros
@@ -718,8 +729,12 @@ def bn_relu_dropout(h, bn, p_drop, stats=None, relu=True):
 _MAX_WGRAD_TILES = 4096
 
 
-def linear_wgrad(g, x, want_bias=True):
-    """(dW (N, K), db (N,) | None) = (g^T x, colsum(g)) for g (B, N), x (B, K): split-batch f32 MFMA kernel."""
+def linear_wgrad(g, x, want_bias=True, weight=None, bias=None):
+    """(dW (N, K), db (N,) | None) = (g^T x, colsum(g)) for g (B, N), x (B, K): split-batch f32 MFMA kernel.
+
+    ``weight`` / ``bias``: the parameters these are the gradients of.  While the trainer's fast path has armed
+    ``ops.deferred`` for them, the per-split slabs are NOT reduced here: they are registered and the function returns
+    None for that gradient (the step's packing launch sums them into the flat bucket)."""
     require_hip(g, x)
     if g.stride(1) != 1:
         g = g.contiguous()
@@ -728,14 +743,29 @@ def linear_wgrad(g, x, want_bias=True):
     B, N = g.shape
     K = x.shape[1]
     dev = g.device
+    if B == 0:
+        return (torch.zeros((N, K), dtype=torch.float32, device=dev),
+                torch.zeros((N,), dtype=torch.float32, device=dev) if want_bias else None)
+    partial = torch.empty(_lib.call("rh_linear_wgrad_workspace", B, N, K), dtype=torch.float32, device=dev)
+    armed = deferred.armed
+    if armed is not None and weight is not None and id(weight) in armed and (not want_bias or
+                                                                              (bias is not None and id(bias) in armed)):
+        S = _lib.call("rh_linear_wgrad_splits", B, N, K)
+        _lib.call("rh_linear_wgrad_partial", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(partial), _stream())
+
+        def reduce_w():
+            return partial[:S * N * K].view(S, N, K).sum(0)
+
+        def reduce_b():
+            return partial[S * N * K:S * N * K + S * N].view(S, N).sum(0)
+
+        dW = deferred.offer(weight, partial.data_ptr(), S, N * K, N * K, reduce_w, partial)
+        db = None
+        if want_bias:
+            db = deferred.offer(bias, partial.data_ptr() + 4 * S * N * K, S, N, N, reduce_b, partial)
+        return dW, db
     dW = torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty((N,), dtype=torch.float32, device=dev) if want_bias else None
-    if B == 0:
-        dW.zero_()
-        if db is not None:
-            db.zero_()
-        return dW, db
-    partial = torch.empty(_lib.call("rh_linear_wgrad_workspace", B, N, K), dtype=torch.float32, device=dev)
     _lib.call("rh_linear_wgrad", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(dW), _p(db), _p(partial),
               _stream())
     return dW, db
@@ -770,6 +800,7 @@ class _LinearFn(torch.autograd.Function):
         want_stats = bn_batches is not None
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)  # the parameter objects themselves (ops.deferred keys gradients by identity)
         M, K = x.shape
         N = weight.shape[0]
         stats = ctr = None
@@ -806,7 +837,7 @@ class _LinearFn(torch.autograd.Function):
                 gx = g.mm(weight)
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = linear_wgrad(g, x, want_bias=ctx.has_bias)
+            dW, db = linear_wgrad(g, x, want_bias=ctx.has_bias, weight=ctx.params[0], bias=ctx.params[1])
         return gx, dW, db, None
 
 
@@ -835,6 +866,46 @@ def _col(t, B):
     if t.numel() != B:
         raise ValueError(f"head term of {tuple(t.shape)} does not match batch {B}")
     return t.reshape(B).contiguous()
+
+
+class DeferredGrads(object):
+    """Parameter gradients that exist only as per-block / per-split partial slabs until the step's ONE packing launch
+    (rh_pack_grads) sums them straight into the flat gradient bucket.
+
+    Armed by the single-GPU fast path of the trainers for the parameters of their bucket.  While armed, the backward of
+    the weight-gradient, head and fused-embedding kernels skips its trailing reduction launch, registers
+    ``(slab, rows, row stride)`` for the parameter and hands autograd ``None`` for it.  A parameter that is used twice in
+    one step (second registration) falls back to the immediate reduction for BOTH uses; a gradient produced by any
+    other op (``p.grad`` set by autograd) is added on top by the packing launch."""
+
+    def __init__(self):
+        self.armed = None  # {id(param): param} of the parameters whose gradients may be deferred
+        self.items = {}    # id(param) -> dict(param, slab, nparts, stride, numel, reduce_now)
+
+    def arm(self, params):
+        self.armed = {id(p): p for p in params}
+        self.items = {}
+
+    def disarm(self):
+        items, self.items, self.armed = self.items, {}, None
+        return items
+
+    def offer(self, param, slab_ptr, nparts, stride, numel, reduce_now, keep):
+        """Called from a backward: returns the gradient to hand to autograd (None = deferred)."""
+        if self.armed is None or param is None or id(param) not in self.armed:
+            return reduce_now()
+        first = self.items.pop(id(param), None)
+        if first is not None:  # second use of this parameter in the step: both reduce now, autograd accumulates
+            g1 = first["reduce_now"]()
+            param.grad = g1 if param.grad is None else param.grad + g1
+            self.armed.pop(id(param))  # no more deferral for it in this step
+            return reduce_now()
+        self.items[id(param)] = dict(param=param, src=slab_ptr, nparts=int(nparts), stride=int(stride), numel=int(numel),
+                                     reduce_now=reduce_now, keep=keep)
+        return None
+
+
+deferred = DeferredGrads()
 
 
 class StepFusion(object):
@@ -909,6 +980,7 @@ class _HeadFn(torch.autograd.Function):
             _lib.call("rh_head_fwd", _p(h), h.stride(0), _p(weight), _p(bias), _p(c0), _p(c1), B, K, _p(y), _stream())
         ctx.save_for_backward(h, weight, y)
         ctx.shapes = (None if e0 is None else e0.shape, None if e1 is None else e1.shape, bias is not None)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -919,19 +991,29 @@ class _HeadFn(torch.autograd.Function):
         dev = h.device
         g_h = torch.empty((B, K), dtype=torch.float32, device=dev)
         g_z = torch.empty((B,), dtype=torch.float32, device=dev)
-        g_w = torch.empty_like(weight)
-        g_b = torch.empty((1,), dtype=torch.float32, device=dev) if has_bias else None
-        partial = torch.empty((_lib.call("rh_head_nblocks", B), K + 1), dtype=torch.float32, device=dev)
+        nblk = _lib.call("rh_head_nblocks", B)
+        partial = torch.empty((nblk, K + 1), dtype=torch.float32, device=dev)
+        wp, bp = ctx.params
+        armed = deferred.armed
+        defer = armed is not None and id(wp) in armed and (not has_bias or id(bp) in armed)
+        g_w = None if defer else torch.empty_like(weight)
+        g_b = torch.empty((1,), dtype=torch.float32, device=dev) if (has_bias and not defer) else None
         g_loss = fusion.g_loss
+        t = gl = None
         if ctx.fused_t is not None and g_loss is not None and g_loss[1] == y.data_ptr():
             # the only consumer of y was the fused BCE: its gradient is formed per row inside this launch
             fusion.g_loss = None
-            _lib.call("rh_head_loss_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(ctx.fused_t), _p(g_loss[0]), B, K,
-                      _p(g_h), _p(g_z), _p(g_w), _p(g_b), _p(partial), _stream())
+            t, gl, g_y = ctx.fused_t, g_loss[0], None
         else:
             g_y = g_y.contiguous()
-            _lib.call("rh_head_bwd", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), B, K, _p(g_h), _p(g_z), _p(g_w),
-                      _p(g_b), _p(partial), _stream())
+        _lib.call("rh_head_bwd_ex", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_h), _p(g_z),
+                  _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _stream())
+        if defer:
+            g_w = deferred.offer(wp, partial.data_ptr(), nblk, K + 1, K, lambda: partial[:, :K].sum(0).view_as(weight),
+                                 partial)
+            if has_bias:
+                g_b = deferred.offer(bp, partial.data_ptr() + 4 * K, nblk, K + 1, 1, lambda: partial[:, K].sum().view(1),
+                                     partial)
         return (g_h, g_w, g_b, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1))
 
 

@@ -152,7 +152,13 @@ class CTRTrainer(object):
         else:
             y_pred, other_loss = self.model(x_dict)
             loss = self._criterion(y_pred, y) + other_loss
-        return loss + self.reg_loss_fn(self.model)
+        return self._add_reg(loss)
+
+    def _add_reg(self, loss):
+        """loss + RegularizationLoss (ctr_trainer.py:92-95); the reference adds the python float 0.0 when every
+        coefficient is zero -- which would be one add-scalar launch per step here."""
+        reg = self.reg_loss_fn(self.model)
+        return loss if (isinstance(reg, float) and reg == 0.0) else loss + reg
 
     def _criterion(self, y_pred, y):
         # torch.nn.BCELoss() (the reference default, ctr_trainer.py:62) runs as one HIP launch each way
@@ -175,21 +181,42 @@ class CTRTrainer(object):
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
-        loss.backward()
         fast = isinstance(self.optimizer, TableAdam)
+        packed = fast and self.optimizer._bucket is not None
+        # single GPU, packed optimizer: the weight-gradient / head / LR backward kernels leave their partial slabs to the
+        # step's ONE packing launch (ops.DeferredGrads) instead of reducing them one by one
+        defer = packed and self.dp is None and os.environ.get("RECHUB_STEP_FUSION", "1") == "1"
+        if defer:
+            ops.deferred.arm(self.bucket.params)
+        try:
+            loss.backward(self._grad_root(loss))
+        finally:
+            items = ops.deferred.disarm() if defer else {}
         if fast and not self._bucket_attached:
             # first step: every dense parameter must receive a gradient for the packed one-launch optimizer path
             # (torch.optim.Adam skips parameters without a gradient; the packed path cannot)
             self._bucket_attached = True
             if self.bucket.all_present() and self.bucket.params:
                 self.optimizer.attach_bucket(self.bucket)
-        packed = fast and self.optimizer._bucket is not None
-        if packed and not self.bucket.all_present():
+            packed = self.optimizer._bucket is not None  # attached in THIS step: pack it the plain way below
+        if packed and not all(p.grad is not None or id(p) in items for p in self.bucket.params):
             raise RuntimeError("a dense parameter stopped receiving gradients; rebuild the trainer")
-        if packed or self.dp is not None:
+        if defer:
+            self.bucket.pack(items)
+        elif packed or self.dp is not None:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
         return report
+
+    def _grad_root(self, loss):
+        """d loss / d loss = 1 as a cached tensor: autograd's implicit ones_like is a fill launch per step."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            one = torch.ones_like(loss)
+            self._one = one
+        return one
 
     # -- data-parallel step in three phases: [A: batch, forward, backward, pack] -> [X: RCCL collectives] ->
     #    [B: scatter gathered rows, optimizer].  Under hipGraph the three are captured as ONE graph (dp_graph =
@@ -201,7 +228,7 @@ class CTRTrainer(object):
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
-        loss.backward()
+        loss.backward(self._grad_root(loss))
         if not self._bucket_attached:
             self._bucket_attached = True
             if self.bucket.all_present() and self.bucket.params:

@@ -101,7 +101,7 @@ class MatchTrainer(CTRTrainer):
             loss = self.criterion(pos_score, neg_score)
         else:
             loss = self.criterion(self.model(x_dict), y)
-        return loss + self.reg_loss_fn(self.model)
+        return self._add_reg(loss)
 
     def evaluate(self, model, data_loader):
         self.flush()

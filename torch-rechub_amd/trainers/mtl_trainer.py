@@ -70,7 +70,7 @@ class MTLTrainer(CTRTrainer):
             loss = loss.reshape(())
         else:
             loss = sum(losses) / self.n_task
-        return loss + self.reg_loss_fn(self.model)
+        return self._add_reg(loss)
 
     def _criterion_of(self, i, y_pred, y):
         fn = self.loss_fns[i]
