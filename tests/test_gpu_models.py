@@ -336,6 +336,96 @@ def test_graph_mode_flush_leaves_no_row_behind_match_trainer():
         assert torch.equal(ta.optimizer.state[pa]["exp_avg_sq"], tb.optimizer.state[pb]["exp_avg_sq"])
 
 
+def test_padded_width_embeddings_train_like_the_reference_op_chain():
+    """embed_dim = 10 (not a kernel width; the reference's default embed_dim=None yields such widths, features.py:54-60):
+    tables stored 16 wide, kernels run on the padded rows, the layers cut the padding off.  Forward, loss, every
+    gradient and three Adam steps against the reference's op chain on CPU (oracle/cpu_port.py, pinned to the reference by
+    tests/test_oracle_golden.py) from the SAME state_dict -- which has the reference's shapes."""
+    from oracle.cpu_port import PortDeepFM
+    from torch_rechub_amd.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    from torch_rechub_amd.basic.layers import EmbeddingLayer
+    from torch_rechub_amd.models.ranking import DeepFM
+    from torch_rechub_amd.trainers import CTRTrainer
+    D, B = 10, 96
+    vocabs = {"C0": 5, "C1": 40, "C2": 700, "C3": 9000}
+    g = torch.Generator().manual_seed(5)
+    torch.manual_seed(11)
+    dense = [DenseFeature(f"I{i}") for i in range(3)]
+    sparse = [SparseFeature(n, v, D) for n, v in vocabs.items()]
+    model = DeepFM(dense + sparse, sparse, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"})
+    with torch.no_grad():
+        for e in model.embedding.embed_dict.values():
+            e.weight[:, :D].normal_(0, 0.05, generator=g)
+    port = PortDeepFM(vocabs, [f.name for f in dense], embed_dim=D, dims=(32, 16), dropout=0.0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert sd["embedding.embed_dict.C2.weight"].shape == (700, D)
+    port.load_state_dict(sd)
+    batches = []
+    for _ in range(3):
+        x = {n: torch.randint(0, v, (B,), generator=g) for n, v in vocabs.items()}
+        x.update({f.name: torch.rand(B, generator=g) for f in dense})
+        batches.append((x, (torch.rand(B, generator=g) < 0.3).float()))
+    model.to(dev())
+    # forward + loss + gradients on the first batch
+    x, y = batches[0]
+    port.train()
+    model.train()
+    yp = port(x)
+    lp = torch.nn.BCELoss()(yp, y)
+    lp.backward()
+    ym = model(to_dev(x))
+    lm = torch.nn.BCELoss()(ym, y.to(dev()))
+    lm.backward()
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yp.detach().numpy(), rtol=1e-5, atol=2e-6)
+    assert abs(lm.item() - lp.item()) < 2e-6
+    pg = dict(port.named_parameters())
+    for n, p in model.named_parameters():
+        want = pg[n].grad.numpy()
+        got = p.grad.detach().cpu().numpy()
+        if got.shape != want.shape:  # padded table: gradient of the padding columns is exactly zero
+            assert not got[:, D:].any(), n
+            got = got[:, :D]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6 * max(1.0, np.abs(want).max()), err_msg=n)
+    # three optimizer steps (lazy-exact Adam on the padded tables) against torch.optim.Adam on the reference shapes
+    from torch_rechub_amd import ops
+    for p in model.parameters():
+        p.grad = None
+        if hasattr(p, "_rh_grad"):
+            ops.grad_buffer(p).zero_()
+            p._rh_dirty = False
+    port.zero_grad()
+    trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": 1e-3, "lazy_small_rows": 64}, lazy_k=4,
+                         device="cuda:0", show_progress=False)
+    opt = torch.optim.Adam(port.parameters(), lr=1e-2, weight_decay=1e-3)
+    for x, y in batches:
+        trainer.train_step(to_dev(x), y.to(dev()))
+        loss = torch.nn.BCELoss()(port(x), y)
+        port.zero_grad()
+        loss.backward()
+        opt.step()
+    trainer.flush()
+    mine, ref = model.state_dict(), port.state_dict()
+    for k, v in ref.items():
+        got = mine[k].detach().cpu().numpy()
+        assert got.shape == tuple(v.shape), k
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.endswith("running_mean") or k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias"):
+            continue  # bias in front of BatchNorm: rounding-noise gradient, Adam makes its path arbitrary
+        assert_trajectory_close(got, v.numpy(), 1e-2 * 3, k)
+    for e in model.embedding.embed_dict.values():
+        assert not e.weight[:, D:].any()  # the padding stayed zero through weight decay and Adam
+    # sequence pooling and the plain layer call on padded tables
+    feas = [SparseFeature("u", 30, 6), SequenceFeature("h", 50, 6, pooling="mean", padding_idx=0)]
+    layer = EmbeddingLayer(feas).to(dev())
+    xs = {"u": torch.randint(0, 30, (8,), generator=g), "h": torch.randint(0, 50, (8, 5), generator=g)}
+    out = layer(to_dev(xs), feas, squeeze_dim=True)
+    wu, wh = layer.embed_dict["u"].weight.detach().cpu()[:, :6], layer.embed_dict["h"].weight.detach().cpu()[:, :6]
+    mask = (xs["h"] != 0).float()
+    pooled = (wh[xs["h"]] * mask.unsqueeze(-1)).sum(1) / (mask.sum(1, keepdim=True) + 1e-16)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), torch.cat([wu[xs["u"]], pooled], 1).numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_fit_evaluate_predict_and_checkpoint_roundtrip(tmp_path):
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DataGenerator

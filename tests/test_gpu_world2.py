@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 VOCABS = [3, 4, 10, 27, 105, 305, 583 * 40, 40, 1460 * 40, 24, 18, 15, 633 * 40]
 STEPS, B = 6, 64
+DEVICE = "cuda:0"  # the two gloo ranks share the box's one GPU; the RCCL variant below gives each rank its own
 
 
 def _data(seed=11):
@@ -36,7 +37,7 @@ def _model():
     sparse = [SparseFeature(f"C{i}", v, 16) for i, v in enumerate(VOCABS)]
     # no hidden layer: BatchNorm statistics are per replica by design and would differ from the
     # single-process global-batch statistics this test compares against
-    return DeepFM(dense + sparse, sparse, {"dims": [], "dropout": 0.0}).to("cuda:0"), dense, sparse
+    return DeepFM(dense + sparse, sparse, {"dims": [], "dropout": 0.0}).to(DEVICE), dense, sparse
 
 
 def _train(rows_of_step, world, tables="replicate"):
@@ -48,7 +49,7 @@ def _train(rows_of_step, world, tables="replicate"):
     min_rows = 300 if tables == "shard>=300" else 0
     placement = "shard" if tables.startswith("shard") else tables
     trainer = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64},
-                         device="cuda:0", show_progress=False, lazy_k=4, tables=placement if world > 1 else None,
+                         device=DEVICE, show_progress=False, lazy_k=4, tables=placement if world > 1 else None,
                          shard_min_rows=min_rows)
     assert (trainer.dp is not None) == (world > 1)
     if world > 1 and placement == "shard":
@@ -60,9 +61,9 @@ def _train(rows_of_step, world, tables="replicate"):
     losses = []
     for s in range(STEPS):
         rows = rows_of_step(s)
-        x = {f.name: sparse[rows, j].to("cuda:0") for j, f in enumerate(sfe)}
-        x.update({f.name: dense[rows, j].to("cuda:0") for j, f in enumerate(dfe)})
-        losses.append(float(trainer.train_step(x, label[rows].to("cuda:0"))))
+        x = {f.name: sparse[rows, j].to(DEVICE) for j, f in enumerate(sfe)}
+        x.update({f.name: dense[rows, j].to(DEVICE) for j, f in enumerate(dfe)})
+        losses.append(float(trainer.train_step(x, label[rows].to(DEVICE))))
     trainer.flush()
     torch.cuda.synchronize()
     full = sharding.full_state_dict(model) if trainer.tables == "shard" else model.state_dict()
@@ -72,30 +73,49 @@ def _train(rows_of_step, world, tables="replicate"):
     return sd, losses
 
 
-def _worker(rank, port, outdir, train, arg):
+def _worker(rank, port, outdir, train, arg, backend="gloo"):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    global DEVICE
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":  # RCCL over xGMI: one device per rank
+        DEVICE = f"cuda:{rank}"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device(DEVICE))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(rank if backend == "nccl" else 0)
         sd, losses = train(lambda s: slice(s * 2 * B + rank * B, s * 2 * B + (rank + 1) * B), 2, arg)
         torch.save({"sd": sd, "losses": losses}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def _two_ranks(tmp_path, train, arg):
+def _two_ranks(tmp_path, train, arg, backend="gloo"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(port, str(tmp_path), train, arg), nprocs=2, join=True)
+    mp.spawn(_worker, args=(port, str(tmp_path), train, arg, backend), nprocs=2, join=True)
     return torch.load(os.path.join(tmp_path, "rank0.pt")), torch.load(os.path.join(tmp_path, "rank1.pt"))
+
+
+@pytest.mark.parametrize("tables", ["replicate", "shard"])
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X: the world-2 parity check over real RCCL / xGMI")
+def test_two_devices_over_rccl_reproduce_one_process_on_the_global_batch(tmp_path, tables):
+    """The same parity check with the production transport: backend nccl (= RCCL), one device per rank -- dense bucket
+    all-reduce on the side stream, all-gather of (indices, gradient rows) / index all-gather + row reduce-scatter.
+    Skipped on the 1-GPU test box (RCCL refuses two ranks on one device); runs wherever two devices are visible."""
+    _check_against_one_process(tmp_path, tables, "nccl")
 
 
 @pytest.mark.parametrize("tables", ["replicate", "shard", "shard>=300"])
 def test_two_ranks_reproduce_one_process_on_the_global_batch(tmp_path, tables):
-    r0, r1 = _two_ranks(tmp_path, _train, tables)
+    _check_against_one_process(tmp_path, tables, "gloo")
+
+
+def _check_against_one_process(tmp_path, tables, backend):
+    r0, r1 = _two_ranks(tmp_path, _train, tables, backend)
     single, losses = _train(lambda s: slice(s * 2 * B, (s + 1) * 2 * B), world=1)
     assert set(single) == set(r0["sd"]) and all(single[k].shape == r0["sd"][k].shape for k in single)
     # the mean of the two per-rank losses is the global-batch loss

@@ -113,6 +113,48 @@ class EmbeddingLayer(nn.Module):
     def table_of(self, fea):
         return self.embed_dict[fea.name if fea.shared_with is None else fea.shared_with]
 
+    def phys_dim(self, fea):
+        """Row width the kernels see: ``embed_dim``, or the padded width of a PaddedEmbedding (initializers.py)."""
+        return int(self.table_of(fea).weight.shape[1])
+
+    _compact_cols = {}
+
+    def compact(self, out, sparse_feas, n_tail=0):
+        """(B, sum(phys) + n_tail) kernel output -> (B, sum(embed_dim) + n_tail): drops the zero padding columns of
+        PaddedEmbedding tables (one index_select; identity when no table is padded)."""
+        dims = tuple((self.phys_dim(f), f.embed_dim) for f in sparse_feas)
+        if all(p == d for p, d in dims):
+            return out
+        key = (dims, n_tail, str(out.device))
+        cols = EmbeddingLayer._compact_cols.get(key)
+        if cols is None:
+            if out.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("torch_rechub_amd: run the step eagerly once before capturing a hipGraph")
+            idx, at = [], 0
+            for p, d in dims:
+                idx += list(range(at, at + d))
+                at += p
+            idx += list(range(at, at + n_tail))
+            cols = torch.tensor(idx, dtype=torch.long, device=out.device)
+            EmbeddingLayer._compact_cols[key] = cols
+        return out.index_select(1, cols)
+
+    def pad_lr_weight(self, lr_w, sparse_feas):
+        """LR weight (1, sum(embed_dim)) -> (1, sum(phys)) with zeros under the padding columns (differentiable)."""
+        if lr_w is None or all(self.phys_dim(f) == f.embed_dim for f in sparse_feas):
+            return lr_w
+        pieces, at = [], 0
+        for f in sparse_feas:
+            pieces.append(torch.nn.functional.pad(lr_w[:, at:at + f.embed_dim], (0, self.phys_dim(f) - f.embed_dim)))
+            at += f.embed_dim
+        return torch.cat(pieces, dim=1).contiguous()
+
+    def fused(self, x, sparse_feas, dense_feas=(), lr_w=None, lr_b=None, want_fm=False):
+        """The fused gather (+ FM, + LR, + dense append) on logical widths: (out, fm, lr)."""
+        call = self.make_call(x, sparse_feas, dense_feas, want_fm=want_fm, want_lr=lr_w is not None)
+        out, fm, lr = ops.fused_embedding(call, self.pad_lr_weight(lr_w, sparse_feas), lr_b)
+        return self.compact(out, sparse_feas, len(call.dense)), fm, lr
+
     # -- helpers ---------------------------------------------------------------------------
     def _dense_columns(self, x, dense_feas):
         cols = []
@@ -142,7 +184,7 @@ class EmbeddingLayer(nn.Module):
             return False
         for fea in features:
             if isinstance(fea, SparseFeature):
-                dims.add(fea.embed_dim)
+                dims.add(self.phys_dim(fea))
             elif isinstance(fea, SequenceFeature):
                 return False
             elif x[fea.name].dim() != 1:
@@ -185,9 +227,8 @@ class EmbeddingLayer(nn.Module):
 
         if self.can_fuse(x, features):
             sparse = table_feas
-            call = self.make_call(x, sparse, dense_feas if squeeze_dim else ())
-            out, _, _ = ops.fused_embedding(call)
-            return out if squeeze_dim else out.view(call.B, call.F, call.D)
+            out, _, _ = self.fused(x, sparse, dense_feas if squeeze_dim else ())
+            return out if squeeze_dim else out.view(out.shape[0], len(sparse), sparse[0].embed_dim)
         if self.can_fuse_sharded(x, features):
             rows = self.sharded_rows(x, table_feas)
             if squeeze_dim and dense_feas:  # dense values appended by one launch over the received rows (Q1)
@@ -199,22 +240,23 @@ class EmbeddingLayer(nn.Module):
         groups = {}
         for i, fea in enumerate(table_feas):
             if isinstance(fea, SparseFeature):
-                groups.setdefault((fea.embed_dim, sharding.is_sharded(self.table_of(fea))), []).append(i)
+                groups.setdefault((self.phys_dim(fea), sharding.is_sharded(self.table_of(fea))), []).append(i)
         for (dim, sharded), members in groups.items():
             if not _fusable_dim(dim):
-                raise RuntimeError(f"torch_rechub_amd: embed_dim={dim} has no HIP gather kernel yet "
-                                   "(supported: 4, 8, 16, 32, 64, 128); refusing to fall back to a CPU/eager path")
+                raise RuntimeError(f"torch_rechub_amd: embed_dim={dim} has no HIP gather kernel "
+                                   "(1 .. 128 supported, widths other than 4, 8, 16, 32, 64, 128 through padded storage); "
+                                   "refusing to fall back to a CPU/eager path")
             feas = [table_feas[i] for i in members]
             if sharded:
                 out = sharding.lookup([self.table_of(f) for f in feas], [_as_index(x[f.name]) for f in feas])
             else:
                 out, _, _ = ops.fused_embedding(self.make_call(x, feas))
             for k, i in enumerate(members):
-                pieces[i] = out[:, k * dim:(k + 1) * dim].unsqueeze(1)
+                pieces[i] = out[:, k * dim:k * dim + table_feas[i].embed_dim].unsqueeze(1)
         for i, fea in enumerate(table_feas):
             if isinstance(fea, SequenceFeature):
-                if not _fusable_dim(fea.embed_dim):
-                    raise RuntimeError(f"torch_rechub_amd: sequence embed_dim={fea.embed_dim} has no HIP kernel yet")
+                if not _fusable_dim(self.phys_dim(fea)):
+                    raise RuntimeError(f"torch_rechub_amd: sequence embed_dim={fea.embed_dim} has no HIP kernel (> 128)")
                 table = self.table_of(fea)
                 idx = _as_index(x[fea.name])
                 if not sharding.is_sharded(table):
@@ -224,6 +266,8 @@ class EmbeddingLayer(nn.Module):
                     pooled = sharding.lookup([table] * L, [idx[:, j] for j in range(L)]).view(-1, L, fea.embed_dim)
                 else:
                     pooled = sharding.pooled_lookup(table, idx, fea.pooling)
+                if pooled.shape[-1] != fea.embed_dim:  # PaddedEmbedding: cut the zero padding columns off
+                    pooled = pooled[..., :fea.embed_dim]
                 pieces[i] = pooled.unsqueeze(1)
         sparse_emb = torch.cat(pieces, dim=1)
         if not squeeze_dim:

@@ -34,8 +34,7 @@ class AFM(nn.Module):
     def forward(self, x):
         emb = self.embedding
         if emb.can_fuse(x, self.fm_features):
-            call = emb.make_call(x, self.fm_features, (), want_fm=False, want_lr=True)
-            flat, _, y_linear = ops.fused_embedding(call, self.linear.fc.weight, self.linear.fc.bias)
+            flat, _, y_linear = emb.fused(x, self.fm_features, (), self.linear.fc.weight, self.linear.fc.bias)
             input_fm = flat.view(flat.shape[0], len(self.fm_features), -1)
         else:
             input_fm = emb(x, self.fm_features, squeeze_dim=False)

@@ -37,8 +37,7 @@ class DeepFM(torch.nn.Module):
         if emb.can_fuse(x, self.fm_features):
             # replicated tables: the gather kernel emits the MLP input, the FM scalar and the LR scalar
             shared = self._same_sparse_lists() and emb.can_fuse(x, self.deep_features)
-            call = emb.make_call(x, self.fm_features, dense if shared else (), want_fm=True, want_lr=True)
-            input_deep, y_fm, y_linear = ops.fused_embedding(call, w, b)
+            input_deep, y_fm, y_linear = emb.fused(x, self.fm_features, dense if shared else (), w, b, want_fm=True)
         elif emb.can_fuse_sharded(x, self.fm_features):
             # row-sharded tables: ONE exchange for both feature lists, then the same fused stage over the received rows
             shared = self._same_sparse_lists() and emb.can_fuse_sharded(x, self.deep_features)

@@ -56,7 +56,15 @@ class ActivationUnit(nn.Module):
     def forward(self, history, target):
         B, L, D = history.shape
         if not ops.din_dim_ok(D):
-            raise RuntimeError(f"torch_rechub_amd: ActivationUnit emb_dim={D} has no HIP kernel (4,8,16,32,64,128)")
+            # widths outside 4, 8, 16, 32, 64, 128 (PaddedEmbedding tables): the reference's op chain (din.py:77-92) on
+            # the device -- gathers, the attention MLP's fused layers and the optimizer are still the HIP path
+            ops.require_hip(history, target)
+            t = target.unsqueeze(1).expand(-1, L, -1)
+            att_input = torch.cat([t, history, t - history, t * history], dim=-1).view(-1, 4 * D)
+            att_weight = self.attention(att_input).view(-1, L)
+            if self.use_softmax:
+                att_weight = att_weight.softmax(dim=-1)
+            return (att_weight.unsqueeze(-1) * history).sum(dim=1)
         att_input = ops.din_att_input(history, target)  # (B*L, 4D) = [t, h, t-h, t*h], one kernel
         att_weight = self.attention(att_input).view(-1, L)
         if self.use_softmax:

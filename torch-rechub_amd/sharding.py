@@ -102,6 +102,9 @@ def shard_tables(model, group=None, min_rows=0):
         raise RuntimeError("row-sharded tables need an initialised process group (launch with torchrun)")
     out, seen = [], set()
     for m in model.modules():
+        if hasattr(m, "logical_dim") and isinstance(m, nn.Embedding) and m.weight.shape[0] >= min_rows:
+            raise NotImplementedError("row-sharded placement of a padded-width table (embed_dim not in 4, 8, 16, 32, 64, "
+                                      "128) is not implemented: use tables='replicate' or a kernel width")
         if (isinstance(m, nn.Embedding) and id(m) not in seen and m.weight.shape[0] >= min_rows and
                 not getattr(m, "_rh_dense", False)):
             seen.add(id(m))

@@ -438,6 +438,8 @@ class CTRTrainer(object):
                     break
         # row-sharded tables are reassembled (a collective): the file has the reference's layout whatever the placement
         weights = sharding.full_state_dict(self.model) if self.tables == "shard" else self.model.state_dict()
+        # (a padded-width table exposes its (vocab, embed_dim) view: save a compact copy, not the padded storage)
+        weights = {k: (v if not torch.is_tensor(v) or v.is_contiguous() else v.contiguous()) for k, v in weights.items()}
         if self.rank == 0:
             torch.save(weights, os.path.join(self.model_path, "model.pth"))
         for logger in self._iter_loggers():
