@@ -93,6 +93,7 @@ static __device__ __forceinline__ int wave_min_uniform(int v) {
   const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
   return min(min(r0, r1), min(r2, r3));
 }
+static __device__ __forceinline__ int wave_max_uniform(int v) { return -wave_min_uniform(-v); }
 // hardware fp32 atomic add on global memory (global_atomic_add_f32, result unused)
 static __device__ __forceinline__ void gatomic_add_f32(float* p, float v) {
   (void)__builtin_amdgcn_global_atomic_fadd_f32(

@@ -268,10 +268,20 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     // The replay loop runs on a wavefront-uniform counter (scalar ALU, ring entry read once per wavefront) from the
     // oldest row of the wavefront; rows that are more recent join later under the exec mask.
     const int first = work ? u.old + 1 : t;
-    const int jmin = wave_min_uniform(first);
-    for (int j = jmin; j < t; ++j) {
-      const float A = ring_s[2 * (j & a.ring_mask)], E = ring_s[2 * (j & a.ring_mask) + 1];
-      if (j >= first) adam_f4_zero_g(u.P, u.M, u.V, h, A, E);
+    // The replay runs in SEGMENTS between the steps at which rows of the wavefront join (rows of one window were last
+    // swept together; rows the batch touched since join later): inside a segment the set of replaying lanes is fixed
+    // (one exec mask) and the step counter is scalar.  The per-iteration form (`if (j >= first)` inside one loop) cost
+    // ~22 of 158 cycles per iteration in v_cmp / s_and_saveexec / s_or exec / counter VALU ops.
+    int j = wave_min_uniform(first);
+    while (j < t) {  // wavefront-uniform
+      const int nxt = wave_min_uniform(first > j ? first : t);  // the next joining step, > j
+      if (first <= j) {
+        for (int jj = j; jj < nxt; ++jj) {
+          const float A = ring_s[2 * (jj & a.ring_mask)], E = ring_s[2 * (jj & a.ring_mask) + 1];
+          adam_f4_zero_g(u.P, u.M, u.V, h, A, E);
+        }
+      }
+      j = nxt;
     }
     if (work) {
       // lazy tables never carry a gradient here (their rows got it in the touched pass): short form, no select
@@ -346,16 +356,29 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
       if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
     }
     old = __shfl(old, lane - q, RH_WAVE);
-    if (!valid || old >= t) continue;
-    float4 P = gload<float4>(p + r * D + q * 4);
-    float4 M = gload<float4>(m + r * D + q * 4);
-    float4 V = gload<float4>(v + r * D + q * 4);
-    float4 G = f4_zero();
-    if (!REFRESH) G = gload<float4>(g + r * D + q * 4);
-    for (int j = old + 1; j < t; ++j) {
-      const float A = a.ring[2 * (j & a.ring_mask)], E = a.ring[2 * (j & a.ring_mask) + 1];
-      adam_f4_zero_g(P, M, V, h, A, E);
+    const bool act = valid && old < t;  // this lane group claimed the row
+    float4 P = f4_zero(), M = f4_zero(), V = f4_zero(), G = f4_zero();
+    if (act) {
+      P = gload<float4>(p + r * D + q * 4);
+      M = gload<float4>(m + r * D + q * 4);
+      V = gload<float4>(v + r * D + q * 4);
+      if (!REFRESH) G = gload<float4>(g + r * D + q * 4);
     }
+    // replay in segments between the steps at which rows of the wavefront join (see adam_lazy_sweep_kernel): fixed exec
+    // mask and a scalar step counter inside a segment (the ring entry becomes a scalar load)
+    const int first = act ? old + 1 : t;
+    int j = wave_min_uniform(first);
+    while (j < t) {
+      const int nxt = wave_min_uniform(first > j ? first : t);
+      if (first <= j) {
+        for (int jj = j; jj < nxt; ++jj) {
+          const float A = a.ring[2 * (jj & a.ring_mask)], E = a.ring[2 * (jj & a.ring_mask) + 1];
+          adam_f4_zero_g(P, M, V, h, A, E);
+        }
+      }
+      j = nxt;
+    }
+    if (!act) continue;
     if (REFRESH) adam_f4_zero_g(P, M, V, h, h.A, h.E);
     else adam_f4(P, G, M, V, h, h.A, h.E);
     gstore<float4>(p + r * D + q * 4, P);
