@@ -332,16 +332,24 @@ def gather_sweep(model, wl, device, batches=(4096, 16384, 65536), iters=40):
     g = torch.Generator(device=device).manual_seed(7)
     w, b = model.linear.fc.weight, model.linear.fc.bias
     for B in batches:
-        idx = torch.stack([torch.randint(0, v, (B,), device=device, generator=g) for v in wl.vocabs], 1).contiguous()
-        den = torch.rand(B, len(wl.dense_feas), device=device, generator=g)
-        x = {f.name: idx[:, j] for j, f in enumerate(wl.sparse_feas)}
-        x.update({f.name: den[:, j] for j, f in enumerate(wl.dense_feas)})
-        call = model.embedding.make_call(x, wl.sparse_feas, wl.dense_feas, want_fm=True, want_lr=True)
-        g_out = torch.randn(B, call.width, device=device, generator=g)
+        # several index sets, cycled: one set re-gathered in a loop would sit in the 256 MiB Infinity Cache (65536 x 26
+        # rows = 109 MB) and flatter the kernel; training never looks up the same rows twice in a row
+        nsets = max(2, min(16, -(-400_000_000 // (B * len(wl.vocabs) * 64))))
+        calls = []
+        for _ in range(nsets):
+            idx = torch.stack([torch.randint(0, v, (B,), device=device, generator=g) for v in wl.vocabs], 1).contiguous()
+            den = torch.rand(B, len(wl.dense_feas), device=device, generator=g)
+            x = {f.name: idx[:, j] for j, f in enumerate(wl.sparse_feas)}
+            x.update({f.name: den[:, j] for j, f in enumerate(wl.dense_feas)})
+            calls.append(model.embedding.make_call(x, wl.sparse_feas, wl.dense_feas, want_fm=True, want_lr=True))
+        g_out = torch.randn(B, calls[0].width, device=device, generator=g)
         g_fm = torch.randn(B, 1, device=device, generator=g)
         g_lr = torch.randn(B, 1, device=device, generator=g)
+        turn = [0]
 
         def once():
+            call = calls[turn[0] % nsets]
+            turn[0] += 1
             o, fm, lr = ops.fused_embedding(call, w, b)
             torch.autograd.backward([o, fm, lr], [g_out, g_fm, g_lr])
             w.grad = b.grad = None

@@ -178,6 +178,10 @@ int rh_cross_mix_epilogue_fwd(const float* x0, const float* xl, const float* uv,
                               int B, int d, int E, float* out, void* stream);
 int rh_cross_mix_epilogue_bwd(const float* x0, const float* uv, const float* gate, const float* bias, const float* g,
                               int B, int d, int E, float* g_x0, float* g_uv, float* g_gate, void* stream);
+/* the same, also emitting the bias gradient as rh_cross_mix_nblocks(B) x d per-block partial rows (summed by the caller) */
+int rh_cross_mix_nblocks(int B);
+int rh_cross_mix_epilogue_bwd_b(const float* x0, const float* uv, const float* gate, const float* bias, const float* g, int B,
+                                int d, int E, float* g_x0, float* g_uv, float* g_gate, float* g_bias_partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DIN: Dice activation and the memory-bound ends of the ActivationUnit

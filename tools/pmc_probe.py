@@ -19,7 +19,7 @@ def main():
     from torch_rechub_amd.optim import TableAdam
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
-    F, D, B = len(CRITEO_VOCABS), 16, 4096
+    F, D, B = len(CRITEO_VOCABS), 16, int(os.environ.get("PMC_B", "4096"))
     tables = [torch.nn.Parameter(torch.randn(v, D, device=dev, generator=g) * 1e-2) for v in CRITEO_VOCABS]
     lr_w = torch.nn.Parameter(torch.randn(1, F * D, device=dev))
     lr_b = torch.nn.Parameter(torch.randn(1, device=dev))

@@ -228,7 +228,7 @@ class EmbeddingLayer(nn.Module):
         if self.can_fuse(x, features):
             sparse = table_feas
             out, _, _ = self.fused(x, sparse, dense_feas if squeeze_dim else ())
-            return out if squeeze_dim else out.view(out.shape[0], len(sparse), sparse[0].embed_dim)
+            return out if squeeze_dim else out.reshape(out.shape[0], len(sparse), sparse[0].embed_dim)
         if self.can_fuse_sharded(x, features):
             rows = self.sharded_rows(x, table_feas)
             if squeeze_dim and dense_feas:  # dense values appended by one launch over the received rows (Q1)
@@ -452,7 +452,7 @@ class CrossNetMix(nn.Module):
             uv = torch.bmm(v, U.transpose(1, 2))  # (E, B, d): U_e v
             if d <= 2048 and E <= 16:
                 # bias + Hadamard with x0 + gate-weighted expert mix + residual: one pass (csrc/crossmix.hip)
-                xl = ops.cross_mix_epilogue(x0, xl, uv, gate, self.bias[i].view(d))
+                xl = ops.cross_mix_epilogue(x0, xl, uv, gate, self.bias[i])
             else:
                 expert = x0.unsqueeze(0) * (uv + self.bias[i].view(1, 1, d))  # (E, B, d)
                 xl = (expert * gate.t().unsqueeze(2)).sum(dim=0) + xl

@@ -51,6 +51,7 @@ struct MixArgs {
   float* g_uv;        // (E, B, d)
   float* g_gate;      // (B, E)
   int B, d, E;
+  float* g_bias_partial;  // (gridDim.x, d) per-block sums of g * x0 * sum_e gate_e, or null (backward)
 };
 
 template <int EPL, bool BWD>
@@ -65,8 +66,12 @@ __global__ __launch_bounds__(RH_BLOCK) void cross_mix_kernel(const MixArgs a) {
     const int e = lane + RH_WAVE * k;
     bv[k] = e < d ? a.bias[e] : 0.f;
   }
+  float gb[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) gb[k] = 0.f;
   for (int64_t s = (int64_t)blockIdx.x * kWaves + wave; s < a.B; s += nw) {
     float a0[EPL], acc[EPL], gv[EPL];
+    float gsum = 0.f;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(RH_BLOCK) void cross_mix_kernel(const MixArgs a) {
     }
     for (int ex = 0; ex < E; ++ex) {
       const float gt = a.gate[s * E + ex];
+      gsum += gt;
       float dot = 0.f;
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
@@ -100,6 +106,19 @@ __global__ __launch_bounds__(RH_BLOCK) void cross_mix_kernel(const MixArgs a) {
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
       if (e < d) a.out[s * d + e] = BWD ? gv[k] * acc[k] : acc[k] + a.xl[s * d + e];
+      if (BWD) gb[k] = fmaf(gv[k] * a0[k], gsum, gb[k]);  // d/d bias = g x0 sum_e gate_e
+    }
+  }
+  if (BWD && a.g_bias_partial != nullptr) {  // the block's 4 wavefronts in fixed order -> one partial row per block
+    __shared__ float red[kWaves][RH_WAVE * EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) red[wave][lane + RH_WAVE * k] = gb[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < d; e += RH_BLOCK) {
+      float v = red[0][e];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) v += red[w][e];
+      a.g_bias_partial[(int64_t)blockIdx.x * d + e] = v;
     }
   }
 }
@@ -161,22 +180,40 @@ extern "C" int rh_cross_mix_epilogue_fwd(const float* x0, const float* xl, const
   RH_REQUIRE(d >= 1 && d <= 2048 && E >= 1 && E <= kMaxExperts && B >= 0, RH_E_UNSUPPORTED,
              "rh_cross_mix_epilogue_fwd: d=%d E=%d unsupported (d <= 2048, E <= %d)", d, E, kMaxExperts);
   if (B == 0) return 0;
-  MixArgs a{x0, xl, uv, gate, bias, nullptr, out, nullptr, nullptr, B, d, E};
+  MixArgs a{x0, xl, uv, gate, bias, nullptr, out, nullptr, nullptr, B, d, E, nullptr};
   int rc = mix_dispatch<false>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_cross_mix_epilogue_fwd");
   return 0;
 }
 
+extern "C" int rh_cross_mix_nblocks(int B) { return (int)wave_grid(B); }
+
+static int mix_bwd_impl(const float* x0, const float* uv, const float* gate, const float* bias, const float* g, int B, int d,
+                        int E, float* g_x0, float* g_uv, float* g_gate, float* g_bias_partial, void* stream);
+
 extern "C" int rh_cross_mix_epilogue_bwd(const float* x0, const float* uv, const float* gate, const float* bias,
                                          const float* g, int B, int d, int E, float* g_x0, float* g_uv, float* g_gate,
                                          void* stream) {
+  return mix_bwd_impl(x0, uv, gate, bias, g, B, d, E, g_x0, g_uv, g_gate, nullptr, stream);
+}
+
+// the same + the bias gradient as rh_cross_mix_nblocks(B) x d per-block partial rows (the caller / rh_pack_grads sums them)
+extern "C" int rh_cross_mix_epilogue_bwd_b(const float* x0, const float* uv, const float* gate, const float* bias,
+                                           const float* g, int B, int d, int E, float* g_x0, float* g_uv, float* g_gate,
+                                           float* g_bias_partial, void* stream) {
+  RH_REQUIRE(g_bias_partial != nullptr, RH_E_BADARG, "rh_cross_mix_epilogue_bwd_b: null partial buffer");
+  return mix_bwd_impl(x0, uv, gate, bias, g, B, d, E, g_x0, g_uv, g_gate, g_bias_partial, stream);
+}
+
+static int mix_bwd_impl(const float* x0, const float* uv, const float* gate, const float* bias, const float* g, int B, int d,
+                        int E, float* g_x0, float* g_uv, float* g_gate, float* g_bias_partial, void* stream) {
   RH_REQUIRE(x0 && uv && gate && bias && g && g_x0 && g_uv && g_gate, RH_E_BADARG,
              "rh_cross_mix_epilogue_bwd: null pointer");
   RH_REQUIRE(d >= 1 && d <= 2048 && E >= 1 && E <= kMaxExperts && B >= 0, RH_E_UNSUPPORTED,
              "rh_cross_mix_epilogue_bwd: d=%d E=%d unsupported (d <= 2048, E <= %d)", d, E, kMaxExperts);
   if (B == 0) return 0;
-  MixArgs a{x0, nullptr, uv, gate, bias, g, g_x0, g_uv, g_gate, B, d, E};
+  MixArgs a{x0, nullptr, uv, gate, bias, g, g_x0, g_uv, g_gate, B, d, E, g_bias_partial};
   int rc = mix_dispatch<true>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_cross_mix_epilogue_bwd");

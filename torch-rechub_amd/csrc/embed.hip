@@ -55,6 +55,14 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
   float Qs = 0.f, Ls = 0.f;
   bool oob_any = false;
   float* orow = a.out + b * a.out_stride + q * 4;
+  // The LR weights (F x D floats, the same for every sample) wait in LDS instead of 8 float4 registers per lane: the
+  // kernel drops from 144 to 114 VGPRs, i.e. from 3 to 4 wavefronts per SIMD of gathers in flight.
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  if (HAS_LR) {
+    for (int i = tid; i < F * LPR; i += RH_BLOCK)
+      *reinterpret_cast<float4*>(wlds + 4 * i) = gload<float4>(a.lr_w + 4 * i);
+  }
+  bool staged = !HAS_LR;
 
   // dense values appended after the sparse block (layers.py:120 order).  The first column of every lane rides along
   // with the gathers (descriptor with the field descriptors, value with the indices): as a tail loop after the
@@ -95,14 +103,16 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
     if (j0 == 0 && dense0) dv0 = gload<float>(dp0 + b * ds0);
     // phase 2: row gathers (16 B per lane), all in flight together
     float4 v[U];
-    float4 w[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool oob = (uint64_t)row[u] >= (uint64_t)voc[u];
       oob_any |= (oob && ok[u]);
       const int64_t r = oob ? 0 : row[u];
       v[u] = gload<float4>(tab[u] + r * D + q * 4);
-      if (HAS_LR) w[u] = gload<float4>(a.lr_w + fcl[u] * D + q * 4);
+    }
+    if (!staged) {  // block-uniform: the staged LR weights become visible (first pass only)
+      __syncthreads();
+      staged = true;
     }
     // phase 3: accumulate (branch-free selects) + emit
 #pragma unroll
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
       const float4 vm = ok[u] ? v[u] : f4_zero();
       S = f4_add(S, vm);
       Qs += f4_dot(vm, vm);
-      if (HAS_LR) Ls += f4_dot(w[u], vm);
+      if (HAS_LR) Ls += f4_dot(*reinterpret_cast<const float4*>(wlds + (fcl[u] * LPR + q) * 4), vm);
       if (ok[u] && live) gstore<float4>(orow + col[u], v[u]);
     }
   }
@@ -150,7 +160,8 @@ int launch_fwd(const EmbedFwdArgs& a, hipStream_t s) {
   constexpr int SPB = RH_BLOCK / (LPR * FS);
   const unsigned grid = (unsigned)((a.B + SPB - 1) / SPB);
   if (a.lr_w != nullptr)
-    hipLaunchKernelGGL((embed_fwd_kernel<LPR, FS, IdxT, true>), dim3(grid), dim3(RH_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((embed_fwd_kernel<LPR, FS, IdxT, true>), dim3(grid), dim3(RH_BLOCK),
+                       (size_t)a.F * a.D * sizeof(float), s, a);
   else
     hipLaunchKernelGGL((embed_fwd_kernel<LPR, FS, IdxT, false>), dim3(grid), dim3(RH_BLOCK), 0, s, a);
   return 0;
@@ -468,6 +479,8 @@ extern "C" int rh_embed_fwd(const int64_t* fdesc, const int64_t* idesc, int idx_
              dense_col, n_dense);
   RH_REQUIRE(n_dense == 0 || ddesc != nullptr, RH_E_BADARG, "rh_embed_fwd: n_dense > 0 but ddesc is null");
   RH_REQUIRE(lr_out == nullptr || lr_w != nullptr, RH_E_BADARG, "rh_embed_fwd: lr_out without lr_w");
+  RH_REQUIRE(lr_out == nullptr || (int64_t)F * D <= 12288, RH_E_UNSUPPORTED,
+             "rh_embed_fwd: fused LR keeps the F*D = %lld weights in LDS (<= 12288 floats)", (long long)F * D);
   if (B == 0) return 0;
   EmbedFwdArgs a{fdesc, idesc, ddesc, B, F, D, n_dense, dense_col, out, out_stride, lr_w, lr_b, lr_out, fm_out, s_out, err_flag};
   if (lr_out == nullptr) a.lr_w = nullptr;

@@ -171,8 +171,12 @@ static __device__ __forceinline__ void chan_combine(const BnArgs& a, int c, int 
   var = fmaxf(m2 / (float)a.B, 0.f);
 }
 
-template <int MODE>
+// FINCOLS columns x (256 / FINCOLS) chunk groups per block.  The backward of a B * L = 409600-row layer (DIN's attention
+// MLP) hands over 2048 partial rows: with 32 columns per block that is 8 blocks walking 256 rows each (68 us measured);
+// 4 columns per block = 64 blocks x 32 rows.
+template <int MODE, int FINCOLS = kFinCols>
 __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
+  constexpr int kFinCols = FINCOLS;  // shadows the file-level default inside this kernel
   constexpr int GROUPS = RH_BLOCK / kFinCols;
   __shared__ float red[2 * GROUPS * (kFinCols + 1)];
   const int cl = threadIdx.x % kFinCols;
@@ -497,8 +501,12 @@ extern "C" int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, 
   RH_REQUIRE(partial && stat && dgamma && dbeta && rows >= 1 && C >= 1, RH_E_BADARG, "rh_bn_finalize_bwd: bad arguments");
   BnArgs a{};
   a.partial = partial; a.stat = stat; a.dgamma = dgamma; a.dbeta = dbeta; a.C = C; a.nchunks = rows; a.B = 1;
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
-                     reinterpret_cast<hipStream_t>(stream), a);
+  if (rows > 512)
+    hipLaunchKernelGGL((bn_finalize_kernel<1, 4>), dim3((unsigned)((C + 3) / 4)), dim3(RH_BLOCK), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
   RH_LAUNCH_CHECK("rh_bn_finalize_bwd");
   return 0;
 }

@@ -35,7 +35,7 @@ class AFM(nn.Module):
         emb = self.embedding
         if emb.can_fuse(x, self.fm_features):
             flat, _, y_linear = emb.fused(x, self.fm_features, (), self.linear.fc.weight, self.linear.fc.bias)
-            input_fm = flat.view(flat.shape[0], len(self.fm_features), -1)
+            input_fm = flat.reshape(flat.shape[0], len(self.fm_features), -1)
         else:
             input_fm = emb(x, self.fm_features, squeeze_dim=False)
             y_linear = self.linear(input_fm.flatten(start_dim=1))

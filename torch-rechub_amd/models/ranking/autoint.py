@@ -42,7 +42,7 @@ class AutoInt(nn.Module):
         emb = self.sparse_embedding
         if emb.can_fuse(x, self.sparse_features):
             flat, _, _ = emb.fused(x, self.sparse_features, ())
-            sparse_emb = flat.view(flat.shape[0], self.num_sparse, self.embed_dim)
+            sparse_emb = flat.reshape(flat.shape[0], self.num_sparse, self.embed_dim)
         else:
             sparse_emb = emb(x, self.sparse_features, squeeze_dim=False)
         if self.dense_features:

@@ -289,7 +289,11 @@ class _EmbedFused(torch.autograd.Function):
     def forward(ctx, call, lr_w, lr_b, *weights):
         B, F, D = call.B, call.F, call.D
         dev = call.device
-        out = torch.empty((B, call.width), dtype=torch.float32, device=dev)
+        # row pitch rounded up to 64 bytes: with 13 dense columns a (B, 429) row is 1716 B, every 64-byte field chunk
+        # straddles two cache lines and every store is a partial-line write; at pitch 432 the chunks ARE lines.  The
+        # result is the (B, width) view of the padded buffer (row stride 432): GEMMs take a leading dimension.
+        pitch = (call.width + 15) // 16 * 16
+        out = torch.empty((B, pitch), dtype=torch.float32, device=dev)[:, :call.width]
         fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if call.want_fm else None
         lr = torch.empty((B, 1), dtype=torch.float32, device=dev) if call.want_lr else None
         s_sum = torch.empty((B, D), dtype=torch.float32, device=dev) if call.want_fm else None
@@ -1298,7 +1302,9 @@ class _CrossMixEpilogue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, xl, uv, gate, bias):
         require_hip(x0, xl, uv, gate, bias)
-        x0, xl, uv, gate, bias = x0.contiguous(), xl.contiguous(), uv.contiguous(), gate.contiguous(), bias.contiguous()
+        ctx.bias_param, ctx.bias_shape = bias, bias.shape  # the (d, 1) / (d,) parameter itself (ops.deferred keys by identity)
+        x0, xl, uv, gate = x0.contiguous(), xl.contiguous(), uv.contiguous(), gate.contiguous()
+        bias = bias.reshape(-1).contiguous()
         E, B, d = uv.shape
         out = torch.empty_like(x0)
         _lib.call("rh_cross_mix_epilogue_fwd", _p(x0), _p(xl), _p(uv), _p(gate), _p(bias), B, d, E, _p(out), _stream())
@@ -1313,9 +1319,13 @@ class _CrossMixEpilogue(torch.autograd.Function):
         g_x0 = torch.empty_like(x0)
         g_uv = torch.empty_like(uv)
         g_gate = torch.empty_like(gate)
-        _lib.call("rh_cross_mix_epilogue_bwd", _p(x0), _p(uv), _p(gate), _p(bias), _p(g), B, d, E, _p(g_x0), _p(g_uv),
-                  _p(g_gate), _stream())
-        g_bias = (g * x0 * gate.sum(dim=1, keepdim=True)).sum(0)
+        nblk = _lib.call("rh_cross_mix_nblocks", B)
+        partial = torch.empty((nblk, d), dtype=torch.float32, device=g.device)
+        _lib.call("rh_cross_mix_epilogue_bwd_b", _p(x0), _p(uv), _p(gate), _p(bias), _p(g), B, d, E, _p(g_x0), _p(g_uv),
+                  _p(g_gate), _p(partial), _stream())
+        # d/d bias = sum_b g x0 sum_e gate_e: per-block partial rows from the same pass (was 2 multiplies + 2 reductions)
+        shape = ctx.bias_shape
+        g_bias = deferred.offer(ctx.bias_param, partial.data_ptr(), nblk, d, d, lambda: partial.sum(0).view(shape), partial)
         return g_x0, g, g_uv, g_gate, g_bias
 
 
