@@ -1205,3 +1205,32 @@ def test_sharded_history_lookup_many_positions_of_one_table():
         assert not got[mine.shape[0]:].any()
     assert np.array_equal(total.cpu().numpy(), want)
     ops.check_errors()
+
+
+def test_torch_library_ops_opcheck_and_values():
+    """torch.ops.rechub_hip.{fm, cross_network, dice}: schema / fake impl / autograd registration validated by
+    torch.library.opcheck on the device, values and gradients equal to the autograd.Function path of the layers."""
+    import torch_rechub_amd.library  # noqa: F401
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(33, 7, 16, generator=g).to(dev()).requires_grad_()
+    z = torch.randn(65, 45, generator=g).to(dev()).requires_grad_()
+    W = (torch.randn(3, 45, generator=g) / 8).to(dev()).requires_grad_()
+    b = (torch.randn(3, 45, generator=g) / 8).to(dev()).requires_grad_()
+    h = torch.randn(50, 36, generator=g).to(dev()).requires_grad_()
+    alpha = torch.randn(1, generator=g).to(dev()).requires_grad_()
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(torch.ops.rechub_hip.fm.default, (x, True), test_utils=tests)
+    torch.library.opcheck(torch.ops.rechub_hip.cross_network.default, (z, W, b), test_utils=tests)
+    torch.library.opcheck(torch.ops.rechub_hip.dice.default, (h, alpha, 1e-9), test_utils=tests)
+    for a, bfn, args in ((torch.ops.rechub_hip.fm, ops.fm, (x, True)),
+                         (torch.ops.rechub_hip.cross_network, ops.cross_network, (z, W, b)),
+                         (torch.ops.rechub_hip.dice, ops.dice, (h, alpha, 1e-9))):
+        leaves = [t for t in args if torch.is_tensor(t)]
+        ya = a(*args)
+        ga = torch.autograd.grad(ya.sum() * 0.5 + (ya * ya).sum(), leaves)
+        yb = bfn(*args)
+        gb = torch.autograd.grad(yb.sum() * 0.5 + (yb * yb).sum(), leaves)
+        assert torch.equal(ya, yb)
+        for u, v in zip(ga, gb):
+            assert torch.allclose(u, v, rtol=1e-6, atol=1e-7)

@@ -352,3 +352,27 @@ def test_padded_width_tables_keep_the_reference_checkpoint_layout():
     assert got == list(range(18)) + list(range(32, 42)) + list(range(48, 64)) + [64, 65]
     lw = layer.pad_lr_weight(torch.arange(44.0).view(1, 44), feas)
     assert lw.shape == (1, 64) and lw[0, 18:32].abs().sum() == 0 and lw[0, 32] == 18 and lw[0, 48] == 28
+
+
+def test_torch_library_ops_trace_under_fake_tensors():
+    """the stateless interaction kernels are registered with torch.library (schema + fake impl + autograd):
+    FakeTensorMode propagates shapes through them without a device or a kernel, and the real implementations still
+    refuse CPU tensors (no fallback)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    import torch_rechub_amd.library  # noqa: F401  (registers torch.ops.rechub_hip.*)
+    with FakeTensorMode():
+        x = torch.empty(64, 26, 16)
+        assert torch.ops.rechub_hip.fm(x, True).shape == (64, 1)
+        assert torch.ops.rechub_hip.fm(x, False).shape == (64, 16)
+        z = torch.empty(64, 429, requires_grad=True)
+        W, b = torch.empty(3, 429, requires_grad=True), torch.empty(3, 429, requires_grad=True)
+        out = torch.ops.rechub_hip.cross_network(z, W, b)
+        assert out.shape == (64, 429) and out.requires_grad
+        out.sum().backward()  # the autograd formula traces too
+        assert z.grad.shape == (64, 429) and W.grad.shape == (3, 429) and b.grad.shape == (3, 429)
+        assert torch.ops.rechub_hip.dice(torch.empty(100, 36), torch.empty(1), 1e-9).shape == (100, 36)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        torch.ops.rechub_hip.fm(torch.zeros(2, 3, 4), True)
+    schema = str(torch.ops.rechub_hip.cross_network.default._schema)
+    assert schema.startswith("rechub_hip::cross_network(Tensor x, Tensor W, Tensor b) -> Tensor")

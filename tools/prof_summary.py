@@ -52,10 +52,13 @@ def main():
         for row in csv.DictReader(open(f)):
             acc[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     total = sum(sum(v) for v in acc.values())
-    print("# rocprofv3 --kernel-trace --stats summary (durations in us)")
-    print(f"{'kernel':100s} {'calls':>7s} {'avg_us':>10s} {'min_us':>10s} {'total_ms':>10s} {'pct':>6s}")
+    print("# rocprofv3 --kernel-trace --stats summary (durations in us).  median_us = the steady-state launch: the mean also")
+    print("# holds the short first sweeps after a flush, the 6 ms flush itself and the B = 16384 / 65536 launches of bench.py's")
+    print("# gather-kernel sweep")
+    print(f"{'kernel':100s} {'calls':>7s} {'avg_us':>10s} {'median_us':>10s} {'min_us':>10s} {'total_ms':>10s} {'pct':>6s}")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:45]:
-        print(f"{k:100s} {len(v):7d} {sum(v) / len(v) / 1e3:10.2f} {min(v) / 1e3:10.2f} {sum(v) / 1e6:10.3f} "
+        med = sorted(v)[len(v) // 2]
+        print(f"{k:100s} {len(v):7d} {sum(v) / len(v) / 1e3:10.2f} {med / 1e3:10.2f} {min(v) / 1e3:10.2f} {sum(v) / 1e6:10.3f} "
               f"{100.0 * sum(v) / total:6.2f}")
 
 

@@ -6,7 +6,9 @@ import test_gpu_world2 as T
 if __name__ == "__main__":
     tmp = pathlib.Path(tempfile.mkdtemp())
     r0, r1 = T._two_ranks(tmp, T._train, sys.argv[1] if len(sys.argv) > 1 else "replicate")
-    single, losses = T._train(lambda s: slice(s * 2 * T.B, (s + 1) * 2 * T.B), world=1)
+    arg = sys.argv[1] if len(sys.argv) > 1 else "replicate"
+    single, losses = T._train(lambda s: slice(s * 2 * T.B, (s + 1) * 2 * T.B), world=1,
+                              tables="replicate+l2" if arg.endswith("+l2") else "replicate")
     sparse, _, _ = T._data()
     print("losses r0", r0["losses"], "\nlosses r1", r1["losses"], "\nsingle", losses)
     for k, want in single.items():
