@@ -57,6 +57,7 @@ const char* rh_last_error(void);
                                   other streams find free wave slots while it runs */
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
 #define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
+#define RH_TUNE_FWD_PATH 7      /* rh_embed_fwd: 0 auto (by batch size), 1 lane-split kernel only, 2 field-uniform kernel only */
 #define RH_TUNE_BWD_PATH 6      /* rh_embed_bwd experiments: 0 auto, 1 global atomics for every table, 3 no sink */
 int rh_set_tuning(int key, int value);
 

@@ -104,6 +104,67 @@ def test_embed_fwd(B, vocabs, D, ND, idt, packed, fs):
     close(lr, y_lr, what="lr")
 
 
+@pytest.fixture
+def uniform_fwd_kernel():
+    """Force the field-uniform forward kernel (the automatic choice from B * F >= 12288 * 26 on): RH_TUNE_FWD_PATH = 2."""
+    from torch_rechub_amd import _lib
+    _lib.call("rh_set_tuning", 7, 2)
+    yield
+    _lib.call("rh_set_tuning", 7, 0)
+
+
+@pytest.mark.parametrize("B,vocabs,D,ND,idt,packed,want_lr", [
+    (4096, CRITEO_LIKE, 16, 13, torch.int64, True, True),
+    (1000, CRITEO_LIKE, 16, 13, torch.int32, False, True),
+    (17, CRITEO_LIKE, 16, 21, torch.int64, True, True),      # more dense columns than the lanes prefetch (tail loop)
+    (300, [50] * 39, 16, 0, torch.int64, True, True),        # 39 fields: a wavefront walks 10 > 8 of them (two phases)
+    (300, [50] * 70, 8, 3, torch.int64, True, False),        # 18 fields per wavefront: three phases, no LR
+    (1, [5, 9], 16, 1, torch.int64, True, True),             # fewer fields than wavefronts: two of them idle
+    (63, [11], 16, 2, torch.int64, False, True),
+    (129, [7, 300, 41], 4, 3, torch.int64, True, True),
+    (129, [7, 300, 41], 8, 0, torch.int32, False, True),
+    (200, [7, 300, 41, 9], 32, 5, torch.int64, True, True),
+    (77, [7, 300, 41], 64, 1, torch.int64, True, True),
+    (33, [7, 300], 128, 2, torch.int64, True, False),
+])
+def test_embed_fwd_field_uniform_kernel(uniform_fwd_kernel, B, vocabs, D, ND, idt, packed, want_lr):
+    from torch_rechub_amd import ops
+    c = make_case(B, vocabs, D, ND, seed=B + D + 1, idx_dtype=idt, packed=packed)
+    g = c["g"]
+    F = c["F"]
+    lr_w = torch.randn(1, F * D, generator=g).to(dev())
+    lr_b = torch.randn(1, generator=g).to(dev())
+    call = ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"], c["dense_cols"], want_fm=True, want_lr=want_lr)
+    out, fm, lr = ops.fused_embedding(call, *((lr_w, lr_b) if want_lr else ()))
+    torch.cuda.synchronize()
+    ops.check_errors()
+    deep, y_fm, y_lr = O.deepfm_sparse_part(c["np_tables"], c["idx"].numpy(), lr_w.cpu().numpy().astype(F64),
+                                            lr_b.cpu().numpy().astype(F64), c["dense"].numpy().astype(F64))
+    exact = O.embedding_layer_squeeze([t.numpy() for t in c["tables"]], c["idx"].numpy(), c["dense"].numpy())
+    assert np.array_equal(out.detach().cpu().numpy(), exact)
+    close(fm, y_fm, what="fm")
+    if want_lr:
+        close(lr, y_lr, what="lr")
+    from torch_rechub_amd import _lib
+    _lib.call("rh_set_tuning", 7, 1)  # the lane-split kernel on the same call
+    out1, fm1, _ = ops.fused_embedding(call, *((lr_w, lr_b) if want_lr else ()))
+    assert torch.equal(out1, out)
+    close(fm1, y_fm, what="fm (lane-split kernel)")
+
+
+def test_embed_fwd_field_uniform_kernel_flags_bad_indices(uniform_fwd_kernel):
+    from torch_rechub_amd import ops
+    c = make_case(64, [5, 6, 7, 8, 9], 16, 0, seed=5)
+    c["idx_cols"][4][7] = 9  # == vocab, in the last wavefront's share of the fields
+    ops.fused_embedding(ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"]))
+    with pytest.raises(IndexError):
+        ops.check_errors()
+    c["idx_cols"][4][7] = -1
+    ops.fused_embedding(ops.EmbedCall(c["wts"], c["pads"], c["idx_cols"]))
+    with pytest.raises(IndexError):
+        ops.check_errors()
+
+
 def test_embed_fwd_plain_gather_no_fm_no_lr_and_3d_view():
     from torch_rechub_amd import ops
     c = make_case(500, [9, 1000, 3], 16, 0, seed=3)
@@ -138,7 +199,17 @@ def test_embed_index_out_of_range_raises_index_error():
     (64, [40], 64, None, None, 0),
     (1, [40, 3], 16, None, None, 0),
 ])
-def test_embed_bwd(B, vocabs, D, shared, pads, spb):
+@pytest.mark.parametrize("fwd_path", [1, 2])  # the forward kernel that saved S (the FM backward's per-sample field sum)
+def test_embed_bwd(B, vocabs, D, shared, pads, spb, fwd_path):
+    from torch_rechub_amd import _lib, ops
+    _lib.call("rh_set_tuning", 7, fwd_path)
+    try:
+        _embed_bwd_case(B, vocabs, D, shared, pads, spb)
+    finally:
+        _lib.call("rh_set_tuning", 7, 0)
+
+
+def _embed_bwd_case(B, vocabs, D, shared, pads, spb):
     from torch_rechub_amd import ops
     ND = 2
     c = make_case(B, vocabs, D, ND, seed=B + 7 * D, shared=shared, pads=pads)

@@ -155,6 +155,180 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs 
   if (oob_any && a.err != nullptr) atomicOr(a.err, RH_FLAG_INDEX_OOB);
 }
 
+// Field-uniform kernel: a wavefront holds 64 / LPR samples (LPR lanes each) and walks ITS share of the fields -- the
+// WS wavefronts of a workgroup split the fields of the same samples between them -- so the field is wavefront-uniform
+// and its descriptors are scalar loads from the constant cache (SGPRs).  In the lane-split kernel above the five
+// per-lane descriptor loads per gathered row are 35 of the 56 vector-memory instructions of a wavefront and one more
+// dependent round trip; here a wavefront issues ceil(F / WS) index loads, as many row gathers, as many stores, and the
+// chain is index -> row -> store.  Measured at B = 65536 (tools/fwd_probe.py, index sets cycled): what matters is the
+// number of dependent phases per wavefront (26 fields in 4 phases of 8: 60 us; 1 phase of 26 at 2 wavefronts per SIMD:
+// 48 us), hence the split of the fields over wavefronts: ONE phase of <= 8 gathers per lane at full occupancy.
+// FM / LR partial sums run in the lane over its fields (field order), across the LPR lanes by xor-shuffle, across the
+// WS wavefronts through LDS (wavefront order).
+#define RH_CONST __attribute__((address_space(4)))
+static __device__ __forceinline__ int64_t desc_at(const int64_t* p, int i) {
+  return reinterpret_cast<const RH_CONST int64_t*>(reinterpret_cast<uintptr_t>(p))[i];
+}
+
+template <int LPR, int WS, typename IdxT, bool HAS_LR>
+__global__ __launch_bounds__(RH_WAVE * WS) void embed_fwd_uniform_kernel(const EmbedFwdArgs a) {
+  constexpr int SPW = RH_WAVE / LPR;  // samples per wavefront = per workgroup
+  constexpr int NT = RH_WAVE * WS;
+  constexpr int U = 8;   // gathers in flight per lane: ONE phase for F <= 8 * WS fields
+  constexpr int DU = 4;  // dense columns per lane fetched with the first indices (last wavefront)
+  constexpr int D = 4 * LPR;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / RH_WAVE);
+  const int lane = tid % RH_WAVE;
+  const int q = lane % LPR;
+  int64_t b = (int64_t)blockIdx.x * SPW + lane / LPR;
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;
+  const int F = a.F;
+  const int per = (F + WS - 1) / WS;  // fields of a wavefront: [fbeg, fend)
+  const int fbeg = wave * per < F ? wave * per : F;
+  const int fend = fbeg + per < F ? fbeg + per : F;
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  float* wlds = dyn_lds;                                   // HAS_LR: F * D weights
+  float* red = dyn_lds + (HAS_LR ? ((F * D + 3) / 4) * 4 : 0);  // WS > 1: [WS][64][6] partial S, Qs, Ls
+  if (HAS_LR) {
+    for (int i = tid; i < F * LPR; i += NT) *reinterpret_cast<float4*>(wlds + 4 * i) = gload<float4>(a.lr_w + 4 * i);
+  }
+  float4 S = f4_zero();
+  float Qs = 0.f, Ls = 0.f;
+  bool oob_any = false;
+  float* orow = a.out + b * a.out_stride + q * 4;
+
+  const bool dense_wave = wave == WS - 1;  // the last wavefront has the fewest fields
+  float dv[DU];
+#pragma unroll
+  for (int k = 0; k < DU; ++k) {
+    const int j = q + k * LPR;
+    dv[k] = 0.f;
+    if (dense_wave && j < a.ND) dv[k] = gload<float>(reinterpret_cast<const float*>(a.ddesc[j]) + b * a.ddesc[a.ND + j]);
+  }
+
+  int64_t r[U];  // dead once the gathers of the phase are issued: the next phase's indices land in the same registers
+  auto load_idx = [&](int f0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u;
+      r[u] = 0;
+      if (f < fend) {  // wavefront-uniform
+        const IdxT* ip = reinterpret_cast<const IdxT*>(desc_at(a.idesc, f));
+        r[u] = (int64_t)gload<IdxT>(ip + b * desc_at(a.idesc, F + f));
+      }
+    }
+  };
+  auto phase = [&](int f0, bool first) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u;
+      v[u] = f4_zero();
+      if (f < fend) {
+        const float* tab = reinterpret_cast<const float*>(desc_at(a.fdesc, f));
+        const bool oob = (uint64_t)r[u] >= (uint64_t)desc_at(a.fdesc, 2 * F + f);
+        oob_any |= oob;
+        v[u] = gload<float4>(tab + (oob ? 0 : r[u]) * D + q * 4);
+      }
+    }
+    if (f0 + U < fend) load_idx(f0 + U);
+    if (HAS_LR && first) __syncthreads();  // the staged LR weights (every wavefront runs the first phase)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u;
+      if (f < fend) {
+        S = f4_add(S, v[u]);
+        Qs += f4_dot(v[u], v[u]);
+        if (HAS_LR) Ls += f4_dot(*reinterpret_cast<const float4*>(wlds + (f * LPR + q) * 4), v[u]);
+        if (live) gstore<float4>(orow + (int)desc_at(a.idesc, 2 * F + f) * D, v[u]);
+      }
+    }
+  };
+  load_idx(fbeg);
+  phase(fbeg, true);
+#pragma unroll 1
+  for (int f0 = fbeg + U; f0 < fend; f0 += U) phase(f0, false);
+
+  if (live && dense_wave) {
+#pragma unroll
+    for (int k = 0; k < DU; ++k) {
+      const int j = q + k * LPR;
+      if (j < a.ND) a.out[b * a.out_stride + a.dense_col + j] = dv[k];
+    }
+    for (int j = q + DU * LPR; j < a.ND; j += LPR)
+      a.out[b * a.out_stride + a.dense_col + j] =
+          gload<float>(reinterpret_cast<const float*>(a.ddesc[j]) + b * a.ddesc[a.ND + j]);
+  }
+  if (oob_any && a.err != nullptr) atomicOr(a.err, RH_FLAG_INDEX_OOB);
+
+  if (WS > 1) {
+    float* mine = red + (wave * RH_WAVE + lane) * 6;
+    mine[0] = S.x, mine[1] = S.y, mine[2] = S.z, mine[3] = S.w;
+    mine[4] = Qs;
+    mine[5] = Ls;
+    __syncthreads();
+    if (wave != 0) return;
+    S = f4_zero();
+    Qs = Ls = 0.f;
+#pragma unroll
+    for (int w = 0; w < WS; ++w) {
+      const float* o = red + (w * RH_WAVE + lane) * 6;
+      S = f4_add(S, make_float4(o[0], o[1], o[2], o[3]));
+      Qs += o[4];
+      Ls += o[5];
+    }
+  }
+  float t = f4_dot(S, S);
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) {
+    t += __shfl_xor(t, m, RH_WAVE);
+    Qs += __shfl_xor(Qs, m, RH_WAVE);
+    Ls += __shfl_xor(Ls, m, RH_WAVE);
+  }
+  if (live) {
+    if (a.s_out != nullptr) gstore<float4>(a.s_out + b * D + q * 4, S);
+    if (q == 0) {
+      if (a.fm_out != nullptr) a.fm_out[b] = 0.5f * (t - Qs);
+      if (a.lr_out != nullptr) a.lr_out[b] = Ls + (a.lr_b != nullptr ? a.lr_b[0] : 0.f);
+    }
+  }
+}
+
+int g_fwd_path = 0;  // tuning knob RH_TUNE_FWD_PATH: 0 auto (by batch size), 1 lane-split kernel, 2 field-uniform kernel
+// B * F from which the field-uniform kernel wins (rocprofv3 kernel durations, F = 26, D = 16: B = 4096 6.4 vs 8.2 us,
+// 8192 9.1 vs 9.5, 16384 14.7 vs 12.2, 65536 59.8 vs 50.3): below, its extra barrier + LDS exchange and the cold
+// scalar cache cost more than the descriptor loads it saves
+constexpr int64_t kUniformMinLookups = 12288 * 26;
+constexpr int kUniformWaves = 4;  // measured at B = 65536: 8 / 4 / 2 / 1 wavefronts per sample group = 58.6 / 50.3 / 52.5 / 58.3 us
+
+template <int LPR, int WS, typename IdxT>
+int launch_fwd_uniform(const EmbedFwdArgs& a, hipStream_t s) {
+  constexpr int SPW = RH_WAVE / LPR;
+  const unsigned grid = (unsigned)((a.B + SPW - 1) / SPW);
+  const size_t red = WS > 1 ? (size_t)WS * RH_WAVE * 6 * sizeof(float) : 0;
+  if (a.lr_w != nullptr)
+    hipLaunchKernelGGL((embed_fwd_uniform_kernel<LPR, WS, IdxT, true>), dim3(grid), dim3(RH_WAVE * WS),
+                       (size_t)((a.F * a.D + 3) / 4) * 4 * sizeof(float) + red, s, a);
+  else
+    hipLaunchKernelGGL((embed_fwd_uniform_kernel<LPR, WS, IdxT, false>), dim3(grid), dim3(RH_WAVE * WS), red, s, a);
+  return 0;
+}
+
+template <int WS, typename IdxT>
+int dispatch_uniform(const EmbedFwdArgs& a, hipStream_t s) {
+  switch (a.D / 4) {
+    case 1: return launch_fwd_uniform<1, WS, IdxT>(a, s);
+    case 2: return launch_fwd_uniform<2, WS, IdxT>(a, s);
+    case 4: return launch_fwd_uniform<4, WS, IdxT>(a, s);
+    case 8: return launch_fwd_uniform<8, WS, IdxT>(a, s);
+    case 16: return launch_fwd_uniform<16, WS, IdxT>(a, s);
+    case 32: return launch_fwd_uniform<32, WS, IdxT>(a, s);
+    default: return RH_E_UNSUPPORTED;
+  }
+}
+
 template <int LPR, int FS, typename IdxT>
 int launch_fwd(const EmbedFwdArgs& a, hipStream_t s) {
   constexpr int SPB = RH_BLOCK / (LPR * FS);
@@ -495,7 +669,10 @@ extern "C" int rh_embed_fwd(const int64_t* fdesc, const int64_t* idesc, int idx_
   }
   while (fs > 1 && lpr * fs > RH_WAVE) fs /= 2;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int rc = idx_is_i64 ? dispatch_lpr<int64_t>(a, fs, s) : dispatch_lpr<int32_t>(a, fs, s);
+  const bool uniform = field_split <= 0 && (g_fwd_path == 2 || (g_fwd_path == 0 && (int64_t)B * F >= kUniformMinLookups));
+  int rc;
+  if (uniform) rc = idx_is_i64 ? dispatch_uniform<kUniformWaves, int64_t>(a, s) : dispatch_uniform<kUniformWaves, int32_t>(a, s);
+  else rc = idx_is_i64 ? dispatch_lpr<int64_t>(a, fs, s) : dispatch_lpr<int32_t>(a, fs, s);
   if (rc != 0) return rc;
   RH_LAUNCH_CHECK("rh_embed_fwd");
   return 0;
@@ -534,6 +711,10 @@ extern "C" int rh_set_tuning(int key, int value) {
   }
   if (key == RH_TUNE_BWD_PATH) {
     g_bwd_path = value;
+    return 0;
+  }
+  if (key == RH_TUNE_FWD_PATH) {
+    g_fwd_path = value;
     return 0;
   }
   if (key == RH_TUNE_BWD_SPLIT || key == RH_TUNE_BWD_SLABS) return 0;  // retired knobs (kept so old probes still run)
