@@ -185,6 +185,39 @@ int rh_cross_mix_epilogue_bwd_b(const float* x0, const float* uv, const float* g
                                 int d, int E, float* g_x0, float* g_uv, float* g_gate, float* g_bias_partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * CrossNetMix (DCN-v2 mixture of low-rank experts) as two dense products per layer (csrc/moe.hip)
+ * replaces: the layer x expert loops of CrossNetMix.forward torch_rechub/basic/layers.py:470-506 and their autograd.
+ *   KP = rh_cross_moe_kp(E, r) = E r + E rounded up to a multiple of 4.  Per layer l:
+ *     PG (B, KP) = x_l VgT_l^T;  mid pass: v1 = tanh(PG[:, :E r]), v2_e = tanh(C_e v1_e), gate = softmax(PG[:, E r:E r+E]),
+ *     wp (B, KP) = [gate_e v2_e | sum_e gate_e | 0];  Y (B, d) = wp UTb_l^T;  x_{l+1} = x0 * Y + x_l.
+ *   rh_cross_moe_pack: VgT (L, KP, d) rows e r + k = V_l[e][:, k], rows E r + e = gating_e.weight;
+ *                      UTb (L, d, KP) columns e r + k = U_l[e][:, k], column E r = bias_l.  U / V / bias / Wg: HOST arrays
+ *                      of device pointers (L, L, L, E entries).
+ *   rh_cross_moe_mid_fwd / _bwd: the pass between the two products; the backward takes g_wp (B, KP), writes g_PG (B, KP)
+ *                      and rh_cross_moe_mid_blocks(B, E, r) partial rows (E r r) of g_C.
+ *   rh_cross_moe_res_bwd: g_Y = g * x0, acc = (first ? 0 : acc) + g * Y  (acc: running gradient of x0; g, x0 with row strides).
+ *   rh_cross_moe_unpack: sums the weight-gradient slabs of the two products (rh_linear_wgrad_partial: slabV_l = S1_l slabs
+ *                      (KP, d) of g_PG^T x_l, slabU_l = S2_l slabs (d, KP) of g_Y^T wp) and the g_C partials into g_U, g_V
+ *                      (E, d, r), g_bias (d,), g_C (E, r, r) per layer and g_Wg (d,) per expert (summed over the layers).
+ *   Supported: L <= 8, E <= 16, r in {4, 8, 16, 32, 64}, E r <= 256 (rh_cross_moe_supported); anything else runs the
+ *   batched-GEMM formulation with rh_cross_mix_epilogue_*.
+ */
+int rh_cross_moe_kp(int E, int r);
+int rh_cross_moe_supported(int L, int E, int d, int r);
+int rh_cross_moe_mid_blocks(int B, int E, int r);
+int rh_cross_moe_pack(const float* const* U, const float* const* V, const float* const* bias, const float* const* Wg, int L,
+                      int E, int d, int r, float* VgT, float* UTb, void* stream);
+int rh_cross_moe_mid_fwd(const float* PG, const float* C, int B, int E, int r, float* v1, float* v2, float* gate, float* wp,
+                         void* stream);
+int rh_cross_moe_mid_bwd(const float* g_wp, const float* v1, const float* v2, const float* gate, const float* C, int B, int E,
+                         int r, float* g_PG, float* gC_partial, void* stream);
+int rh_cross_moe_res_bwd(const float* g, int64_t ldg, const float* x0, int64_t ldx0, const float* Y, int B, int d, int first,
+                         float* g_Y, float* acc, void* stream);
+int rh_cross_moe_unpack(const float* const* slabV, const int* S1, const float* const* slabU, const int* S2,
+                        const float* const* gC, const int* NB, int L, int E, int d, int r, float* const* g_U,
+                        float* const* g_V, float* const* g_bias, float* const* g_C, float* const* g_Wg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * DIN: Dice activation and the memory-bound ends of the ActivationUnit
  * rh_dice_fwd/bwd replaces: Dice.forward torch_rechub/basic/activation.py:15-25 (row-wise statistics over the neurons)
  *   x (N, C) contiguous, alpha (1,), eps; bwd writes gx (N, C) and per-block partial sums of d/d alpha into

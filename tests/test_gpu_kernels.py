@@ -1305,3 +1305,100 @@ def test_torch_library_ops_opcheck_and_values():
         assert torch.equal(ya, yb)
         for u, v in zip(ga, gb):
             assert torch.allclose(u, v, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("shapes", [
+    [(1, 1000), (3, 429), (512, 429), (33, 64), (700, 1), (64, 7), (0, 50), (40, 300), (200, 5000)],
+    [(2048, 65), (31, 31), (32, 256), (33, 256)] + [(1, 17)] * 40,  # > 32 items: two launches
+])
+def test_pack_grads_sums_partial_slabs_in_one_launch(shapes):
+    """rh_pack_grads: flat[off + i] = sum_r src[r, i] (+ add[i]); plain copies, few parts, deep stacks of partial rows (the
+    rows split over the wavefronts), tall-and-thin bias stacks, a parameter without gradient (zeros)."""
+    import ctypes
+
+    from torch_rechub_amd import _lib, ops
+    g = torch.Generator().manual_seed(len(shapes))
+    items = (_lib.PackItem * len(shapes))()
+    keep, want, off = [], [], 0
+    for i, (nparts, numel) in enumerate(shapes):
+        stride = numel + (3 if i % 2 else 0)  # slabs with a pitch
+        src = torch.randn(max(nparts, 1), stride, generator=g).to(dev())
+        add = torch.randn(numel, generator=g).to(dev()) if i % 3 == 0 and nparts > 0 else None
+        keep += [src, add]
+        it = items[i]
+        it.src, it.nparts, it.stride = (src.data_ptr(), nparts, stride) if nparts else (0, 0, 0)
+        it.add = add.data_ptr() if add is not None else 0
+        it.numel, it.dst_offset = numel, off
+        ref = src[:nparts, :numel].double().sum(0) if nparts else torch.zeros(numel, dtype=torch.float64, device=dev())
+        want.append(ref + (add.double() if add is not None else 0))
+        off += numel
+    flat = torch.full((off + 8,), 7.0, device=dev())
+    _lib.call("rh_pack_grads", ctypes.cast(items, ctypes.c_void_p), len(shapes), ops._p(flat), ops._stream())
+    torch.cuda.synchronize()
+    got, ref = flat[:off].double(), torch.cat(want)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 2e-5 * scale
+    assert torch.all(flat[off:] == 7.0)
+    again = flat.clone()
+    _lib.call("rh_pack_grads", ctypes.cast(items, ctypes.c_void_p), len(shapes), ops._p(flat), ops._stream())
+    assert torch.equal(flat, again)  # fixed summation order: bit-reproducible
+
+
+def _cross_net_mix_reference(x, U, V, C, bias, Wg):
+    """CrossNetMix.forward as the reference writes it (basic/layers.py:470-506), in float64 on the CPU."""
+    x0 = x.unsqueeze(2)
+    xl = x0
+    for i in range(len(U)):
+        outs, scores = [], []
+        for e in range(len(Wg)):
+            scores.append(xl.squeeze(2) @ Wg[e].t())
+            v = torch.tanh(torch.matmul(V[i][e].t(), xl))
+            v = torch.tanh(torch.matmul(C[i][e], v))
+            outs.append((x0 * (torch.matmul(U[i][e], v) + bias[i])).squeeze(2))
+        moe = torch.matmul(torch.stack(outs, 2), torch.stack(scores, 1).softmax(1))
+        xl = moe + xl
+    return xl.squeeze(2)
+
+
+@pytest.mark.parametrize("B,d,L,E,r,strided", [
+    (300, 429, 3, 4, 32, True),    # the DCN-v2 configuration of BASELINE.json configs[2]
+    (64, 37, 2, 3, 8, False),      # the golden fixture's shape: 24 threads per sample, 10 samples per pass
+    (1, 5, 1, 1, 4, False),
+    (1000, 64, 2, 2, 64, False),
+    (257, 130, 8, 16, 16, True),   # the limits: 8 layers, 16 experts, 256 threads per sample
+    (40, 33, 2, 4, 5, False),      # rank 5: not a kernel rank -> the batched-GEMM formulation
+])
+def test_cross_net_mix_two_product_form_vs_reference_formula(B, d, L, E, r, strided):
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import CrossNetMix
+    g = torch.Generator().manual_seed(B + d)
+    mix = CrossNetMix(d, num_layers=L, low_rank=r, num_experts=E)
+    with torch.no_grad():
+        for b in mix.bias:
+            b.copy_(torch.randn(b.shape, generator=g) * 0.3)
+        for t in list(mix.u_list) + list(mix.v_list):
+            t.mul_(3.0)
+    x = torch.randn(B, d, generator=g)
+    gy = torch.randn(B, d, generator=g)
+    ref_params = [[t.detach().double().requires_grad_() for t in lst] for lst in
+                  (mix.u_list, mix.v_list, mix.c_list, mix.bias, [m.weight for m in mix.gating])]
+    xr = x.double().requires_grad_()
+    want = _cross_net_mix_reference(xr, *ref_params)
+    want.backward(gy.double())
+    mix = mix.to(dev())
+    assert bool(ops.cross_moe_ok(x.to(dev()), L, E, d, r)) == (r != 5)
+    if strided:  # the embedding layer hands over a (B, d) view of a buffer with a 64-byte row pitch
+        buf = torch.zeros(B, (d + 15) // 16 * 16, device=dev())
+        buf[:, :d] = x.to(dev())
+        xd = buf[:, :d].detach().requires_grad_()
+    else:
+        xd = x.to(dev()).requires_grad_()
+    out = mix(xd)
+    out.backward(gy.to(dev()))
+    torch.cuda.synchronize()
+    close(out, want.detach().numpy(), rtol=2e-5, atol_scale=2e-6, what="crossmix out")
+    close(xd.grad, xr.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what="crossmix g_x")
+    ours = (mix.u_list, mix.v_list, mix.c_list, mix.bias, [m.weight for m in mix.gating])
+    for name, mine, theirs in zip("U V C bias gating".split(), ours, ref_params):
+        for i, (a, b) in enumerate(zip(mine, theirs)):
+            close(a.grad, b.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what=f"crossmix g_{name}[{i}]")

@@ -439,6 +439,11 @@ class CrossNetMix(nn.Module):
         ops.require_hip(x)
         B, d = x.shape
         E = self.num_experts
+        if (all(type(g) is nn.Linear and g.bias is None for g in self.gating) and
+                ops.cross_moe_ok(x, self.num_layers, E, d, self.u_list[0].shape[2])):
+            # two dense products + three fused passes per layer (csrc/moe.hip): the experts are the K dimension
+            return ops.cross_moe(x, list(self.u_list), list(self.v_list), list(self.c_list), list(self.bias),
+                                 [g.weight for g in self.gating])
         x0 = x
         xl = x
         Wg = torch.cat([g.weight for g in self.gating], dim=0)  # (E, d)

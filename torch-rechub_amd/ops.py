@@ -1334,6 +1334,117 @@ def cross_mix_epilogue(x0, xl, uv, gate, bias):
 
 
 # --------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    import ctypes
+    return (ctypes.c_int * len(values))(*values)
+
+
+def cross_moe_ok(x, L, E, d, r):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1 and x.stride(1) == 1 and
+            _lib.call("rh_cross_moe_supported", L, E, d, r) == 1)
+
+
+class _CrossMoeFn(torch.autograd.Function):
+    """CrossNetMix.forward (reference basic/layers.py:470-506) for ALL its layers: per layer two library GEMMs
+    (B, d) x (d, KP) and (B, KP) x (KP, d), the mid pass between them and one addcmul (csrc/moe.hip); the backward is two
+    GEMMs + two split-batch weight-gradient launches + two fused passes per layer, and ONE launch that turns the
+    weight-gradient slabs of all layers into the gradients of u_list / v_list / c_list / bias / gating.
+
+    inputs: x, then L x U, L x V, L x C, L x bias, E x gating weight."""
+
+    @staticmethod
+    def forward(ctx, x, L, E, *params):
+        import ctypes
+        require_hip(x, *params)
+        U, V, C, bias, Wg = (params[0:L], params[L:2 * L], params[2 * L:3 * L], params[3 * L:4 * L], params[4 * L:4 * L + E])
+        B, d = x.shape
+        r = U[0].shape[2]
+        KP = _lib.call("rh_cross_moe_kp", E, r)
+        dev = x.device
+        cont = [t.contiguous() for t in params]
+        Uc, Vc, Cc, bc, Wgc = cont[0:L], cont[L:2 * L], cont[2 * L:3 * L], cont[3 * L:4 * L], cont[4 * L:4 * L + E]
+        VgT = torch.empty((L, KP, d), dtype=torch.float32, device=dev)
+        UTb = torch.empty((L, d, KP), dtype=torch.float32, device=dev)
+        _lib.call("rh_cross_moe_pack", ctypes.cast(_ptr_array(Uc), ctypes.c_void_p), ctypes.cast(_ptr_array(Vc), ctypes.c_void_p),
+                  ctypes.cast(_ptr_array(bc), ctypes.c_void_p), ctypes.cast(_ptr_array(Wgc), ctypes.c_void_p), L, E, d, r,
+                  _p(VgT), _p(UTb), _stream())
+        xl, saved = x, []
+        for l in range(L):
+            PG = torch.mm(xl, VgT[l].t())
+            v1 = torch.empty((B, E * r), dtype=torch.float32, device=dev)
+            v2 = torch.empty_like(v1)
+            gate = torch.empty((B, E), dtype=torch.float32, device=dev)
+            wp = torch.empty((B, KP), dtype=torch.float32, device=dev)
+            _lib.call("rh_cross_moe_mid_fwd", _p(PG), _p(Cc[l]), B, E, r, _p(v1), _p(v2), _p(gate), _p(wp), _stream())
+            Y = torch.mm(wp, UTb[l].t())
+            nxt = torch.addcmul(xl, x, Y)
+            saved += [xl, v1, v2, gate, wp, Y]
+            xl = nxt
+        ctx.dims = (L, E, B, d, r, KP)
+        ctx.shapes = [t.shape for t in params]
+        ctx.save_for_backward(x, VgT, UTb, *Cc, *saved)
+        return xl
+
+    @staticmethod
+    def backward(ctx, G):
+        import ctypes
+        L, E, B, d, r, KP = ctx.dims
+        x, VgT, UTb = ctx.saved_tensors[:3]
+        Cc = ctx.saved_tensors[3:3 + L]
+        saved = ctx.saved_tensors[3 + L:]
+        dev = x.device
+        if G.stride(1) != 1:
+            G = G.contiguous()
+        acc = torch.empty((B, d), dtype=torch.float32, device=dev)  # running gradient of x0
+        nb = _lib.call("rh_cross_moe_mid_blocks", B, E, r)
+        s1 = _lib.call("rh_linear_wgrad_splits", B, KP, d)
+        s2 = _lib.call("rh_linear_wgrad_splits", B, d, KP)
+        ws1 = _lib.call("rh_linear_wgrad_workspace", B, KP, d)
+        ws2 = _lib.call("rh_linear_wgrad_workspace", B, d, KP)
+        slabV, slabU, gC = [], [], []
+        for l in reversed(range(L)):
+            xl, v1, v2, gate, wp, Y = saved[6 * l:6 * l + 6]
+            g_Y = torch.empty((B, d), dtype=torch.float32, device=dev)
+            _lib.call("rh_cross_moe_res_bwd", _p(G), G.stride(0), _p(x), x.stride(0), _p(Y), B, d, 1 if l == L - 1 else 0,
+                      _p(g_Y), _p(acc), _stream())
+            pu = torch.empty((ws2,), dtype=torch.float32, device=dev)  # g_UTb (d, KP) = g_Y^T wp
+            _lib.call("rh_linear_wgrad_partial", _p(g_Y), d, _p(wp), KP, B, d, KP, _p(pu), _stream())
+            g_wp = torch.mm(g_Y, UTb[l])
+            g_PG = torch.empty((B, KP), dtype=torch.float32, device=dev)
+            pc = torch.empty((nb, E * r * r), dtype=torch.float32, device=dev)
+            _lib.call("rh_cross_moe_mid_bwd", _p(g_wp), _p(v1), _p(v2), _p(gate), _p(Cc[l]), B, E, r, _p(g_PG), _p(pc),
+                      _stream())
+            pv = torch.empty((ws1,), dtype=torch.float32, device=dev)  # g_VgT (KP, d) = g_PG^T x_l
+            _lib.call("rh_linear_wgrad_partial", _p(g_PG), KP, _p(xl), xl.stride(0), B, KP, d, _p(pv), _stream())
+            G = torch.addmm(G, g_PG, VgT[l])  # gradient of x_l: residual + through the first product
+            slabV.append(pv), slabU.append(pu), gC.append(pc)
+        slabV.reverse(), slabU.reverse(), gC.reverse()
+        g_x = G + acc  # x is both x_0 (Hadamard factor of every layer) and the first x_l
+        g_U = [torch.empty(ctx.shapes[l], dtype=torch.float32, device=dev) for l in range(L)]
+        g_V = [torch.empty(ctx.shapes[L + l], dtype=torch.float32, device=dev) for l in range(L)]
+        g_C = [torch.empty(ctx.shapes[2 * L + l], dtype=torch.float32, device=dev) for l in range(L)]
+        g_b = [torch.empty(ctx.shapes[3 * L + l], dtype=torch.float32, device=dev) for l in range(L)]
+        g_W = [torch.empty(ctx.shapes[4 * L + e], dtype=torch.float32, device=dev) for e in range(E)]
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        _lib.call("rh_cross_moe_unpack", cast(_ptr_array(slabV)), cast(_int_array([s1] * L)), cast(_ptr_array(slabU)),
+                  cast(_int_array([s2] * L)), cast(_ptr_array(gC)), cast(_int_array([nb] * L)), L, E, d, r,
+                  cast(_ptr_array(g_U)), cast(_ptr_array(g_V)), cast(_ptr_array(g_b)), cast(_ptr_array(g_C)),
+                  cast(_ptr_array(g_W)), _stream())
+        return (g_x, None, None) + tuple(g_U) + tuple(g_V) + tuple(g_C) + tuple(g_b) + tuple(g_W)
+
+
+def cross_moe(x, u_list, v_list, c_list, bias_list, gating_weights):
+    """The whole CrossNetMix stack (all layers) through csrc/moe.hip; check ``cross_moe_ok`` first."""
+    L, E = len(u_list), len(gating_weights)
+    return _CrossMoeFn.apply(x, L, E, *u_list, *v_list, *c_list, *bias_list, *gating_weights)
+
+
+# --------------------------------------------------------------------------------------------
 class _AugruFn(torch.autograd.Function):
     """h_all (B, T, D) = gated recurrence over xw (B, T, 3D), attn (B, T) | None, U (D, 3D), state_bias (3D) | None
     (csrc/augru.hip)."""
