@@ -80,7 +80,7 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_mid_fwd_kernel(const MoeMidArgs 
   const int E = a.E, ER = E * R, KP = a.KP;
   const int SPB = RH_BLOCK / ER;
   float* Cs = lds;                       // [E][R][R + 1]
-  float* v1s = lds + E * R * (R + 1);    // [SPB][ER]
+  float* v1s = lds + (E * R * (R + 1) + 3) / 4 * 4;    // [SPB][ER], 16-byte aligned
   for (int i = threadIdx.x; i < E * R * R; i += RH_BLOCK) Cs[(i / R) * (R + 1) + i % R] = a.C[i];
   const int s = threadIdx.x / ER, c = threadIdx.x % ER, e = c / R, k = c % R;
   const bool slot = s < SPB;
@@ -95,10 +95,16 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_mid_fwd_kernel(const MoeMidArgs 
     __syncthreads();
     if (live) {
       const float* crow = Cs + (e * R + k) * (R + 1);
-      const float* vin = v1s + s * ER + e * R;
+      const float4* vin = reinterpret_cast<const float4*>(v1s + s * ER + e * R);
       float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < R; ++j) acc = fmaf(crow[j], vin[j], acc);
+      for (int j = 0; j < R / 4; ++j) {
+        const float4 v4 = vin[j];
+        acc = fmaf(crow[4 * j + 0], v4.x, acc);
+        acc = fmaf(crow[4 * j + 1], v4.y, acc);
+        acc = fmaf(crow[4 * j + 2], v4.z, acc);
+        acc = fmaf(crow[4 * j + 3], v4.w, acc);
+      }
       const float a2 = tanhf(acc);
       // softmax over the E gating scores of the sample (every thread of the sample, redundantly: E <= 16)
       const float* lg = a.PG + b * KP + ER;
@@ -134,10 +140,9 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_mid_bwd_kernel(const MoeMidArgs 
   const int E = a.E, ER = E * R, KP = a.KP;
   const int SPB = RH_BLOCK / ER;
   float* Cs = lds;                      // [E][R][R + 1]
-  float* v1s = Cs + E * R * (R + 1);    // [SPB][ER]
+  float* v1s = Cs + (E * R * (R + 1) + 3) / 4 * 4;    // [SPB][ER], 16-byte aligned
   float* gcs = v1s + SPB * ER;          // [SPB][ER]   g_c = g_v2 * (1 - v2^2)
-  float* tmp = gcs + SPB * ER;          // [SPB][ER]   g_wp * v2
-  float* ggs = tmp + SPB * ER;          // [SPB][E]    g_gate
+  float* ggs = gcs + SPB * ER;          // [SPB][E]    g_gate
   float* red = ggs + SPB * kMaxExperts; // [SPB][ER][R] (after the loop)
   for (int i = threadIdx.x; i < E * R * R; i += RH_BLOCK) Cs[(i / R) * (R + 1) + i % R] = a.C[i];
   const int s = threadIdx.x / ER, c = threadIdx.x % ER, e = c / R, k = c % R;
@@ -146,39 +151,55 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_mid_bwd_kernel(const MoeMidArgs 
 #pragma unroll
   for (int j = 0; j < R; ++j) acc[j] = 0.f;
   const int64_t groups = ((int64_t)a.B + SPB - 1) / SPB;
+  float n1 = 0.f, n2 = 0.f, nw = 0.f, ne = 0.f, ns = 0.f;  // the next pass's inputs, in flight during this pass
+  auto fetch = [&](int64_t grp) {
+    const int64_t b = grp * SPB + s;
+    n1 = n2 = nw = ne = ns = 0.f;
+    if (slot && grp < groups && b < a.B) {
+      n1 = a.v1[b * ER + c];
+      n2 = a.v2[b * ER + c];
+      nw = a.g_wp[b * KP + c];
+      ne = a.gate[b * E + e];
+      ns = a.g_wp[b * KP + ER];
+    }
+  };
+  fetch(blockIdx.x);
   for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     const int64_t b = grp * SPB + s;
     const bool live = slot && b < a.B;
-    float a1 = 0.f, a2 = 0.f, gw = 0.f, ge = 0.f, g_sg = 0.f;
-    if (live) {
-      a1 = a.v1[b * ER + c];
-      a2 = a.v2[b * ER + c];
-      gw = a.g_wp[b * KP + c];
-      ge = a.gate[b * E + e];
-      g_sg = a.g_wp[b * KP + ER];
-    }
+    const float a1 = n1, a2 = n2, gw = nw, ge = ne, g_sg = ns;
+    fetch(grp + gridDim.x);
     const float gc = gw * ge * (1.f - a2 * a2);
     __syncthreads();  // Cs staged (first pass) / the previous pass is done with the staging arrays
+    // g_gate_e = sum_k g_wp[e, k] v2[e, k] + g_(sum of the gates): the R threads of (sample, expert) are R consecutive
+    // lanes of one wavefront (R | 64, groups aligned): xor-shuffle sum
+    float gg = gw * a2;
+#pragma unroll
+    for (int m = 1; m < R; m <<= 1) gg += __shfl_xor(gg, m, RH_WAVE);
     if (slot) {
       v1s[s * ER + c] = a1;
       gcs[s * ER + c] = gc;
-      tmp[s * ER + c] = gw * a2;
+      if (k == 0) ggs[s * kMaxExperts + e] = gg + g_sg;
     }
     __syncthreads();
-    if (slot && k == 0) {  // g_gate_e = sum_k g_wp[e, k] v2[e, k] + g_(sum of the gates)
-      float t = 0.f;
-      for (int j = 0; j < R; ++j) t += tmp[s * ER + e * R + j];
-      ggs[s * kMaxExperts + e] = t + g_sg;
-    }
     // g_v1[e][k] = sum_k' C[e][k'][k] g_c[e][k']   (this thread's k is the COLUMN here)
     float gv1 = 0.f;
     if (slot) {
-      const float* gin = gcs + s * ER + e * R;
+      const float4* gin = reinterpret_cast<const float4*>(gcs + s * ER + e * R);
+      const float4* vin = reinterpret_cast<const float4*>(v1s + s * ER + e * R);
+      const float* ccol = Cs + e * R * (R + 1) + k;
 #pragma unroll
-      for (int j = 0; j < R; ++j) gv1 = fmaf(Cs[(e * R + j) * (R + 1) + k], gin[j], gv1);
-      const float* vin = v1s + s * ER + e * R;
-#pragma unroll
-      for (int j = 0; j < R; ++j) acc[j] = fmaf(gc, vin[j], acc[j]);
+      for (int j = 0; j < R / 4; ++j) {
+        const float4 g4 = gin[j], v4 = vin[j];
+        gv1 = fmaf(ccol[(4 * j + 0) * (R + 1)], g4.x, gv1);
+        gv1 = fmaf(ccol[(4 * j + 1) * (R + 1)], g4.y, gv1);
+        gv1 = fmaf(ccol[(4 * j + 2) * (R + 1)], g4.z, gv1);
+        gv1 = fmaf(ccol[(4 * j + 3) * (R + 1)], g4.w, gv1);
+        acc[4 * j + 0] = fmaf(gc, v4.x, acc[4 * j + 0]);
+        acc[4 * j + 1] = fmaf(gc, v4.y, acc[4 * j + 1]);
+        acc[4 * j + 2] = fmaf(gc, v4.z, acc[4 * j + 2]);
+        acc[4 * j + 3] = fmaf(gc, v4.w, acc[4 * j + 3]);
+      }
     }
     __syncthreads();  // ggs complete
     if (live) {
@@ -249,12 +270,41 @@ static __device__ __forceinline__ float sum_parts(const float* p, int64_t stride
   return v;
 }
 
-__global__ __launch_bounds__(RH_BLOCK) void moe_unpack_kernel(const MoeUnpackArgs a) {
+// workgroups [0, cblocks): g_C -- 64 outputs each, the (up to 256) per-workgroup partial rows of the mid backward split
+// over the 4 wavefronts, 8 loads in flight, summed in wavefront order (one thread per output would walk them as one
+// dependent chain).  The rest: one thread per output of g_U / g_V / g_bias / g_gating over the few wgrad slabs.
+__global__ __launch_bounds__(RH_BLOCK) void moe_unpack_kernel(const MoeUnpackArgs a, int cblocks) {
   const int E = a.E, d = a.d, r = a.r, KP = a.KP, ER = E * r;
   const int64_t nU = (int64_t)E * d * r, nC = (int64_t)E * r * r;
-  const int64_t per_layer = 2 * nU + d + nC;  // g_U, g_V, g_bias, g_C
+  if ((int)blockIdx.x < cblocks) {
+    __shared__ float part[RH_BLOCK];
+    const int per = (int)((nC + RH_WAVE - 1) / RH_WAVE);  // workgroups per layer
+    const int l = blockIdx.x / per;
+    const int wave = threadIdx.x / RH_WAVE, lane = threadIdx.x % RH_WAVE;
+    const int64_t o = (int64_t)(blockIdx.x % per) * RH_WAVE + lane;
+    float v = 0.f;
+    if (o < nC) {
+      const float* p = a.gC[l] + o;
+      int x = wave;
+      for (; x + 28 < a.NB[l]; x += 32) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[(int64_t)(x + 4 * k) * nC];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += t[k];
+      }
+      for (; x < a.NB[l]; x += 4) v += p[(int64_t)x * nC];
+    }
+    part[threadIdx.x] = v;
+    __syncthreads();
+    if (wave == 0 && o < nC)
+      a.g_C[l][o] = ((part[lane] + part[RH_WAVE + lane]) + part[2 * RH_WAVE + lane]) + part[3 * RH_WAVE + lane];
+    return;
+  }
+  const int64_t per_layer = 2 * nU + d;  // g_U, g_V, g_bias
   const int64_t total = a.L * per_layer + (int64_t)E * d;
-  for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * RH_BLOCK) {
+  const int64_t nthreads = (int64_t)(gridDim.x - cblocks) * RH_BLOCK;
+  for (int64_t i = (int64_t)(blockIdx.x - cblocks) * RH_BLOCK + threadIdx.x; i < total; i += nthreads) {
     if (i >= a.L * per_layer) {  // gating weights: shared by the layers, summed over them in layer order
       const int64_t o = i - a.L * per_layer;
       const int e = (int)(o / d), j = (int)(o % d);
@@ -268,29 +318,32 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_unpack_kernel(const MoeUnpackArg
     if (o < nU) {  // g_U[e][j][k] = g_UTb[j][e r + k]
       const int e = (int)(o / ((int64_t)d * r)), j = (int)((o / r) % d), k = (int)(o % r);
       a.g_U[l][o] = sum_parts(a.slabU[l] + (int64_t)j * KP + e * r + k, a.strideU[l], a.S2[l]);
-    } else if ((o -= nU) < nU) {  // g_V[e][j][k] = g_VgT[e r + k][j]
-      const int e = (int)(o / ((int64_t)d * r)), j = (int)((o / r) % d), k = (int)(o % r);
-      a.g_V[l][o] = sum_parts(a.slabV[l] + (int64_t)(e * r + k) * d + j, a.strideV[l], a.S1[l]);
-    } else if ((o -= nU) < d) {  // g_bias[j] = g_UTb[j][E r]
+    } else if ((o -= nU) < nU) {  // g_V[e][j][k] = g_VgT[e r + k][j]; walked along j: the slab rows are read coalesced
+      const int row = (int)(o / d), j = (int)(o % d);
+      a.g_V[l][((int64_t)(row / r) * d + j) * r + row % r] =
+          sum_parts(a.slabV[l] + (int64_t)row * d + j, a.strideV[l], a.S1[l]);
+    } else {  // g_bias[j] = g_UTb[j][E r]
+      o -= nU;
       a.g_bias[l][o] = sum_parts(a.slabU[l] + o * KP + ER, a.strideU[l], a.S2[l]);
-    } else {
-      o -= d;
-      a.g_C[l][o] = sum_parts(a.gC[l] + o, nC, a.NB[l]);
     }
   }
 }
 
-int mid_grid(int B, int E, int r) {
+// forward: one pass per workgroup while they last (a pass is two dependent round trips + two barriers: ~2.5 us, walking 16
+// of them per workgroup was 42 us per layer); backward: every workgroup leaves a g_C partial (E r r floats), so fewer
+// workgroups, each prefetching its next pass
+int mid_grid(int B, int E, int r, bool bwd) {
   const int spb = RH_BLOCK / (E * r);
   int64_t g = ((int64_t)B + spb - 1) / spb;
-  if (g > 128) g = 128;  // the backward leaves one g_C partial per workgroup
+  const int64_t cap = bwd ? 256 : 2048;
+  if (g > cap) g = cap;
   return g < 1 ? 1 : (int)g;
 }
 
 size_t mid_lds(int E, int r, bool bwd) {
   const int ER = E * r, spb = RH_BLOCK / ER;
-  size_t n = (size_t)E * r * (r + 1) + (size_t)spb * ER;
-  if (bwd) n += 2 * (size_t)spb * ER + (size_t)spb * kMaxExperts + (size_t)spb * ER * r;
+  size_t n = ((size_t)E * r * (r + 1) + 3) / 4 * 4 + (size_t)spb * ER;
+  if (bwd) n += (size_t)spb * ER + (size_t)spb * kMaxExperts + (size_t)spb * ER * r;
   return n * sizeof(float);
 }
 
@@ -304,7 +357,7 @@ int launch_mid(const MoeMidArgs& a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     RH_REQUIRE(e == hipSuccess, (int)e, "rh_cross_moe_mid: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(fn, dim3(mid_grid(a.B, a.E, R)), dim3(RH_BLOCK), lds, s, a);
+  hipLaunchKernelGGL(fn, dim3(mid_grid(a.B, a.E, R, BWD)), dim3(RH_BLOCK), lds, s, a);
   return 0;
 }
 
@@ -337,7 +390,7 @@ extern "C" int rh_cross_moe_supported(int L, int E, int d, int r) {
           mid_lds(E, r, true) <= 160 * 1024) ? 1 : 0;
 }
 
-extern "C" int rh_cross_moe_mid_blocks(int B, int E, int r) { return mid_grid(B, E, r); }
+extern "C" int rh_cross_moe_mid_blocks(int B, int E, int r) { return mid_grid(B, E, r, true); }
 
 extern "C" int rh_cross_moe_pack(const float* const* U, const float* const* V, const float* const* bias,
                                  const float* const* Wg, int L, int E, int d, int r, float* VgT, float* UTb, void* stream) {
@@ -409,10 +462,12 @@ extern "C" int rh_cross_moe_unpack(const float* const* slabV, const int* S1, con
     a.g_U[l] = g_U[l], a.g_V[l] = g_V[l], a.g_bias[l] = g_bias[l], a.g_C[l] = g_C[l];
   }
   for (int e = 0; e < E; ++e) a.g_Wg[e] = g_Wg[e];
-  const int64_t total = (int64_t)L * (2 * (int64_t)E * d * r + d + (int64_t)E * r * r) + (int64_t)E * d;
+  const int64_t total = (int64_t)L * (2 * (int64_t)E * d * r + d) + (int64_t)E * d;
   int64_t grid = (total + RH_BLOCK - 1) / RH_BLOCK;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(moe_unpack_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const int cblocks = L * (int)(((int64_t)E * r * r + RH_WAVE - 1) / RH_WAVE);
+  hipLaunchKernelGGL(moe_unpack_kernel, dim3((unsigned)(grid + cblocks)), dim3(RH_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), a, cblocks);
   RH_LAUNCH_CHECK("rh_cross_moe_unpack");
   return 0;
 }
