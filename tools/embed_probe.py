@@ -59,13 +59,14 @@ def main():
                 g_out = torch.randn(B, F * D + nd, device=dev)
                 g_y = torch.randn(B, device=dev)
                 fdesc_g = call.fdesc(True)
-                nch = _lib.call("rh_embed_bwd_nchunks", B, 0)
+                SPB = int(os.environ.get("PROBE_SPB", "0"))
+                nch = _lib.call("rh_embed_bwd_nchunks", B, SPB)
                 partial = torch.empty(nch, F * D, device=dev)
 
                 def bwd():
                     _lib.call("rh_embed_bwd", ops._p(fdesc_g), ops._p(idesc), i64, B, F, D, ops._p(g_out),
                               g_out.stride(0), ops._p(out), out.stride(0), ops._p(ssum), ops._p(g_y), ops._p(g_y),
-                              ops._p(lr_w), ops._p(partial), 1.0, 0, ops._p(None), 0, ops._p(ops.err_flag(dev)),
+                              ops._p(lr_w), ops._p(partial), 1.0, 0, ops._p(None), SPB, ops._p(ops.err_flag(dev)),
                               ops._stream())
 
                 us_b = []

@@ -48,18 +48,32 @@ def main():
     if not files:
         sys.exit("no kernel_trace.csv under " + a.dir)
     acc = defaultdict(list)
+    by_shape = defaultdict(list)  # the gather kernels per launch shape = per batch size (bench.py's gather_kernel_sweep)
     for f in files:
         for row in csv.DictReader(open(f)):
-            acc[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            acc[short(row["Kernel_Name"])].append(dur)
+            if "embed_fwd" in row["Kernel_Name"] or "embed_bwd" in row["Kernel_Name"]:
+                name = "embed_fwd_uniform" if "uniform" in row["Kernel_Name"] else short(row["Kernel_Name"]).split("::")[-1]
+                by_shape[(name, int(row["Grid_Size_X"]) // max(1, int(row["Workgroup_Size_X"])))].append(dur)
     total = sum(sum(v) for v in acc.values())
     print("# rocprofv3 --kernel-trace --stats summary (durations in us).  median_us = the steady-state launch: the mean also")
     print("# holds the short first sweeps after a flush, the 6 ms flush itself and the B = 16384 / 65536 launches of bench.py's")
     print("# gather-kernel sweep")
     print(f"{'kernel':100s} {'calls':>7s} {'avg_us':>10s} {'median_us':>10s} {'min_us':>10s} {'total_ms':>10s} {'pct':>6s}")
+    tail = []
+    for (name, blocks), v in sorted(by_shape.items()):
+        if len(v) >= 8:
+            med = sorted(v)[len(v) // 2]
+            tail.append(f"#   {name:22s} workgroups {blocks:7d}  launches {len(v):5d}  avg {sum(v) / len(v) / 1e3:8.2f} us  median {med / 1e3:8.2f} us")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:45]:
         med = sorted(v)[len(v) // 2]
         print(f"{k:100s} {len(v):7d} {sum(v) / len(v) / 1e3:10.2f} {med / 1e3:10.2f} {min(v) / 1e3:10.2f} {sum(v) / 1e6:10.3f} "
               f"{100.0 * sum(v) / total:6.2f}")
+    if tail:
+        print("# gather kernels per launch shape (forward: lane-split kernel 16 samples / workgroup, field-uniform kernel 16 samples /")
+        print("# workgroup of 4 wavefronts; backward: ceil8(B / 256) x 26 workgroups):")
+        print("\n".join(tail))
 
 
 if __name__ == "__main__":
