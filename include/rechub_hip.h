@@ -257,6 +257,20 @@ int rh_din_pool_fwd(const float* hist, int64_t hist_stride, const float* w, int 
                     void* stream);
 int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, const float* g, int B, int L, int D,
                     float* g_hist, float* g_w, void* stream);
+/* First layer of the ActivationUnit's MLP with the operand built in registers (csrc/dinmlp.hip); replaces
+ * models/ranking/din.py:81-85 (expand + cat + view) and the Linear(4 D, N) of basic/layers.py:279 on it:
+ *   z (B L, N) = [t, h, t - h, t * h] W^T + bias;  the (B L, 4 D) operand never exists in memory.
+ *   partial (optional): ceil(B L / rh_din_att_l1_chunk_rows(B L)) x 2 x N per-chunk (sum, M2 about the chunk mean) of z --
+ *   the BatchNorm statistics, combined by rh_bn_stats_from_partial (no pass over z).
+ *   Supported (rh_din_att_l1_supported): D in {4, 8, 16}, N a multiple of 64 up to 256. */
+int rh_din_att_l1_supported(int D, int N);
+int rh_din_att_l1_chunk_rows(int64_t rows);
+int rh_din_att_l1_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* W,
+                      const float* bias, int B, int L, int D, int N, float* z, float* partial, void* stream);
+/* rh_bn_stats_fwd (training) from per-chunk partials that a producer already emitted: finalize only. */
+int rh_bn_stats_from_partial(const float* partial, int rows_per_chunk, int B, int C, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                             float eps, float* stat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MLP Linear weight gradient, the (., 1) output head and the BCE loss (csrc/linear.hip)

@@ -1402,3 +1402,72 @@ def test_cross_net_mix_two_product_form_vs_reference_formula(B, d, L, E, r, stri
     for name, mine, theirs in zip("U V C bias gating".split(), ours, ref_params):
         for i, (a, b) in enumerate(zip(mine, theirs)):
             close(a.grad, b.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what=f"crossmix g_{name}[{i}]")
+
+
+@pytest.mark.parametrize("B,L,D,dims,softmax", [
+    (37, 50, 16, [256, 128], False),   # configs[3] layer widths; 1850 rows: not a multiple of 32
+    (5, 7, 8, [64], True),
+    (64, 100, 4, [128, 64], False),
+    (3, 11, 16, [192], False),
+])
+def test_activation_unit_first_layer_on_register_built_operand(B, L, D, dims, softmax, monkeypatch):
+    """The ActivationUnit with its first Linear on the never-materialised [t, h, t-h, t*h] operand + BatchNorm statistics
+    from the GEMM epilogue (csrc/dinmlp.hip) against the same module on the materialised operand (rh_din_att_input +
+    library GEMM + statistics pass): outputs, running statistics and every gradient."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.models.ranking.din import ActivationUnit
+    g = torch.Generator().manual_seed(B + L)
+    au = ActivationUnit(D, dims=dims, activation="dice", use_softmax=softmax)
+    twin = ActivationUnit(D, dims=dims, activation="dice", use_softmax=softmax)
+    twin.load_state_dict(au.state_dict())
+    au, twin = au.to(dev()).train(), twin.to(dev()).train()
+    big = torch.randn(B, L + 3, D, generator=g).to(dev())
+    hist = big[:, 1:L + 1, :]  # rows contiguous inside a sample, sample stride (L + 3) * D
+    tgt = torch.randn(B, D, generator=g).to(dev())
+    gy = torch.randn(B, D, generator=g).to(dev())
+    assert ops.din_att_l1_ok(hist, tgt, au.attention.mlp[0])
+    h1, t1 = hist.detach().clone().requires_grad_(), tgt.detach().clone().requires_grad_()
+    out = au(h1, t1)
+    out.backward(gy)
+    monkeypatch.setattr(ops, "din_att_l1_ok", lambda *a: False)
+    h2, t2 = hist.detach().clone().requires_grad_(), tgt.detach().clone().requires_grad_()
+    ref = twin(h2, t2)
+    ref.backward(gy)
+    torch.cuda.synchronize()
+
+    def same(a, b, what, rtol=2e-4, atol=2e-5, floor=1.0):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        scale = max(floor, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= atol * scale + rtol * float(b.abs().max()), what
+
+    same(out, ref, "attention output")
+    same(h1.grad, h2.grad, "g_history")
+    same(t1.grad, t2.grad, "g_target")
+    # a Linear bias in front of BatchNorm has the exact gradient 0: what both paths hold there is rounding noise of the
+    # size of one ulp of the layer's other gradients, so every parameter is compared on the scale of the largest gradient
+    gmax = max(float(q.grad.abs().max()) for q in twin.parameters())
+    for (n, p), (_, q) in zip(au.named_parameters(), twin.named_parameters()):
+        same(p.grad, q.grad, f"g_{n}", floor=gmax)
+    for (n, p), (_, q) in zip(au.named_buffers(), twin.named_buffers()):
+        same(p, q, f"buffer {n}", rtol=1e-5, atol=1e-6)
+
+
+def test_din_att_l1_matches_linear_on_materialised_operand_and_chunk_statistics():
+    from torch_rechub_amd import _lib, ops
+    g = torch.Generator().manual_seed(3)
+    B, L, D, N = 130, 100, 16, 256
+    hist = torch.randn(B, L, D, generator=g).to(dev())
+    tgt = torch.randn(B, D, generator=g).to(dev())
+    W = (torch.randn(N, 4 * D, generator=g) * 0.2).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    z, part = ops.din_att_l1(hist, tgt, W, b, True)
+    t = tgt.unsqueeze(1).expand(-1, L, -1)
+    att = torch.cat([t, hist, t - hist, t * hist], dim=-1).view(-1, 4 * D)
+    want = torch.nn.functional.linear(att.double(), W.double(), b.double())
+    assert float((z.double() - want).abs().max()) <= 2e-5
+    rows = _lib.call("rh_din_att_l1_chunk_rows", B * L)
+    assert part.shape == (-(-(B * L) // rows), 2, N)
+    for k in range(part.shape[0]):  # every chunk's (sum, M2) against float64 on the same rows
+        blk = want[k * rows:(k + 1) * rows]
+        assert torch.allclose(part[k, 0].double(), blk.sum(0), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(part[k, 1].double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-4, atol=1e-3)

@@ -46,5 +46,25 @@ def main():
               f"err {err:.1e} | dgrad lib {t_dlib:7.1f} us own {t_down:7.1f} us ({fl / t_down / 1e6:5.1f} TF) err {derr:.1e}", flush=True)
 
 
+def att_l1():
+    """The fused first attention layer (operand built in registers + statistics epilogue) against its three-launch form."""
+    from torch_rechub_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, L, D, N = 4096, 100, 16, 256
+    hist, tgt = torch.randn(B, L, D, device=dev), torch.randn(B, D, device=dev)
+    W, b = torch.randn(N, 4 * D, device=dev) * 0.1, torch.randn(N, device=dev)
+    t_fused = timeit(lambda: ops.din_att_l1(hist, tgt, W, b, True))
+    t_nostat = timeit(lambda: ops.din_att_l1(hist, tgt, W, b, False))
+
+    def three():
+        att = ops.din_att_input(hist, tgt)
+        return torch.nn.functional.linear(att, W, b)
+
+    t_three = timeit(three)
+    print(f"att layer 1 (B={B}, L={L}, D={D}, N={N}): fused {t_fused:.1f} us (without statistics {t_nostat:.1f}), "
+          f"operand kernel + library GEMM {t_three:.1f} us (+ the statistics pass over z)", flush=True)
+
+
 if __name__ == "__main__":
+    att_l1()
     main()

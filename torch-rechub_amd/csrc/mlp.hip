@@ -495,6 +495,26 @@ extern "C" int rh_bn_stats_fwd(const float* h, int B, int C, const float* gamma,
   return 0;
 }
 
+// The same from per-chunk (sum, M2) partials some producer already emitted (csrc/dinmlp.hip: the epilogue of the fused
+// first attention layer): chunk k covers rows [k * rows_per_chunk, (k + 1) * rows_per_chunk) of the B rows.
+extern "C" int rh_bn_stats_from_partial(const float* partial, int rows_per_chunk, int B, int C, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, float momentum, float eps, float* stat, void* stream) {
+  RH_REQUIRE(partial && gamma && beta && stat && B >= 1 && C >= 1 && rows_per_chunk >= 1, RH_E_BADARG,
+             "rh_bn_stats_from_partial: bad arguments");
+  BnArgs a{};
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.num_batches_tracked = num_batches_tracked; a.partial = const_cast<float*>(partial); a.stat = stat; a.B = B; a.C = C;
+  a.momentum = momentum; a.eps = eps; a.training = 1; a.affine_out = 1;
+  a.rows_per_chunk = rows_per_chunk;
+  a.nchunks = (B + rows_per_chunk - 1) / rows_per_chunk;
+  a.bookkeep = 2;  // count the batch; there is no dropout stream to advance
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  RH_LAUNCH_CHECK("rh_bn_stats_from_partial");
+  return 0;
+}
+
 // Column sums of (rows, 2, C) partials -> stat rows 2, 3 (sum g, sum g * xhat) and dbeta / dgamma.
 extern "C" int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta,
                                   void* stream) {

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ...basic.activation import Dice
 from ...basic.layers import MLP, EmbeddingLayer
 
 
@@ -65,8 +66,20 @@ class ActivationUnit(nn.Module):
             if self.use_softmax:
                 att_weight = att_weight.softmax(dim=-1)
             return (att_weight.unsqueeze(-1) * history).sum(dim=1)
-        att_input = ops.din_att_input(history, target)  # (B*L, 4D) = [t, h, t-h, t*h], one kernel
-        att_weight = self.attention(att_input).view(-1, L)
+        mods = list(self.attention.mlp)
+        fused = (len(mods) >= 3 and ops.din_att_l1_ok(history, target, mods[0]) and type(mods[1]) is nn.BatchNorm1d and
+                 type(mods[2]) is Dice and ops.bn_dice_ok(history.new_empty((2, mods[0].out_features)), mods[1], mods[2]) and
+                 not (torch.is_grad_enabled() and not mods[1].training))
+        if fused:
+            # first layer on the operand built in registers, BatchNorm statistics as its epilogue (csrc/dinmlp.hip):
+            # the (B*L, 4D) tensor of din.py:81-85 never exists in the forward
+            z, stats = ops.din_att_l1(history, target, mods[0].weight, mods[0].bias, mods[1].training)
+            rows = ops._lib.call("rh_din_att_l1_chunk_rows", B * L) if stats is not None else 0
+            x = ops.bn_dice(z, mods[1], mods[2].alpha, mods[2].epsilon, chunk_stats=stats, chunk_rows=rows)
+            att_weight = self.attention._run(mods[3:], x).view(-1, L)
+        else:
+            att_input = ops.din_att_input(history, target)  # (B*L, 4D) = [t, h, t-h, t*h], one kernel
+            att_weight = self.attention(att_input).view(-1, L)
         if self.use_softmax:
             att_weight = att_weight.softmax(dim=-1)
         return ops.din_att_pool(att_weight, history)  # sum_l w_l * h_l, one kernel

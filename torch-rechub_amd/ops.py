@@ -1140,15 +1140,21 @@ class _BnDiceFn(torch.autograd.Function):
     normalised tensor is never written.  Training mode; running statistics and num_batches_tracked updated in place."""
 
     @staticmethod
-    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, alpha, eps):
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, alpha, eps,
+                chunk_stats=None, chunk_rows=0):
         require_hip(h, gamma, beta, alpha)
         h = h.contiguous()
         N, C = h.shape
         dev = h.device
         stat = torch.empty((6, C), dtype=torch.float32, device=dev)
-        partial = torch.empty((_lib.call("rh_bn_act_nchunks", N), 2, C), dtype=torch.float32, device=dev)
-        _lib.call("rh_bn_stats_fwd", _p(h), N, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                  _p(num_batches_tracked), float(momentum), float(bn_eps), 1, _p(partial), _p(stat), _stream())
+        if chunk_stats is not None:  # the producer of h already emitted per-chunk (sum, M2): no pass over h
+            _lib.call("rh_bn_stats_from_partial", _p(chunk_stats), int(chunk_rows), N, C, _p(gamma), _p(beta),
+                      _p(running_mean), _p(running_var), _p(num_batches_tracked), float(momentum), float(bn_eps), _p(stat),
+                      _stream())
+        else:
+            partial = torch.empty((_lib.call("rh_bn_act_nchunks", N), 2, C), dtype=torch.float32, device=dev)
+            _lib.call("rh_bn_stats_fwd", _p(h), N, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                      _p(num_batches_tracked), float(momentum), float(bn_eps), 1, _p(partial), _p(stat), _stream())
         out = torch.empty_like(h)
         _lib.call("rh_dice_fwd", _p(h), _p(alpha), float(eps), N, C, _p(stat[4]), _p(stat[5]), _p(out), _stream())
         ctx.eps = float(eps)
@@ -1170,7 +1176,7 @@ class _BnDiceFn(torch.autograd.Function):
         _lib.call("rh_bn_finalize_bwd", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _stream())
         dh = torch.empty_like(h)
         _lib.call("rh_bn_dice_bwd_apply", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(dh), _stream())
-        return dh, dgamma, dbeta, None, None, None, None, None, alpha_partial.sum().reshape(1), None
+        return dh, dgamma, dbeta, None, None, None, None, None, alpha_partial.sum().reshape(1), None, None, None
 
 
 def bn_dice_ok(h, bn, dice_mod):
@@ -1178,11 +1184,12 @@ def bn_dice_ok(h, bn, dice_mod):
             bn.affine and bn.track_running_stats and bn.momentum is not None)
 
 
-def bn_dice(h, bn, alpha, eps):
-    """Dice(bn(h)) for a Linear -> BatchNorm1d -> Dice block: folded into two passes over h (training) or one (eval)."""
+def bn_dice(h, bn, alpha, eps, chunk_stats=None, chunk_rows=0):
+    """Dice(bn(h)) for a Linear -> BatchNorm1d -> Dice block: folded into two passes over h (training) or one (eval).
+    ``chunk_stats`` / ``chunk_rows``: per-chunk (sum, M2) of h from its producer (din_att_l1), replacing the statistics pass."""
     if bn.training:
         return _BnDiceFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                               bn.eps, alpha, eps)
+                               bn.eps, alpha, eps, chunk_stats, chunk_rows)
     require_hip(h)
     h = h.contiguous()
     N, C = h.shape
@@ -1252,6 +1259,69 @@ class _AttPoolFn(torch.autograd.Function):
         _lib.call("rh_din_pool_bwd", _p(history), history.stride(0), _p(weight), _p(g), B, L, D, _p(g_hist), _p(g_w),
                   _stream())
         return g_w, g_hist
+
+
+class _AttL1Fn(torch.autograd.Function):
+    """z (B*L, N) = [t, h, t-h, t*h] W^T + b with the operand built in registers (csrc/dinmlp.hip) and, when asked, the
+    per-chunk BatchNorm statistics of z as an epilogue.  Backward: the operand is rebuilt once (rh_din_att_input_fwd) for
+    the split-batch weight gradient; input gradient = library GEMM + rh_din_att_input_bwd."""
+
+    @staticmethod
+    def forward(ctx, history, target, weight, bias, want_stats):
+        require_hip(history, target, weight)
+        history, hs = _hist_layout(history)
+        if target.stride(1) != 1:
+            target = target.contiguous()
+        weight_c = weight.contiguous()
+        B, L, D = history.shape
+        N = weight.shape[0]
+        dev = history.device
+        z = torch.empty((B * L, N), dtype=torch.float32, device=dev)
+        partial = None
+        if want_stats:
+            rows = _lib.call("rh_din_att_l1_chunk_rows", B * L)
+            partial = torch.empty((-(-(B * L) // rows), 2, N), dtype=torch.float32, device=dev)
+        _lib.call("rh_din_att_l1_fwd", _p(history), hs, _p(target), target.stride(0), _p(weight_c),
+                  _p(None if bias is None else bias.contiguous()), B, L, D, N, _p(z), _p(partial), _stream())
+        ctx.save_for_backward(history, target, weight_c)
+        ctx.params = (weight, bias)
+        if partial is None:
+            return z, None
+        ctx.mark_non_differentiable(partial)
+        return z, partial
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        history, target, weight = ctx.saved_tensors
+        B, L, D = history.shape
+        wp, bp = ctx.params
+        g = g.contiguous()
+        dev = g.device
+        dW = db = None
+        if ctx.needs_input_grad[2] or (bp is not None and ctx.needs_input_grad[3]):
+            att = torch.empty((B * L, 4 * D), dtype=torch.float32, device=dev)
+            _lib.call("rh_din_att_input_fwd", _p(history), history.stride(0), _p(target), target.stride(0), B, L, D, _p(att),
+                      _stream())
+            dW, db = linear_wgrad(g, att, want_bias=bp is not None, weight=wp, bias=bp)
+        g_hist = g_tgt = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g_att = g.mm(weight)
+            g_hist = torch.empty((B, L, D), dtype=torch.float32, device=dev)
+            g_tgt = torch.empty((B, D), dtype=torch.float32, device=dev)
+            _lib.call("rh_din_att_input_bwd", _p(history), history.stride(0), _p(target), target.stride(0), _p(g_att), B, L,
+                      D, _p(g_hist), _p(g_tgt), _stream())
+        return g_hist, g_tgt, dW, db, None
+
+
+def din_att_l1_ok(history, target, lin):
+    return (history.is_cuda and history.dtype == torch.float32 and history.dim() == 3 and history.shape[0] >= 1 and
+            type(lin) is torch.nn.Linear and lin.in_features == 4 * history.shape[2] and
+            _lib.call("rh_din_att_l1_supported", history.shape[2], lin.out_features) == 1)
+
+
+def din_att_l1(history, target, weight, bias, want_stats):
+    """(z, chunk_stats | None): the ActivationUnit's first Linear on the never-materialised [t, h, t-h, t*h] operand."""
+    return _AttL1Fn.apply(history, target, weight, bias, want_stats)
 
 
 def din_att_input(history, target):
