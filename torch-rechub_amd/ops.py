@@ -1305,7 +1305,11 @@ class _AttL1Fn(torch.autograd.Function):
             dW, db = linear_wgrad(g, att, want_bias=bp is not None, weight=wp, bias=bp)
         g_hist = g_tgt = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            g_att = g.mm(weight)
+            # (B*L, N) x (N, 4D): the tile kernel of csrc/gemm.hip runs this tall, narrow-output product at 184 us against
+            # the library's 260 us at configs[3] (tools/gemm_tall_probe.py)
+            g_att = torch.empty((B * L, 4 * D), dtype=torch.float32, device=dev)
+            _lib.call("rh_linear_dgrad", _p(g), g.stride(0), _p(weight), 4 * D, B * L, weight.shape[0], 4 * D, _p(g_att),
+                      4 * D, _stream())
             g_hist = torch.empty((B, L, D), dtype=torch.float32, device=dev)
             g_tgt = torch.empty((B, D), dtype=torch.float32, device=dev)
             _lib.call("rh_din_att_input_bwd", _p(history), history.stride(0), _p(target), target.stride(0), _p(g_att), B, L,
