@@ -439,6 +439,11 @@ int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream);
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
+/* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
+ * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
+int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
 

@@ -193,6 +193,17 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_dense_kernel(const AdamArgs a) 
 // HBM traffic per step falls from 28 B x all elements to ~1/K of that; the arithmetic (one adam_elem per element per
 // step) is unchanged and becomes the bound.
 // ldesc (device int64 [8*T]): p, g, m, v, last(int32*) pointers, rows, K_t, window rows w_t
+struct LazyTouchedArgs {
+  const int64_t* ldesc;        // [8*T] as above
+  const int64_t* field_table;  // [2*F]: table index of the field (-1: skip), padding_idx (-1: none)
+  const int64_t* idesc;        // [>=2*F] index column pointer + stride per field
+  const double* hyper;
+  const float* ring;
+  int ring_mask;
+  int T, B, F, spb;
+  int* err;
+};
+
 struct LazySweepArgs {
   const int64_t* ldesc;
   const double* hyper;
@@ -203,12 +214,33 @@ struct LazySweepArgs {
   int64_t t_value;  // >= 0: the step this sweep belongs to, by value (deferred sweep); < 0: hyper[12]
   int64_t total_vblocks;
   int64_t vb_prefix[kMaxTensors + 1];
+  // merged launch (rh_adam_lazy_step): the first touch_blocks workgroups run the touched-rows step of the batch, the rest
+  // the window sweep.  Both claim a lazy row with atomicMax on its last-step word, and whoever claims it replays it AND
+  // applies its gradient row (the sweep then reads the gradient of every window row)
+  int touch_blocks, touch_chunks, touch_period;
+  LazyTouchedArgs touch;
 };
 
-template <int LPR>
+template <int LPR, typename IdxT, bool REFRESH>
+static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f);
+
+template <int LPR, bool MERGED = false>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySweepArgs a) {
   constexpr int RPB = RH_BLOCK / LPR;  // rows per block
   constexpr int D = 4 * LPR;
+  // merged launch: every touch_period-th workgroup is a touched-rows workgroup (INTERLEAVED with the sweep's: put first,
+  // they fill every CU before a sweep workgroup starts and the two parts run one after the other -- measured)
+  int64_t bid = blockIdx.x, nblk = gridDim.x;
+  if (MERGED) {
+    const int bx = (int)blockIdx.x, P = a.touch_period;
+    const int slot_ = bx / P;
+    if (bx % P == 0 && slot_ < a.touch_blocks) {
+      lazy_touched_body<LPR, int64_t, false>(a.touch, slot_ % a.touch_chunks, slot_ / a.touch_chunks);
+      return;
+    }
+    bid = bx - (slot_ + 1 < a.touch_blocks ? slot_ + 1 : a.touch_blocks);
+    nblk = (int64_t)gridDim.x - a.touch_blocks;
+  }
   AdamScalars h = load_scalars(a.hyper);
   const int t = a.t_value >= 0 ? (int)a.t_value : (int)a.hyper[12];
   if (a.t_value >= 0) {  // deferred: hyper[12..14] may already belong to the next step; the ring entry of t does not
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     int* last;
     int64_t r;
     int old;
-    bool live, with_g;
+    bool live, with_g, claimed;
     float4 P, M, V, G;
   };
   auto fetch = [&](int64_t vb, Unit& u) {
@@ -255,12 +287,24 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     const int64_t local = (vb - a.vb_prefix[ti]) * RPB + slot;
     u.r = wstart + local;
     if (local >= w || u.r >= rows) return;
-    u.old = gload<int>(u.last + u.r);
     u.with_g = (K == 1);  // dense tables receive their gradient here; others had it applied when touched
+    const bool claim = MERGED && K != 1;
+    u.claimed = claim;
+    if (claim) {
+      // the touched-rows workgroups of this launch may want the same row: claim it (exactly one claimant sees a value
+      // < t) and take over its gradient row.  Unconditional (a window row appears once): ONE round trip, in flight
+      // together with the row's loads -- a load-then-atomic pair in front of them cost 10 us per launch
+      u.old = t;
+      if (q == 0) u.old = atomicMax(u.last + u.r, t);
+      u.with_g = true;
+    } else {
+      u.old = gload<int>(u.last + u.r);
+    }
     u.P = gload<float4>(u.p + u.r * D + q * 4);
     u.M = gload<float4>(u.m + u.r * D + q * 4);
     u.V = gload<float4>(u.v + u.r * D + q * 4);
     u.G = u.with_g ? gload<float4>(u.g + u.r * D + q * 4) : f4_zero();
+    if (claim) u.old = __shfl(u.old, (int)(threadIdx.x % RH_WAVE) - q, RH_WAVE);
     u.live = true;
   };
   auto process = [&](Unit& u) {
@@ -292,38 +336,26 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
       gstore<float4>(u.v + u.r * D + q * 4, u.V);
       if (u.with_g && (u.G.x != 0.f || u.G.y != 0.f || u.G.z != 0.f || u.G.w != 0.f))
         gstore<float4>(u.g + u.r * D + q * 4, f4_zero());
-      if (q == 0) u.last[u.r] = t;
+      if (q == 0 && !(MERGED && u.with_g && u.claimed)) u.last[u.r] = t;
     }
   };
   // two units ping-pong (no register copies): the loads of one are in flight while the other is replayed
   Unit ua, ub;
-  fetch(blockIdx.x, ua);
-  for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += 2 * (int64_t)gridDim.x) {
-    fetch(vb + gridDim.x, ub);
+  fetch(bid, ua);
+  for (int64_t vb = bid; vb < a.total_vblocks; vb += 2 * nblk) {
+    fetch(vb + nblk, ub);
     process(ua);
-    fetch(vb + 2 * (int64_t)gridDim.x, ua);
+    fetch(vb + 2 * nblk, ua);
     process(ub);
   }
 }
 
-struct LazyTouchedArgs {
-  const int64_t* ldesc;        // [8*T] as above
-  const int64_t* field_table;  // [2*F]: table index of the field (-1: skip), padding_idx (-1: none)
-  const int64_t* idesc;        // [>=2*F] index column pointer + stride per field
-  const double* hyper;
-  const float* ring;
-  int ring_mask;
-  int T, B, F, spb;
-  int* err;
-};
-
 // REFRESH: the pre-gather pass -- the rows carry no gradient yet (their gradient rows are zero), so they are neither
 // read nor re-zeroed and the closing step is the zero-gradient form too (a quarter less traffic per row)
 template <int LPR, typename IdxT, bool REFRESH>
-__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
+static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f) {
   constexpr int LPP = RH_BLOCK / LPR;
   constexpr int D = 4 * LPR;
-  const int f = blockIdx.y;
   const int T = a.T, F = a.F;
   const int64_t ti = a.field_table[f];
   if (ti < 0) return;
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
   const int lane = threadIdx.x % RH_WAVE;
-  const int64_t b0 = (int64_t)blockIdx.x * a.spb;
+  const int64_t b0 = (int64_t)bx * a.spb;
   const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
   for (int64_t base = b0; base < b1; base += LPP) {  // uniform trip count: the claim is broadcast by shuffle
     const int64_t b = base + slot;
@@ -388,8 +420,14 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
   }
 }
 
+template <int LPR, typename IdxT, bool REFRESH>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
+  lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 template <int LPR>
-int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_t* h_window, hipStream_t s) {
+int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_t* h_window, hipStream_t s,
+                 const LazyTouchedArgs* touch = nullptr) {
   constexpr int RPB = RH_BLOCK / LPR;
   a.vb_prefix[0] = 0;
   for (int t = 0; t < a.T; ++t) {
@@ -400,12 +438,31 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
   }
   for (int t = a.T + 1; t <= kMaxTensors; ++t) a.vb_prefix[t] = a.vb_prefix[a.T];
   a.total_vblocks = a.vb_prefix[a.T];
-  if (a.total_vblocks == 0) return 0;
+  a.touch_blocks = a.touch_chunks = 0;
+  a.touch_period = 1;
+  if (touch != nullptr) {
+    a.touch = *touch;
+    a.touch_chunks = (touch->B + touch->spb - 1) / touch->spb;
+    a.touch_blocks = a.touch_chunks * touch->F;
+  }
+  if (a.total_vblocks == 0 && a.touch_blocks == 0) return 0;
   // persistent-style grid: each workgroup walks several virtual blocks so the prefetch has something to overlap
   int64_t grid = a.total_vblocks;
   const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)g_sweep_lds_pad, s, a);
+  if (touch != nullptr) {
+    if (grid < 1) grid = 1;
+    // every period-th workgroup is a touched one: (touch_blocks - 1) * period < grid + touch_blocks, so all of them exist;
+    // fewer sweep than touched workgroups (small tables): period 1 = touched first
+    int64_t period = (grid + a.touch_blocks) / a.touch_blocks;
+    if (period > 1 && period % 8 == 0) period -= 1;  // block id mod 8 = XCD: keep the touched workgroups on all of them
+    a.touch_period = (int)period;
+    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK),
+                       (size_t)g_sweep_lds_pad, s, a);
+  } else {
+    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, false>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)g_sweep_lds_pad,
+                       s, a);
+  }
   return 0;
 }
 
@@ -685,6 +742,44 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
   }
 #undef RH_LT
   RH_LAUNCH_CHECK("rh_adam_lazy_touched");
+  return 0;
+}
+
+// ONE launch for the end of the step: the touched-rows step of the batch (as rh_adam_lazy_touched, refresh = 0) AND the
+// window sweep of every table (as rh_adam_lazy_sweep, RH_SWEEP_WINDOW) -- the first is a short latency-bound pass of a few
+// hundred workgroups, the second saturates the vector ALUs: run together, the first hides under the second.  int64 indices.
+extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                 const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                 const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
+                                 void* stream) {
+  RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc, RH_E_BADARG,
+             "rh_adam_lazy_step: null pointer");
+  RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1, RH_E_BADARG, "rh_adam_lazy_step: bad shape");
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
+             "rh_adam_lazy_step: ring_size must be a power of two <= %d", kMaxRing);
+  const int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
+  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
+  LazySweepArgs a;
+  a.ldesc = ldesc;
+  a.hyper = hyper;
+  a.ring = ring;
+  a.ring_mask = ring_size - 1;
+  a.T = T;
+  a.flush = 0;
+  a.t_value = -1;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = RH_E_UNSUPPORTED;
+  switch (D / 4) {
+    case 1: rc = launch_sweep<1>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    case 2: rc = launch_sweep<2>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    case 4: rc = launch_sweep<4>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    case 8: rc = launch_sweep<8>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    case 16: rc = launch_sweep<16>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    case 32: rc = launch_sweep<32>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    default: break;
+  }
+  RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_step: embed_dim %d unsupported", D);
+  RH_LAUNCH_CHECK("rh_adam_lazy_step");
   return 0;
 }
 

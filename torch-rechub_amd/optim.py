@@ -286,8 +286,28 @@ class TableAdam(torch.optim.Adam):
         if any(id(w) in self._table_ids for w in rec["weights"]):
             self._touch_log.append(rec)
 
+    def _merged_step(self, groups, stream):
+        """The touched-rows step of the batch and the window sweep as ONE launch (rh_adam_lazy_step) when the step has a
+        single index batch over a single table group with int64 indices -- the DeepFM / DCN / WideDeep step.  The short,
+        latency-bound touched pass then runs under the ALU-bound sweep instead of in front of it."""
+        if (os.environ.get("RECHUB_MERGE_STEP", "1") != "1" or self.overlap_sweep or len(self._touch_log) != 1 or
+                len(groups) != 1):
+            return False
+        rec, grp = self._touch_log[0], groups[0]
+        if grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or \
+                not any(id(w) in grp["local"] for w in rec["weights"]):
+            return False
+        _lib.call("rh_adam_lazy_step", ops._p(grp["ldesc"]), len(grp["members"]),
+                  ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                  ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
+                  ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), stream)
+        return True
+
     def _lazy_step(self, stream):
         groups = self._lazy_setup()
+        if self._merged_step(groups, stream):
+            del self._touch_log[:]
+            return
         for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
             self._touch(rec, groups, stream)
         del self._touch_log[:]
