@@ -406,6 +406,9 @@ typedef struct RhPackItem {
   int64_t dst_offset; /* offset of the parameter inside flat */
 } RhPackItem;
 int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream);
+/* the same + the Adam step of every packed parameter on the element just summed (= rh_pack_grads then rh_adam_small over the
+ * same n parameters, sdesc in rh_adam_small's layout, hyper already holding this step's scalars): one launch */
+int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)

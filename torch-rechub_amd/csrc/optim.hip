@@ -525,12 +525,32 @@ struct PackArgs {
   int64_t vb_prefix[kPackItems + 1];
   int n;
   float* flat;
+  // rh_pack_grads_adam: the Adam step of the parameter the item belongs to, on the gradient element just packed
+  // (sdesc as rh_adam_small: [5 * T] p, m, v pointers, numel, flat offset; item i of this launch = parameter base + i)
+  const int64_t* sdesc;
+  const double* hyper;
+  int T, base;
 };
+
+static __device__ __forceinline__ void pack_adam(const PackArgs& a, const AdamScalars& h, int item, int64_t i, float g) {
+  const int t = a.base + item;
+  float* p = reinterpret_cast<float*>(a.sdesc[0 * a.T + t]);
+  float* m = reinterpret_cast<float*>(a.sdesc[1 * a.T + t]);
+  float* v = reinterpret_cast<float*>(a.sdesc[2 * a.T + t]);
+  float P = p[i], M = m[i], V = v[i];
+  adam_elem(P, g, M, V, h, h.A, h.E);
+  p[i] = P;
+  m[i] = M;
+  v[i] = V;
+}
 constexpr int kPackChunk = RH_BLOCK;  // outputs per virtual block
 constexpr int kPackDeep = 32;          // more partial rows than this: the rows are split over the wavefronts
 
+template <bool ADAM>
 __global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) {
   __shared__ float red[RH_BLOCK / RH_WAVE];
+  AdamScalars h{};
+  if (ADAM) h = load_scalars(a.hyper);
   for (int64_t vb = blockIdx.x; vb < a.vb_prefix[a.n]; vb += gridDim.x) {
     int lo = 0, hi = a.n;
     while (hi - lo > 1) {
@@ -550,7 +570,11 @@ __global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) 
         acc = wave_sum(acc);
         if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) dst[e] = (((red[0] + red[1]) + red[2]) + red[3]) + (add ? add[e] : 0.f);
+        if (threadIdx.x == 0) {
+          const float gsum = (((red[0] + red[1]) + red[2]) + red[3]) + (add ? add[e] : 0.f);
+          dst[e] = gsum;
+          if (ADAM) pack_adam(a, h, lo, e, gsum);
+        }
         __syncthreads();
       }
       continue;
@@ -577,9 +601,12 @@ __global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) 
       __syncthreads();
       deep[threadIdx.x] = v;
       __syncthreads();
-      if (wave == 0 && i < it.numel)
-        dst[i] = (((deep[lane] + deep[RH_WAVE + lane]) + deep[2 * RH_WAVE + lane]) + deep[3 * RH_WAVE + lane]) +
-                 (add ? add[i] : 0.f);
+      if (wave == 0 && i < it.numel) {
+        const float gsum = (((deep[lane] + deep[RH_WAVE + lane]) + deep[2 * RH_WAVE + lane]) + deep[3 * RH_WAVE + lane]) +
+                           (add ? add[i] : 0.f);
+        dst[i] = gsum;
+        if (ADAM) pack_adam(a, h, lo, i, gsum);
+      }
       continue;
     }
     const int64_t i = (vb - a.vb_prefix[lo]) * kPackChunk + threadIdx.x;
@@ -594,19 +621,24 @@ __global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) 
       for (; r < it.nparts; ++r) v += src[r * it.stride + i];
       if (add) v += add[i];
       dst[i] = v;
+      if (ADAM) pack_adam(a, h, lo, i, v);
     }
   }
 }
 
 }  // namespace
 
-extern "C" int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream) {
+static int pack_impl(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper, void* stream) {
   RH_REQUIRE(items != nullptr && flat != nullptr && n >= 0, RH_E_BADARG, "rh_pack_grads: null pointer");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int base = 0; base < n; base += kPackItems) {
     PackArgs a;
     a.n = n - base < kPackItems ? n - base : kPackItems;
     a.flat = flat;
+    a.sdesc = sdesc;
+    a.hyper = hyper;
+    a.T = n;
+    a.base = base;
     a.vb_prefix[0] = 0;
     for (int i = 0; i < a.n; ++i) {
       const RhPackItem& it = items[base + i];
@@ -621,10 +653,23 @@ extern "C" int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* 
     if (a.vb_prefix[a.n] == 0) continue;
     int64_t grid = a.vb_prefix[a.n];
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_grads_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, st, a);
+    if (sdesc != nullptr) hipLaunchKernelGGL(pack_grads_kernel<true>, dim3((unsigned)grid), dim3(RH_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL(pack_grads_kernel<false>, dim3((unsigned)grid), dim3(RH_BLOCK), 0, st, a);
   }
   RH_LAUNCH_CHECK("rh_pack_grads");
   return 0;
+}
+
+extern "C" int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream) {
+  return pack_impl(items, n, flat, nullptr, nullptr, stream);
+}
+
+// rh_pack_grads + rh_adam_small in one launch: item i is the gradient of parameter i of sdesc (n = T entries, the
+// rh_adam_small layout), hyper holds THIS step's scalars already (rh_step_scalars / rh_adam_prepare ran before).
+extern "C" int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper,
+                                  void* stream) {
+  RH_REQUIRE(sdesc != nullptr && hyper != nullptr, RH_E_BADARG, "rh_pack_grads_adam: null pointer");
+  return pack_impl(items, n, flat, sdesc, hyper, stream);
 }
 
 extern "C" int rh_optim_set_tuning(int key, int value) {

@@ -64,6 +64,7 @@ class TableAdam(torch.optim.Adam):
         self._tables = tables
         self._others = others
         self._bucket = None  # distributed.DenseGradBucket: when attached, dense params step through rh_adam_small
+        self._small_done = False  # this step's rh_adam_small was folded into the packing launch (small_adam_args)
         self._t_hyper_host = None
         self.lazy_k = int(lazy_k) if tables else 0
         if self.lazy_k >= self.RING:
@@ -355,6 +356,16 @@ class TableAdam(torch.optim.Adam):
         self._prepared = True
         return self._t_hyper, self._t_step, self._t_ring, self.RING
 
+    def small_adam_args(self):
+        """(sdesc, hyper) for rh_pack_grads_adam when the dense parameters' step may ride on the packing launch of this
+        step -- i.e. when this step's Adam scalars are already on the device (fuse_prepare ran in the forward, so
+        step_tables() would not launch rh_adam_prepare) -- else None.  The following step_tables() then skips rh_adam_small."""
+        if (self._bucket is None or not self._prepared or not self._groups_agree() or
+                os.environ.get("RECHUB_PACK_ADAM", "1") != "1"):
+            return None
+        self._small_done = True
+        return self._s_desc, self._t_hyper
+
     def step_tables(self):
         """One Adam step over every table (+ in-pass re-zeroing of the gradient rows)."""
         if not self._tables and self._bucket is None:
@@ -374,7 +385,9 @@ class TableAdam(torch.optim.Adam):
         else:
             _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
                       stream)
-        if self._bucket is not None:
+        if self._bucket is not None and self._small_done:
+            self._small_done = False  # the packing launch of this step already stepped the dense parameters
+        elif self._bucket is not None:
             b = self._bucket
             if not all(b.packed):
                 raise RuntimeError("TableAdam: the dense gradient bucket was not packed (call bucket.finish() first)")

@@ -202,7 +202,9 @@ class CTRTrainer(object):
         if packed and not all(p.grad is not None or id(p) in items for p in self.bucket.params):
             raise RuntimeError("a dense parameter stopped receiving gradients; rebuild the trainer")
         if defer:
-            self.bucket.pack(items)
+            # with this step's Adam scalars already on the device (the step's scalar launch computed them in the forward),
+            # the packing launch also steps the dense parameters: rh_pack_grads + rh_adam_small as ONE launch
+            self.bucket.pack(items, adam=self.optimizer.small_adam_args())
         elif packed or self.dp is not None:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
