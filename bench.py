@@ -467,8 +467,10 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0  # host time to ENQUEUE the steps (diagnostic: close to dt = launch-bound host)
     fence()
     dt = time.perf_counter() - t0
+    res["host_enqueue_ms_per_step"] = 1e3 * t_enq / args.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -479,7 +481,7 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     # ---- per-kernel HIP-event timing, eager launches of the same step in the SAME regime (no flush in between) ----
     n_prof = max(8, min(args.steps, 30))
     if profile:
-        names = ["rh_embed_fwd", "rh_embed_bwd", "rh_adam_dense", "rh_adam_lazy_touched", "rh_adam_lazy_sweep",
+        names = ["rh_embed_fwd", "rh_embed_bwd", "rh_adam_dense", "rh_adam_lazy_touched", "rh_adam_lazy_sweep", "rh_adam_lazy_step",
                  "rh_batch_gather", "rh_embed_scatter_rows", "rh_shard_localize", "rh_seq_pool_fwd", "rh_seq_pool_bwd"]
         timer = KernelTimer(names)
         comm = CommTimer(trainer.bucket) if trainer.dp is not None else None
@@ -527,13 +529,18 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     # lazy sweep: bytes one launch must move = its 1/K window of every table (read + write p, m, v; 4 B/row of `last`
     # both ways) + the K=1 (small) tables in full incl. their gradient.  The other 1 - 1/K of the dense pass's traffic
     # is replaced by replay arithmetic, which is what bounds this kernel (VALU).
-    sweep_bytes = 0
+    sweep_bytes = step_bytes = 0
     for p_ in (opt._tables if hasattr(opt, "_tables") else []):
         rows, d_ = p_.shape
         k_ = 1 if (opt.lazy_k <= 1 or rows <= opt.lazy_small_rows) else opt.lazy_k
         win = -(-rows // k_)
         sweep_bytes += win * (d_ * 4 * (7 if k_ == 1 else 6) + 8)
+        # merged launch (rh_adam_lazy_step): the sweep also reads the gradient row of every window row, and the rows
+        # the batch touched (one lookup per field and sample, counted once each: an upper bound under duplicates) are
+        # read and written with their gradient: p, m, v, g both ways + index + last-step word
+        step_bytes += win * (d_ * 4 * 7 + 8) + (0 if k_ == 1 else min(B, rows) * (d_ * 4 * 8 + 16))
     res["sweep_bytes"] = sweep_bytes
+    res["step_bytes"] = step_bytes
     res["overlap_sweep"] = bool(getattr(opt, "overlap_sweep", False))
     # the north-star kernels over batch sizes (same tables, same stream, HIP events): their bandwidth regime starts
     # where the launch is no longer three dependent memory round trips long.  Last: it leaves junk gradient rows behind.
@@ -609,7 +616,8 @@ def main():
     if rank == 0:
         ms = head.get("kernel_ms", {})
         total_elems, sweep_bytes = head["total_elems"], head["sweep_bytes"]
-        alg = {"rh_adam_dense": ADAM_BYTES_PER_ELEM * total_elems, "rh_adam_lazy_sweep": sweep_bytes}
+        alg = {"rh_adam_dense": ADAM_BYTES_PER_ELEM * total_elems, "rh_adam_lazy_sweep": sweep_bytes,
+               "rh_adam_lazy_step": head.get("step_bytes", sweep_bytes)}
         if wl.name in ("deepfm", "dcnv2") and best != "shard":
             alg.update({"rh_embed_fwd": FWD_BYTES_PER_SAMPLE * B, "rh_embed_bwd": BWD_BYTES_PER_SAMPLE * B,
                         "rh_batch_gather": GATHER_BYTES_PER_SAMPLE * B})
@@ -643,7 +651,7 @@ def main():
                 # configuration (2*FETCH + WRITE, gfx950 correction, calibrated on rh_adam_dense): profiles/r01_pmc_traffic.md
                 roofline["traffic"] = pmc_traffic
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
-            if dominant == "rh_adam_lazy_sweep":
+            if dominant in ("rh_adam_lazy_sweep", "rh_adam_lazy_step"):
                 # The kernel's own bound is the replay arithmetic.  In the steady state every table element advances
                 # lazy_k steps per lazy_k launches, so one launch replays AT MOST total_elems element-steps (the rows the
                 # batch touched are replayed by rh_adam_lazy_touched instead): an upper bound on the work, hence on frac.
@@ -655,6 +663,10 @@ def main():
                 roofline["valu"] = {"achieved_upper_bound": round(es / 1e9, 1), "peak": round(valu_peak / 1e9, 1),
                                     "unit": "G element-steps/s", "frac_upper_bound": round(frac, 4) if frac <= 1 else None,
                                     "element_steps_per_launch_upper_bound": total_elems}
+                if dominant == "rh_adam_lazy_step":
+                    roofline["merged"] = ("rh_adam_lazy_touched (the batch's rows, with their gradient) + rh_adam_lazy_sweep "
+                                          "(window) as one launch; algorithmic bytes = window rows x (p, m, v both ways + "
+                                          "gradient read + last-step word) + touched rows x (p, m, v, g both ways + index)")
                 roofline["note"] = ("blocked-lazy exact Adam: this launch moves 1/K of the dense pass's bytes and replays "
                                     "the rest in registers (VALU-bound); the HBM fraction is low BY CONSTRUCTION; the "
                                     "dense pass it replaces (rh_adam_dense) runs at 64-75 % of HBM peak, see profiles/")
@@ -736,6 +748,7 @@ def main():
             },
             "flush_ms": head["flush_ms"],
             "rows_behind_after_flush": head.get("rows_behind_after_flush"),
+            "host_enqueue_ms_per_step": round(head.get("host_enqueue_ms_per_step", 0.0), 4),
             "epoch_amortised": {"steps_per_epoch": steps_per_epoch,
                                 "value": round(world * B * steps_per_epoch /
                                                (steps_per_epoch * head["ms_per_step"] * 1e-3 + head["flush_ms"] * 1e-3), 1),

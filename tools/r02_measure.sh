@@ -14,7 +14,7 @@ echo "== rocprof kernel stats of the default command"
 python tools/prof_summary.py "$OUT/prof" > "$OUT/prof_summary.txt" 2>&1
 cp "$OUT"/prof/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
 find "$OUT/prof" -name '*kernel_trace.csv' -size +20M -delete
-for B in 4096 65536; do for c in FETCH_SIZE WRITE_SIZE; do
+for B in ${PMC_BATCHES:-4096 65536}; do for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && PMC_B=$B timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_${B}_$c" -o probe -- python "$OLDPWD/tools/pmc_probe.py" > /dev/null 2> "$OLDPWD/$OUT/pmc_${B}_$c.err"); echo "pmc $B $c rc=$?"
   python tools/prof_summary.py "$OUT/pmc_${B}_$c" --pmc $c --tail 15 > "$OUT/pmc_${B}_${c}.txt" 2>&1
   find "$OUT/pmc_${B}_$c" -name '*.csv' -size +5M -delete
