@@ -353,9 +353,11 @@ template <int R, bool BWD>
 int launch_mid(const MoeMidArgs& a, hipStream_t s) {
   const size_t lds = mid_lds(a.E, R, BWD);
   auto* fn = BWD ? moe_mid_bwd_kernel<R> : moe_mid_fwd_kernel<R>;
-  if (lds > 48 * 1024) {
+  static size_t reserved = 48 * 1024;  // per instantiation: raise the dynamic-LDS limit once per size class
+  if (lds > reserved) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     RH_REQUIRE(e == hipSuccess, (int)e, "rh_cross_moe_mid: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    reserved = lds;
   }
   hipLaunchKernelGGL(fn, dim3(mid_grid(a.B, a.E, R, BWD)), dim3(RH_BLOCK), lds, s, a);
   return 0;
