@@ -388,13 +388,41 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
     }
     old = __shfl(old, lane - q, RH_WAVE);
-    const bool act = valid && old < t;  // this lane group claimed the row
+    bool act = valid && old < t;  // this lane group claimed the row
+    int64_t rr = r;
+    if (REFRESH) {
+      // The replay below costs a wavefront the LONGEST lag among its rows (the others idle under the exec mask), and the
+      // rows of one pass lag anything from 0 to K steps: with 64 / LPR random rows per wavefront that is ~ K every time.
+      // Re-deal the claimed rows of the pass over the lane groups in order of their lag (rank by counting through LDS):
+      // the wavefronts then hold rows of similar lag and their maxima add up to ~ 5/8 of what they were.  Which lane
+      // group replays a row changes nothing in its arithmetic.
+      __shared__ int s_key[LPP];
+      __shared__ int s_old[LPP];
+      __shared__ int64_t s_row[LPP];
+      const int lag = act ? t - old : 0;
+      __syncthreads();  // the previous pass is done with the arrays
+      if (q == 0) s_key[slot] = lag;
+      __syncthreads();
+      int rank = 0;
+      for (int j = 0; j < LPP; ++j) {
+        const int kj = s_key[j];
+        rank += (kj > lag || (kj == lag && j < slot)) ? 1 : 0;
+      }
+      if (q == 0) {
+        s_row[rank] = r;
+        s_old[rank] = act ? old : t;  // t = nothing to do
+      }
+      __syncthreads();
+      rr = s_row[slot];
+      old = s_old[slot];
+      act = old < t;
+    }
     float4 P = f4_zero(), M = f4_zero(), V = f4_zero(), G = f4_zero();
     if (act) {
-      P = gload<float4>(p + r * D + q * 4);
-      M = gload<float4>(m + r * D + q * 4);
-      V = gload<float4>(v + r * D + q * 4);
-      if (!REFRESH) G = gload<float4>(g + r * D + q * 4);
+      P = gload<float4>(p + rr * D + q * 4);
+      M = gload<float4>(m + rr * D + q * 4);
+      V = gload<float4>(v + rr * D + q * 4);
+      if (!REFRESH) G = gload<float4>(g + rr * D + q * 4);
     }
     // replay in segments between the steps at which rows of the wavefront join (see adam_lazy_sweep_kernel): fixed exec
     // mask and a scalar step counter inside a segment (the ring entry becomes a scalar load)
@@ -413,10 +441,10 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     if (!act) continue;
     if (REFRESH) adam_f4_zero_g(P, M, V, h, h.A, h.E);
     else adam_f4(P, G, M, V, h, h.A, h.E);
-    gstore<float4>(p + r * D + q * 4, P);
-    gstore<float4>(m + r * D + q * 4, M);
-    gstore<float4>(v + r * D + q * 4, V);
-    if (!REFRESH) gstore<float4>(g + r * D + q * 4, f4_zero());
+    gstore<float4>(p + rr * D + q * 4, P);
+    gstore<float4>(m + rr * D + q * 4, M);
+    gstore<float4>(v + rr * D + q * 4, V);
+    if (!REFRESH) gstore<float4>(g + rr * D + q * 4, f4_zero());
   }
 }
 
