@@ -263,6 +263,11 @@ int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, cons
  *   partial (optional): ceil(B L / rh_din_att_l1_chunk_rows(B L)) x 2 x N per-chunk (sum, M2 about the chunk mean) of z --
  *   the BatchNorm statistics, combined by rh_bn_stats_from_partial (no pass over z).
  *   Supported (rh_din_att_l1_supported): D in {4, 8, 16}, N a multiple of 64 up to 256. */
+/* nn.PReLU() with one slope (activation_layer("prelu"), torch_rechub/basic/activation.py:40-41; the DSSM towers): x contiguous,
+ * n elements; bwd writes gx and rh_prelu_nblocks(n) per-block partial sums of d / d slope. */
+int rh_prelu_nblocks(int64_t n);
+int rh_prelu_fwd(const float* x, const float* slope, int64_t n, float* out, void* stream);
+int rh_prelu_bwd(const float* x, const float* g, const float* slope, int64_t n, float* gx, float* partial, void* stream);
 int rh_din_att_l1_supported(int D, int N);
 int rh_din_att_l1_chunk_rows(int64_t rows);
 int rh_din_att_l1_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* W,

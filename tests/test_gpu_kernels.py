@@ -1471,3 +1471,25 @@ def test_din_att_l1_matches_linear_on_materialised_operand_and_chunk_statistics(
         blk = want[k * rows:(k + 1) * rows]
         assert torch.allclose(part[k, 0].double(), blk.sum(0), rtol=1e-5, atol=1e-3)
         assert torch.allclose(part[k, 1].double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(4096, 512), (1000, 257), (3,), (1, 1), (7, 5, 3)])
+def test_prelu_single_slope_vs_torch(shape):
+    """nn.PReLU() (activation_layer("prelu"): the DSSM towers) through rh_prelu_fwd / rh_prelu_bwd against ATen on the
+    device: outputs and input gradient bit-equal (same per-element arithmetic), slope gradient up to summation order."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(len(shape))
+    x = torch.randn(*shape, generator=g).to(dev())
+    x.view(-1)[0] = 0.0  # the kink: forward 0, backward takes the slope branch
+    gy = torch.randn(*shape, generator=g).to(dev())
+    mod = torch.nn.PReLU(init=0.3).to(dev())
+    assert ops.prelu_ok(mod, x)
+    x1 = x.clone().requires_grad_()
+    y1 = ops.prelu(x1, mod.weight)
+    y1.backward(gy)
+    g_slope, mod.weight.grad = mod.weight.grad.clone(), None
+    x2 = x.clone().requires_grad_()
+    y2 = mod(x2)
+    y2.backward(gy)
+    assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+    assert torch.allclose(g_slope, mod.weight.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(mod.weight.grad.abs())))

@@ -348,6 +348,9 @@ class MLP(nn.Module):
             elif isinstance(mods[i], nn.Linear):
                 x = self._linear(mods[i], x)
                 i += 1
+            elif ops.prelu_ok(mods[i], x):
+                x = ops.prelu(x, mods[i].weight)  # nn.PReLU() of the two-tower MLPs: one pass each way
+                i += 1
             else:
                 x = mods[i](x)
                 i += 1

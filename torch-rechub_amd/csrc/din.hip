@@ -322,6 +322,85 @@ int att_check(const char* who, int B, int L, int D) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// PReLU with one learnable slope (nn.PReLU(), the activation of the DSSM towers: activation_layer("prelu"),
+// torch_rechub/basic/activation.py:40-41 -> MLP basic/layers.py:283).  ATen runs the backward as a two-output
+// elementwise kernel (26 us at 4096 x 512) + a full reduction for the slope gradient; here one pass each way, the slope
+// gradient as per-block partial sums (summed by the caller / the step's packing launch).
+namespace {
+__global__ __launch_bounds__(RH_BLOCK) void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                             int64_t n4, int64_t n, float* __restrict__ out) {
+  const float a = slope[0];
+  for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RH_BLOCK) {
+    float4 v = gload<float4>(x + 4 * i);
+    v.x = v.x > 0.f ? v.x : a * v.x;
+    v.y = v.y > 0.f ? v.y : a * v.y;
+    v.z = v.z > 0.f ? v.z : a * v.z;
+    v.w = v.w > 0.f ? v.w : a * v.w;
+    gstore<float4>(out + 4 * i, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // the last 1..3 elements
+    const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+    out[i] = x[i] > 0.f ? x[i] : a * x[i];
+  }
+}
+
+__global__ __launch_bounds__(RH_BLOCK) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ slope, int64_t n4, int64_t n,
+                                                             float* __restrict__ gx, float* __restrict__ partial) {
+  __shared__ float red[RH_BLOCK / RH_WAVE];
+  const float a = slope[0];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RH_BLOCK) {
+    const float4 v = gload<float4>(x + 4 * i), d = gload<float4>(g + 4 * i);
+    float4 o;
+    o.x = v.x > 0.f ? d.x : a * d.x;
+    o.y = v.y > 0.f ? d.y : a * d.y;
+    o.z = v.z > 0.f ? d.z : a * d.z;
+    o.w = v.w > 0.f ? d.w : a * d.w;
+    acc += (v.x > 0.f ? 0.f : d.x * v.x) + (v.y > 0.f ? 0.f : d.y * v.y) + (v.z > 0.f ? 0.f : d.z * v.z) +
+           (v.w > 0.f ? 0.f : d.w * v.w);
+    gstore<float4>(gx + 4 * i, o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+    gx[i] = x[i] > 0.f ? g[i] : a * g[i];
+    acc += x[i] > 0.f ? 0.f : g[i] * x[i];
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+unsigned prelu_grid(int64_t n) {
+  int64_t g = (n / 4 + RH_BLOCK - 1) / RH_BLOCK;
+  if (g > 1024) g = 1024;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+}  // namespace
+
+extern "C" int rh_prelu_nblocks(int64_t n) { return (int)prelu_grid(n); }
+
+extern "C" int rh_prelu_fwd(const float* x, const float* slope, int64_t n, float* out, void* stream) {
+  RH_REQUIRE(x && slope && out && n >= 0, RH_E_BADARG, "rh_prelu_fwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(prelu_grid(n)), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     slope, n / 4, n, out);
+  RH_LAUNCH_CHECK("rh_prelu_fwd");
+  return 0;
+}
+
+// gx = g * (x > 0 ? 1 : slope);  partial[rh_prelu_nblocks(n)]: per-block sums of g * x over x <= 0 (d / d slope)
+extern "C" int rh_prelu_bwd(const float* x, const float* g, const float* slope, int64_t n, float* gx, float* partial,
+                            void* stream) {
+  RH_REQUIRE(x && g && slope && gx && partial && n >= 1, RH_E_BADARG, "rh_prelu_bwd: bad arguments");
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(prelu_grid(n)), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x, g,
+                     slope, n / 4, n, gx, partial);
+  RH_LAUNCH_CHECK("rh_prelu_bwd");
+  return 0;
+}
+
 extern "C" int rh_dice_nblocks(int64_t N) { return (int)dice_grid(N); }
 extern "C" int rh_bn_dice_stats_blocks(int64_t N) { return (int)dice_grid(N, kStatsBlocks); }
 

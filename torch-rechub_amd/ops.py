@@ -1135,6 +1135,40 @@ def dice(x, alpha, eps):
     return _DiceFn.apply(x, alpha, eps)
 
 
+class _PReluFn(torch.autograd.Function):
+    """nn.PReLU() with one slope: one pass each way (csrc/din.hip); the slope gradient leaves as per-block partials
+    (summed by the step's packing launch when the trainer armed ops.deferred for the parameter)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        require_hip(x, weight)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _lib.call("rh_prelu_fwd", _p(x), _p(weight), x.numel(), _p(out), _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.param = weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        nb = _lib.call("rh_prelu_nblocks", x.numel())
+        partial = torch.empty((nb,), dtype=torch.float32, device=x.device)
+        _lib.call("rh_prelu_bwd", _p(x), _p(g), _p(weight), x.numel(), _p(gx), _p(partial), _stream())
+        return gx, deferred.offer(ctx.param, partial.data_ptr(), nb, 1, 1, lambda: partial.sum().reshape(1), partial)
+
+
+def prelu_ok(mod, x):
+    return (type(mod) is torch.nn.PReLU and mod.weight.numel() == 1 and x.is_cuda and x.dtype == torch.float32 and
+            x.numel() >= 1)
+
+
+def prelu(x, weight):
+    return _PReluFn.apply(x, weight)
+
+
 class _BnDiceFn(torch.autograd.Function):
     """Dice(BatchNorm1d(h)) with the normalisation folded into the Dice passes (csrc/din.hip, csrc/mlp.hip): the
     normalised tensor is never written.  Training mode; running statistics and num_batches_tracked updated in place."""
