@@ -1450,6 +1450,14 @@ def test_activation_unit_first_layer_on_register_built_operand(B, L, D, dims, so
         same(p.grad, q.grad, f"g_{n}", floor=gmax)
     for (n, p), (_, q) in zip(au.named_buffers(), twin.named_buffers()):
         same(p, q, f"buffer {n}", rtol=1e-5, atol=1e-6)
+    # inference (eval mode, no autograd): the fused first layer without the statistics epilogue + running statistics
+    au.eval(), twin.eval()
+    with torch.no_grad():
+        ref_e = twin(hist, tgt)
+        monkeypatch.undo()
+        assert ops.din_att_l1_ok(hist, tgt, au.attention.mlp[0])
+        out_e = au(hist, tgt)
+    same(out_e, ref_e, "attention output (eval)")
 
 
 def test_din_att_l1_matches_linear_on_materialised_operand_and_chunk_statistics():

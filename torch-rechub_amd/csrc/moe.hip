@@ -335,7 +335,7 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_unpack_kernel(const MoeUnpackArg
 int mid_grid(int B, int E, int r, bool bwd) {
   const int spb = RH_BLOCK / (E * r);
   int64_t g = ((int64_t)B + spb - 1) / spb;
-  const int64_t cap = bwd ? 256 : 2048;
+  const int64_t cap = bwd ? 512 : 2048;
   if (g > cap) g = cap;
   return g < 1 ? 1 : (int)g;
 }
