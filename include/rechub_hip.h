@@ -335,6 +335,13 @@ int rh_colsum(const float* a, int rows, int cols, float* out, const float* v, in
 int rh_head_bwd_ex(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                    const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b, float* partial,
                    int reduce, void* stream);
+/* rh_head_bwd_ex + the BatchNorm-backward column sums of the hidden layer below the head, when h = dropout(relu(bn(bn_z)))
+ * and the head is its only consumer: bn_partial (rh_head_nblocks(B), 2, K) per-block (sum g1, sum g1 * xhat) with the mask
+ * arithmetic of rh_bn_relu_dropout_bwd; rh_bn_relu_dropout_bwd_pre then needs no statistics pass.  K % 4 == 0, K <= 256. */
+int rh_head_bwd_bn(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                   const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b, float* partial,
+                   int reduce, const float* bn_z, const float* bn_stat, const float* bn_gamma, const float* bn_beta,
+                   float bn_p, const int64_t* bn_rng, const int64_t* bn_ctr, int bn_relu, float* bn_partial, void* stream);
 int rh_head_loss_nblocks(int B);
 int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
                      int K, float* y, const float* t, float* loss_partial, void* stream);
@@ -368,6 +375,10 @@ int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, con
                            float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
                            int training, int64_t* rng, int64_t* saved_ctr, float* partial, int partial_rows, float* stat,
                            float* out, int relu, void* stream);
+/* the same with the column sums already formed by the producer of dy (rh_head_bwd_bn): nchunks_pre <= 128 partial rows */
+int rh_bn_relu_dropout_bwd_pre(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta,
+                               float p_drop, const int64_t* rng, const int64_t* saved_ctr, const float* partial,
+                               int nchunks_pre, float* stat, float* dx, float* dgamma, float* dbeta, int relu, void* stream);
 int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta,
                            float p_drop, const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat,
                            float* dx, float* dgamma, float* dbeta, int relu, void* stream);

@@ -84,6 +84,10 @@ SIGNATURES = {
     "rh_linear_wgrad_partial": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_head_bwd_ex": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                        c_int, c_ptr],
+    "rh_head_bwd_bn": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
+                       c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
+    "rh_bn_relu_dropout_bwd_pre": [c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr,
+                                   c_ptr, c_ptr, c_int, c_ptr],
     "rh_pack_grads": [c_ptr, c_int, c_ptr, c_ptr],
     "rh_pack_grads_adam": [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_head_nblocks": [c_int],

@@ -113,3 +113,13 @@ static __device__ __forceinline__ void gatomic_add_f4(float* p, float4 v) {
     unsafeAtomicAdd(&(base)[(off) + 2], (v).z); \
     unsafeAtomicAdd(&(base)[(off) + 3], (v).w); \
   } while (0)
+
+// Counter-based dropout hash of csrc/mlp.hip (seed, call counter, element index) -> 32 random bits; shared with the head
+// backward of csrc/linear.hip, which forms the BatchNorm-backward column sums of the layer below from the same mask.
+static __device__ __forceinline__ uint32_t rh_drop_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed + ctr * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}

@@ -268,9 +268,21 @@ struct HeadBwdArgs {
   float* partial;      // (gridDim.x, K + 1)
   float* g_w;          // (K,)
   float* g_b;          // (1,) or null
+  // BN = true: h is the output of BatchNorm1d (+ ReLU, + Dropout) over bn_z, and g_h is that layer's whole upstream
+  // gradient: its backward column sums (sum g1, sum g1 * xhat; csrc/mlp.hip bn_partial_kernel<1>, same mask arithmetic)
+  // are formed here from the rows this workgroup walks anyway -> bn_partial (gridDim.x, 2, K)
+  const float* bn_z;
+  const float* bn_stat;  // (>= 2, K): mean, rstd
+  const float* bn_gamma;
+  const float* bn_beta;
+  const int64_t* bn_rng;
+  const int64_t* bn_ctr;
+  float* bn_partial;
+  float bn_p;
+  int bn_relu;
 };
 
-template <int MAXV>
+template <int MAXV, bool BN = false>
 __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a) {
   __shared__ float red[kHeadRows][kHeadLanes * 4 + 1];
   __shared__ float gb_red[kHeadRows];
@@ -283,6 +295,28 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
     wacc[i] = f4_zero();
     const int v = sub + i * kHeadLanes;
     wv[i] = v < nv ? gload<float4>(a.w + 4 * v) : f4_zero();
+  }
+  float4 bmean[BN ? MAXV : 1], brstd[BN ? MAXV : 1], bgam[BN ? MAXV : 1], bbet[BN ? MAXV : 1];
+  float4 bs1[BN ? MAXV : 1], bs2[BN ? MAXV : 1];
+  float keep_scale = 1.f;
+  uint32_t thr = 0;
+  uint64_t seed = 0, ctr = 0;
+  if (BN) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = sub + i * kHeadLanes;
+      bs1[i] = bs2[i] = f4_zero();
+      bmean[i] = v < nv ? gload<float4>(a.bn_stat + 4 * v) : f4_zero();
+      brstd[i] = v < nv ? gload<float4>(a.bn_stat + K + 4 * v) : f4_zero();
+      bgam[i] = v < nv ? gload<float4>(a.bn_gamma + 4 * v) : f4_zero();
+      bbet[i] = v < nv ? gload<float4>(a.bn_beta + 4 * v) : f4_zero();
+    }
+    if (a.bn_p > 0.f) {
+      keep_scale = 1.f / (1.f - a.bn_p);
+      thr = (uint32_t)(a.bn_p * 4294967296.0);
+      seed = (uint64_t)a.bn_rng[0];
+      ctr = (uint64_t)a.bn_ctr[0];
+    }
   }
   float gb = 0.f;
   // K % 4 tail columns 4 nv + sub (sub < K - 4 nv <= 3): one scalar lane each
@@ -312,7 +346,24 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
         wacc[i].y = fmaf(gz, hv.y, wacc[i].y);
         wacc[i].z = fmaf(gz, hv.z, wacc[i].z);
         wacc[i].w = fmaf(gz, hv.w, wacc[i].w);
-        gstore<float4>(a.g_h + row * K + 4 * v, make_float4(gz * wv[i].x, gz * wv[i].y, gz * wv[i].z, gz * wv[i].w));
+        const float4 gh = make_float4(gz * wv[i].x, gz * wv[i].y, gz * wv[i].z, gz * wv[i].w);
+        gstore<float4>(a.g_h + row * K + 4 * v, gh);
+        if (BN) {
+          const float4 zv = gload<float4>(a.bn_z + row * K + 4 * v);
+          const uint64_t e0 = (uint64_t)row * K + 4 * v;
+          auto one = [&](float z, float mean, float rstd, float gam, float bet, float g, uint64_t e, float& s1, float& s2) {
+            const float xhat = (z - mean) * rstd;
+            const float bn = fmaf(xhat, gam, bet);
+            float g1 = (!a.bn_relu || bn > 0.f) ? g : 0.f;
+            if (a.bn_p > 0.f) g1 = rh_drop_hash(seed, ctr, e) >= thr ? g1 * keep_scale : 0.f;
+            s1 += g1;
+            s2 = fmaf(g1, xhat, s2);
+          };
+          one(zv.x, bmean[i].x, brstd[i].x, bgam[i].x, bbet[i].x, gh.x, e0 + 0, bs1[i].x, bs2[i].x);
+          one(zv.y, bmean[i].y, brstd[i].y, bgam[i].y, bbet[i].y, gh.y, e0 + 1, bs1[i].y, bs2[i].y);
+          one(zv.z, bmean[i].z, brstd[i].z, bgam[i].z, bbet[i].z, gh.z, e0 + 2, bs1[i].z, bs2[i].z);
+          one(zv.w, bmean[i].w, brstd[i].w, bgam[i].w, bbet[i].w, gh.w, e0 + 3, bs1[i].w, bs2[i].w);
+        }
       }
     }
   }
@@ -333,6 +384,25 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
       for (int r = 0; r < kHeadRows; ++r) v += red[r][threadIdx.x];
       const int col = i * kHeadLanes * 4 + threadIdx.x;
       if (col < K) part[col] = v;
+    }
+    if (BN) {  // the same reduction over the row groups for the two BatchNorm sums of these 64 columns
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float4 src = which == 0 ? bs1[i] : bs2[i];
+        __syncthreads();
+        red[grp][sub * 4 + 0] = src.x;
+        red[grp][sub * 4 + 1] = src.y;
+        red[grp][sub * 4 + 2] = src.z;
+        red[grp][sub * 4 + 3] = src.w;
+        __syncthreads();
+        if (threadIdx.x < kHeadLanes * 4) {
+          float v = 0.f;
+#pragma unroll
+          for (int r = 0; r < kHeadRows; ++r) v += red[r][threadIdx.x];
+          const int col = i * kHeadLanes * 4 + threadIdx.x;
+          if (col < K) a.bn_partial[((int64_t)blockIdx.x * 2 + which) * K + col] = v;
+        }
+      }
     }
   }
   __syncthreads();
@@ -600,9 +670,33 @@ extern "C" int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, con
   return 0;
 }
 
+struct HeadBnArgs {
+  const float *z, *stat, *gamma, *beta;
+  const int64_t *rng, *ctr;
+  float* partial;
+  float p;
+  int relu;
+};
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
-                         float* partial, void* stream, int reduce = 1);
+                         float* partial, void* stream, int reduce = 1, const HeadBnArgs* bn = nullptr);
+
+// rh_head_bwd_ex + the BatchNorm-backward column sums of the hidden layer below the head (h = dropout(relu(bn(bn_z)))
+// and the head is its only consumer): bn_partial (rh_head_nblocks(B), 2, K) = per-block (sum g1, sum g1 * xhat), what
+// rh_bn_relu_dropout_bwd_pre takes instead of launching its own statistics pass.  K % 4 == 0.
+extern "C" int rh_head_bwd_bn(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                              const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
+                              float* partial, int reduce, const float* bn_z, const float* bn_stat, const float* bn_gamma,
+                              const float* bn_beta, float bn_p, const int64_t* bn_rng, const int64_t* bn_ctr, int bn_relu,
+                              float* bn_partial, void* stream) {
+  RH_REQUIRE((g_y != nullptr) != (t != nullptr && g_loss != nullptr), RH_E_BADARG,
+             "rh_head_bwd_bn: give either g_y or (t, g_loss)");
+  RH_REQUIRE(bn_z && bn_stat && bn_gamma && bn_beta && bn_partial && (bn_p <= 0.f || (bn_rng && bn_ctr)), RH_E_BADARG,
+             "rh_head_bwd_bn: null pointer");
+  RH_REQUIRE(K % 4 == 0 && bn_p >= 0.f && bn_p < 1.f, RH_E_UNSUPPORTED, "rh_head_bwd_bn: K=%d p=%g unsupported", K, bn_p);
+  const HeadBnArgs bn{bn_z, bn_stat, bn_gamma, bn_beta, bn_rng, bn_ctr, bn_partial, bn_p, bn_relu};
+  return head_bwd_impl(h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, g_w, g_b, partial, stream, reduce, &bn);
+}
 
 // One entry point for every combination: g_y given (t, g_loss null) or the BCE gradient formed inline (g_y null);
 // reduce == 0: g_w / g_b are not produced, the caller sums the rh_head_nblocks(B) x (K + 1) partial rows (rh_pack_grads).
@@ -629,7 +723,7 @@ extern "C" int rh_head_loss_bwd(const float* h, int64_t ldh, const float* w, con
 
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
-                         float* partial, void* stream, int reduce) {
+                         float* partial, void* stream, int reduce, const HeadBnArgs* bn) {
   RH_REQUIRE(h && w && y && g_h && g_z && (g_w || !reduce) && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
   RH_REQUIRE(B >= 1 && K >= 1 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
              "rh_head_bwd: K=%d unsupported (1 .. %d)", K, 4 * kHeadLanes * kHeadMaxV4);
@@ -637,6 +731,14 @@ static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const floa
   const int need = K < 4 ? 1 : (K / 4 + kHeadLanes - 1) / kHeadLanes;
   const dim3 grid(head_grid(B)), block(RH_BLOCK);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (bn != nullptr) {
+    a.bn_z = bn->z, a.bn_stat = bn->stat, a.bn_gamma = bn->gamma, a.bn_beta = bn->beta, a.bn_rng = bn->rng;
+    a.bn_ctr = bn->ctr, a.bn_partial = bn->partial, a.bn_p = bn->p, a.bn_relu = bn->relu;
+    RH_REQUIRE(need <= 4, RH_E_UNSUPPORTED, "rh_head_bwd_bn: K=%d too wide (max %d)", K, 4 * kHeadLanes * 4);
+    if (need <= 1) hipLaunchKernelGGL((head_bwd_kernel<1, true>), grid, block, 0, st, a);
+    else if (need <= 2) hipLaunchKernelGGL((head_bwd_kernel<2, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((head_bwd_kernel<4, true>), grid, block, 0, st, a);
+  } else
   if (need <= 1) hipLaunchKernelGGL(head_bwd_kernel<1>, grid, block, 0, st, a);
   else if (need <= 2) hipLaunchKernelGGL(head_bwd_kernel<2>, grid, block, 0, st, a);
   else if (need <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, grid, block, 0, st, a);

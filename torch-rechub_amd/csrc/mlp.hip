@@ -46,11 +46,7 @@ struct BnArgs {
 };
 
 static __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {
-  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed + ctr * 0xD1B54A32D192ED03ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  return rh_drop_hash(seed, ctr, idx);
 }
 
 // thread (rsub, c): column c of the tile, rows rsub, rsub+RS, ... of the chunk.  MODE 0: sums of (x-s), (x-s)^2 with
@@ -380,8 +376,12 @@ bool fused_path_ok(int B) { return (B + kFusedRows - 1) / kFusedRows <= kFusedMa
 
 // partial_rows > 0: a.partial already holds (sum, M2) per partial_rows-row slab (written by the GEMM in front)
 template <int MODE>
-void launch_fused(BnArgs a, hipStream_t s, int partial_rows = 0) {
-  if (partial_rows > 0) {
+void launch_fused(BnArgs a, hipStream_t s, int partial_rows = 0, int pre_chunks = 0) {
+  if (pre_chunks > 0) {  // backward: the partial rows exist already (any row partition: they are only summed)
+    a.rows_per_chunk = (a.B + pre_chunks - 1) / pre_chunks;
+    a.nchunks = pre_chunks;
+    a.bookkeep = 0;
+  } else if (partial_rows > 0) {
     a.rows_per_chunk = partial_rows;
     a.nchunks = (a.B + partial_rows - 1) / partial_rows;
     a.bookkeep = 0;  // the GEMM that wrote the partials advanced the dropout counter / num_batches_tracked
@@ -528,6 +528,25 @@ extern "C" int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, 
     hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
   RH_LAUNCH_CHECK("rh_bn_finalize_bwd");
+  return 0;
+}
+
+// The backward with the column sums (sum g1, sum g1 * xhat) ALREADY formed by the producer of dy (csrc/linear.hip: the
+// output head's backward writes them as nchunks_pre partial rows (2, C) each): one launch (finalize + apply).
+extern "C" int rh_bn_relu_dropout_bwd_pre(const float* h, const float* dy, int B, int C, const float* gamma,
+                                          const float* beta, float p_drop, const int64_t* rng, const int64_t* saved_ctr,
+                                          const float* partial, int nchunks_pre, float* stat, float* dx, float* dgamma,
+                                          float* dbeta, int relu, void* stream) {
+  RH_REQUIRE(h && dy && gamma && beta && rng && saved_ctr && partial && stat && dx && dgamma && dbeta, RH_E_BADARG,
+             "rh_bn_relu_dropout_bwd_pre: null pointer");
+  RH_REQUIRE(B >= 1 && C >= 1 && nchunks_pre >= 1 && nchunks_pre <= kFusedMaxChunks, RH_E_UNSUPPORTED,
+             "rh_bn_relu_dropout_bwd_pre: %d partial rows (max %d)", nchunks_pre, kFusedMaxChunks);
+  BnArgs a{};
+  a.h = h; a.dy = dy; a.out = dx; a.gamma = gamma; a.beta = beta; a.partial = const_cast<float*>(partial); a.stat = stat;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.rng = const_cast<int64_t*>(rng); a.saved_ctr = const_cast<int64_t*>(saved_ctr);
+  a.B = B; a.C = C; a.p_drop = p_drop; a.training = 1; a.relu = relu != 0;
+  launch_fused<1>(a, reinterpret_cast<hipStream_t>(stream), 0, nchunks_pre);
+  RH_LAUNCH_CHECK("rh_bn_relu_dropout_bwd_pre");
   return 0;
 }
 

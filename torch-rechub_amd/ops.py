@@ -705,6 +705,15 @@ class _BnReluDropoutFn(torch.autograd.Function):
         dx = torch.empty_like(h)
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
+        pre = getattr(ctx, "rh_pre", None)
+        ctx.rh_pre = None
+        if pre is not None and pre[0] == dy.data_ptr():
+            # dy is exactly the tensor the output head's backward produced (the head was the only consumer of this
+            # layer): its launch already summed (g1, g1 * xhat) per column -> finalize + apply only
+            _lib.call("rh_bn_relu_dropout_bwd_pre", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop,
+                      _p(_dropout_rng(dev)), _p(saved_ctr), _p(pre[1]), pre[2], _p(stat), _p(dx), _p(dgamma), _p(dbeta),
+                      1 if ctx.relu else 0, _stream())
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
         partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
         _lib.call("rh_bn_relu_dropout_bwd", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop, _p(_dropout_rng(dev)),
                   _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), 1 if ctx.relu else 0, _stream())
@@ -985,6 +994,11 @@ class _HeadFn(torch.autograd.Function):
         ctx.save_for_backward(h, weight, y)
         ctx.shapes = (None if e0 is None else e0.shape, None if e1 is None else e1.shape, bias is not None)
         ctx.params = (weight, bias)
+        # h straight out of a BatchNorm1d + ReLU + Dropout layer (the MLP's last hidden layer): the backward below then
+        # also forms that layer's BatchNorm-backward column sums (one statistics launch less per step)
+        node = h.grad_fn
+        ctx.bn_node = node if (node is not None and type(node).__name__ == "_BnReluDropoutFnBackward" and
+                               os.environ.get("RECHUB_HEAD_BN", "1") == "1") else None
         return y
 
     @staticmethod
@@ -1010,8 +1024,17 @@ class _HeadFn(torch.autograd.Function):
             t, gl, g_y = ctx.fused_t, g_loss[0], None
         else:
             g_y = g_y.contiguous()
-        _lib.call("rh_head_bwd_ex", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_h), _p(g_z),
-                  _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _stream())
+        bn = ctx.bn_node
+        if bn is not None and K % 4 == 0 and K <= 256 and nblk <= 128 and h.stride(0) == K:
+            z, gamma, beta, stat, saved_ctr = bn.saved_tensors
+            bn_partial = torch.empty((nblk, 2, K), dtype=torch.float32, device=dev)
+            _lib.call("rh_head_bwd_bn", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_h),
+                      _p(g_z), _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _p(z), _p(stat), _p(gamma), _p(beta),
+                      float(bn.p_drop), _p(_dropout_rng(dev)), _p(saved_ctr), 1 if bn.relu else 0, _p(bn_partial), _stream())
+            bn.rh_pre = (g_h.data_ptr(), bn_partial, nblk)  # valid only if the layer's upstream gradient IS this g_h
+        else:
+            _lib.call("rh_head_bwd_ex", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_h),
+                      _p(g_z), _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _stream())
         if defer:
             g_w = deferred.offer(wp, partial.data_ptr(), nblk, K + 1, K, lambda: partial[:, :K].sum(0).view_as(weight),
                                  partial)
