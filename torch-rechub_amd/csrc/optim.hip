@@ -408,6 +408,10 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
         const int kj = s_key[j];
         rank += (kj > lag || (kj == lag && j < slot)) ? 1 : 0;
       }
+      // wavefront w of every workgroup lands on the same SIMD of its CU: rotate the sorted order by a workgroup-dependent
+      // number of wavefronts, or one SIMD would collect the longest-lag wavefront of every workgroup
+      constexpr int kPerWave = RH_WAVE / LPR;
+      rank = (rank + (bx % (LPP / kPerWave > 0 ? LPP / kPerWave : 1)) * kPerWave) % LPP;
       if (q == 0) {
         s_row[rank] = r;
         s_old[rank] = act ? old : t;  // t = nothing to do
