@@ -377,6 +377,15 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   const int lane = threadIdx.x % RH_WAVE;
   const int64_t b0 = (int64_t)bx * a.spb;
   const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
+  // REFRESH replays up to K steps per row: the per-step (A, E) ring entries come from LDS, as in the sweep.  Read from
+  // global memory inside the replay loop they were one dependent L2 round trip per replayed step (the compiler emits a
+  // vector load + s_waitcnt vmcnt per iteration): the pass was bound by that latency, 26.8 us in the DeepFM step.
+  __shared__ float ring_t[REFRESH ? 2 * kMaxRing : 2];
+  if (REFRESH) {
+    for (int i = threadIdx.x; i < 2 * (a.ring_mask + 1); i += RH_BLOCK) ring_t[i] = a.ring[i];
+    __syncthreads();
+  }
+  const float* ring = REFRESH ? ring_t : a.ring;
   for (int64_t base = b0; base < b1; base += LPP) {  // uniform trip count: the claim is broadcast by shuffle
     const int64_t b = base + slot;
     const bool ok = b < b1;
@@ -436,7 +445,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       const int nxt = wave_min_uniform(first > j ? first : t);
       if (first <= j) {
         for (int jj = j; jj < nxt; ++jj) {
-          const float A = a.ring[2 * (jj & a.ring_mask)], E = a.ring[2 * (jj & a.ring_mask) + 1];
+          const float A = ring[2 * (jj & a.ring_mask)], E = ring[2 * (jj & a.ring_mask) + 1];
           adam_f4_zero_g(P, M, V, h, A, E);
         }
       }
@@ -793,7 +802,8 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
                                     void* stream) {
   RH_REQUIRE(ldesc && field_table && idesc && hyper && ring, RH_E_BADARG, "rh_adam_lazy_touched: null pointer");
   RH_REQUIRE(T >= 1 && F >= 1 && F <= 65535 && B >= 0, RH_E_BADARG, "rh_adam_lazy_touched: bad shape");
-  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0, RH_E_BADARG, "rh_adam_lazy_touched: ring_size");
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
+             "rh_adam_lazy_touched: ring_size must be a power of two <= %d", kMaxRing);
   if (B == 0) return 0;
   int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
   LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
