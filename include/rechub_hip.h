@@ -268,6 +268,14 @@ int rh_din_pool_bwd(const float* hist, int64_t hist_stride, const float* w, cons
 int rh_prelu_nblocks(int64_t n);
 int rh_prelu_fwd(const float* x, const float* slope, int64_t n, float* out, void* stream);
 int rh_prelu_bwd(const float* x, const float* g, const float* slope, int64_t n, float* gx, float* partial, void* stream);
+/* In-batch negatives without the (B, C) score matrix (csrc/match.hip); replaces, for RANDOM negatives,
+ * `scores = user @ item.T` + `gather_inbatch_logits(scores, neg_indices)` of trainers/match_trainer.py:118-138 /
+ * utils/match.py:148-153 and their autograd:  logits[i, 0] = u_i . v_(row0 + i),  logits[i, 1 + k] = u_i . v_neg[i, k];
+ * bwd: g_u (B, D) written, g_v (C, D) accumulated with float atomics into a buffer the caller zeroed.  D <= 1024. */
+int rh_inbatch_logits_fwd(const float* u, int64_t ldu, const float* v, int64_t ldv, const int64_t* neg, int B, int C, int D,
+                          int K, int row0, float* logits, int32_t* err_flag, void* stream);
+int rh_inbatch_logits_bwd(const float* u, int64_t ldu, const float* v, int64_t ldv, const int64_t* neg, const float* g, int B,
+                          int C, int D, int K, int row0, float* g_u, float* g_v, void* stream);
 int rh_din_att_l1_supported(int D, int N);
 int rh_din_att_l1_chunk_rows(int64_t rows);
 int rh_din_att_l1_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* W,

@@ -1529,3 +1529,29 @@ def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monk
     for a, b in zip(grads["1"], grads["0"]):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-4 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("B,C,row0,D,K", [(4096, 4096, 0, 64, 20), (300, 900, 300, 16, 7), (5, 5, 0, 100, 4),
+                                           (64, 64, 0, 300, 1), (33, 40, 7, 8, 0)])
+def test_inbatch_logits_without_the_score_matrix(B, C, row0, D, K):
+    """ops.inbatch_logits (csrc/match.hip) == gather_inbatch_logits(user @ item.T, neg_indices) of the reference
+    (utils/match.py:148-153), values and both gradients; rows of a rank's slice of a global batch (row0, C > B) included."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.utils.match import gather_inbatch_logits
+    g = torch.Generator().manual_seed(B + D)
+    u = torch.randn(B, D, generator=g).to(dev())
+    v = torch.randn(C, D, generator=g).to(dev())
+    neg = torch.randint(0, C, (B, K), generator=g).to(dev())
+    gl = torch.randn(B, 1 + K, generator=g).to(dev())
+    assert ops.inbatch_logits_ok(u, v)
+    u1, v1 = u.clone().requires_grad_(), v.clone().requires_grad_()
+    out = ops.inbatch_logits(u1, v1, neg, row0)
+    out.backward(gl)
+    u2, v2 = u.double().requires_grad_(), v.double().requires_grad_()
+    ref = gather_inbatch_logits(u2 @ v2.t(), neg, row_offset=row0)
+    ref.backward(gl.double())
+    torch.cuda.synchronize()
+    ops.check_errors()
+    for a, b, what in ((out, ref, "logits"), (u1.grad, u2.grad, "g_user"), (v1.grad, v2.grad, "g_item")):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a.double() - b).abs().max()) <= 2e-5 * scale, what

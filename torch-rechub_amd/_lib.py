@@ -66,6 +66,9 @@ SIGNATURES = {
     "rh_din_att_input_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "rh_din_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_din_pool_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_inbatch_logits_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_inbatch_logits_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
+                              c_ptr],
     "rh_prelu_nblocks": [c_i64],
     "rh_prelu_fwd": [c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_prelu_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr],

@@ -7,7 +7,7 @@ INC=../../include
 FLAGS="--offload-arch=gfx950 -mcode-object-version=5 -munsafe-fp-atomics -O3 -std=c++17 -fPIC -I$INC -I. -Wall -Wno-unused-function"
 mkdir -p _build
 pids=()
-for src in api.cpp embed.hip cross.hip optim.hip data.hip fm.hip seqpool.hip mlp.hip din.hip dinmlp.hip crossmix.hip moe.hip linear.hip gemm.hip shard.hip augru.hip; do
+for src in api.cpp embed.hip cross.hip optim.hip data.hip match.hip fm.hip seqpool.hip mlp.hip din.hip dinmlp.hip crossmix.hip moe.hip linear.hip gemm.hip shard.hip augru.hip; do
   [ -f "$src" ] || continue
   obj="_build/${src%.*}.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ $INC/rechub_hip.h -nt "$obj" ]; then

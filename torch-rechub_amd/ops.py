@@ -1652,6 +1652,49 @@ def gru(gru_mod, x):
 _sample_rng = {}
 
 
+class _InbatchLogitsFn(torch.autograd.Function):
+    """(B, 1 + K) in-batch logits straight from the tower outputs (csrc/match.hip): no (B, C) score matrix."""
+
+    @staticmethod
+    def forward(ctx, u, v, neg, row0):
+        require_hip(u, v, neg)
+        if u.stride(1) != 1:
+            u = u.contiguous()
+        if v.stride(1) != 1:
+            v = v.contiguous()
+        neg = neg.contiguous()
+        B, D = u.shape
+        C, K = v.shape[0], neg.shape[1]
+        logits = torch.empty((B, 1 + K), dtype=torch.float32, device=u.device)
+        _lib.call("rh_inbatch_logits_fwd", _p(u), u.stride(0), _p(v), v.stride(0), _p(neg), B, C, D, K, int(row0),
+                  _p(logits), _p(err_flag(u.device)), _stream())
+        ctx.save_for_backward(u, v, neg)
+        ctx.row0 = int(row0)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        u, v, neg = ctx.saved_tensors
+        B, D = u.shape
+        C, K = v.shape[0], neg.shape[1]
+        g = g.contiguous()
+        g_u = torch.empty((B, D), dtype=torch.float32, device=u.device)
+        g_v = torch.zeros((C, D), dtype=torch.float32, device=u.device)
+        _lib.call("rh_inbatch_logits_bwd", _p(u), u.stride(0), _p(v), v.stride(0), _p(neg), _p(g), B, C, D, K, ctx.row0,
+                  _p(g_u), _p(g_v), _stream())
+        return g_u, g_v, None, None
+
+
+def inbatch_logits_ok(u, v):
+    return (u.is_cuda and v.is_cuda and u.dtype == torch.float32 and v.dtype == torch.float32 and u.dim() == 2 and
+            v.dim() == 2 and u.shape[1] == v.shape[1] and 1 <= u.shape[1] <= 1024 and u.shape[0] >= 1)
+
+
+def inbatch_logits(u, v, neg, row0=0):
+    """logits[i, 0] = u_i . v_(row0 + i), logits[i, 1 + k] = u_i . v_neg[i, k]  (== gather_inbatch_logits(u @ v.T, neg))."""
+    return _InbatchLogitsFn.apply(u, v, neg, row0)
+
+
 def inbatch_sample(batch_size, k, device, seed=None, cols=None, row0=0):
     """(B, K) int64: per row K distinct in-batch negatives (never the row itself), uniformly at random; hipGraph-safe.
 

@@ -14,7 +14,7 @@ import tqdm
 
 from .. import ops, sharding
 from ..basic.loss_func import BPRLoss
-from ..utils.match import gather_inbatch_logits, inbatch_negative_sampling
+from ..utils.match import gather_inbatch_logits, inbatch_negative_sampling, random_inbatch_negatives
 from .ctr_trainer import CTRTrainer
 
 
@@ -87,11 +87,22 @@ class MatchTrainer(CTRTrainer):
             if self.global_negatives and self.dp is not None:
                 row0 = self.dp.rank * item_embedding.size(0)
                 item_embedding = sharding.gather_rows(item_embedding, self.dp.group)
-            scores = torch.matmul(user_embedding, item_embedding.t())
-            neg_indices = inbatch_negative_sampling(scores, neg_ratio=self.in_batch_neg_ratio,
-                                                    hard_negative=self.hard_negative, generator=self._sampler_generator,
-                                                    row_offset=row0, stream=self.sampler_stream)
-            logits = gather_inbatch_logits(scores, neg_indices, row_offset=row0)
+            if (not self.hard_negative and ops.inbatch_logits_ok(user_embedding, item_embedding) and
+                    os.environ.get("RECHUB_INBATCH_DIRECT", "1") == "1"):
+                # random negatives read 1 + K of a row's scores: the wanted dot products straight from the tower outputs
+                # (csrc/match.hip), no (B, C) score matrix and no (B, C)-sized gradients
+                neg_indices = random_inbatch_negatives(user_embedding.size(0), item_embedding.size(0),
+                                                       user_embedding.device, neg_ratio=self.in_batch_neg_ratio,
+                                                       generator=self._sampler_generator, row_offset=row0,
+                                                       stream=self.sampler_stream)
+                logits = ops.inbatch_logits(user_embedding, item_embedding, neg_indices, row0)
+            else:
+                scores = torch.matmul(user_embedding, item_embedding.t())
+                neg_indices = inbatch_negative_sampling(scores, neg_ratio=self.in_batch_neg_ratio,
+                                                        hard_negative=self.hard_negative,
+                                                        generator=self._sampler_generator, row_offset=row0,
+                                                        stream=self.sampler_stream)
+                logits = gather_inbatch_logits(scores, neg_indices, row_offset=row0)
             if self.mode == 1:
                 loss = self.criterion(logits[:, 0], logits[:, 1:], in_batch_neg=True)
             else:

@@ -55,7 +55,17 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
     row_offset + i and its negatives come from the other C - 1 columns."""
     if scores.dim() != 2:
         raise ValueError(f"inbatch_negative_sampling expects 2D scores, got shape {tuple(scores.shape)}")
-    batch_size, n_cols = scores.size(0), scores.size(1)
+    return _sample(scores.size(0), scores.size(1), scores.device, scores, neg_ratio, hard_negative, generator, row_offset,
+                   stream)
+
+
+def random_inbatch_negatives(batch_size, n_cols, device, neg_ratio=None, generator=None, row_offset=0, stream=None):
+    """The random branch of ``inbatch_negative_sampling`` for a (batch_size, n_cols) score matrix that is never formed
+    (ops.inbatch_logits computes only the 1 + K wanted dot products per row): same streams, same indices."""
+    return _sample(batch_size, n_cols, device, None, neg_ratio, False, generator, row_offset, stream)
+
+
+def _sample(batch_size, n_cols, device, scores, neg_ratio, hard_negative, generator, row_offset, stream):
     if n_cols <= 1:
         raise ValueError("In-batch negative sampling requires batch_size > 1")
     if row_offset < 0 or row_offset + batch_size > n_cols:
@@ -63,14 +73,14 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
     max_neg = n_cols - 1
     if neg_ratio is None or neg_ratio <= 0 or neg_ratio > max_neg:
         neg_ratio = max_neg
-    device = scores.device
-    own = _own_mask(batch_size, n_cols, row_offset, device)
+    own = _own_mask(batch_size, n_cols, row_offset, device) if (hard_negative or n_cols > 65536 or
+                                                                 not str(device).startswith("cuda")) else None
     if hard_negative:
         keys = scores.detach().masked_fill(own, float("-inf"))
         return torch.topk(keys, k=neg_ratio, dim=1).indices
     if stream not in (None, "fast", "reference"):
         raise ValueError("stream must be 'fast' or 'reference'")
-    if stream == "reference" or not scores.is_cuda:
+    if stream == "reference" or not str(device).startswith("cuda"):
         return _reference_stream(batch_size, n_cols, row_offset, neg_ratio, device, generator)
     if n_cols <= 65536:
         # HIP sampler (Floyd's algorithm per row, counter-based RNG): one launch, replayable from a hipGraph
@@ -79,7 +89,7 @@ def inbatch_negative_sampling(scores, neg_ratio=None, hard_negative=False, gener
         if n_cols == batch_size:
             return ops.inbatch_sample(batch_size, neg_ratio, device, seed)
         return ops.inbatch_sample(batch_size, neg_ratio, device, seed, cols=n_cols, row0=row_offset)
-    keys = torch.rand(tuple(scores.shape), device=device, generator=generator).masked_fill(own, -1.0)
+    keys = torch.rand((batch_size, n_cols), device=device, generator=generator).masked_fill(own, -1.0)
     return torch.topk(keys, k=neg_ratio, dim=1).indices  # > 65536 columns: top-k of i.i.d. uniform keys (same set law)
 
 
