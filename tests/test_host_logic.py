@@ -235,6 +235,19 @@ def test_inbatch_random_stream_is_the_references_bit_for_bit():
         part = inbatch_negative_sampling(torch.zeros(3, 6), neg_ratio=3, generator=torch.Generator().manual_seed(5),
                                          row_offset=3 * r)
         assert torch.equal(part, whole[3 * r:3 * r + 3])
+    # the form without a score matrix (the trainer's default for random negatives: ops.inbatch_logits needs only the
+    # indices): same stream, same indices, same argument checks
+    from torch_rechub_amd.utils.match import random_inbatch_negatives
+    for B, C, row0, k in ((7, 7, 0, 3), (3, 6, 3, 2), (5, 5, 0, None)):
+        a = inbatch_negative_sampling(torch.zeros(B, C), neg_ratio=k, generator=torch.Generator().manual_seed(9),
+                                      row_offset=row0)
+        b = random_inbatch_negatives(B, C, torch.device("cpu"), neg_ratio=k, generator=torch.Generator().manual_seed(9),
+                                     row_offset=row0)
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        random_inbatch_negatives(1, 1, torch.device("cpu"))
+    with pytest.raises(ValueError):
+        random_inbatch_negatives(3, 4, torch.device("cpu"), row_offset=2)
 
 
 def test_inbatch_random_stream_against_the_live_reference():
