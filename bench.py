@@ -532,7 +532,7 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     sweep_bytes = step_bytes = 0
     for p_ in (opt._tables if hasattr(opt, "_tables") else []):
         rows, d_ = p_.shape
-        k_ = 1 if (opt.lazy_k <= 1 or rows <= opt.lazy_small_rows) else opt.lazy_k
+        k_ = opt.table_k(p_)
         win = -(-rows // k_)
         sweep_bytes += win * (d_ * 4 * (7 if k_ == 1 else 6) + 8)
         # merged launch (rh_adam_lazy_step): the sweep also reads the gradient row of every window row, and the rows
