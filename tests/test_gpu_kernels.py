@@ -541,7 +541,7 @@ def test_batch_gather_vs_oracle():
     assert int(dl.pos.item()) == 0  # wrapped
 
 
-def _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed, flush_every=None):
+def _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed, flush_every=None, nb=97):
     """Drive a dense TableAdam and a lazy one with identical lookup-style gradients; returns both after a flush."""
     from torch_rechub_amd import ops
     from torch_rechub_amd.optim import TableAdam
@@ -551,7 +551,6 @@ def _lazy_vs_dense(lazy_k, small_rows, steps, shapes, seed, flush_every=None):
     Bp = [torch.nn.Parameter(t.clone().to(dev())) for t in init]
     dense = TableAdam(A, table_params=A, lr=1e-2, weight_decay=1e-3)
     lazy = TableAdam(Bp, table_params=Bp, lr=1e-2, weight_decay=1e-3, lazy_k=lazy_k, lazy_small_rows=small_rows)
-    nb = 97
     for t in range(steps):
         idx_cols = []
         for i, s in enumerate(shapes):
@@ -593,6 +592,21 @@ def test_adam_lazy_is_bit_identical_to_dense(lazy_k, small_rows, steps, flush_ev
     for last in lazy._t_last:
         assert torch.all(last == steps)  # flush brought every row to the current step
     assert int(lazy._t_step.item()) == steps
+
+
+def test_adam_lazy_moves_heavily_looked_up_tables_to_dense_stepping():
+    """Default placement (no explicit lazy_small_rows): at the first step a table whose rows are looked up often enough
+    (rows <= 4 x lookups per step; 1500 lookups here) is stepped densely like the small tables, the others stay lazy; the
+    result is the dense optimizer's either way, bit for bit."""
+    shapes = [(300, 16), (6000, 16), (6001, 16), (40000, 16)]
+    A, Bp, dense, lazy = _lazy_vs_dense(8, None, 19, shapes, seed=3, nb=1500)
+    assert [lazy.table_k(p) for p in Bp] == [1, 1, 8, 8] and lazy.lazy_small_rows == 4096 and lazy.lazy_dense_ratio == 4.0
+    for a, b in zip(A, Bp):
+        assert torch.equal(a.detach(), b.detach())
+        assert torch.equal(dense.state[a]["exp_avg_sq"], lazy.state[b]["exp_avg_sq"])
+    # an explicit lazy_small_rows is the whole rule
+    _, Bq, _, lazy2 = _lazy_vs_dense(8, 16, 3, shapes, seed=3, nb=1500)
+    assert [lazy2.table_k(p) for p in Bq] == [8, 8, 8, 8]
 
 
 def test_adam_lazy_rows_lag_at_most_k_steps():
