@@ -412,6 +412,7 @@ unsigned apply_grid(int64_t n) {
 
 // rows per partial chunk on the three-launch path: 16 for batch-sized inputs (enough workgroups to fill the chip), growing
 // with B so that the finalize launch never has more than ~512 chunks per column to combine (DIN: B * L = 409600 rows)
+static void launch_finalize_fwd(const BnArgs& a, hipStream_t s);
 static int big_chunk_rows(int B) {
   int r = kRowsPerChunk;
   while ((B + r - 1) / r > 512) r *= 2;
@@ -461,10 +462,20 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
     ap.bookkeep = 0;  // the finalize launch below does it
     hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, ap, CW);
   }
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
+  launch_finalize_fwd(a, s);
   hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(apply_grid((int64_t)B * C)), dim3(RH_BLOCK), 0, s, a);
   RH_LAUNCH_CHECK("rh_bn_relu_dropout_fwd");
   return 0;
+}
+
+// Forward finalize (Chan combination of the per-chunk partials): 32 columns x 8 chunk groups per workgroup for the short
+// lists of batch-sized inputs; long lists (DIN: 400 - 800 chunks of the 409 600 attention rows) with 8 workgroups walking
+// ~100 dependent iterations each took 22 - 29 us -- 4 columns x 64 chunk groups then (C / 4 workgroups).
+static void launch_finalize_fwd(const BnArgs& a, hipStream_t s) {
+  if (a.nchunks > 256)
+    hipLaunchKernelGGL((bn_finalize_kernel<0, 4>), dim3((unsigned)((a.C + 3) / 4)), dim3(RH_BLOCK), 0, s, a);
+  else
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((a.C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
 }
 
 // Statistics only (no apply): for the activations that fold the normalisation into their own pass (csrc/din.hip: Dice).
@@ -490,7 +501,7 @@ extern "C" int rh_bn_stats_fwd(const float* h, int B, int C, const float* gamma,
   const dim3 pg((unsigned)((C + kSlabCols - 1) / kSlabCols), (unsigned)a.nchunks);
   hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(RH_BLOCK), 0, s, a, kSlabCols);
   a.bookkeep = 2;  // count the batch; there is no dropout stream to advance
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0, s, a);
+  launch_finalize_fwd(a, s);
   RH_LAUNCH_CHECK("rh_bn_stats_fwd");
   return 0;
 }
@@ -509,8 +520,7 @@ extern "C" int rh_bn_stats_from_partial(const float* partial, int rows_per_chunk
   a.rows_per_chunk = rows_per_chunk;
   a.nchunks = (B + rows_per_chunk - 1) / rows_per_chunk;
   a.bookkeep = 2;  // count the batch; there is no dropout stream to advance
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
-                     reinterpret_cast<hipStream_t>(stream), a);
+  launch_finalize_fwd(a, reinterpret_cast<hipStream_t>(stream));
   RH_LAUNCH_CHECK("rh_bn_stats_from_partial");
   return 0;
 }
