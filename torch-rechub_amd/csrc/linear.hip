@@ -473,7 +473,7 @@ void launch_colsum(const float* a, int rows, int cols, float* out, int split, fl
 }
 
 int head_grid(int B) {
-  int g = (B + kHeadRows * 4 - 1) / (kHeadRows * 4);  // >= 4 rows per lane group
+  int g = (B + kHeadRows * 2 - 1) / (kHeadRows * 2);  // >= 2 rows per lane group (4: 64 workgroups at B = 4096, a quarter of the CUs)
   if (g > 256) g = 256;
   if (g < 1) g = 1;
   return g;
