@@ -651,6 +651,12 @@ def main():
                 # configuration (2*FETCH + WRITE, gfx950 correction, calibrated on rh_adam_dense): profiles/r01_pmc_traffic.md
                 roofline["traffic"] = pmc_traffic
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
+            if dominant == "rh_adam_lazy_step" and args.lazy_k == 64 and args.vocab_scale == 1.0 and best is None and B == 4096:
+                # the merged launch under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py,
+                # 2 * FETCH + WRITE with the gfx950 correction calibrated on rh_adam_dense): 2 * 83 842 + 119 775 KiB
+                roofline["traffic"] = 294.4e6
+                roofline["traffic_source"] = ("profiles/r02_pmc_4096_{FETCH,WRITE}_SIZE.txt (rocprofv3 --pmc, separate passes; "
+                                              "not re-collected by bench.py)")
             if dominant in ("rh_adam_lazy_sweep", "rh_adam_lazy_step"):
                 # The kernel's own bound is the replay arithmetic.  In the steady state every table element advances
                 # lazy_k steps per lazy_k launches, so one launch replays AT MOST total_elems element-steps (the rows the
