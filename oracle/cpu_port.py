@@ -1,7 +1,7 @@
 """CPU port (plain eager PyTorch, fp32) of the reference's DeepFM / DCN training step — the ``cpu_baseline`` that
 ``bench.py`` times on the GPU box's host cores, where /root/reference does not exist.
 
-TEST / BASELINE INFRASTRUCTURE ONLY: never imported by ``torch-rechub_amd``.
+TEST / BASELINE INFRASTRUCTURE ONLY: never imported by ``torch_rechub_amd``.
 
 It restates the reference's op chain one-for-one, so that its cost profile is the reference's:
   * one ``nn.Embedding`` per sparse feature, looked up per feature and concatenated

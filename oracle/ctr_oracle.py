@@ -1,6 +1,6 @@
 """CPU oracle (numpy) for the CTR hot path of datawhalechina/torch-rechub v0.8.0.
 
-TEST INFRASTRUCTURE ONLY.  Nothing under ``torch-rechub_amd/`` may import this package; only ``tests/``,
+TEST INFRASTRUCTURE ONLY.  Nothing under ``torch_rechub_amd/`` may import this package; only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, as the checker.
 
 Every function restates one reference op chain (citations are ``path:line`` under /root/reference) in

@@ -1,5 +1,5 @@
 /* Plain-C restatement of the integer / index paths of the CTR hot path -- a second, independent checker next to the
- * numpy oracle (oracle/ctr_oracle.py).  TEST INFRASTRUCTURE ONLY: nothing under torch-rechub_amd/ may link or load it.
+ * numpy oracle (oracle/ctr_oracle.py).  TEST INFRASTRUCTURE ONLY: nothing under torch_rechub_amd/ may link or load it.
  *
  *   o_embedding_gather   EmbeddingLayer.forward's per-field row gather, torch_rechub/basic/layers.py:83,110 (pure copy)
  *   o_batch_gather       TorchDataset.__getitem__ + default_collate over a permutation, torch_rechub/utils/data.py:14-25,61-83

@@ -1,4 +1,4 @@
-// Standalone timing of csrc/gemm.hip (no torch):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../torch-rechub_amd/csrc [-DRH_PROBE=1|2] -x hip gemm_probe.cpp -o gemm_probe
+// Standalone timing of csrc/gemm.hip (no torch):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../torch_rechub_amd/csrc [-DRH_PROBE=1|2] -x hip gemm_probe.cpp -o gemm_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
