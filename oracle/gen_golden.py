@@ -182,6 +182,13 @@ def gen_layers(rh):
     print("layers.npz", len(out), "arrays")
 
 
+# attention MLP widths per DIN fixture.  "din_wide" is the reference's own configuration
+# (examples/ranking/run_amazon_electronics.py:57: attention_mlp_params={"dims": [256, 128]}), the shape whose first layer
+# runs on csrc/dinmlp.hip (register-built operand, BatchNorm statistics in the epilogue, tile-GEMM input gradient);
+# "din_wide64" is the narrowest width that path accepts, with a single hidden layer.
+DIN_ATTENTION_DIMS = {"din_wide": [256, 128], "din_wide64": [64], "din_wide_softmax": [128, 64]}
+
+
 def build_model(rh, cfg):
     from torch_rechub.basic.features import DenseFeature, SequenceFeature, SparseFeature
     from torch_rechub.models.ranking import DCN, DIN, DCNv2, DeepFM, WideDeep
@@ -206,7 +213,8 @@ def build_model(rh, cfg):
         tgt = [SparseFeature("target_item", vocab_size=50, embed_dim=D, padding_idx=0),
                SparseFeature("target_cate", vocab_size=12, embed_dim=D, padding_idx=0)]
         model = DIN(feats, hist, tgt, mlp_params={"dims": [32, 16], "dropout": 0.0},
-                    attention_mlp_params={"dims": [16, 8], "use_softmax": cfg.endswith("softmax")})
+                    attention_mlp_params={"dims": DIN_ATTENTION_DIMS.get(cfg, [16, 8]),
+                                          "use_softmax": cfg.endswith("softmax")})
         return model, {"features": feats, "history_features": hist, "target_features": tgt}
     if cfg in ("bst", "dien"):  # sequence models over the same (history, target) feature pairs as DIN
         feats = [SparseFeature("user_id", vocab_size=30, embed_dim=D)]
@@ -381,6 +389,43 @@ def gen_augru(rh):
     print("augru.npz", len(out), "arrays")
 
 
+def gen_au_wide(rh):
+    """ActivationUnit of the UNMODIFIED reference (models/ranking/din.py:58-93) at the widths its own example uses
+    (dims [256, 128], examples/ranking/run_amazon_electronics.py:57) and at [64], in TRAIN mode (BatchNorm on the batch
+    statistics of the B*L rows, pads included: SURVEY Q6): output, and the gradients of a random linear functional with
+    respect to history, target and every parameter.  Kept in its own file so layers.npz stays byte-identical."""
+    from torch_rechub.models.ranking.din import ActivationUnit
+    torch.manual_seed(SEED + 11)
+    g = torch.Generator().manual_seed(SEED + 12)
+    out = {}
+    for tag, D, B, L, dims, sm in (("w256", 16, 37, 9, [256, 128], False), ("w64", 16, 21, 5, [64], False),
+                                   ("w128sm", 8, 19, 6, [128, 64], True), ("w192d4", 4, 33, 3, [192, 64], False)):
+        au = ActivationUnit(D, dims=dims, activation="dice", use_softmax=sm)
+        au.train()
+        for n, p in au.named_parameters():
+            if n.endswith("alpha"):
+                with torch.no_grad():
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+        hist = (torch.randn(B, L, D, generator=g) * 0.7).requires_grad_(True)
+        tgt = (torch.randn(B, D, generator=g) * 0.7).requires_grad_(True)
+        sd0 = {n: t.clone() for n, t in au.state_dict().items()}
+        y = au(hist, tgt)
+        G = torch.randn(y.shape, generator=g)
+        (y * G).sum().backward()
+        k = f"{tag}."
+        out[k + "dims"], out[k + "softmax"] = np.array(dims), np.array(int(sm))
+        out[k + "hist"], out[k + "tgt"], out[k + "out"], out[k + "G"] = npy(hist), npy(tgt), npy(y), npy(G)
+        out[k + "g_hist"], out[k + "g_tgt"] = npy(hist.grad), npy(tgt.grad)
+        for n, t in sd0.items():
+            out[k + "sd0." + n] = npy(t)
+        for n, t in au.state_dict().items():  # running statistics after the one training forward
+            out[k + "sd1." + n] = npy(t)
+        for n, p in au.named_parameters():
+            out[k + "grad." + n] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, "au_wide.npz"), **out)
+    print("au_wide.npz", len(out), "arrays")
+
+
 MTL_CONFIGS = ["shared_bottom", "esmm", "mmoe", "mmoe_uwl", "ple", "aitm"]
 
 
@@ -488,7 +533,7 @@ def gen_inbatch(rh):
 
 
 CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-           "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
+           "din_softmax", "din_wide", "din_wide64", "din_wide_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
@@ -500,6 +545,8 @@ if __name__ == "__main__":
         gen_augru(rh)
     if not only or "inbatch" in only:
         gen_inbatch(rh)
+    if not only or "au_wide" in only:
+        gen_au_wide(rh)
     for cfg in CONFIGS:
         if not only or cfg in only:
             gen_model(rh, cfg)

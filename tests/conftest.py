@@ -25,7 +25,11 @@ def layers_golden():
 
 
 MODEL_CONFIGS = ["deepfm_tutorial", "deepfm_criteo", "widedeep", "dcn", "dcnv2_mix", "dcnv2_full_stacked", "din",
-                 "din_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
+                 "din_softmax", "din_wide", "din_wide64", "din_wide_softmax", "dssm", "afm", "fibinet", "fibinet_each", "autoint", "edcn", "edcn_attention", "bst", "dien"]
+# attention MLP widths per DIN fixture (oracle/gen_golden.py::DIN_ATTENTION_DIMS).  The "wide" ones are the shapes whose
+# first attention layer runs on csrc/dinmlp.hip -- "din_wide" = the reference's own [256, 128]
+# (examples/ranking/run_amazon_electronics.py:57).
+DIN_ATTENTION_DIMS = {"din_wide": [256, 128], "din_wide64": [64], "din_wide_softmax": [128, 64]}
 AUX_LOSS_CONFIGS = {"dien"}  # forward returns (prediction, weighted auxiliary loss): CTRTrainer(loss_mode=False)
 
 
@@ -75,7 +79,8 @@ def build_amd_model(cfg, groups):
     if cfg.startswith("din"):
         return DIN(groups["features"], groups["history_features"], groups["target_features"],
                    mlp_params={"dims": [32, 16], "dropout": 0.0},
-                   attention_mlp_params={"dims": [16, 8], "use_softmax": cfg.endswith("softmax")})
+                   attention_mlp_params={"dims": DIN_ATTENTION_DIMS.get(cfg, [16, 8]),
+                                         "use_softmax": cfg.endswith("softmax")})
     if cfg.startswith("deepfm"):
         return DeepFM(groups["deep_features"], groups["fm_features"], mlp)
     if cfg == "widedeep":

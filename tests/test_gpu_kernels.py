@@ -1474,6 +1474,51 @@ def test_activation_unit_first_layer_on_register_built_operand(B, L, D, dims, so
     same(out_e, ref_e, "attention output (eval)")
 
 
+@pytest.mark.parametrize("tag", ["w256", "w64", "w128sm", "w192d4"])
+def test_activation_unit_wide_matches_reference_fixture_through_fused_first_layer(tag, monkeypatch):
+    """The path configs[3] runs -- first attention Linear on the register-built operand (csrc/dinmlp.hip), BatchNorm
+    statistics from its epilogue (rh_bn_stats_from_partial), tile-GEMM input gradient -- against the UNMODIFIED
+    reference ActivationUnit in train mode (tests/golden/au_wide.npz, oracle/gen_golden.py::gen_au_wide; reference
+    models/ranking/din.py:58-93 at the widths of examples/ranking/run_amazon_electronics.py:57): output, g_history,
+    g_target, every parameter gradient, and the BatchNorm running statistics after the forward."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.models.ranking.din import ActivationUnit
+    from conftest import load_golden
+    g = load_golden("au_wide.npz")
+    k = tag + "."
+    dims, sm = [int(v) for v in g[k + "dims"]], bool(int(g[k + "softmax"]))
+    hist = torch.from_numpy(g[k + "hist"]).to(dev()).requires_grad_()
+    tgt = torch.from_numpy(g[k + "tgt"]).to(dev()).requires_grad_()
+    au = ActivationUnit(hist.shape[2], dims=dims, activation="dice", use_softmax=sm)
+    au.load_state_dict({n[len(k + "sd0."):]: torch.from_numpy(g[n]) for n in g.files if n.startswith(k + "sd0.")})
+    au = au.to(dev()).train()
+    assert ops.din_att_l1_ok(hist, tgt, au.attention.mlp[0]), "fixture must reach the fused first layer"
+    calls = []
+    real = ops.din_att_l1
+    monkeypatch.setattr(ops, "din_att_l1", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    out = au(hist, tgt)
+    out.backward(torch.from_numpy(g[k + "G"]).to(dev()))
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert calls, "the fused first layer (csrc/dinmlp.hip) did not run"
+    close(out, g[k + "out"], rtol=1e-5, atol_scale=2e-6, what=f"{tag}: attention output")
+    close(hist.grad, g[k + "g_hist"], rtol=1e-4, atol_scale=1e-5, what=f"{tag}: g_history")
+    close(tgt.grad, g[k + "g_tgt"], rtol=1e-4, atol_scale=1e-5, what=f"{tag}: g_target")
+    # a Linear bias in front of BatchNorm has the exact gradient 0 (rounding noise on both sides): every parameter is
+    # compared on the scale of the largest gradient of the unit
+    gmax = max(float(np.abs(g[k + "grad." + n]).max()) for n, _ in au.named_parameters())
+    for n, p in au.named_parameters():
+        want = g[k + "grad." + n]
+        got = p.grad.detach().cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 2e-6 * gmax, f"{tag}: grad of {n}"
+    for n, b in au.named_buffers():
+        want = g[k + "sd1." + n]
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == int(want)
+        else:
+            close(b, want, rtol=1e-5, atol_scale=1e-6, what=f"{tag}: buffer {n}")
+
+
 def test_din_att_l1_matches_linear_on_materialised_operand_and_chunk_statistics():
     from torch_rechub_amd import _lib, ops
     g = torch.Generator().manual_seed(3)

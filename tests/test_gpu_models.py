@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import AUX_LOSS_CONFIGS, MODEL_CONFIGS, MTL_CONFIGS, build_amd_model, build_mtl_model, features_from_spec, golden_batch, golden_state, load_golden
+from conftest import AUX_LOSS_CONFIGS, DIN_ATTENTION_DIMS, MODEL_CONFIGS, MTL_CONFIGS, build_amd_model, build_mtl_model, features_from_spec, golden_batch, golden_state, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -39,10 +39,20 @@ def load_model(cfg):
     return gold, model.to(dev())
 
 
+def spy_fused_attention(monkeypatch):
+    """Counts the launches of the ActivationUnit's fused first layer (csrc/dinmlp.hip) through ops.din_att_l1."""
+    from torch_rechub_amd import ops
+    calls = []
+    real = ops.din_att_l1
+    monkeypatch.setattr(ops, "din_att_l1", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    return calls
+
+
 @pytest.mark.parametrize("cfg", MODEL_CONFIGS)
-def test_forward_loss_and_gradients_match_reference(cfg):
+def test_forward_loss_and_gradients_match_reference(cfg, monkeypatch):
     from torch_rechub_amd import ops
     gold, model = load_model(cfg)
+    fused_calls = spy_fused_attention(monkeypatch)
     x, y = golden_batch(gold, 0)
     xd, yd = to_dev(x), y.to(dev()).float()
     aux = cfg in AUX_LOSS_CONFIGS
@@ -79,13 +89,16 @@ def test_forward_loss_and_gradients_match_reference(cfg):
             continue
         np.testing.assert_allclose(got, ref, rtol=1e-4 if cfg not in ("bst", "dien") else 1e-3,
                                    atol=(2e-6 if cfg not in ("bst", "dien") else 2e-5) * gmax, err_msg=f"{cfg}: grad of {n}")
+    if cfg in DIN_ATTENTION_DIMS:  # the configs[3] attention widths: the fixture must have exercised csrc/dinmlp.hip
+        assert len(fused_calls) >= 4, f"{cfg}: fused first attention layer ran {len(fused_calls)} times"
 
 
 @pytest.mark.parametrize("mode", ["dense", "lazy"])
 @pytest.mark.parametrize("cfg", MODEL_CONFIGS)
-def test_three_step_training_matches_reference_trainer(cfg, mode):
+def test_three_step_training_matches_reference_trainer(cfg, mode, monkeypatch):
     from torch_rechub_amd.trainers import CTRTrainer
     gold, model = load_model(cfg)
+    fused_calls = spy_fused_attention(monkeypatch)
     nb = sum(1 for k in gold.files if k.startswith("y") and k[1:].isdigit())
     batches = [golden_batch(gold, i) for i in range(nb)]
     params = {"lr": float(gold["train.lr"]), "weight_decay": float(gold["train.wd"])}
@@ -101,6 +114,8 @@ def test_three_step_training_matches_reference_trainer(cfg, mode):
                              table_update=mode, lazy_k=2, loss_mode=cfg not in AUX_LOSS_CONFIGS)
     mean_loss = trainer.train_one_epoch(batches)
     assert abs(mean_loss - float(gold["train.mean_loss"])) < 5e-5
+    if cfg in DIN_ATTENTION_DIMS:
+        assert len(fused_calls) >= 6, f"{cfg}: fused first attention layer ran {len(fused_calls)} times in 3 steps"
     ref = golden_state(gold, "sd3.")
     mine = model.state_dict()
     gmax = max(float(np.abs(gold[k]).max()) for k in gold.files if k.startswith("grad."))
