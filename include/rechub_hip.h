@@ -336,6 +336,8 @@ int rh_colsum(const float* a, int rows, int cols, float* out, const float* v, in
  *   (loss_partial: rh_head_loss_nblocks(B) floats; the mean is finished by rh_step_scalars);
  * rh_head_loss_bwd = rh_bce_bwd + rh_head_bwd in one pass: g_y = g_loss[0] / B * (y - t) / max((1 - y) y, 1e-12) is
  *   formed per row with the arithmetic of rh_bce_bwd (bit-identical to the two separate launches).
+ *   rh_head_bwd_ex / rh_head_bwd_bn take g_y, (t, g_loss) or both (a prediction with a second consumer besides the
+ *   loss: the inline BCE gradient and g_y add per row).
  * rh_step_scalars: the scalar work of one training step in ONE single-block launch (each part optional, null = skip):
  *   loss[0] = sum(loss_partial[0..n_partial)) / B;  the bias corrections of the next Adam step (== rh_adam_prepare);
  *   two device counters c = (c + inc) % mod (mod 0 = no wrap): the batch position of the device loader (==

@@ -1590,6 +1590,63 @@ def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monk
         assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-4 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("fused_loss", [False, True])
+def test_hidden_layer_and_prediction_with_two_consumers_each(fused_loss):
+    """The head -> BatchNorm shortcut (rh_head_bwd_bn hands its column sums to the layer below) and the fused BCE (the
+    loss gradient is formed inside the head's backward) both have to notice when the tensor they produced is NOT the only
+    gradient: here the hidden activation h AND the prediction y each feed a second consumer.  Reference = the same
+    modules in float64 on eager torch (what the reference's op chain computes)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import MLP
+    B, K = 256, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 40, generator=g)
+    t = (torch.rand(B, generator=g) < 0.3).float()
+    c = torch.randn(B, K, generator=g)  # weights of the second consumer of h
+    torch.manual_seed(9)
+    mlp = MLP(40, output_layer=True, dims=[K], dropout=0.0, activation="relu").train()
+    ref = MLP.__new__(MLP)
+    torch.nn.Module.__init__(ref)
+    import copy
+    ref.mlp = copy.deepcopy(mlp.mlp).double()
+
+    def run(net, xi, ti, ci, fused):
+        mods = list(net.mlp)
+        if fused is None:  # plain module chain (float64 reference)
+            h = xi
+            for m in mods[:-1]:
+                h = m(h)
+            y = torch.sigmoid(mods[-1](h).squeeze(1))
+            loss = torch.nn.functional.binary_cross_entropy(y, ti)
+        else:
+            if fused:
+                ops.fusion_begin(target=ti)
+            h = net._run(mods[:-1], xi)
+            assert ops.head_ok(h, mods[-1], ())
+            y = ops.head_sigmoid(h, mods[-1].weight, mods[-1].bias)
+            loss = ops.bce_mean(y, ti)
+            if fused:
+                assert type(loss.grad_fn).__name__ == "_FusedBceFnBackward"
+                ops.fusion_end()
+        total = loss + 0.37 * (h * ci).sum() / h.shape[0] + 0.11 * (y * y).sum()
+        total.backward()
+        return total
+
+    xr = x.double().requires_grad_()
+    want = run(ref, xr, t.double(), c.double(), None)
+    mlp = mlp.to(dev())
+    xd = x.to(dev()).requires_grad_()
+    got = run(mlp, xd, t.to(dev()), c.to(dev()), fused_loss)
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert abs(got.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))
+    close(xd.grad, xr.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what="g_x")
+    for (n, p), (_, q) in zip(mlp.named_parameters(), ref.named_parameters()):
+        if n == "mlp.0.bias":  # in front of BatchNorm: exact gradient 0, rounding noise on both sides
+            continue
+        close(p.grad, q.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what=f"g_{n}")
+
+
 @pytest.mark.parametrize("B,C,row0,D,K", [(4096, 4096, 0, 64, 20), (300, 900, 300, 16, 7), (5, 5, 0, 100, 4),
                                            (64, 64, 0, 300, 1), (33, 40, 7, 8, 0)])
 def test_inbatch_logits_without_the_score_matrix(B, C, row0, D, K):

@@ -327,7 +327,9 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
   const float lscale = a.t ? a.g_loss[0] / (float)a.B : 0.f;
   for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < a.B; row += (int64_t)gridDim.x * kHeadRows) {
     const float yv = a.y[row];
-    const float gy = a.t ? lscale * (yv - a.t[row]) / fmaxf((1.f - yv) * yv, 1e-12f) : a.g_y[row];
+    // the BCE gradient formed inline (t given) and / or an upstream gradient of y (another consumer of the prediction)
+    float gy = a.t ? lscale * (yv - a.t[row]) / fmaxf((1.f - yv) * yv, 1e-12f) : a.g_y[row];
+    if (a.t && a.g_y) gy += a.g_y[row];
     const float gz = gy * yv * (1.f - yv);
     if (sub == 0) {
       a.g_z[row] = gz;
@@ -689,8 +691,9 @@ extern "C" int rh_head_bwd_bn(const float* h, int64_t ldh, const float* w, const
                               float* partial, int reduce, const float* bn_z, const float* bn_stat, const float* bn_gamma,
                               const float* bn_beta, float bn_p, const int64_t* bn_rng, const int64_t* bn_ctr, int bn_relu,
                               float* bn_partial, void* stream) {
-  RH_REQUIRE((g_y != nullptr) != (t != nullptr && g_loss != nullptr), RH_E_BADARG,
-             "rh_head_bwd_bn: give either g_y or (t, g_loss)");
+  RH_REQUIRE(g_y != nullptr || (t != nullptr && g_loss != nullptr), RH_E_BADARG,
+             "rh_head_bwd_bn: give g_y and / or (t, g_loss)");
+  RH_REQUIRE((t != nullptr) == (g_loss != nullptr), RH_E_BADARG, "rh_head_bwd_bn: t and g_loss go together");
   RH_REQUIRE(bn_z && bn_stat && bn_gamma && bn_beta && bn_partial && (bn_p <= 0.f || (bn_rng && bn_ctr)), RH_E_BADARG,
              "rh_head_bwd_bn: null pointer");
   RH_REQUIRE(K % 4 == 0 && bn_p >= 0.f && bn_p < 1.f, RH_E_UNSUPPORTED, "rh_head_bwd_bn: K=%d p=%g unsupported", K, bn_p);
@@ -698,13 +701,15 @@ extern "C" int rh_head_bwd_bn(const float* h, int64_t ldh, const float* w, const
   return head_bwd_impl(h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, g_w, g_b, partial, stream, reduce, &bn);
 }
 
-// One entry point for every combination: g_y given (t, g_loss null) or the BCE gradient formed inline (g_y null);
+// One entry point for every combination: g_y given (t, g_loss null), the BCE gradient formed inline (g_y null), or both
+// (the prediction has a second consumer besides the fused loss: the two gradients of y add);
 // reduce == 0: g_w / g_b are not produced, the caller sums the rh_head_nblocks(B) x (K + 1) partial rows (rh_pack_grads).
 extern "C" int rh_head_bwd_ex(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                               const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
                               float* partial, int reduce, void* stream) {
-  RH_REQUIRE((g_y != nullptr) != (t != nullptr && g_loss != nullptr), RH_E_BADARG,
-             "rh_head_bwd_ex: give either g_y or (t, g_loss)");
+  RH_REQUIRE(g_y != nullptr || (t != nullptr && g_loss != nullptr), RH_E_BADARG,
+             "rh_head_bwd_ex: give g_y and / or (t, g_loss)");
+  RH_REQUIRE((t != nullptr) == (g_loss != nullptr), RH_E_BADARG, "rh_head_bwd_ex: t and g_loss go together");
   return head_bwd_impl(h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, g_w, g_b, partial, stream, reduce);
 }
 

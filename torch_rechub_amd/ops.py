@@ -707,11 +707,15 @@ class _BnReluDropoutFn(torch.autograd.Function):
         dbeta = torch.empty_like(beta)
         pre = getattr(ctx, "rh_pre", None)
         ctx.rh_pre = None
-        if pre is not None and pre[0] == dy.data_ptr():
+        if pre is not None and pre[0].data_ptr() == dy.data_ptr() and pre[0].shape == dy.shape and \
+                dy._version == pre[1]:
             # dy is exactly the tensor the output head's backward produced (the head was the only consumer of this
-            # layer): its launch already summed (g1, g1 * xhat) per column -> finalize + apply only
+            # layer): its launch already summed (g1, g1 * xhat) per column -> finalize + apply only.  ``pre`` HOLDS that
+            # tensor: autograd can then neither sum a second consumer's gradient into it in place (InputBuffer only
+            # reuses a buffer it owns alone -> the sum is a new tensor with another address) nor recycle its memory
+            # for another gradient; the version counter covers any other in-place writer.
             _lib.call("rh_bn_relu_dropout_bwd_pre", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop,
-                      _p(_dropout_rng(dev)), _p(saved_ctr), _p(pre[1]), pre[2], _p(stat), _p(dx), _p(dgamma), _p(dbeta),
+                      _p(_dropout_rng(dev)), _p(saved_ctr), _p(pre[2]), pre[3], _p(stat), _p(dx), _p(dgamma), _p(dbeta),
                       1 if ctx.relu else 0, _stream())
             return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
         partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
@@ -1019,9 +1023,17 @@ class _HeadFn(torch.autograd.Function):
         g_loss = fusion.g_loss
         t = gl = None
         if ctx.fused_t is not None and g_loss is not None and g_loss[1] == y.data_ptr():
-            # the only consumer of y was the fused BCE: its gradient is formed per row inside this launch
+            # y went into the fused BCE: that gradient is formed per row inside this launch.  The loss's backward
+            # returned a persistent all-zero placeholder (which it keeps a reference to, so autograd cannot sum into it
+            # in place): if g_y still IS that tensor the loss was the only consumer of y, otherwise g_y = 0 + the other
+            # consumers' gradient and rides along
             fusion.g_loss = None
-            t, gl, g_y = ctx.fused_t, g_loss[0], None
+            t, gl = ctx.fused_t, g_loss[0]
+            zero = g_loss[2]
+            if g_y.data_ptr() == zero.data_ptr() and g_y._version == g_loss[3]:
+                g_y = None
+            else:
+                g_y = g_y.contiguous()
         else:
             g_y = g_y.contiguous()
         bn = ctx.bn_node
@@ -1031,7 +1043,8 @@ class _HeadFn(torch.autograd.Function):
             _lib.call("rh_head_bwd_bn", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_h),
                       _p(g_z), _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _p(z), _p(stat), _p(gamma), _p(beta),
                       float(bn.p_drop), _p(_dropout_rng(dev)), _p(saved_ctr), 1 if bn.relu else 0, _p(bn_partial), _stream())
-            bn.rh_pre = (g_h.data_ptr(), bn_partial, nblk)  # valid only if the layer's upstream gradient IS this g_h
+            # valid only if the layer's upstream gradient IS this g_h, unmodified: the tensor itself + its version
+            bn.rh_pre = (g_h, g_h._version, bn_partial, nblk)
         else:
             _lib.call("rh_head_bwd_ex", _p(h), h.stride(0), _p(weight), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_h),
                       _p(g_z), _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _stream())
@@ -1082,6 +1095,21 @@ def bce_ok(criterion, y, t):
             y.shape == t.shape and 0 < y.numel() <= (1 << 22) and not t.requires_grad)
 
 
+_zero_cache = {}
+
+
+def _zero_placeholder(shape, dev):
+    """A persistent, never-written all-zero float32 tensor per (shape, device) (no memset launch per step)."""
+    key = (tuple(shape), str(dev))
+    z = _zero_cache.get(key)
+    if z is None:
+        z = torch.zeros(shape, dtype=torch.float32, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            return z  # lives in the graph's pool, re-zeroed by the captured fill on every replay: not cached
+        _zero_cache[key] = z
+    return z
+
+
 class _FusedBceFn(torch.autograd.Function):
     """Mean BCE of a head output whose per-block terms were computed by rh_head_loss_fwd: the forward is the step's
     ONE scalar launch (rh_step_scalars: mean of the terms + Adam bias corrections + device counters), the backward only
@@ -1111,9 +1139,11 @@ class _FusedBceFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        fusion.g_loss = (g.contiguous().view(1), ctx.y_ptr)
-        # placeholder: the head's backward does not read it (it recomputes dL/dy from y, t and g)
-        return torch.empty(ctx.shape, dtype=torch.float32, device=ctx.dev), None, None
+        # dL/dy itself is formed inside the head's backward (from y, t and g); what goes back through autograd is a
+        # persistent all-zero tensor, so a second consumer of y adds its gradient to 0 (and not to uninitialised memory)
+        zero = _zero_placeholder(ctx.shape, ctx.dev)
+        fusion.g_loss = (g.contiguous().view(1), ctx.y_ptr, zero, zero._version)
+        return zero, None, None
 
 
 def bce_mean(y, t):
