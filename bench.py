@@ -74,6 +74,13 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives) even on one GPU")
     ap.add_argument("--no-kernel-sweep", action="store_true", help="skip the gather-kernel batch sweep")
+    ap.add_argument("--brief", action="store_true",
+                    help="headline only: skip batch_sweep / zipf / secondary_configs / step_accounting (SURVEY 8d extras)")
+    ap.add_argument("--no-step-accounting", action="store_true", help="skip the nested rocprofv3 pass (step_accounting)")
+    ap.add_argument("--cpu-protocol", default="auto", choices=["auto", "full", "bounded"],
+                    help="cpu_baseline: full = SURVEY 8(d)'s 3 warm-up + 10 timed steps per leg (~90 s at the Criteo shape); "
+                         "bounded = about --cpu-budget seconds of steps; auto = full unless a step is too slow on this host")
+    ap.add_argument("--trace-inner", action="store_true", help=argparse.SUPPRESS)  # child of the step_accounting pass
     return ap.parse_args()
 
 
@@ -162,7 +169,7 @@ class Workload(object):
                          "10M-user tables (D=16) resident in HBM, history L<=50 mean-pooled, towers [256,128,64] prelu")
         self.rows = rows
 
-    def build(self, placement, use_graph):
+    def build(self, placement, use_graph, batch=None):
         """(model, trainer, loader); every call starts from fresh tables (Feature objects cache their nn.Embedding, Q2)."""
         from torch_rechub_amd.trainers import CTRTrainer, MatchTrainer
         from torch_rechub_amd.utils.data import DeviceDataLoader
@@ -195,8 +202,8 @@ class Workload(object):
             t = MatchTrainer(m, mode=0, in_batch_neg=True, in_batch_neg_ratio=20, **kw)
         else:
             t = CTRTrainer(m, **kw)
-        ld = DeviceDataLoader(self.sparse, self.sparse_names, self.dense, self.dense_names, self.label, a.batch,
-                              shuffle=True)
+        ld = DeviceDataLoader(self.sparse, self.sparse_names, self.dense, self.dense_names, self.label,
+                              batch or a.batch, shuffle=True)
         ld.reshuffle()
         m.train()
         t.optimizer.sync_hyper()
@@ -424,7 +431,14 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     """Build, warm up into the steady state, time exactly --steps steps; optionally the per-kernel eager pass; then the
     flush (timed separately) and the no-row-behind check.  Returns a dict."""
     from torch_rechub_amd import ops
-    model, trainer, loader = wl.build(placement, use_graph)
+    main_cus = int(os.environ.get("RECHUB_MAIN_CUS", "0") or 0)
+    if 1 <= main_cus <= 31:  # experiment: the step's launch chain on the LAST n CUs of every XCD (sweep: RECHUB_SWEEP_CUS)
+        import ctypes
+        from torch_rechub_amd import _lib
+        ptr = ctypes.c_void_p()
+        _lib.call("rh_stream_create_cumask", main_cus, 1, ctypes.byref(ptr))
+        torch.cuda.set_stream(torch.cuda.ExternalStream(ptr.value, device=device))
+    model, trainer, loader = wl.build(placement, use_graph, batch=args.batch)
     B = args.batch
     opt = trainer.optimizer
     lazy = getattr(opt, "lazy_k", 0) > 1
@@ -556,6 +570,149 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     return res
 
 
+def _short_run(args, device, rank, use_graph, model=None, batch=None, dist_kind=None, rows=None, steps=30, wl=None):
+    """One short steady-state measurement of another shape (same code path as the headline: run_mode with its own
+    warm-up into the steady state, exactly `steps` timed graph replays, flush verified).  Returns (dict, workload)."""
+    import copy
+    a = copy.copy(args)
+    a.steps, a.no_kernel_sweep = steps, True
+    if model is not None:
+        a.model = model
+    if batch is not None:
+        a.batch = batch
+    if dist_kind is not None:
+        a.dist = dist_kind
+    if rows is not None:
+        a.rows = rows
+    if wl is None:
+        wl = Workload(a, device, rank)
+    else:
+        wl.args = a
+    r = run_mode(a, wl, None, use_graph, 1, rank, device, profile=False)
+    out = {"batch": a.batch, "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 1), "unit": "samples/s",
+           "steps": steps, "warmup_effective": r["warmup_effective"], "hipgraph": r["hipgraph"], "flush_ms": r["flush_ms"],
+           "rows_behind_after_flush": r.get("rows_behind_after_flush")}
+    torch.cuda.empty_cache()
+    return out, wl
+
+
+ACCOUNT_GROUPS = (  # first match wins; kernel-name substring -> row of SURVEY 8(d)'s whole-step accounting
+    ("batch_gather_kernel", "batch_assembly"), ("batch_advance", "batch_assembly"),
+    ("adam_lazy_touched", "table_refresh_before_gather"), ("embed_fwd", "gather_fwd"), ("embed_bwd", "gather_bwd"),
+    ("embed_scatter", "gather_bwd"), ("Cijk_", "mlp_gemm_library"), ("gemm_f32", "mlp_gemm_own"),
+    ("linear_fwd", "mlp_gemm_own"), ("linear_dgrad", "mlp_gemm_own"),
+    ("linear_wgrad", "mlp_weight_gradient"), ("wgrad", "mlp_weight_gradient"), ("bn_", "mlp_batchnorm_relu_dropout"),
+    ("head_", "head_and_loss"), ("step_scalars", "step_scalars"), ("bce_", "head_and_loss"),
+    ("pack_grads", "pack_and_dense_param_adam"), ("adam_small", "pack_and_dense_param_adam"),
+    ("adam_lazy_sweep", "table_optimizer"), ("adam_lazy_step", "table_optimizer"), ("adam_dense", "table_optimizer"),
+    ("adam_prepare", "step_scalars"), ("cross", "cross_network"), ("moe", "cross_network"), ("dice", "attention_mlp"),
+    ("din_", "attention_mlp"), ("seq_pool", "sequence_pooling"), ("inbatch", "inbatch_negatives"), ("prelu", "towers"),
+    ("nccl", "rccl"), ("rccl", "rccl"), ("copyBuffer", "memcpy"),
+)
+
+
+def _account_group(name):
+    for key, grp in ACCOUNT_GROUPS:
+        if key in name:
+            return grp
+    return "other"
+
+
+def parse_step_trace(trace_csv, steps_wanted):
+    """Per-step accounting from a rocprofv3 kernel trace: the last `steps_wanted` steps, a step = everything from one
+    batch_gather_kernel launch (the first kernel of a replayed step) to the next."""
+    import csv
+    rows = []
+    with open(trace_csv) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2]]
+    if len(marks) < 3:
+        return None
+    marks = marks[-(min(steps_wanted, len(marks) - 1) + 1):]
+    n = len(marks) - 1
+    wall = (rows[marks[-1]][0] - rows[marks[0]][0]) / n / 1e3
+    per_kernel, order = {}, []
+    for i in range(marks[0], marks[-1]):
+        st, en, name = rows[i]
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("rechub::", "").split("(")[0][:60]
+        if short not in per_kernel:
+            per_kernel[short] = [0, 0.0, name]
+            order.append(short)
+        per_kernel[short][0] += 1
+        per_kernel[short][1] += (en - st) / 1e3
+    groups = {}
+    kernels = []
+    busy = 0.0
+    for k in order:
+        cnt, tot, full = per_kernel[k]
+        us = tot / n
+        busy += us
+        grp = _account_group(full)
+        groups[grp] = round(groups.get(grp, 0.0) + us, 2)
+        kernels.append({"kernel": k, "launches_per_step": round(cnt / n, 2), "us_per_step": round(us, 2),
+                        "avg_us": round(tot / cnt, 2), "group": grp})
+    groups["idle_between_kernels"] = round(wall - busy, 2)
+    return {"steps_averaged": n, "wall_us_per_step": round(wall, 2), "kernel_launches_per_step": round(sum(
+        k["launches_per_step"] for k in kernels), 1), "groups_us_per_step": groups, "kernels": kernels}
+
+
+def step_accounting(args):
+    """SURVEY 8(d) whole-step accounting from ONE regime: a nested `rocprofv3 --kernel-trace` run of this file's
+    --trace-inner mode (same model, batch, optimizer and hipGraph replay as the headline; a smaller resident dataset),
+    parsed into in-graph kernel durations per step.  H2D is 0 by construction (dataset resident in HBM) and there is no
+    RCCL at N = 1.  Returns None (with a note on stderr) when rocprofv3 cannot be nested."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    if any(k in os.environ for k in ("ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"skipped": "this process already runs under rocprofv3: see profiles/ for the kernel trace of this command"}
+    tmp = tempfile.mkdtemp(prefix="rh_acct_", dir="/tmp")
+    here = os.path.abspath(__file__)
+    steps = 40
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "acct", "--", sys.executable, here,
+           "--trace-inner", "--steps", str(steps), "--warmup", str(args.warmup), "--model", args.model, "--batch",
+           str(args.batch), "--rows", str(min(args.rows or 4_000_000, 4_000_000)), "--lazy-k", str(args.lazy_k),
+           "--table-adam", args.table_adam, "--dist", args.dist, "--vocab-scale", str(args.vocab_scale), "--graph", args.graph]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return {"error": f"nested rocprofv3 run failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-300:]}"}
+        acct = parse_step_trace(max(files, key=os.path.getsize), steps - 2)
+        if acct is None:
+            return {"error": "no steps found in the kernel trace"}
+        acct.update({"source": "nested `rocprofv3 --kernel-trace -- python bench.py --trace-inner` (in-graph kernel durations "
+                               "of hipGraph-replayed steady-state steps; the step under the tracer is a few us longer than "
+                               "ms_per_step of the untraced headline)", "h2d_us_per_step": 0.0, "rccl_us_per_step": 0.0,
+                     "optimizer_mode": f"table_adam={args.table_adam} lazy_k={args.lazy_k}",
+                     "pass_seconds": round(time.perf_counter() - t0, 1)})
+        return acct
+    except subprocess.TimeoutExpired:
+        return {"error": "nested rocprofv3 run timed out"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def trace_inner(args, device, rank):
+    """Child of step_accounting(): steady-state hipGraph steps and nothing else (no flush, no eager passes)."""
+    wl = Workload(args, device, rank)
+    model, trainer, loader = wl.build(None, True, batch=args.batch)
+    trainer._graphed_step(loader)
+    lazy = getattr(trainer.optimizer, "lazy_k", 0) > 1
+    for _ in range(max(args.warmup, (args.lazy_k + 8) if lazy else 0) + args.steps):
+        trainer._graphed_step(loader)
+    torch.cuda.synchronize()
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the result JSON: RCCL / the runtime print banners on fd 1 (seen: "RCCL version :
@@ -581,6 +738,9 @@ def main():
 
     parallel = world > 1 or args.force_dp
     use_graph = args.graph in ("1", "auto")  # N > 1: the RCCL collectives are captured with the rest of the step
+    if args.trace_inner:
+        trace_inner(args, device, rank)
+        return
     wl = Workload(args, device, rank)
     B = args.batch
 
@@ -691,32 +851,86 @@ def main():
                 big = gsweep[max(gsweep, key=int)]
                 north["at_batch_%s" % max(gsweep, key=int)] = {"fwd_frac": big["rh_embed_fwd"]["frac"],
                                                               "bwd_frac": big["rh_embed_bwd"]["frac"]}
+        extras = {}
+        if world == 1 and not args.force_dp and not args.brief and wl.name == "deepfm" and args.batch == 4096 and \
+                args.dist == "uniform" and args.vocab_scale == 1.0:
+            # ---- whole-step batch sweep, Zipf(1.05) line, the other configs, whole-step accounting ----
+            import copy
+
+            def guarded(what, fn):
+                try:
+                    t0 = time.perf_counter()
+                    out = fn()
+                    print(f"[bench] {what}: {time.perf_counter() - t0:.1f} s", file=sys.stderr)
+                    return out
+                except Exception as e:  # noqa: BLE001 -- a secondary line must never take the headline down
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    return {"error": f"{type(e).__name__}: {e}"}
+
+            keep_args = wl.args
+            sweep = {}
+            for b in (2048, 8192, 32768, 65536):
+                sweep[str(b)] = guarded(f"batch_sweep B={b}", lambda b=b: _short_run(args, device, rank, use_graph, batch=b,
+                                                                                    wl=wl)[0])
+            wl.args = keep_args
+            sweep["4096"] = {"batch": 4096, "ms_per_step": round(head["ms_per_step"], 4), "value": round(head["value"], 1),
+                             "unit": "samples/s", "steps": args.steps, "note": "the headline run"}
+            extras["batch_sweep"] = {"what": "whole hipGraph-replayed training step (batch assembly, forward, backward, "
+                                             "dense-exact Adam) at other per-GPU batch sizes, same tables and dataset; 30 "
+                                             "timed steps each after the warm-up into the steady state", "runs": sweep}
+            extras["zipf"] = guarded("zipf", lambda: dict(_short_run(args, device, rank, use_graph, dist_kind="zipf",
+                                                                     rows=8_000_000, steps=50)[0],
+                                                          index_dist="Zipf(1.05) per field (bounded power law)",
+                                                          rows_per_gpu=8_000_000))
+            wl2 = copy.copy(wl)
+            wl2.name = "dcnv2"
+            sec = {"dcnv2": guarded("dcnv2", lambda: dict(_short_run(args, device, rank, use_graph, model="dcnv2", steps=30,
+                                                                     wl=wl2)[0],
+                                                          workload="BASELINE.json configs[2] shape on one GPU: DCN-v2 "
+                                                                   "(CrossNetMix 3 layers, rank 32, 4 experts; parallel DNN)"))}
+            wl.args = keep_args
+            for name in ("din", "dssm"):
+                def one(name=name):
+                    r, w = _short_run(args, device, rank, use_graph, model=name, steps=20, rows=0)
+                    r["workload"] = w.desc
+                    del w
+                    return r
+                sec[name] = guarded(name, one)
+                torch.cuda.empty_cache()
+            extras["secondary_configs"] = sec
+            if not args.no_step_accounting:
+                extras["step_accounting"] = guarded("step_accounting", lambda: step_accounting(args))
         cpu = None
         if world == 1 and not args.no_cpu_baseline and wl.name == "deepfm":
-            from oracle.cpu_port import time_cpu_baseline, time_cpu_end_to_end
+            from oracle.cpu_port import time_cpu_legs
             cpu = {"unit": "samples/s", "kind": "port", "cores": os.cpu_count(), "cpu_model": cpu_model_string()}
             try:
-                r = time_cpu_end_to_end(wl.vocabs, N_DENSE, B, budget_s=args.cpu_budget / 2)
-                cpu["end_to_end"] = {"value": round(r["samples_per_s"], 1), "steps": r["steps"],
-                                     "ms_per_step": round(r["ms_per_step"], 1), "loader_ms_per_step": round(r["loader_ms_per_step"], 1),
-                                     "rows": r["rows"]}
-                cpu["value"], cpu["cores"] = cpu["end_to_end"]["value"], r["cores"]
-                cpu["sample"] = (f"{r['steps']} steps of the reference's CTRTrainer.train_one_epoch loop "
-                                 f"(trainers/ctr_trainer.py:77-108) restated on eager torch CPU (oracle/cpu_port.py): "
-                                 f"DataGenerator-style loader (TorchDataset + random_split 0.7/0.1/0.2 + "
-                                 f"DataLoader(shuffle=True, num_workers=0), x = dict of numpy, {r['rows']} rows) -> "
-                                 f"DeepFM op chain -> BCELoss -> dense Adam over all 33.76M rows, B={B}")
-            except (MemoryError, RuntimeError) as e:
-                cpu["end_to_end"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-                cpu["value"] = None
-            try:
-                r = time_cpu_baseline(wl.vocabs, N_DENSE, B, budget_s=args.cpu_budget / 2)
-                cpu["model_step"] = {"value": round(r["samples_per_s"], 1), "steps": r["steps"],
-                                     "ms_per_step": round(r["ms_per_step"], 1),
-                                     "sample": "model-step-only (fwd+bwd+dense Adam), pre-collated batches, no DataLoader"}
+                r = time_cpu_legs(wl.vocabs, N_DENSE, B, budget_s=args.cpu_budget,
+                                  full={"auto": "auto", "full": True, "bounded": False}[args.cpu_protocol])
+                e, m = r["end_to_end"], r["model_step"]
                 cpu["cores"] = r["cores"]
+                cpu["value"] = round(e["samples_per_s"], 1)
+                cpu["end_to_end"] = {"value": round(e["samples_per_s"], 1), "median_ms_per_step": round(e["median_ms_per_step"], 1),
+                                     "loader_median_ms_per_step": round(e["loader_median_ms_per_step"], 1),
+                                     "warmup_steps": e["warmup_steps"], "timed_steps": e["timed_steps"],
+                                     "step_ms": e["step_ms"], "rows": r["rows"]}
+                cpu["model_step"] = {"value": round(m["samples_per_s"], 1), "median_ms_per_step": round(m["median_ms_per_step"], 1),
+                                     "warmup_steps": m["warmup_steps"], "timed_steps": m["timed_steps"], "step_ms": m["step_ms"],
+                                     "sample": "model-step-only (fwd+bwd+dense Adam), pre-collated batches, no DataLoader; the "
+                                               "model and Adam state are warm from the end-to-end leg"}
+                cpu["sample"] = (f"{e['timed_steps']} timed steps (median) after {e['warmup_steps']} warm-up of the reference's "
+                                 f"CTRTrainer.train_one_epoch loop (trainers/ctr_trainer.py:77-108) restated on eager torch "
+                                 f"CPU (oracle/cpu_port.py): DataGenerator-style loader (TorchDataset + random_split "
+                                 f"0.7/0.1/0.2 + DataLoader(shuffle=True, num_workers=0), x = dict of numpy, {r['rows']} "
+                                 f"rows) -> DeepFM op chain -> BCELoss -> dense Adam over all 33.76M rows, B={B}")
+                cpu["protocol"] = ("SURVEY 8(d): >= 3 warm-up + >= 10 timed steps, median" if r["full_protocol"] else
+                                   f"TRUNCATED to about --cpu-budget = {args.cpu_budget:g} s of CPU steps (a step is ~3 s at "
+                                   "the full vocabulary): 1 warm-up step, then every step timed on its own and the median "
+                                   "taken (step_ms lists them); `--cpu-protocol full` runs SURVEY 8(d)'s 3 + 10 per leg (~90 s)")
             except (MemoryError, RuntimeError) as e:
-                cpu["model_step"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+                cpu["value"] = None
+                cpu["error"] = f"{type(e).__name__}: {e}"
         opt_desc = "dense pass per step"
         if args.table_adam == "lazy":
             opt_desc = (f"blocked-lazy exact replay, K={args.lazy_k}, window sweep "
@@ -765,6 +979,11 @@ def main():
             "gather_kernel_sweep": gsweep,
             "cpu_baseline": cpu,
         }
+        line.update(extras)
+        if kernels:
+            line["kernels_timing_note"] = ("`kernels` / roofline.avg_launch_ms: HIP events around EAGER launches of the same "
+                                           "step in the same regime (launch-to-launch on the stream); the in-graph durations "
+                                           "are in step_accounting (nested rocprofv3) and profiles/")
         if parallel:
             line["scaling_modes"] = {
                 k: {"value": round(v["value"], 1), "ms_per_step": round(v["ms_per_step"], 4), "hipgraph": v["hipgraph"],

@@ -62,6 +62,23 @@ const char* rh_last_error(void);
 int rh_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
+ * Streams with a compute-unit mask (hipExtStreamCreateWithCUMask) and external events, for running the optimizer's
+ * window sweep BESIDE the step's launch chain on its own share of the 256 CUs (torch_rechub_amd/optim.py; the
+ * reference's optimizer.step() is one serial call, trainers/ctr_trainer.py:99).
+ * rh_stream_create_cumask: *out = a new HIP stream restricted to the first `cus_per_xcd` CUs (1..32) of every XCD
+ *   (MI355X: mask bit i = XCD i % 8, CU i / 8 -- measured, tools/probe/cumask_probe.cpp; a mask that empties an XCD is
+ *   ignored by the runtime); `from_top` != 0 takes the LAST cus_per_xcd CUs of every XCD instead.
+ * rh_stream_destroy: releases it.  Events: plain hipEvent handles as void*; rh_event_record / rh_stream_wait_event with
+ *   external != 0 use hipEventRecordExternal / hipEventWaitExternal, i.e. inside a stream capture they become event
+ *   nodes of the graph that synchronise with work OUTSIDE it on every replay. */
+int rh_stream_create_cumask(int cus_per_xcd, int from_top, void** out);
+int rh_stream_destroy(void* stream);
+int rh_event_create(void** out);
+int rh_event_destroy(void* event);
+int rh_event_record(void* event, void* stream, int external);
+int rh_stream_wait_event(void* stream, void* event, int external);
+
+/* ---------------------------------------------------------------------------------------------
  * K1+K2+K3  fused multi-field gather + FM second order + LR first order (+ dense concat)
  * replaces: EmbeddingLayer.forward  torch_rechub/basic/layers.py:77-127  (26x nn.Embedding + cat)
  *           FM.forward              torch_rechub/basic/layers.py:313-319

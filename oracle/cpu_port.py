@@ -216,3 +216,89 @@ def time_cpu_end_to_end(vocabs, n_dense, batch_size, rows=200_000, budget_s=12.0
     dt = time.perf_counter() - t_start
     return dict(samples_per_s=steps * batch_size / dt, steps=steps, ms_per_step=1e3 * dt / steps,
                 loader_ms_per_step=1e3 * loader_s / steps, cores=torch.get_num_threads(), rows=rows)
+
+
+def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=200_000, seed=2022, threads=None):
+    """Both legs of SURVEY 8(d)'s CPU baseline on ONE model / optimizer (the 8.4 GB of p / g / m / v are built once):
+    (i) the reference's ``train_one_epoch`` loop END TO END over a DataGenerator-style loader (dict of numpy columns),
+    (ii) model-step-only on pre-collated batches.  Every step is timed on its own; the MEDIAN is reported.
+
+    ``full``: the protocol as written (3 warm-up + 10 timed steps per leg; ~90 s at the Criteo shape on 128 threads);
+    ``"auto"``: the full protocol unless the first step shows it would take longer than ~8x ``budget_s``.
+    Otherwise the run is bounded to about ``budget_s`` seconds of steps: 1 warm-up step (it allocates the dense
+    gradients and the Adam state) and as many timed steps per leg as fit, at least 3 -- the record says which."""
+    if threads:
+        torch.set_num_threads(threads)
+    rng = np.random.default_rng(seed)
+    names = {f"C{i + 1}": int(v) for i, v in enumerate(vocabs)}
+    dense_names = [f"I{i + 1}" for i in range(n_dense)]
+    x = {n: rng.integers(0, v, rows, dtype=np.int64) for n, v in names.items()}
+    x.update({n: rng.random(rows, dtype=np.float32) for n in dense_names})
+    y = (rng.random(rows) < 0.25).astype(np.int64)
+    torch.manual_seed(seed)
+    t0 = time.perf_counter()
+    train_dl, _, _ = port_dataloaders(x, y, [0.7, 0.1], batch_size)
+    model = PortDeepFM(names, dense_names)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)  # trainer default, ctr_trainer.py:60
+    crit = nn.BCELoss()
+    build_s = time.perf_counter() - t0
+    device = torch.device("cpu")
+    it = iter(train_dl)
+
+    def next_batch():
+        nonlocal it
+        try:
+            xb, yb = next(it)
+        except StopIteration:
+            it = iter(train_dl)
+            xb, yb = next(it)
+        return {k: v.to(device) for k, v in xb.items()}, yb.to(device)  # ctr_trainer.py:84-85
+
+    t0 = time.perf_counter()
+    train_step(model, opt, crit, *next_batch())  # first warm-up step: allocates the dense gradients and the Adam state
+    first_s = time.perf_counter() - t0
+    if full == "auto":  # the full protocol is 25 more steps: only where a step is short enough for the run to stay bounded
+        full = first_s * 2 * 13 <= max(budget_s, 1.0) * 8
+    n_warm, n_timed, n_min = (3, 10, 10) if full else (1, 10, 3)
+    for _ in range(n_warm - 1):
+        train_step(model, opt, crit, *next_batch())
+    leg_budget = budget_s / 2
+    e2e_ms, loader_ms, t_leg = [], [], time.perf_counter()
+    while len(e2e_ms) < n_timed:
+        t0 = time.perf_counter()
+        xb, yb = next_batch()
+        t1 = time.perf_counter()
+        train_step(model, opt, crit, xb, yb)
+        t2 = time.perf_counter()
+        e2e_ms.append(1e3 * (t2 - t0))
+        loader_ms.append(1e3 * (t1 - t0))
+        if not full and len(e2e_ms) >= n_min and time.perf_counter() - t_leg > leg_budget:
+            break
+    g = torch.Generator().manual_seed(seed)
+
+    def batch():
+        xb = {n: torch.randint(0, v, (batch_size,), generator=g) for n, v in names.items()}
+        xb.update({n: torch.rand(batch_size, generator=g) for n in dense_names})
+        return xb, (torch.rand(batch_size, generator=g) < 0.25).long()
+
+    batches = [batch() for _ in range(4)]
+    for i in range(n_warm if full else 0):  # the model and the optimizer state are warm from leg (i) already
+        train_step(model, opt, crit, *batches[i % 4])
+    step_ms, t_leg = [], time.perf_counter()
+    while len(step_ms) < n_timed:
+        t0 = time.perf_counter()
+        train_step(model, opt, crit, *batches[len(step_ms) % 4])
+        step_ms.append(1e3 * (time.perf_counter() - t0))
+        if not full and len(step_ms) >= n_min and time.perf_counter() - t_leg > leg_budget:
+            break
+
+    def leg(ms, warm):
+        med = float(np.median(ms))
+        return dict(median_ms_per_step=med, samples_per_s=batch_size / (med * 1e-3), timed_steps=len(ms), warmup_steps=warm,
+                    step_ms=[round(v, 1) for v in ms])
+
+    e2e = leg(e2e_ms, n_warm)
+    e2e["loader_median_ms_per_step"] = float(np.median(loader_ms))
+    return dict(end_to_end=e2e, model_step=leg(step_ms, n_warm + len(e2e_ms) + (n_warm if full else 0)),
+                cores=torch.get_num_threads(), rows=rows, build_s=build_s, full_protocol=bool(full))

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="sweep grid (rh_set_tuning key 2)")
     ap.add_argument("--pad", type=int, default=0, help="extra LDS bytes per sweep workgroup (rh_set_tuning key 3)")
     ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--cus", type=int, default=0, help="run B on a stream masked to this many CUs of every XCD")
+    ap.add_argument("--cus-a", type=int, default=0, help="run A on a stream masked to the LAST n CUs of every XCD")
     a = ap.parse_args()
     from torch_rechub_amd import _lib, ops
     from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
@@ -45,6 +47,15 @@ def main():
 
     sa = torch.cuda.Stream(priority=-1 if a.prio else 0)
     sb = torch.cuda.Stream()
+    import ctypes
+    if a.cus:
+        ptr = ctypes.c_void_p()
+        _lib.call("rh_stream_create_cumask", a.cus, 0, ctypes.byref(ptr))
+        sb = torch.cuda.ExternalStream(ptr.value, device=dev)
+    if a.cus_a:
+        ptr = ctypes.c_void_p()
+        _lib.call("rh_stream_create_cumask", a.cus_a, 1, ctypes.byref(ptr))
+        sa = torch.cuda.ExternalStream(ptr.value, device=dev)
     with torch.cuda.stream(sa):
         for _ in range(3):
             fwd_bwd()

@@ -21,6 +21,12 @@ SIGNATURES = {
     "rh_abi_version": [],
     "rh_last_error": [],
     "rh_set_tuning": [c_int, c_int],
+    "rh_stream_create_cumask": [c_int, c_int, c_ptr],
+    "rh_stream_destroy": [c_ptr],
+    "rh_event_create": [c_ptr],
+    "rh_event_destroy": [c_ptr],
+    "rh_event_record": [c_ptr, c_ptr, c_int],
+    "rh_stream_wait_event": [c_ptr, c_ptr, c_int],
     "rh_embed_fwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
     "rh_embed_bwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,

@@ -275,11 +275,24 @@ class TableAdam(torch.optim.Adam):
     def _fork_sweep(self):
         """Launch the sweep of the last completed step on the side stream, ordered after everything queued so far."""
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self._tables[0].device)
+            self._side = self._make_side_stream()
         self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
             self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
         self._sweep_pending, self._sweep_inflight = False, True
+
+    def _make_side_stream(self):
+        """The sweep's stream.  RECHUB_SWEEP_CUS=n (1..31) restricts it to n compute units of every XCD
+        (rh_stream_create_cumask): the VALU-saturating sweep then leaves the other 8 * (32 - n) CUs to the step's chain of
+        small dependent kernels instead of competing with them for wave slots on every CU."""
+        dev = self._tables[0].device
+        n = int(os.environ.get("RECHUB_SWEEP_CUS", "0") or 0)
+        if 1 <= n <= 31:
+            ptr = ctypes.c_void_p()
+            _lib.call("rh_stream_create_cumask", n, 0, ctypes.byref(ptr))
+            self._side_raw = ptr.value  # never destroyed: lives as long as the process
+            return torch.cuda.ExternalStream(ptr.value, device=dev)
+        return torch.cuda.Stream(device=dev)
 
     def _join_sweep(self):
         if self._sweep_inflight:
