@@ -431,14 +431,22 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     """Build, warm up into the steady state, time exactly --steps steps; optionally the per-kernel eager pass; then the
     flush (timed separately) and the no-row-behind check.  Returns a dict."""
     from torch_rechub_amd import ops
-    main_cus = int(os.environ.get("RECHUB_MAIN_CUS", "0") or 0)
-    if 1 <= main_cus <= 31:  # experiment: the step's launch chain on the LAST n CUs of every XCD (sweep: RECHUB_SWEEP_CUS)
-        import ctypes
-        from torch_rechub_amd import _lib
-        ptr = ctypes.c_void_p()
-        _lib.call("rh_stream_create_cumask", main_cus, 1, ctypes.byref(ptr))
-        torch.cuda.set_stream(torch.cuda.ExternalStream(ptr.value, device=device))
     model, trainer, loader = wl.build(placement, use_graph, batch=args.batch)
+    ms = trainer.main_stream() if use_graph else None  # RECHUB_MAIN_CUS: the replayed steps on their share of the CUs
+    outer = torch.cuda.current_stream()
+    if ms is not None:
+        ms.wait_stream(outer)
+        torch.cuda.set_stream(ms)
+    try:
+        return _run_mode(args, wl, placement, use_graph, world, rank, device, profile, model, trainer, loader)
+    finally:
+        if ms is not None:
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(outer)
+
+
+def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, model, trainer, loader):
+    from torch_rechub_amd import ops
     B = args.batch
     opt = trainer.optimizer
     lazy = getattr(opt, "lazy_k", 0) > 1

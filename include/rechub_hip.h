@@ -53,7 +53,7 @@ const char* rh_last_error(void);
 /* tuning knobs (process-wide; defaults are the measured winners) */
 #define RH_TUNE_WIDE_ATOMICS 1 /* 1: table-gradient atomics carry whole rows per request (default), 0: 16 B pieces */
 #define RH_TUNE_SWEEP_GRID 2   /* workgroups of rh_adam_lazy_sweep (0 = default 8192) */
-#define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per sweep workgroup (<= 56 KiB): caps its residency so that kernels on
+#define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per sweep workgroup (<= 150 KiB): caps its residency so that kernels on
                                   other streams find free wave slots while it runs */
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
 #define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
@@ -72,6 +72,9 @@ int rh_set_tuning(int key, int value);
  *   external != 0 use hipEventRecordExternal / hipEventWaitExternal, i.e. inside a stream capture they become event
  *   nodes of the graph that synchronise with work OUTSIDE it on every replay. */
 int rh_stream_create_cumask(int cus_per_xcd, int from_top, void** out);
+/* *out = a new non-blocking HIP stream of the given priority (hipStreamCreateWithPriority: lower number = higher priority,
+ * clamped by the runtime to the device's range). */
+int rh_stream_create_priority(int priority, void** out);
 int rh_stream_destroy(void* stream);
 int rh_event_create(void** out);
 int rh_event_destroy(void* event);

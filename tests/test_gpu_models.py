@@ -247,7 +247,8 @@ def _assert_no_row_behind(trainer):
     return t
 
 
-def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer():
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch):
     """Round-1 bug: TableAdam.flush() was driven by a host flag that hipGraph replays never set, so from the second
     epoch on state_dict() / checkpoints held table rows up to K-1 steps behind the dense-Adam semantics of the reference
     (trainers/ctr_trainer.py:99: every row stepped; :138: state_dict saved).  Two epochs from the HBM-resident loader
@@ -273,6 +274,9 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer():
                 e.weight.normal_(0, 0.05)
         return m, [f.name for f in sfe], [f.name for f in dfe]
 
+    # overlap = "1": the window sweep of every step deferred to the side stream under the next step (segmented replay:
+    # join -> [batch assembly, refresh] -> fork sweep by value -> [rest of the step]); same bits demanded
+    monkeypatch.setenv("RECHUB_SWEEP_OVERLAP", overlap)
     kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, device="cuda:0", show_progress=False, use_graph=True)
     ma, names, dnames = build()
     mb, _, _ = build()

@@ -22,6 +22,7 @@ SIGNATURES = {
     "rh_last_error": [],
     "rh_set_tuning": [c_int, c_int],
     "rh_stream_create_cumask": [c_int, c_int, c_ptr],
+    "rh_stream_create_priority": [c_int, c_ptr],
     "rh_stream_destroy": [c_ptr],
     "rh_event_create": [c_ptr],
     "rh_event_destroy": [c_ptr],
@@ -172,6 +173,11 @@ def load():
     if got != ABI_VERSION:
         raise RuntimeError(f"librechub_hip.so ABI {got} != expected {ABI_VERSION}; rebuild it")
     _lib = lib
+    # RECHUB_TUNE="key=value,key=value": rh_set_tuning knobs of include/rechub_hip.h (kernel experiments)
+    for item in filter(None, os.environ.get("RECHUB_TUNE", "").split(",")):
+        k, v = item.split("=")
+        if lib.rh_set_tuning(int(k), int(v)) != 0:
+            raise RuntimeError(f"RECHUB_TUNE: rh_set_tuning({k}, {v}) rejected")
     return lib
 
 

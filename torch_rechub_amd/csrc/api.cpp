@@ -43,6 +43,13 @@ extern "C" int rh_stream_create_cumask(int cus_per_xcd, int from_top, void** out
   *out = st;
   return 0;
 }
+extern "C" int rh_stream_create_priority(int priority, void** out) {
+  if (!out) return RH_E_BADARG;
+  hipStream_t st = nullptr;
+  RH_HIP_OK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority), "hipStreamCreateWithPriority");
+  *out = st;
+  return 0;
+}
 extern "C" int rh_stream_destroy(void* stream) {
   RH_HIP_OK(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)), "hipStreamDestroy");
   return 0;

@@ -30,6 +30,10 @@ extern "C" int rh_optim_set_tuning(int key, int value);
     }                                                                       \
   } while (0)
 
+// Wave priority of the step's latency-bound chain kernels (s_setprio 3 = highest): when the optimizer's VALU-saturating
+// window sweep is resident on the same SIMD (deferred sweep on a side stream), the chain's waves win instruction issue.
+#define RH_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+
 // Pointers fetched from descriptor tables are generic to the compiler; these helpers pin them to
 // the global address space so the access is a global_load/global_store (vmcnt only), not flat_*.
 #define RH_GLOBAL __attribute__((address_space(1)))

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(RH_BLOCK) void batch_gather_kernel(const int64_t* _
                                                                 int64_t* __restrict__ sparse_out,
                                                                 float* __restrict__ dense_out,
                                                                 float* __restrict__ label_out) {
+  RH_CHAIN_PRIO();
   constexpr int G = 16;
   const int lig = threadIdx.x % G;
   const int64_t b = (int64_t)blockIdx.x * (RH_BLOCK / G) + threadIdx.x / G;

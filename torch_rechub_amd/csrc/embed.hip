@@ -38,6 +38,7 @@ struct EmbedFwdArgs {
 // of fields f = j*FS + fs, j = 0..ceil(F/FS)-1.  Groups never straddle a wavefront (G | 64).
 template <int LPR, int FS, typename IdxT, bool HAS_LR>
 __global__ __launch_bounds__(RH_BLOCK) void embed_fwd_kernel(const EmbedFwdArgs a) {
+  RH_CHAIN_PRIO();
   constexpr int G = LPR * FS;
   constexpr int SPB = RH_BLOCK / G;
   constexpr int U = 8;  // gathers in flight per lane
@@ -172,6 +173,7 @@ static __device__ __forceinline__ int64_t desc_at(const int64_t* p, int i) {
 
 template <int LPR, int WS, typename IdxT, bool HAS_LR>
 __global__ __launch_bounds__(RH_WAVE * WS) void embed_fwd_uniform_kernel(const EmbedFwdArgs a) {
+  RH_CHAIN_PRIO();
   constexpr int SPW = RH_WAVE / LPR;  // samples per wavefront = per workgroup
   constexpr int NT = RH_WAVE * WS;
   constexpr int U = 8;   // gathers in flight per lane: ONE phase for F <= 8 * WS fields
@@ -417,6 +419,7 @@ constexpr int kSweeps = 2;  // phase-B sweeps of the small-table path: covers kS
 // gradient with one coalesced atomic instruction (one request per 64-byte line per block and sweep).
 template <int LPR, typename IdxT, int SRC, int SINK>
 __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs a) {
+  RH_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];  // small tables: parked gradient rows + row ids
   __shared__ float4 red[RH_BLOCK / RH_WAVE][32];
   constexpr int LPP = RH_BLOCK / LPR;  // lookups per pass

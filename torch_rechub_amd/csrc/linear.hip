@@ -42,6 +42,7 @@ struct WgradArgs {
 };
 
 __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
+  RH_CHAIN_PRIO();
   extern __shared__ float red[];  // kWaves * kPartStride floats
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int half = lane >> 5, c = lane & 31;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
 // "last block reduces" election needs a device-scope fence per block, which on this 8-XCD part writes back and
 // invalidates the XCD's whole L2 (measured: ~140 us for 500 blocks) -- a 3 us launch is the cheaper barrier.
 __global__ __launch_bounds__(RH_BLOCK) void wgrad_reduce_kernel(const WgradArgs a) {
+  RH_CHAIN_PRIO();
   const int64_t nk = (int64_t)a.N * a.K;
   const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
   const bool is_b = i >= nk;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(RH_BLOCK) void head_fwd_kernel(const float* __restr
                                                             const float* __restrict__ e0, const float* __restrict__ e1,
                                                             int B, int K, float* __restrict__ y,
                                                             const float* __restrict__ t, float* __restrict__ loss_partial) {
+  RH_CHAIN_PRIO();
   __shared__ float lred[kHeadRows];
   const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
   const int nv = K / 4;
@@ -284,6 +287,7 @@ struct HeadBwdArgs {
 
 template <int MAXV, bool BN = false>
 __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a) {
+  RH_CHAIN_PRIO();
   __shared__ float red[kHeadRows][kHeadLanes * 4 + 1];
   __shared__ float gb_red[kHeadRows];
   const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(RH_BLOCK) void colsum_kernel(const float* __restric
                                                           float* __restrict__ out, int split, float* __restrict__ out2,
                                                           const float* __restrict__ v, int64_t n,
                                                           float* __restrict__ vsum) {
+  RH_CHAIN_PRIO();
   __shared__ float red[kCsGroups][kCsCols + 1];
   const int nb_cols = (cols + kCsCols - 1) / kCsCols;
   if ((int)blockIdx.x < nb_cols) {
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(RH_BLOCK) void step_scalars_kernel(const float* __r
                                                                 float* __restrict__ loss, double* hyper, int64_t* step,
                                                                 float* ring, int64_t ring_mask, int64_t* c0, int64_t inc0,
                                                                 int64_t mod0, int64_t* c1, int64_t inc1, int64_t mod1) {
+  RH_CHAIN_PRIO();
   __shared__ float red[RH_BLOCK / RH_WAVE];
   if (loss_partial != nullptr) {
     float acc = 0.f;

@@ -53,6 +53,7 @@ static __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr
 // s = h[0, c].  MODE 1 (backward): sums of g1 and g1*xhat.
 template <int MODE>
 __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, int CW) {
+  RH_CHAIN_PRIO();
   __shared__ float red[2][RH_BLOCK];
   const int RS = RH_BLOCK / CW;
   const int c = blockIdx.x * CW + threadIdx.x % CW;
@@ -172,6 +173,7 @@ static __device__ __forceinline__ void chan_combine(const BnArgs& a, int c, int 
 // 4 columns per block = 64 blocks x 32 rows.
 template <int MODE, int FINCOLS = kFinCols>
 __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
+  RH_CHAIN_PRIO();
   constexpr int kFinCols = FINCOLS;  // shadows the file-level default inside this kernel
   constexpr int GROUPS = RH_BLOCK / kFinCols;
   __shared__ float red[2 * GROUPS * (kFinCols + 1)];
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_eval_affine_kernel(const BnArgs a
 // MODE 0 forward apply, MODE 1 backward dx, MODE 2 eval-mode forward (running statistics, no dropout)
 template <int MODE>
 __global__ __launch_bounds__(RH_BLOCK) void bn_apply_kernel(const BnArgs a) {
+  RH_CHAIN_PRIO();
   const int64_t n = (int64_t)a.B * a.C;
   const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
@@ -289,6 +292,7 @@ constexpr int kSlabCols = 32, kSlabLanes = RH_BLOCK / kSlabCols;
 
 template <int MODE>  // 0 forward, 1 backward
 __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, int rows_per_block) {
+  RH_CHAIN_PRIO();
   __shared__ float red[2 * kSlabLanes * (kSlabCols + 1)];
   const int cl = threadIdx.x % kSlabCols, grp = threadIdx.x / kSlabCols;
   const int c = blockIdx.x * kSlabCols + cl;

@@ -29,6 +29,7 @@ struct AdamArgs {
 };
 
 __global__ void adam_prepare_kernel(double* hyper, int64_t* step, float* ring, int64_t ring_mask) {
+  RH_CHAIN_PRIO();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int64_t t = *step + 1;
     *step = t;
@@ -463,6 +464,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
 
 template <int LPR, typename IdxT, bool REFRESH>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
+  RH_CHAIN_PRIO();
   lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -501,6 +503,14 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
     hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK),
                        (size_t)g_sweep_lds_pad, s, a);
   } else {
+    if (g_sweep_lds_pad > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per workgroup is opt-in
+      static int raised = 0;
+      if (raised < g_sweep_lds_pad) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_lazy_sweep_kernel<LPR, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, g_sweep_lds_pad);
+        raised = g_sweep_lds_pad;
+      }
+    }
     hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, false>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)g_sweep_lds_pad,
                        s, a);
   }
@@ -524,6 +534,7 @@ struct AdamSmallArgs {
 constexpr int kSmallChunk = 1024;  // elements per virtual block (4 per thread, strided)
 
 __global__ __launch_bounds__(RH_BLOCK) void adam_small_kernel(const AdamSmallArgs a) {
+  RH_CHAIN_PRIO();
   const AdamScalars h = load_scalars(a.hyper);
   const int T = a.T;
   for (int64_t vb = blockIdx.x; vb < a.total_vblocks; vb += gridDim.x) {
@@ -589,6 +600,7 @@ constexpr int kPackDeep = 32;          // more partial rows than this: the rows 
 
 template <bool ADAM>
 __global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) {
+  RH_CHAIN_PRIO();
   __shared__ float red[RH_BLOCK / RH_WAVE];
   AdamScalars h{};
   if (ADAM) h = load_scalars(a.hyper);
@@ -719,7 +731,7 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     return 0;
   }
   if (key == RH_TUNE_SWEEP_LDS_PAD) {
-    g_sweep_lds_pad = value < 0 ? 0 : (value > 56 * 1024 ? 56 * 1024 : value);
+    g_sweep_lds_pad = value < 0 ? 0 : (value > 150 * 1024 ? 150 * 1024 : value);
     return 0;
   }
   return RH_E_BADARG;

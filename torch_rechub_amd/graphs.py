@@ -26,6 +26,7 @@ class SegmentedGraph(object):
     def __init__(self):
         self.segments = []   # [CUDAGraph, eager fn | None]: fn runs after the graph
         self.before = []     # eager fns that run before the first segment of every replay
+        self.after_fns = []  # eager fns that run after the last segment of every replay
         self._stream = None
         self._pool = None
 
@@ -74,6 +75,13 @@ class SegmentedGraph(object):
         """``fn`` runs eagerly before the first segment of every replay."""
         self.before.append(fn)
 
+    def after(self, fn):
+        """``fn`` runs eagerly after the last segment of every replay -- i.e. after the WHOLE step has been enqueued.
+        Where in stream order its launches land is up to ``fn`` itself: the sidecar sweep of optim.TableAdam waits on an
+        EXTERNAL event recorded by a node in the middle of the graph (hipEventRecordExternal), so it starts when that
+        node has run, not when the graph has finished -- without cutting the graph into segments."""
+        self.after_fns.append(fn)
+
     # -- replay ----------------------------------------------------------------------------
     def replay(self):
         for fn in self.before:
@@ -82,6 +90,8 @@ class SegmentedGraph(object):
             g.replay()
             if fn is not None:
                 fn()
+        for fn in self.after_fns:
+            fn()
 
     def pool(self):
         return self._pool

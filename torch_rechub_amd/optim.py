@@ -111,6 +111,15 @@ class TableAdam(torch.optim.Adam):
                 # step's ~40 dependent small kernels contend for the same wave slots, so the overlap hides only
                 # ~40 us of the 185 us sweep and the two extra graph boundaries cost ~30 us.
                 self.overlap_sweep = os.environ.get("RECHUB_SWEEP_OVERLAP", "0") == "1"
+                # Sidecar form of the deferred sweep under hipGraph replay (RECHUB_SWEEP_EVENTS=1, opt-in with the
+                # overlap): the step stays ONE graph.  A captured hipStreamWaitEvent(hipEventWaitExternal) in front of
+                # the first refresh waits for the previous sidecar sweep, a captured hipEventRecordWithFlags(
+                # hipEventRecordExternal) after the last refresh marks where the sweep may start, and after every replay
+                # the host enqueues  wait(e_ref) -> sweep(step by value) -> record(e_sweep)  on the side stream
+                # (graphs.SegmentedGraph.after).  No graph boundary, no host synchronisation.
+                self.sweep_events = os.environ.get("RECHUB_SWEEP_EVENTS", "0") == "1"
+                self._ev_ref = self._ev_sweep = None
+                self._sidecar_seg = None
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
                 self._side = None
@@ -243,13 +252,18 @@ class TableAdam(torch.optim.Adam):
             return
         seg = graphs.active()
         capturing = torch.cuda.is_current_stream_capturing()
-        if self._sweep_inflight:  # the previous step's sweep must be done before rows are refreshed again
-            if capturing and seg is not None:
-                if self._join_seg is not seg:
-                    seg.at_start(self._join_sweep)  # replayed steps: join eagerly before the first segment
-                    self._join_seg = seg
-                self._sweep_inflight = False
-            elif capturing:
+        if capturing and seg is not None and self.overlap_sweep and self.sweep_events:
+            self._gather_sidecar(rec, seg)
+            return
+        if capturing and seg is not None and self.overlap_sweep:
+            # segmented replay: EVERY replay joins the sweep forked by the previous one before its first segment (the
+            # refresh below must not meet a row the sweep is still writing), whatever the state at capture time was
+            if self._join_seg is not seg:
+                seg.at_start(self._join_sweep)
+                self._join_seg = seg
+            self._sweep_inflight = False
+        elif self._sweep_inflight:  # the previous step's sweep must be done before rows are refreshed again
+            if capturing:
                 raise RuntimeError("TableAdam: a deferred table sweep is in flight on the side stream; call "
                                    "optimizer.flush() before capturing a training step into a plain hipGraph "
                                    "(or capture with torch_rechub_amd.graphs.SegmentedGraph)")
@@ -264,7 +278,59 @@ class TableAdam(torch.optim.Adam):
                 elif seg is not None:
                     seg.cut(self._fork_sweep)  # every replay: eager side-stream launch after the refresh above
                     self._sweep_pending, self._sweep_inflight = False, True
+            elif capturing and seg is not None and self.overlap_sweep and self._gathers >= (self._gathers_per_step or 1):
+                # captured from a settled state (nothing pending at capture time): the replays still fork one sweep each
+                seg.cut(self._fork_sweep)
+                self._sweep_inflight = True
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
+
+    def _events(self):
+        if self._ev_ref is None:
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.call("rh_event_create", ctypes.byref(a))
+            _lib.call("rh_event_create", ctypes.byref(b))
+            self._ev_ref, self._ev_sweep = a, b
+        return self._ev_ref, self._ev_sweep
+
+    def _gather_sidecar(self, rec, seg):
+        """Pre-gather hook while a SegmentedGraph captures the step in sidecar mode (see __init__)."""
+        if self._sweep_inflight or self._sweep_pending:
+            raise RuntimeError("TableAdam: call optimizer.settle_sweep() before capturing a step in sidecar mode")
+        e_ref, e_sweep = self._events()
+        stream = ops._stream()
+        training = rec.get("training", torch.is_grad_enabled())
+        if training and self._gathers == 0:
+            _lib.call("rh_stream_wait_event", stream, e_sweep, 1)  # graph node: the previous replay's sidecar sweep is done
+        self._touch(rec, self._lazy_setup(), stream, refresh=True)
+        if training:
+            self._gathers += 1
+            if self._gathers >= (self._gathers_per_step or 1):
+                _lib.call("rh_event_record", e_ref, stream, 1)  # graph node: every row of this step's batches is current
+                if self._sidecar_seg is not seg:
+                    seg.after(self._sidecar_after_replay)
+                    self._sidecar_seg = seg
+
+    def _sidecar_after_replay(self):
+        """Runs on the host after every replay of a step captured in sidecar mode: the window sweep of the step that was
+        complete BEFORE this replay goes to the side stream, behind the replay's refresh marker; the replay's own step then
+        counts as completed (its sweep is launched by the next replay, or by whatever eager call comes first)."""
+        e_ref, e_sweep = self._events()
+        if self._side is None:
+            self._side = self._make_side_stream()
+        side = ctypes.c_void_p(self._side.cuda_stream)
+        _lib.call("rh_stream_wait_event", side, e_ref, 0)
+        if self._host_step > 0:
+            self._sweep(SWEEP_LAZY_TABLES, side, t_value=self._host_step)
+        _lib.call("rh_event_record", e_sweep, side, 0)
+        self._host_step += 1
+        self._sweep_pending, self._sweep_inflight = True, True
+
+    def settle_sweep(self):
+        """Bring the deferred-sweep state to rest (nothing in flight, nothing pending) without a full flush: what a
+        capture in sidecar mode starts from."""
+        if self.lazy_k > 1 and self._tables and self.overlap_sweep:
+            self._join_sweep()
+            self._finish_sweep()
 
     def _sweep(self, mode, stream, t_value=-1):
         for grp in self._lazy_setup():
@@ -277,8 +343,9 @@ class TableAdam(torch.optim.Adam):
         if self._side is None:
             self._side = self._make_side_stream()
         self._side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side):
-            self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+        if self._host_step > 0:
+            with torch.cuda.stream(self._side):
+                self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
         self._sweep_pending, self._sweep_inflight = False, True
 
     def _make_side_stream(self):
@@ -291,6 +358,12 @@ class TableAdam(torch.optim.Adam):
             ptr = ctypes.c_void_p()
             _lib.call("rh_stream_create_cumask", n, 0, ctypes.byref(ptr))
             self._side_raw = ptr.value  # never destroyed: lives as long as the process
+            return torch.cuda.ExternalStream(ptr.value, device=dev)
+        prio = os.environ.get("RECHUB_SWEEP_PRIO")
+        if prio not in (None, ""):  # experiment: the sweep's queue below (positive) / above (negative) the step's
+            ptr = ctypes.c_void_p()
+            _lib.call("rh_stream_create_priority", int(prio), ctypes.byref(ptr))
+            self._side_raw = ptr.value
             return torch.cuda.ExternalStream(ptr.value, device=dev)
         return torch.cuda.Stream(device=dev)
 
@@ -395,8 +468,9 @@ class TableAdam(torch.optim.Adam):
 
     # -- the step's scalar launch (ops.StepFusion): rh_step_scalars may do this optimizer's rh_adam_prepare --------
     def can_fuse_prepare(self):
-        return (self._tables or self._bucket is not None) and not self._prepared and \
-            not getattr(self, "overlap_sweep", False)
+        # (with the deferred sweep too: it takes its step number by value and its (A, E) from the ring entry of that
+        # step, so the early advance of hyper[12..14] by this step's scalar launch does not reach it)
+        return (self._tables or self._bucket is not None) and not self._prepared
 
     def fuse_prepare(self):
         """Arguments of the prepare part of rh_step_scalars; the next step_tables() then skips rh_adam_prepare.  Must
@@ -427,8 +501,12 @@ class TableAdam(torch.optim.Adam):
             if self._gathers:
                 self._gathers_per_step, self._gathers = self._gathers, 0
             seg = graphs.active()
-            if seg is not None and self.overlap_sweep:
-                seg.cut(self._advance_host_step)  # replays count their steps on the host too (sweep step by value)
+            if seg is not None and self.overlap_sweep and self.sweep_events:
+                pass  # sidecar mode: _sidecar_after_replay counts the replayed steps
+            elif seg is not None and self.overlap_sweep:
+                if getattr(self, "_advance_seg", None) is not seg:  # replays count their steps on the host too (the
+                    seg.after(self._advance_host_step)              # sweep takes its step by value), after the last segment
+                    self._advance_seg = seg
             elif not torch.cuda.is_current_stream_capturing():
                 self._host_step += 1
         if self._prepared:

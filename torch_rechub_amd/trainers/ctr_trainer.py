@@ -262,6 +262,28 @@ class CTRTrainer(object):
 
     GRAPH_WARMUP = 3
 
+    def main_stream(self):
+        """The stream hipGraph-replayed steps run on: None (the current stream) unless RECHUB_MAIN_CUS=n (1..31) asks for
+        the step's launch chain on the LAST n compute units of every XCD (rh_stream_create_cumask) -- the counterpart of
+        RECHUB_SWEEP_CUS, which puts the optimizer's deferred window sweep on the FIRST n: with disjoint shares the
+        VALU-saturating sweep and the chain of small dependent kernels run side by side instead of contending for wave
+        slots on every CU.  ``train_one_epoch`` switches to it around its replay loop."""
+        if not hasattr(self, "_main_stream"):
+            import ctypes
+            self._main_stream = None
+            n = int(os.environ.get("RECHUB_MAIN_CUS", "0") or 0)
+            if 1 <= n <= 31 and torch.device(self.device).type == "cuda":
+                from .. import _lib
+                ptr = ctypes.c_void_p()
+                _lib.call("rh_stream_create_cumask", n, 1, ctypes.byref(ptr))
+                self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
+            elif os.environ.get("RECHUB_MAIN_PRIO") not in (None, "") and torch.device(self.device).type == "cuda":
+                from .. import _lib  # experiment: the replayed steps on a queue of another priority than the sweep's
+                ptr = ctypes.c_void_p()
+                _lib.call("rh_stream_create_priority", int(os.environ["RECHUB_MAIN_PRIO"]), ctypes.byref(ptr))
+                self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
+        return self._main_stream
+
     def _graphed_step(self, loader):
         """Replay the captured (batch assembly + train_step); the first call warms up eagerly and captures.
 
@@ -282,7 +304,10 @@ class CTRTrainer(object):
                     total += self._split_step(x, y) if split else self.train_step(x, y)
             torch.cuda.current_stream().wait_stream(side)
             # Segmented capture: the optimizer cuts the step where it launches the deferred table sweep eagerly on
-            # its side stream (graphs.SegmentedGraph); without cuts this is one ordinary hipGraph.
+            # its side stream (graphs.SegmentedGraph); without cuts this is one ordinary hipGraph.  In sidecar mode the
+            # step stays one graph with two external-event nodes and starts from a settled sweep state.
+            if hasattr(self.optimizer, "settle_sweep"):
+                self.optimizer.settle_sweep()
             self._graph = graphs.SegmentedGraph()
 
             def whole_step():
@@ -364,6 +389,11 @@ class CTRTrainer(object):
         batch_count = 0
         full = data_loader.N // data_loader.batch_size if device_loader else 0
         if device_loader and self.use_graph and (self._graph is not None or full > self.GRAPH_WARMUP):
+            ms = self.main_stream()
+            if ms is not None:  # CU-masked stream for the replay loop; everything before / after stays ordered with it
+                outer = torch.cuda.current_stream()
+                ms.wait_stream(outer)
+                torch.cuda.set_stream(ms)
             data_loader.reshuffle()
             rem = data_loader.N - full * data_loader.batch_size
             it = tqdm.tqdm(total=full, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
@@ -388,6 +418,9 @@ class CTRTrainer(object):
                 x, y = self._load(data_loader, rem)
                 epoch += self.train_step(x, y)
                 batch_count += 1
+            if ms is not None:
+                outer.wait_stream(ms)
+                torch.cuda.set_stream(outer)
         else:
             it = tqdm.tqdm(data_loader, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
             for i, (x_dict, y) in enumerate(it):
