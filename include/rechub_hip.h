@@ -53,8 +53,9 @@ const char* rh_last_error(void);
 /* tuning knobs (process-wide; defaults are the measured winners) */
 #define RH_TUNE_WIDE_ATOMICS 1 /* 1: table-gradient atomics carry whole rows per request (default), 0: 16 B pieces */
 #define RH_TUNE_SWEEP_GRID 2   /* workgroups of rh_adam_lazy_sweep (0 = default 8192) */
-#define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per sweep workgroup (<= 150 KiB): caps its residency so that kernels on
-                                  other streams find free wave slots while it runs */
+#define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per workgroup of a DEFERRED sweep (rh_adam_lazy_sweep with t_value >= 0; <= 150
+                                  KiB, -1 = default 58 KiB): caps its residency so that the kernels of the step it runs beside
+                                  find wave slots and issue cycles */
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
 #define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
 #define RH_TUNE_FWD_PATH 7      /* rh_embed_fwd: 0 auto (by batch size), 1 lane-split kernel only, 2 field-uniform kernel only */
@@ -493,6 +494,12 @@ int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                       const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                       const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, void* stream);
+/* rh_adam_lazy_step with the sweep part restricted as rh_adam_lazy_sweep's `mode` (RH_SWEEP_WINDOW or RH_SWEEP_DENSE_TABLES:
+ * touched rows + the dense K = 1 tables only, for a step whose lazy-table window sweep is deferred to a side stream). */
+int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
+                           void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
 

@@ -120,6 +120,8 @@ SIGNATURES = {
     "rh_adam_small": [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_step": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr,
                           c_ptr],
+    "rh_adam_lazy_step_mode": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
+                               c_ptr, c_int, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
     "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr],

@@ -15,7 +15,13 @@ namespace {
 constexpr int kMaxTensors = 128;
 constexpr int kMaxRing = 1024;  // entries of the (A, E) ring kept in LDS by the lazy sweep
 int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workgroups, the measured best)
-int g_sweep_lds_pad = 0;  // tuning knob RH_TUNE_SWEEP_LDS_PAD: extra dynamic LDS bytes per workgroup (caps residency)
+// tuning knob RH_TUNE_SWEEP_LDS_PAD: extra dynamic LDS bytes per workgroup of a DEFERRED sweep (one that runs on a side
+// stream beside the step's launch chain: rh_adam_lazy_sweep with t_value >= 0).  It caps the sweep's residency -- 8 KB of
+// ring + 58 KB of pad = 2 workgroups (2 wavefronts per SIMD) per CU of 160 KB -- so that the chain's kernels find wave
+// slots and issue cycles; measured on the DeepFM step: 0.365 ms (no pad) / 0.353 (48 KB) / 0.311 (58 KB) / 0.327 (60 KB) /
+// 0.35 (64 KB) / 0.42 (88 KB: one workgroup per CU, the sweep itself becomes the long pole).  -1 = that default.
+int g_sweep_lds_pad = -1;
+static const int kDeferredSweepPad = 58 * 1024;
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -500,19 +506,19 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
     int64_t period = (grid + a.touch_blocks) / a.touch_blocks;
     if (period > 1 && period % 8 == 0) period -= 1;  // block id mod 8 = XCD: keep the touched workgroups on all of them
     a.touch_period = (int)period;
-    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK),
-                       (size_t)g_sweep_lds_pad, s, a);
+    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK), 0, s,
+                       a);
   } else {
-    if (g_sweep_lds_pad > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per workgroup is opt-in
+    const int pad = a.t_value >= 0 ? (g_sweep_lds_pad < 0 ? kDeferredSweepPad : g_sweep_lds_pad) : 0;
+    if (pad > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per workgroup is opt-in
       static int raised = 0;
-      if (raised < g_sweep_lds_pad) {
+      if (raised < pad) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_lazy_sweep_kernel<LPR, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, g_sweep_lds_pad);
-        raised = g_sweep_lds_pad;
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+        raised = pad;
       }
     }
-    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, false>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)g_sweep_lds_pad,
-                       s, a);
+    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, false>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)pad, s, a);
   }
   return 0;
 }
@@ -731,7 +737,7 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     return 0;
   }
   if (key == RH_TUNE_SWEEP_LDS_PAD) {
-    g_sweep_lds_pad = value < 0 ? 0 : (value > 150 * 1024 ? 150 * 1024 : value);
+    g_sweep_lds_pad = value < 0 ? -1 : (value > 150 * 1024 ? 150 * 1024 : value);
     return 0;
   }
   return RH_E_BADARG;
@@ -847,10 +853,36 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
 // ONE launch for the end of the step: the touched-rows step of the batch (as rh_adam_lazy_touched, refresh = 0) AND the
 // window sweep of every table (as rh_adam_lazy_sweep, RH_SWEEP_WINDOW) -- the first is a short latency-bound pass of a few
 // hundred workgroups, the second saturates the vector ALUs: run together, the first hides under the second.  int64 indices.
+static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                          const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                          const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
+                          void* stream);
+
 extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                                  const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                                  const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
                                  void* stream) {
+  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
+                        err_flag, RH_SWEEP_WINDOW, stream);
+}
+
+// rh_adam_lazy_step with the sweep part restricted as rh_adam_lazy_sweep's `mode`: RH_SWEEP_DENSE_TABLES = the touched-rows
+// step + the dense (K = 1) tables only -- the end of a step whose window sweep of the lazy tables is deferred to a side
+// stream (torch_rechub_amd/optim.py, overlap mode).
+extern "C" int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
+                                      int sweep_mode, void* stream) {
+  RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
+             "rh_adam_lazy_step_mode: sweep_mode %d", sweep_mode);
+  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
+                        err_flag, sweep_mode, stream);
+}
+
+static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                          const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                          const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
+                          void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc, RH_E_BADARG,
              "rh_adam_lazy_step: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1, RH_E_BADARG, "rh_adam_lazy_step: bad shape");
@@ -869,12 +901,12 @@ extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_r
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
-    case 1: rc = launch_sweep<1>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
-    case 2: rc = launch_sweep<2>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
-    case 4: rc = launch_sweep<4>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
-    case 8: rc = launch_sweep<8>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
-    case 16: rc = launch_sweep<16>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
-    case 32: rc = launch_sweep<32>(a, RH_SWEEP_WINDOW, h_rows, h_window, s, &ta); break;
+    case 1: rc = launch_sweep<1>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 2: rc = launch_sweep<2>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 4: rc = launch_sweep<4>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 8: rc = launch_sweep<8>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 16: rc = launch_sweep<16>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 32: rc = launch_sweep<32>(a, sweep_mode, h_rows, h_window, s, &ta); break;
     default: break;
   }
   RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_step: embed_dim %d unsupported", D);

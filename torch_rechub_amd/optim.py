@@ -101,16 +101,19 @@ class TableAdam(torch.optim.Adam):
                 self._ft_cache = {}
                 self._touch_log = []
                 self._table_ids = {id(p) for p in tables}
-                # Deferred sweep (opt-in, RECHUB_SWEEP_OVERLAP=1): the window sweep of step s (lazy tables) is launched
-                # on a side stream at the start of step s + 1, right after that step's rows were refreshed, with its
-                # step number BY VALUE; it then runs under the whole of step s + 1 (forward, backward, exchange,
+                # Deferred sweep (default; RECHUB_SWEEP_OVERLAP=0 sweeps in line): the window sweep of step s (lazy tables)
+                # is launched on a side stream at the start of step s + 1, right after that step's rows were refreshed,
+                # with its step number BY VALUE; it then runs under the whole of step s + 1 (forward, backward, exchange,
                 # optimizer: none of them touches a row that is behind step s) and is joined before step s + 2
                 # refreshes its rows.  The launch is eager, so inside a hipGraph capture it needs a
-                # graphs.SegmentedGraph (plain captures sweep in line).  Exact (bit-identical after flush(), see
-                # tests/test_gpu_properties.py) but OFF by default: on MI355X the VALU-saturating sweep and the
-                # step's ~40 dependent small kernels contend for the same wave slots, so the overlap hides only
-                # ~40 us of the 185 us sweep and the two extra graph boundaries cost ~30 us.
-                self.overlap_sweep = os.environ.get("RECHUB_SWEEP_OVERLAP", "0") == "1"
+                # graphs.SegmentedGraph (two segments per step; plain captures sweep in line).  Exact (bit-identical
+                # after flush(): tests/test_gpu_properties.py, tests/test_gpu_models.py::test_graph_mode_flush_*).
+                # Round 2 measured no gain (the VALU-saturating sweep starved the step's small dependent kernels: they
+                # ran 2.6x slower under it).  What makes it pay (round 3): the sweep's residency capped at
+                # two workgroups per CU (RH_TUNE_SWEEP_LDS_PAD), the chain's kernels at wave priority 3
+                # (RH_CHAIN_PRIO), the step's scalar / packing fusions kept, and only two graph segments:
+                # DeepFM 0.365 -> 0.310 ms, DSSM 1.43 -> 1.22 ms per step.
+                self.overlap_sweep = os.environ.get("RECHUB_SWEEP_OVERLAP", "1") == "1"
                 # Sidecar form of the deferred sweep under hipGraph replay (RECHUB_SWEEP_EVENTS=1, opt-in with the
                 # overlap): the step stays ONE graph.  A captured hipStreamWaitEvent(hipEventWaitExternal) in front of
                 # the first refresh waits for the previous sidecar sweep, a captured hipEventRecordWithFlags(
@@ -385,17 +388,21 @@ class TableAdam(torch.optim.Adam):
         """The touched-rows step of the batch and the window sweep as ONE launch (rh_adam_lazy_step) when the step has a
         single index batch over a single table group with int64 indices -- the DeepFM / DCN / WideDeep step.  The short,
         latency-bound touched pass then runs under the ALU-bound sweep instead of in front of it."""
-        if (os.environ.get("RECHUB_MERGE_STEP", "1") != "1" or self.overlap_sweep or len(self._touch_log) != 1 or
-                len(groups) != 1):
+        if os.environ.get("RECHUB_MERGE_STEP", "1") != "1" or len(self._touch_log) != 1 or len(groups) != 1:
             return False
         rec, grp = self._touch_log[0], groups[0]
         if grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or \
                 not any(id(w) in grp["local"] for w in rec["weights"]):
             return False
-        _lib.call("rh_adam_lazy_step", ops._p(grp["ldesc"]), len(grp["members"]),
+        # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
+        mode = SWEEP_DENSE_TABLES if self.overlap_sweep else SWEEP_WINDOW
+        _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
                   ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
                   ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
-                  ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), stream)
+                  ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), mode,
+                  stream)
+        if self.overlap_sweep:
+            self._sweep_pending = True
         return True
 
     def table_k(self, p):
