@@ -483,8 +483,14 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
 
     # warm-up INTO the steady state: after a flush the first lazy_k window sweeps replay 1, 2, ... steps only
     warm = max(args.warmup, (args.lazy_k + 8) if lazy else 0)
+    if lazy and graph_ok and trainer.dp is None:
+        # + the trainer's self-tuning of the step's form (deferred / in-line sweep, residency cap): it starts once the
+        # optimizer is in its steady state and must be over before the timed region
+        warm += len(trainer.TUNE_CANDIDATES) * (trainer.TUNE_SETTLE + trainer.TUNE_STEPS) + 4
     for _ in range(warm):
         step()
+    if getattr(trainer, "_tune", None) and trainer._tune.get("active"):
+        raise RuntimeError("the trainer's step-form tuning is still running at the start of the timed region")
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -504,6 +510,8 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
     n_prof = max(8, min(args.steps, 30))
     if profile:
         names = ["rh_embed_fwd", "rh_embed_bwd", "rh_adam_dense", "rh_adam_lazy_touched", "rh_adam_lazy_sweep", "rh_adam_lazy_step",
+                 "rh_adam_lazy_step_mode",
+                 "rh_adam_lazy_step_mode",
                  "rh_batch_gather", "rh_embed_scatter_rows", "rh_shard_localize", "rh_seq_pool_fwd", "rh_seq_pool_bwd"]
         timer = KernelTimer(names)
         comm = CommTimer(trainer.bucket) if trainer.dp is not None else None
@@ -521,6 +529,11 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
             eager_step()
         res["kernel_ms"] = timer.mean_ms()
         res["kernel_calls_per_step"] = {n: round(c / n_prof, 2) for n, c in timer.calls().items() if c}
+        for d_ in (res["kernel_ms"], res["kernel_calls_per_step"]):  # the merged end-of-step launch under its round-2 name
+            if d_.get("rh_adam_lazy_step_mode") is not None:
+                d_["rh_adam_lazy_step"] = d_.pop("rh_adam_lazy_step_mode")
+            else:
+                d_.pop("rh_adam_lazy_step_mode", None)
         timer.remove()
         if comm is not None:
             comm.remove()
@@ -564,6 +577,10 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
     res["sweep_bytes"] = sweep_bytes
     res["step_bytes"] = step_bytes
     res["overlap_sweep"] = bool(getattr(opt, "overlap_sweep", False))
+    tune = getattr(trainer, "_tune", None) or {}
+    res["step_form"] = {"chosen": {"deferred_sweep": tune["chosen"][0], "sweep_lds_pad_bytes": tune["chosen"][1]},
+                        "candidates": [{"deferred_sweep": c[0], "sweep_lds_pad_bytes": c[1]} for c in tune["cands"]],
+                        "ms_per_step_during_tuning": tune.get("ms")} if tune.get("chosen") else None
     # the north-star kernels over batch sizes (same tables, same stream, HIP events): their bandwidth regime starts
     # where the launch is no longer three dependent memory round trips long.  Last: it leaves junk gradient rows behind.
     if profile and wl.name == "deepfm" and trainer.dp is None and not args.no_kernel_sweep:
@@ -598,6 +615,7 @@ def _short_run(args, device, rank, use_graph, model=None, batch=None, dist_kind=
         wl.args = a
     r = run_mode(a, wl, None, use_graph, 1, rank, device, profile=False)
     out = {"batch": a.batch, "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 1), "unit": "samples/s",
+           "step_form": (r.get("step_form") or {}).get("chosen"),
            "steps": steps, "warmup_effective": r["warmup_effective"], "hipgraph": r["hipgraph"], "flush_ms": r["flush_ms"],
            "rows_behind_after_flush": r.get("rows_behind_after_flush")}
     torch.cuda.empty_cache()
@@ -633,7 +651,7 @@ def parse_step_trace(trace_csv, steps_wanted):
     rows = []
     with open(trace_csv) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2]]
     if len(marks) < 3:
@@ -642,9 +660,12 @@ def parse_step_trace(trace_csv, steps_wanted):
     n = len(marks) - 1
     wall = (rows[marks[-1]][0] - rows[marks[0]][0]) / n / 1e3
     per_kernel, order = {}, []
+    main_q = rows[marks[0]][3]
     for i in range(marks[0], marks[-1]):
-        st, en, name = rows[i]
+        st, en, name, q = rows[i]
         short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("rechub::", "").split("(")[0][:60]
+        if q != main_q:
+            short += " [side stream]"
         if short not in per_kernel:
             per_kernel[short] = [0, 0.0, name]
             order.append(short)
@@ -656,8 +677,10 @@ def parse_step_trace(trace_csv, steps_wanted):
     for k in order:
         cnt, tot, full = per_kernel[k]
         us = tot / n
-        busy += us
-        grp = _account_group(full)
+        side = k.endswith("[side stream]")
+        if not side:
+            busy += us
+        grp = _account_group(full) + ("_deferred_on_side_stream_overlapped" if side else "")
         groups[grp] = round(groups.get(grp, 0.0) + us, 2)
         kernels.append({"kernel": k, "launches_per_step": round(cnt / n, 2), "us_per_step": round(us, 2),
                         "avg_us": round(tot / cnt, 2), "group": grp})
@@ -716,7 +739,10 @@ def trace_inner(args, device, rank):
     model, trainer, loader = wl.build(None, True, batch=args.batch)
     trainer._graphed_step(loader)
     lazy = getattr(trainer.optimizer, "lazy_k", 0) > 1
-    for _ in range(max(args.warmup, (args.lazy_k + 8) if lazy else 0) + args.steps):
+    warm = max(args.warmup, (args.lazy_k + 8) if lazy else 0)
+    if lazy:  # past the trainer's self-tuning of the step's form, as the headline's timed region is
+        warm += len(trainer.TUNE_CANDIDATES) * (trainer.TUNE_SETTLE + trainer.TUNE_STEPS) + 4
+    for _ in range(warm + args.steps):
         trainer._graphed_step(loader)
     torch.cuda.synchronize()
 
@@ -942,7 +968,8 @@ def main():
         opt_desc = "dense pass per step"
         if args.table_adam == "lazy":
             opt_desc = (f"blocked-lazy exact replay, K={args.lazy_k}, window sweep "
-                        + ("of step t on a side stream under step t+1's forward/backward" if head["overlap_sweep"]
+                        + ("of step t on a side stream under step t+1's forward/backward (joined before step t+2 refreshes "
+                           "its rows; residency-capped, chosen by the trainer's self-tuning)" if head["overlap_sweep"]
                            else "in line")
                         + f"; timed region = steady state ({head['warmup_effective']} untimed steps since the last flush: "
                         "the rows' lag distribution is the same at its start and end, no deferred work crosses it); the "
@@ -973,6 +1000,7 @@ def main():
                            "replicate": "one replica per rank, gradient rows exchanged",
                            None: "single copy"}[best],
                 "vocab_scale": args.vocab_scale,
+                "step_form": head.get("step_form"),
             },
             "flush_ms": head["flush_ms"],
             "rows_behind_after_flush": head.get("rows_behind_after_flush"),

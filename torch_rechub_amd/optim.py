@@ -510,10 +510,11 @@ class TableAdam(torch.optim.Adam):
             seg = graphs.active()
             if seg is not None and self.overlap_sweep and self.sweep_events:
                 pass  # sidecar mode: _sidecar_after_replay counts the replayed steps
-            elif seg is not None and self.overlap_sweep:
+            elif seg is not None:
                 if getattr(self, "_advance_seg", None) is not seg:  # replays count their steps on the host too (the
-                    seg.after(self._advance_host_step)              # sweep takes its step by value), after the last segment
-                    self._advance_seg = seg
+                    seg.after(self._advance_host_step)              # deferred sweep takes its step by value), after the
+                    self._advance_seg = seg                         # last segment -- in-line captures as well: a trainer
+                                                                    # may alternate between the two forms of the step
             elif not torch.cuda.is_current_stream_capturing():
                 self._host_step += 1
         if self._prepared:

@@ -284,6 +284,96 @@ class CTRTrainer(object):
                 self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
         return self._main_stream
 
+    # Candidates of the step's self-tuning: (deferred sweep?, residency cap of the side-stream sweep in bytes of LDS pad).
+    # 58 KB / 88 KB = 2 / 1 sweep workgroups per CU.  The in-line form (merged end-of-step launch) is always a candidate:
+    # the deferred sweep pays when the step's chain is latency-bound (DeepFM / DSSM at B = 4096: -15 %), not when its
+    # kernels are heavy themselves (B >= 8192: the sweep slows them by more than it hides).
+    TUNE_CANDIDATES = ((True, 58 * 1024), (True, 88 * 1024), (False, 0))
+    TUNE_SETTLE, TUNE_STEPS = 6, 16
+
+    def _tune_step_form(self, loader):
+        """Self-tuning of HOW the captured step ends, over real training steps (nothing is thrown away): once the lazy
+        optimizer is in its steady state (lazy_k + 8 replays after the capture: the window sweeps have their full
+        length), every candidate of TUNE_CANDIDATES runs TUNE_SETTLE + TUNE_STEPS steps bracketed by HIP events, then ONE
+        event synchronisation picks the fastest.  The residency cap is an argument of the EAGER side-stream launch and can
+        change between replays of one graph; the in-line form is a second capture of the same step (its own graph, same
+        arithmetic: the optimizer's bit-equality tests cover both).  RECHUB_STEP_FORM=overlap|inline and
+        RECHUB_SWEEP_PAD=bytes pin the choice; data-parallel steps keep the configured form."""
+        opt = self.optimizer
+        st = getattr(self, "_tune", None)
+        if st is None:
+            from .. import _lib
+            lazy = isinstance(opt, TableAdam) and getattr(opt, "lazy_k", 0) > 1 and bool(opt._tables)
+            form = os.environ.get("RECHUB_STEP_FORM", "")
+            pad = os.environ.get("RECHUB_SWEEP_PAD", "")
+            if pad:
+                _lib.call("rh_set_tuning", 3, int(pad))
+            cands = [c for c in self.TUNE_CANDIDATES if (form != "overlap" or c[0]) and (form != "inline" or not c[0]) and
+                     (not pad or not c[0] or c[1] == self.TUNE_CANDIDATES[0][1])]
+            active = (lazy and self.dp is None and "RECHUB_SWEEP_OVERLAP" not in os.environ and len(cands) > 1 and
+                      "3=" not in os.environ.get("RECHUB_TUNE", ""))
+            st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
+                               "cands": cands}
+            if lazy and form == "inline" and opt.overlap_sweep:
+                self._switch_form(False, loader)
+        if not st["active"]:
+            return
+        if st["wait"] > 0:
+            st["wait"] -= 1
+            return
+        from .. import _lib
+        per = self.TUNE_SETTLE + self.TUNE_STEPS
+        i, n = st["i"], st["n"]
+        if n == 0:
+            self._apply_candidate(st["cands"][i], loader)
+        if n == self.TUNE_SETTLE:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st["ev"].append([e0, None])
+        st["n"] = n + 1
+        if st["n"] == per:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()  # in front of this step's replay: TUNE_STEPS - 1 whole steps since e0, for every candidate alike
+            st["ev"][i][1] = e1
+            st["i"], st["n"] = i + 1, 0
+            if st["i"] == len(st["cands"]):
+                times = []
+                for e0, e1 in st["ev"]:
+                    e1.synchronize()
+                    times.append(e0.elapsed_time(e1))
+                best = min(range(len(times)), key=times.__getitem__)
+                st.update(active=False, chosen=st["cands"][best], ms=[round(t / (self.TUNE_STEPS - 1), 4) for t in times])
+                st["pending"] = st["cands"][best]  # applied in front of the NEXT replay (this one still belongs to the last candidate)
+        return
+
+    def _apply_candidate(self, cand, loader):
+        from .. import _lib
+        overlap, pad = cand
+        if overlap:
+            _lib.call("rh_set_tuning", 3, int(pad))
+        if bool(self.optimizer.overlap_sweep) != bool(overlap):
+            self._switch_form(overlap, loader)
+
+    def _switch_form(self, overlap, loader):
+        """Continue with the other form of the captured step (deferred sweep <-> in-line sweep), capturing it on first
+        use.  The switch happens between two steps from a settled sweep state, so both graphs see the same invariants."""
+        opt = self.optimizer
+        opt.settle_sweep()
+        forms = self.__dict__.setdefault("_graph_forms", {})
+        forms[bool(opt.overlap_sweep)] = (self._graph, self._graph_loss)
+        opt.overlap_sweep = bool(overlap)
+        if bool(overlap) in forms:
+            self._graph, self._graph_loss = forms[bool(overlap)]
+            return
+        g = graphs.SegmentedGraph()
+
+        def whole_step():
+            x, y = self._load(loader)
+            return self.train_step(x, y)
+
+        self._graph_loss = g.capture(whole_step)
+        self._graph = g
+
     def _graphed_step(self, loader):
         """Replay the captured (batch assembly + train_step); the first call warms up eagerly and captures.
 
@@ -344,6 +434,10 @@ class CTRTrainer(object):
                 self._phase_b(gathered)
             self._graph_b.replay()
             return total + self._graph_loss, self.GRAPH_WARMUP + 1
+        self._tune_step_form(loader)
+        pend = self._tune.pop("pending", None)
+        if pend is not None:
+            self._apply_candidate(pend, loader)
         self._graph.replay()
         if split and self._graph_b is not None:
             self.bucket._deferred_runs = [(0, len(self.bucket.params))]
