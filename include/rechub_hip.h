@@ -54,8 +54,9 @@ const char* rh_last_error(void);
 #define RH_TUNE_WIDE_ATOMICS 1 /* 1: table-gradient atomics carry whole rows per request (default), 0: 16 B pieces */
 #define RH_TUNE_SWEEP_GRID 2   /* workgroups of rh_adam_lazy_sweep (0 = default 8192) */
 #define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per workgroup of a DEFERRED sweep (rh_adam_lazy_sweep with t_value >= 0; <= 150
-                                  KiB, -1 = default 58 KiB): caps its residency so that the kernels of the step it runs beside
-                                  find wave slots and issue cycles */
+                                  KiB, -1 = default 0): one way of capping its residency beside the step's launch chain */
+#define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
+                                  the residency cap that lets the step's chain keep its wave slots and issue cycles */
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
 #define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
 #define RH_TUNE_FWD_PATH 7      /* rh_embed_fwd: 0 auto (by batch size), 1 lane-split kernel only, 2 field-uniform kernel only */

@@ -247,7 +247,7 @@ def _assert_no_row_behind(trainer):
     return t
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("overlap", ["0", "1", "auto"])
 def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch):
     """Round-1 bug: TableAdam.flush() was driven by a host flag that hipGraph replays never set, so from the second
     epoch on state_dict() / checkpoints held table rows up to K-1 steps behind the dense-Adam semantics of the reference
@@ -276,7 +276,14 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
 
     # overlap = "1": the window sweep of every step deferred to the side stream under the next step (segmented replay:
     # join -> [batch assembly, refresh] -> fork sweep by value -> [rest of the step]); same bits demanded
-    monkeypatch.setenv("RECHUB_SWEEP_OVERLAP", overlap)
+    # overlap = "auto": nothing pinned -- the trainer's self-tuning alternates between the forms of the step (deferred sweep
+    # at two residency caps, in-line sweep: two captured graphs of the same step) over real steps and settles on one
+    epochs = 2
+    if overlap == "auto":
+        monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
+        epochs = 9  # 3 eager + 105 replayed steps: past lazy_k + 8 + 3 candidates x 22 steps of tuning
+    else:
+        monkeypatch.setenv("RECHUB_SWEEP_OVERLAP", overlap)
     kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, device="cuda:0", show_progress=False, use_graph=True)
     ma, names, dnames = build()
     mb, _, _ = build()
@@ -287,11 +294,14 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
     losses = []
     for t in (ta, tb):
         dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
-        losses.append([t.train_one_epoch(dl) for _ in range(2)])  # epoch 2 = graph replays only
+        losses.append([t.train_one_epoch(dl) for _ in range(epochs)])  # epoch 2 on = graph replays only
         assert t._graph is not None
     assert losses[0] == losses[1]
+    if overlap == "auto":
+        assert ta._tune["active"] is False and ta._tune["chosen"] in ta.TUNE_CANDIDATES and len(ta._tune["ms"]) == 3
+        assert ta._graph_forms  # the other form of the step was captured and replayed too
     steps = _assert_no_row_behind(ta)
-    assert steps == 2 * nb
+    assert steps == epochs * nb
     sa, sb = ma.state_dict(), mb.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r3c; export TMPDIR=/tmp
-run() { tag=$1; shift; env "$@" timeout 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-sweep --brief "${EXTRA[@]}" 2> gpurun_out/r3c/$tag.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['rows_behind_after_flush'])" || tail -5 gpurun_out/r3c/$tag.err; }
-for m in dcnv2 din; do EXTRA=(--model $m); for pad in 66000 90112 122880; do run ${m}_ovl_pad$pad RECHUB_SWEEP_OVERLAP=1 RECHUB_TUNE=3=$pad; done; done
-EXTRA=(--model dcnv2); run dcnv2_ovl_pad90k_g2048 RECHUB_SWEEP_OVERLAP=1 RECHUB_TUNE=3=90112,2=2048
+run() { tag=$1; shift; env "$@" timeout 200 python bench.py --warmup 10 --no-cpu-baseline --no-kernel-sweep --brief "${EXTRA[@]}" 2> gpurun_out/r3c/$tag.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['host_enqueue_ms_per_step'])" || tail -5 gpurun_out/r3c/$tag.err; }
+for i in 1 2 3; do EXTRA=(--steps 20); run tuned20_$i RECHUB_X=1; done
+for i in 1 2; do EXTRA=(--steps 20); run inline20_$i RECHUB_SWEEP_OVERLAP=0; done
+EXTRA=(--steps 200); run tuned200 RECHUB_X=1

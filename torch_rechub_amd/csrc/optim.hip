@@ -15,13 +15,20 @@ namespace {
 constexpr int kMaxTensors = 128;
 constexpr int kMaxRing = 1024;  // entries of the (A, E) ring kept in LDS by the lazy sweep
 int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workgroups, the measured best)
-// tuning knob RH_TUNE_SWEEP_LDS_PAD: extra dynamic LDS bytes per workgroup of a DEFERRED sweep (one that runs on a side
-// stream beside the step's launch chain: rh_adam_lazy_sweep with t_value >= 0).  It caps the sweep's residency -- 8 KB of
-// ring + 58 KB of pad = 2 workgroups (2 wavefronts per SIMD) per CU of 160 KB -- so that the chain's kernels find wave
-// slots and issue cycles; measured on the DeepFM step: 0.365 ms (no pad) / 0.353 (48 KB) / 0.311 (58 KB) / 0.327 (60 KB) /
-// 0.35 (64 KB) / 0.42 (88 KB: one workgroup per CU, the sweep itself becomes the long pole).  -1 = that default.
+// A DEFERRED sweep (rh_adam_lazy_sweep with t_value >= 0) runs on a side stream BESIDE the step's launch chain.  Left at
+// its in-line shape (8192 persistent workgroups, every wave slot it can get) it starves the chain: measured on the DeepFM
+// step, the chain's kernels ran 2.6x slower under it and the overlap gained nothing.  Its residency is therefore capped:
+//   RH_TUNE_DEFERRED_GRID  persistent workgroups of a deferred sweep (default 512 = 2 per CU = 2 wavefronts per SIMD; the
+//                          trainer's self-tuning also tries 256 = 1 per CU, which wins under long chains: DCN-v2, B >= 8192)
+//   RH_TUNE_SWEEP_LDS_PAD  extra dynamic LDS bytes per workgroup of a deferred sweep (default 0).  The first cap tried:
+//                          8 KB ring + 58 KB pad = 2 workgroups per CU of 160 KB.  It works (0.365 -> 0.311 ms) but the
+//                          padding also keeps LDS-hungry kernels of the chain (library GEMMs) off the CU; the grid cap
+//                          reaches the same residency without that: 0.302 ms.
+// Step time by cap (DeepFM, B = 4096, same box): pad 0 / 48 / 58 / 64 / 88 KB at grid 8192: 0.365 / 0.353 / 0.311 / 0.35 /
+// 0.42 ms; grid 256 / 384 / 448 / 512 / 576 / 640 / 1024 at pad 0: 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.
 int g_sweep_lds_pad = -1;
-static const int kDeferredSweepPad = 58 * 1024;
+int g_deferred_grid = 512;
+static const int kDeferredSweepPad = 0;
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -497,7 +504,8 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
   if (a.total_vblocks == 0 && a.touch_blocks == 0) return 0;
   // persistent-style grid: each workgroup walks several virtual blocks so the prefetch has something to overlap
   int64_t grid = a.total_vblocks;
-  const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
+  const int64_t cap = (a.t_value >= 0 && touch == nullptr && g_deferred_grid > 0) ? g_deferred_grid
+                      : (g_sweep_grid > 0 ? g_sweep_grid : 256 * 32);
   if (grid > cap) grid = cap;
   if (touch != nullptr) {
     if (grid < 1) grid = 1;
@@ -734,6 +742,10 @@ extern "C" int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, c
 extern "C" int rh_optim_set_tuning(int key, int value) {
   if (key == RH_TUNE_SWEEP_GRID) {
     g_sweep_grid = value;
+    return 0;
+  }
+  if (key == RH_TUNE_DEFERRED_GRID) {
+    g_deferred_grid = value;
     return 0;
   }
   if (key == RH_TUNE_SWEEP_LDS_PAD) {

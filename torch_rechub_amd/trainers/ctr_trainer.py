@@ -284,34 +284,34 @@ class CTRTrainer(object):
                 self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
         return self._main_stream
 
-    # Candidates of the step's self-tuning: (deferred sweep?, residency cap of the side-stream sweep in bytes of LDS pad).
-    # 58 KB / 88 KB = 2 / 1 sweep workgroups per CU.  The in-line form (merged end-of-step launch) is always a candidate:
-    # the deferred sweep pays when the step's chain is latency-bound (DeepFM / DSSM at B = 4096: -15 %), not when its
-    # kernels are heavy themselves (B >= 8192: the sweep slows them by more than it hides).
-    TUNE_CANDIDATES = ((True, 58 * 1024), (True, 88 * 1024), (False, 0))
+    # Candidates of the step's self-tuning: (deferred sweep?, persistent workgroups of the side-stream sweep:
+    # RH_TUNE_DEFERRED_GRID, 512 / 256 = 2 / 1 per CU).  The in-line form (merged end-of-step launch) is always a candidate:
+    # the deferred sweep pays when the step's chain is latency-bound (DeepFM / DSSM at B = 4096: -17 %), less when its
+    # kernels are heavy themselves (DIN, B = 65536: the sweep slows them by what it hides).
+    TUNE_CANDIDATES = ((True, 512), (True, 256), (False, 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
     def _tune_step_form(self, loader):
         """Self-tuning of HOW the captured step ends, over real training steps (nothing is thrown away): once the lazy
         optimizer is in its steady state (lazy_k + 8 replays after the capture: the window sweeps have their full
         length), every candidate of TUNE_CANDIDATES runs TUNE_SETTLE + TUNE_STEPS steps bracketed by HIP events, then ONE
-        event synchronisation picks the fastest.  The residency cap is an argument of the EAGER side-stream launch and can
+        event synchronisation picks the fastest.  The residency cap is a parameter of the EAGER side-stream launch and can
         change between replays of one graph; the in-line form is a second capture of the same step (its own graph, same
         arithmetic: the optimizer's bit-equality tests cover both).  RECHUB_STEP_FORM=overlap|inline and
-        RECHUB_SWEEP_PAD=bytes pin the choice; data-parallel steps keep the configured form."""
+        RECHUB_SWEEP_GRID=workgroups pin the choice; data-parallel steps keep the configured form."""
         opt = self.optimizer
         st = getattr(self, "_tune", None)
         if st is None:
             from .. import _lib
             lazy = isinstance(opt, TableAdam) and getattr(opt, "lazy_k", 0) > 1 and bool(opt._tables)
             form = os.environ.get("RECHUB_STEP_FORM", "")
-            pad = os.environ.get("RECHUB_SWEEP_PAD", "")
+            pad = os.environ.get("RECHUB_SWEEP_GRID", "")
             if pad:
-                _lib.call("rh_set_tuning", 3, int(pad))
+                _lib.call("rh_set_tuning", 8, int(pad))
             cands = [c for c in self.TUNE_CANDIDATES if (form != "overlap" or c[0]) and (form != "inline" or not c[0]) and
                      (not pad or not c[0] or c[1] == self.TUNE_CANDIDATES[0][1])]
             active = (lazy and self.dp is None and "RECHUB_SWEEP_OVERLAP" not in os.environ and len(cands) > 1 and
-                      "3=" not in os.environ.get("RECHUB_TUNE", ""))
+                      "8=" not in os.environ.get("RECHUB_TUNE", "") and "3=" not in os.environ.get("RECHUB_TUNE", ""))
             st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
                                "cands": cands}
             if lazy and form == "inline" and opt.overlap_sweep:
@@ -348,9 +348,9 @@ class CTRTrainer(object):
 
     def _apply_candidate(self, cand, loader):
         from .. import _lib
-        overlap, pad = cand
+        overlap, grid = cand
         if overlap:
-            _lib.call("rh_set_tuning", 3, int(pad))
+            _lib.call("rh_set_tuning", 8, int(grid))
         if bool(self.optimizer.overlap_sweep) != bool(overlap):
             self._switch_form(overlap, loader)
 
