@@ -133,6 +133,22 @@ int rh_embed_bwd_nchunks(int B, int samples_per_block);
 int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F,
                           int D, const float* rows, float scale, int samples_per_block,
                           int32_t* err_flag, void* stream);
+/* Row-list form of the table gradient (the single-GPU fused step; the reference's loss.backward() + optimizer.step(),
+ * trainers/ctr_trainer.py:97-99, never needs the vocab-sized .grad tensor in between): rh_embed_bwd with the gradient rows
+ * of the flagged fields written where they are produced -- rl_rows (B * F, D), coalesced plain stores -- and the lookups
+ * that hit the same table row linked into a chain (rl_next (B * F) int32: next lookup of the row, -1 end, -2 dead lookup)
+ * through an open-addressing hash rl_hash (rl_slots uint64, a power of two >= 2 * B * F, all zero on entry; slot = key
+ * 34 bits | chain head 21 bits).  rl_field (F, device int64): 0 = the field keeps the dense gradient buffer of its fdesc
+ * entry (small / densely stepped tables: LDS pre-reduction or atomics as in rh_embed_bwd), t + 1 = row list for table t.
+ * The chain head owns the row's update: rh_adam_lazy_touched_rows / rh_adam_lazy_step_rows sum the chain and apply ONE
+ * Adam step; the next forward's pre-gather pass (rh_adam_lazy_touched_rows, refresh = 1) empties the hash.
+ * No memory-side read-modify-write into a vocab-sized buffer, no re-read / re-zero of gradient rows by the optimizer.
+ * Limits: B * F < 2^21 lookups, rows per row-list table < 2^27; indices and upstream gradients as rh_embed_bwd. */
+int rh_embed_bwd_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F, int D, const float* g_out,
+                      int64_t g_stride, const float* emb, int64_t emb_stride, const float* s_sum, const float* g_fm,
+                      const float* g_lr, const float* lr_w, float* lr_wgrad, float scale, float* rl_rows, int32_t* rl_next,
+                      uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, int samples_per_block, int32_t* err_flag,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FM on an arbitrary (B, F, D) tensor (row stride x_stride floats per sample, fields contiguous)
@@ -501,6 +517,18 @@ int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, c
                            const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                            const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
                            void* stream);
+/* Optimizer side of the row-list gradient (rh_embed_bwd_rows; same rl_* arguments): rh_adam_lazy_touched with the chain
+ * head of every table row as the owner of its update (refresh = 0), or with the hash emptied for the coming backward
+ * (refresh = 1, the pre-gather pass); rh_adam_lazy_step_rows = that touched pass + the sweep of the dense (K = 1) tables in
+ * one launch (the lazy tables' window sweep is its own launch: rh_adam_lazy_sweep, RH_SWEEP_LAZY_TABLES). */
+int rh_adam_lazy_touched_rows(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc, int idx_is_i64,
+                              int B, int F, int D, const double* hyper, const float* ring, int ring_size,
+                              int samples_per_block, int refresh, int32_t* err_flag, float* rl_rows, int32_t* rl_next,
+                              uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, void* stream);
+int rh_adam_lazy_step_rows(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, float* rl_rows,
+                           int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
 

@@ -5,6 +5,8 @@ parameters after the reference's own CTRTrainer.train_one_epoch ran three Adam s
 Tolerances: probabilities atol 2e-6; gradients rtol 1e-4 + atol 2e-6*max|g|; three-step trajectory atol 3e-4
 (Adam normalises by sqrt(v): elements whose gradient is at rounding level may flip by a fraction of lr=1e-2).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -247,7 +249,7 @@ def _assert_no_row_behind(trainer):
     return t
 
 
-@pytest.mark.parametrize("overlap", ["0", "1", "auto"])
+@pytest.mark.parametrize("overlap", ["0", "1", "auto", "0+rowlist", "1+rowlist"])
 def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch):
     """Round-1 bug: TableAdam.flush() was driven by a host flag that hipGraph replays never set, so from the second
     epoch on state_dict() / checkpoints held table rows up to K-1 steps behind the dense-Adam semantics of the reference
@@ -279,6 +281,11 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
     # overlap = "auto": nothing pinned -- the trainer's self-tuning alternates between the forms of the step (deferred sweep
     # at two residency caps, in-line sweep: two captured graphs of the same step) over real steps and settles on one
     epochs = 2
+    if overlap.endswith("+rowlist"):
+        # opt-in row-list form of the table gradient (rh_embed_bwd_rows: per-lookup rows + duplicate chains, the chain head
+        # owns the row's update): B = 64 lookups into tables of 65 .. 20000 rows = many duplicate chains; same bits demanded
+        monkeypatch.setenv("RECHUB_ROWLIST", "1")
+        overlap = overlap[0]
     if overlap == "auto":
         monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
         epochs = 9  # 3 eager + 105 replayed steps: past lazy_k + 8 + 3 candidates x 22 steps of tuning
@@ -291,15 +298,18 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
     ta = CTRTrainer(ma, table_update="lazy", lazy_k=4, lazy_small_rows=8, **kw)
     tb = CTRTrainer(mb, table_update="dense", **kw)
     assert ta.optimizer.lazy_k == 4 and ta.optimizer.lazy_small_rows == 8
-    losses = []
+    losses, loaders = [], []
     for t in (ta, tb):
         dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        loaders.append(dl)
         losses.append([t.train_one_epoch(dl) for _ in range(epochs)])  # epoch 2 on = graph replays only
         assert t._graph is not None
     assert losses[0] == losses[1]
     if overlap == "auto":
         assert ta._tune["active"] is False and ta._tune["chosen"] in ta.TUNE_CANDIDATES and len(ta._tune["ms"]) == 3
         assert ta._graph_forms  # the other form of the step was captured and replayed too
+    if os.environ.get("RECHUB_ROWLIST") == "1":
+        assert ta.optimizer._rl_cache, "the row-list path did not engage"
     steps = _assert_no_row_behind(ta)
     assert steps == epochs * nb
     sa, sb = ma.state_dict(), mb.state_dict()
@@ -310,11 +320,14 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
         assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
         assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
     # a second flush after more replays: optimizer.state_dict() flushes too
-    dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
     for _ in range(5):
-        ta._graphed_step(dl)
+        ta._graphed_step(loaders[0])
     ta.optimizer.state_dict()
     assert _assert_no_row_behind(ta) == steps + 5
+    # the captured step reads the static buffers of the loader it was captured with: another loader is refused
+    other = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+    with pytest.raises(RuntimeError, match="captured with another DeviceDataLoader"):
+        ta._graphed_step(other)
 
 
 def test_graph_mode_flush_leaves_no_row_behind_match_trainer(monkeypatch):

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r3c; export TMPDIR=/tmp
 cd /tmp
-for cfg in "pad58k RECHUB_SWEEP_OVERLAP=1 RECHUB_TUNE=3=59392"; do
+for cfg in "g512 RECHUB_STEP_FORM=overlap RECHUB_SWEEP_GRID=512"; do
   set -- $cfg; tag=$1; shift
   rm -rf /tmp/tl_$tag
   env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$tag -o t -- python $OLDPWD/bench.py --trace-inner --steps 30 --warmup 10 --rows 4000000 > /dev/null 2> $OLDPWD/gpurun_out/r3c/tl_$tag.err

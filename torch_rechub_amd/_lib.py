@@ -32,6 +32,8 @@ SIGNATURES = {
                      c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
     "rh_embed_bwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
                      c_ptr, c_ptr, c_f32, c_int, c_ptr, c_int, c_ptr, c_ptr],
+    "rh_embed_bwd_rows": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                          c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_ptr],
     "rh_embed_bwd_nchunks": [c_int, c_int],
     "rh_embed_scatter_rows": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_f32, c_int, c_ptr, c_ptr],
     "rh_fm_fwd": [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
@@ -124,6 +126,10 @@ SIGNATURES = {
                                c_ptr, c_int, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
+    "rh_adam_lazy_touched_rows": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
+                                  c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
+    "rh_adam_lazy_step_rows": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
+                               c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr],
     "rh_adam_dense": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     "rh_batch_gather": [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],

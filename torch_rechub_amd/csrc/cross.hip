@@ -21,6 +21,7 @@ __global__ __launch_bounds__(RH_BLOCK) void cross_fwd_kernel(const float* __rest
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias, int B, int d,
                                                              float* __restrict__ out, int64_t out_stride) {
+  RH_CHAIN_PRIO();
   const int lane = threadIdx.x % RH_WAVE;
   const int wave = threadIdx.x / RH_WAVE;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(RH_BLOCK) void cross_bwd_kernel(
     const float* __restrict__ w, const float* __restrict__ bias, int B, int d,
     const float* __restrict__ g_out, int64_t g_stride, float* __restrict__ g_x0, float* __restrict__ g_x,
     int64_t gx_stride, int sum_into_gx, float* __restrict__ partials) {
+  RH_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [waves][2][NL][EPL*64]
   const int lane = threadIdx.x % RH_WAVE;
   const int wave = threadIdx.x / RH_WAVE;

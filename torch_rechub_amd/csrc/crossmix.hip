@@ -29,6 +29,7 @@ __global__ __launch_bounds__(RH_BLOCK) void cross_v2_kernel(const float* __restr
                                                             const float* __restrict__ b, const float* __restrict__ x,
                                                             const float* __restrict__ g, int64_t n, int d,
                                                             float* __restrict__ o1, float* __restrict__ o2) {
+  RH_CHAIN_PRIO();
   for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * RH_BLOCK) {
     if (!BWD) {
       o1[i] = fmaf(x0[i], y[i], b[i % d]) + x[i];
@@ -56,6 +57,7 @@ struct MixArgs {
 
 template <int EPL, bool BWD>
 __global__ __launch_bounds__(RH_BLOCK) void cross_mix_kernel(const MixArgs a) {
+  RH_CHAIN_PRIO();
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int64_t nw = (int64_t)gridDim.x * kWaves;
   const int d = a.d, E = a.E;

@@ -44,6 +44,7 @@ struct DiceArgs {
 
 template <int EPL, int MODE>
 __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
+  RH_CHAIN_PRIO();
   __shared__ float red[kWaves];
   extern __shared__ float colred[];  // MODE 2: kWaves * 2 * EPL * 64 floats
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
@@ -246,6 +247,7 @@ struct AttArgs {
 // MODE 0: att_input fwd, 1: att_input bwd, 2: weighted pooling fwd, 3: weighted pooling bwd
 template <int LPR, int LS, int MODE>
 __global__ __launch_bounds__(RH_BLOCK) void att_kernel(const AttArgs a) {
+  RH_CHAIN_PRIO();
   constexpr int G = LPR * LS;
   const int lig = threadIdx.x % G;
   const int q = lig % LPR, ls = lig / LPR;
@@ -348,6 +350,7 @@ int att_check(const char* who, int B, int L, int D) {
 namespace {
 __global__ __launch_bounds__(RH_BLOCK) void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
                                                              int64_t n4, int64_t n, float* __restrict__ out) {
+  RH_CHAIN_PRIO();
   const float a = slope[0];
   for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RH_BLOCK) {
     float4 v = gload<float4>(x + 4 * i);
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(RH_BLOCK) void prelu_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(RH_BLOCK) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                              const float* __restrict__ slope, int64_t n4, int64_t n,
                                                              float* __restrict__ gx, float* __restrict__ partial) {
+  RH_CHAIN_PRIO();
   __shared__ float red[RH_BLOCK / RH_WAVE];
   const float a = slope[0];
   float acc = 0.f;

@@ -40,6 +40,7 @@ struct AttL1Args {
 
 template <int D>
 __global__ __launch_bounds__(RH_BLOCK) void din_att_l1_kernel(const AttL1Args a) {
+  RH_CHAIN_PRIO();
   constexpr int H = 2 * D;  // floats of a lane's operand half = MFMA steps
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int i = lane & 31, kk = lane >> 5;

@@ -12,6 +12,7 @@ namespace {
 template <int G>
 __global__ __launch_bounds__(RH_BLOCK) void fm_fwd_kernel(const float* __restrict__ x, int64_t xs, int B, int F,
                                                           int D, int reduce_sum, float* __restrict__ out) {
+  RH_CHAIN_PRIO();
   const int lig = threadIdx.x % G;
   int64_t b = (int64_t)blockIdx.x * (RH_BLOCK / G) + threadIdx.x / G;
   const bool live = b < B;
@@ -44,6 +45,7 @@ template <int G>
 __global__ __launch_bounds__(RH_BLOCK) void fm_bwd_kernel(const float* __restrict__ x, int64_t xs, int B, int F,
                                                           int D, int reduce_sum, const float* __restrict__ g_out,
                                                           float* __restrict__ g_x, int64_t gxs) {
+  RH_CHAIN_PRIO();
   const int lig = threadIdx.x % G;
   const int64_t b = (int64_t)blockIdx.x * (RH_BLOCK / G) + threadIdx.x / G;
   if (b >= B) return;

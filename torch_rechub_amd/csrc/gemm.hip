@@ -62,6 +62,7 @@ static __device__ __forceinline__ float4 load4_guard(const float* row, int k, in
 
 template <int WM, int WN, bool B_KMAJOR, bool STATS>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a) {
+  RH_CHAIN_PRIO();
   constexpr int NT = 64 * WM * WN;      // threads
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int A_V4 = BM * kBK / 4 / NT;              // float4 per thread per A tile

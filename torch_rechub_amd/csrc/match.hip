@@ -36,6 +36,7 @@ struct InbatchArgs {
 
 template <int PL, bool BWD>  // PL = ceil(D / 64) floats per lane
 __global__ __launch_bounds__(RH_BLOCK) void inbatch_logits_kernel(const InbatchArgs a) {
+  RH_CHAIN_PRIO();
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int K1 = a.K + 1;
   bool bad = false;

@@ -36,6 +36,7 @@ struct MoePackArgs {
 };
 
 __global__ __launch_bounds__(RH_BLOCK) void moe_pack_kernel(const MoePackArgs a) {
+  RH_CHAIN_PRIO();
   const int64_t per = (int64_t)a.KP * a.d;
   const int64_t total = 2 * a.L * per;
   const int ER = a.E * a.r;
@@ -76,6 +77,7 @@ struct MoeMidArgs {
 // One thread per (sample slot s, expert e, rank index k); SPB = 256 / (E R) samples per pass of a workgroup.
 template <int R>
 __global__ __launch_bounds__(RH_BLOCK) void moe_mid_fwd_kernel(const MoeMidArgs a) {
+  RH_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int E = a.E, ER = E * R, KP = a.KP;
   const int SPB = RH_BLOCK / ER;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_mid_fwd_kernel(const MoeMidArgs 
 
 template <int R>
 __global__ __launch_bounds__(RH_BLOCK) void moe_mid_bwd_kernel(const MoeMidArgs a) {
+  RH_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int E = a.E, ER = E * R, KP = a.KP;
   const int SPB = RH_BLOCK / ER;
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_res_bwd_kernel(const float* __re
                                                                const float* __restrict__ x0, int64_t ldx0,
                                                                const float* __restrict__ Y, int B, int d, int first,
                                                                float* __restrict__ g_Y, float* __restrict__ acc) {
+  RH_CHAIN_PRIO();
   const int64_t n = (int64_t)B * d;
   for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * RH_BLOCK) {
     const int64_t b = i / d;
@@ -274,6 +278,7 @@ static __device__ __forceinline__ float sum_parts(const float* p, int64_t stride
 // over the 4 wavefronts, 8 loads in flight, summed in wavefront order (one thread per output would walk them as one
 // dependent chain).  The rest: one thread per output of g_U / g_V / g_bias / g_gating over the few wgrad slabs.
 __global__ __launch_bounds__(RH_BLOCK) void moe_unpack_kernel(const MoeUnpackArgs a, int cblocks) {
+  RH_CHAIN_PRIO();
   const int E = a.E, d = a.d, r = a.r, KP = a.KP, ER = E * r;
   const int64_t nU = (int64_t)E * d * r, nC = (int64_t)E * r * r;
   if ((int)blockIdx.x < cblocks) {

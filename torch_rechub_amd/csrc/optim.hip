@@ -216,6 +216,9 @@ struct LazyTouchedArgs {
   int ring_mask;
   int T, B, F, spb;
   int* err;
+  RhRowList rl;  // rows != nullptr: the gradient of the fields flagged in rl.field comes as a row list (common.h) -- the
+                 // chain head of a table row owns its update, no claim word atomics, no dense gradient row; REFRESH clears
+                 // the hash for the coming backward
 };
 
 struct LazySweepArgs {
@@ -386,6 +389,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   const int64_t st = a.idesc[F + f];
   const AdamScalars h = load_scalars(a.hyper);
   const int t = (int)a.hyper[12];
+  const int64_t rl_tag = (!REFRESH && a.rl.rows != nullptr) ? a.rl.field[f] : 0;  // block-uniform
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
   const int lane = threadIdx.x % RH_WAVE;
@@ -407,8 +411,13 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     const bool valid = ok && (uint64_t)r < (uint64_t)rows && r != pad;
     int old = t;
     if (valid && q == 0) {
-      old = gload<int>(last + r);
-      if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
+      if (rl_tag != 0) {
+        // row list: the head of the row's chain owns the update (exactly one lookup per table row and step)
+        if (rl_head(a.rl, rl_key(rl_tag, r)) == (int)(b * F + f)) old = gload<int>(last + r);
+      } else {
+        old = gload<int>(last + r);
+        if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
+      }
     }
     old = __shfl(old, lane - q, RH_WAVE);
     bool act = valid && old < t;  // this lane group claimed the row
@@ -449,7 +458,17 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       P = gload<float4>(p + rr * D + q * 4);
       M = gload<float4>(m + rr * D + q * 4);
       V = gload<float4>(v + rr * D + q * 4);
-      if (!REFRESH) G = gload<float4>(g + rr * D + q * 4);
+      if (!REFRESH) {
+        if (rl_tag != 0) {  // sum of the chain's gradient rows (one row unless the batch looked the table row up twice)
+          int j = (int)(b * F + f);
+          do {
+            G = f4_add(G, gload<float4>(a.rl.rows + (int64_t)j * D + q * 4));
+            j = gload<int>(a.rl.next + j);
+          } while (j >= 0);
+        } else {
+          G = gload<float4>(g + rr * D + q * 4);
+        }
+      }
     }
     // replay in segments between the steps at which rows of the wavefront join (see adam_lazy_sweep_kernel): fixed exec
     // mask and a scalar step counter inside a segment (the ring entry becomes a scalar load)
@@ -471,13 +490,23 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     gstore<float4>(p + rr * D + q * 4, P);
     gstore<float4>(m + rr * D + q * 4, M);
     gstore<float4>(v + rr * D + q * 4, V);
-    if (!REFRESH) gstore<float4>(g + rr * D + q * 4, f4_zero());
+    if (!REFRESH) {
+      if (rl_tag == 0) gstore<float4>(g + rr * D + q * 4, f4_zero());
+      else if (q == 0) last[rr] = t;  // (the claim of the dense-buffer path wrote it with its atomicMax)
+    }
   }
 }
 
 template <int LPR, typename IdxT, bool REFRESH>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
   RH_CHAIN_PRIO();
+  if (REFRESH && a.rl.hash != nullptr) {
+    // the pre-gather pass of a step also empties the duplicate-chain hash of the row list for the coming backward
+    const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * RH_BLOCK;
+    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * RH_BLOCK + threadIdx.x; i <= (int64_t)a.rl.mask;
+         i += nthreads)
+      a.rl.hash[i] = 0ull;
+  }
   lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -826,17 +855,56 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
   return 0;
 }
 
+static int lazy_touched_impl(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
+                             int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
+                             int ring_size, int samples_per_block, int refresh, int32_t* err_flag, const RhRowList& rl,
+                             void* stream);
+
 extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                                     int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                                     int ring_size, int samples_per_block, int refresh, int32_t* err_flag,
                                     void* stream) {
+  return lazy_touched_impl(ldesc, T, field_table, idesc, idx_is_i64, B, F, D, hyper, ring, ring_size, samples_per_block,
+                           refresh, err_flag, RhRowList{}, stream);
+}
+
+static int rl_check(const char* who, const float* rl_rows, const int32_t* rl_next, const uint64_t* rl_hash, int64_t rl_slots,
+                    const int64_t* rl_field, int B, int F) {
+  RH_REQUIRE(rl_rows && rl_next && rl_hash && rl_field, RH_E_BADARG, "%s: null row-list pointer", who);
+  RH_REQUIRE(rl_slots >= 2 && (rl_slots & (rl_slots - 1)) == 0 && rl_slots >= 2 * (int64_t)B * F && rl_slots <= (1ll << 31),
+             RH_E_BADARG, "%s: rl_slots = %lld must be a power of two >= 2 * B * F", who, (long long)rl_slots);
+  RH_REQUIRE((int64_t)B * F < (1ll << kRlHeadBits), RH_E_UNSUPPORTED, "%s: B * F = %lld lookups (max 2^21 - 1)", who,
+             (long long)B * F);
+  return 0;
+}
+
+// rh_adam_lazy_touched for a step whose table gradients came from rh_embed_bwd_rows (same row-list arguments).
+// refresh = 1 (the pre-gather pass of the NEXT forward): as rh_adam_lazy_touched, and the hash is emptied for the coming
+// backward.  refresh = 0: the head of every table row's chain sums the chain's gradient rows and applies the step.
+extern "C" int rh_adam_lazy_touched_rows(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
+                                         int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
+                                         int ring_size, int samples_per_block, int refresh, int32_t* err_flag,
+                                         float* rl_rows, int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots,
+                                         const int64_t* rl_field, void* stream) {
+  if (int rc = rl_check("rh_adam_lazy_touched_rows", rl_rows, rl_next, rl_hash, rl_slots, rl_field, B, F)) return rc;
+  return lazy_touched_impl(ldesc, T, field_table, idesc, idx_is_i64, B, F, D, hyper, ring, ring_size, samples_per_block,
+                           refresh, err_flag,
+                           RhRowList{rl_rows, rl_next, reinterpret_cast<unsigned long long*>(rl_hash),
+                                     (unsigned int)(rl_slots - 1), rl_field},
+                           stream);
+}
+
+static int lazy_touched_impl(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
+                             int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
+                             int ring_size, int samples_per_block, int refresh, int32_t* err_flag, const RhRowList& rl,
+                             void* stream) {
   RH_REQUIRE(ldesc && field_table && idesc && hyper && ring, RH_E_BADARG, "rh_adam_lazy_touched: null pointer");
   RH_REQUIRE(T >= 1 && F >= 1 && F <= 65535 && B >= 0, RH_E_BADARG, "rh_adam_lazy_touched: bad shape");
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_touched: ring_size must be a power of two <= %d", kMaxRing);
   if (B == 0) return 0;
   int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
+  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag, rl};
   const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)F);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define RH_LT(LPR)                                                                                             \
@@ -868,14 +936,14 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
 static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                          void* stream);
+                          const RhRowList& rl, void* stream);
 
 extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                                  const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                                  const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
                                  void* stream) {
   return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, RH_SWEEP_WINDOW, stream);
+                        err_flag, RH_SWEEP_WINDOW, RhRowList{}, stream);
 }
 
 // rh_adam_lazy_step with the sweep part restricted as rh_adam_lazy_sweep's `mode`: RH_SWEEP_DENSE_TABLES = the touched-rows
@@ -888,20 +956,37 @@ extern "C" int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t
   RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
              "rh_adam_lazy_step_mode: sweep_mode %d", sweep_mode);
   return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, sweep_mode, stream);
+                        err_flag, sweep_mode, RhRowList{}, stream);
+}
+
+// rh_adam_lazy_step_mode for a step whose table gradients came from rh_embed_bwd_rows.  Only RH_SWEEP_DENSE_TABLES: the
+// sweep part of this launch claims window rows of the lazy tables by their last-step word and expects their gradient
+// in the dense buffer, which a row-list step does not fill -- the lazy tables' window is swept by its own launch
+// (rh_adam_lazy_sweep, RH_SWEEP_LAZY_TABLES: deferred to a side stream, or in line after this one).
+extern "C" int rh_adam_lazy_step_rows(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
+                                      float* rl_rows, int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots,
+                                      const int64_t* rl_field, void* stream) {
+  if (int rc = rl_check("rh_adam_lazy_step_rows", rl_rows, rl_next, rl_hash, rl_slots, rl_field, B, F)) return rc;
+  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
+                        err_flag, RH_SWEEP_DENSE_TABLES,
+                        RhRowList{rl_rows, rl_next, reinterpret_cast<unsigned long long*>(rl_hash),
+                                  (unsigned int)(rl_slots - 1), rl_field},
+                        stream);
 }
 
 static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                          void* stream) {
+                          const RhRowList& rl, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc, RH_E_BADARG,
              "rh_adam_lazy_step: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1, RH_E_BADARG, "rh_adam_lazy_step: bad shape");
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_step: ring_size must be a power of two <= %d", kMaxRing);
   const int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
+  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag, rl};
   LazySweepArgs a;
   a.ldesc = ldesc;
   a.hyper = hyper;

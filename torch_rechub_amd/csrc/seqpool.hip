@@ -29,6 +29,7 @@ struct SeqArgs {
 
 template <int LPR, int LS, typename IdxT, bool BWD>
 __global__ __launch_bounds__(RH_BLOCK) void seq_pool_kernel(const SeqArgs a) {
+  RH_CHAIN_PRIO();
   constexpr int G = LPR * LS;
   constexpr int SPB = RH_BLOCK / G;
   constexpr int U = 8;

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(RH_BLOCK) void shard_localize_kernel(const IdxT* __
                                                                   const int64_t* __restrict__ desc, uint32_t world,
                                                                   uint32_t rank, int32_t* __restrict__ local,
                                                                   int* err) {
+  RH_CHAIN_PRIO();
   const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int f = (int)(i % F);

@@ -237,10 +237,10 @@ def _listeners():
     return [r() for r in live]
 
 
-def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep):
+def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep, rl=None):
     for lst in _listeners():
         lst.on_touch(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
-                          keep=keep))
+                          keep=keep, rl=rl))
 
 
 def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D, training=None):
@@ -251,6 +251,46 @@ def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D, training=None):
     for lst in _listeners():
         lst.on_gather(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
                            training=bool(training)))
+
+
+class RowList(object):
+    """Buffers of one call site's row-list gradient (include/rechub_hip.h, rh_embed_bwd_rows): per-lookup gradient rows,
+    duplicate chains, the chain-head hash (zero on creation; emptied by every pre-gather refresh pass afterwards) and
+    the per-field flags chosen by the optimizer (0 = dense gradient buffer, t + 1 = row list of table t)."""
+
+    def __init__(self, B, F, D, field, device):
+        slots = 1
+        while slots < 2 * B * F:
+            slots *= 2
+        self.B, self.F, self.D, self.slots = B, F, D, max(slots, 2)
+        self.rows = torch.empty((B * F, D), dtype=torch.float32, device=device)
+        self.next = torch.empty((B * F,), dtype=torch.int32, device=device)
+        self.hash = torch.zeros((self.slots,), dtype=torch.int64, device=device)
+        self.field_host = list(field)
+        self.field = torch.tensor(self.field_host, dtype=torch.int64).to(device)
+
+    def args(self):
+        return (_p(self.rows), _p(self.next), _p(self.hash), self.slots, _p(self.field))
+
+
+class _RowListArm(object):
+    """Armed by a trainer around the ONE backward of its training step (never by user code): the fused gather's backward
+    may then hand the table gradient to ``provider`` (optim.TableAdam) as a row list instead of scatter-adding into the
+    vocab-sized ``weight.grad`` buffers, which nobody else reads inside that step."""
+
+    def __init__(self):
+        self.provider = None
+
+    def arm(self, provider):
+        self.provider = provider
+        if hasattr(provider, "_rl_pending"):
+            provider._rl_pending = False  # a new step: whatever an abandoned backward left behind is dropped
+
+    def disarm(self):
+        self.provider = None
+
+
+rowlist = _RowListArm()
 
 
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
@@ -333,24 +373,32 @@ class _EmbedFused(torch.autograd.Function):
         # local_grads: a lookup over row-sharded tables already holds the gradient rows of the global batch
         exchange = _sparse_exchange if (any_table and not call.local_grads) else None
         if any_table or want_wgrad:
+            rl = None
             if exchange is None:
                 fdesc = call.fdesc(True)
                 rows = None
                 sink = 0
+                if any_table and rowlist.provider is not None and not call.local_grads and B > 0:
+                    rl = rowlist.provider.rowlist_for(call)  # optim.TableAdam: RowList, or None = dense buffers
             else:
                 fdesc = call.fdesc(False)
                 rows = torch.empty((B, F, D), dtype=torch.float32, device=dev)
                 sink = 1
-            _lib.call("rh_embed_bwd", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
-                      0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
-                      _p(lr_w), _p(partial), 1.0, sink, _p(rows), call.samples_per_block, _p(err_flag(dev)),
-                      _stream())
+            if rl is not None:
+                _lib.call("rh_embed_bwd_rows", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
+                          0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
+                          _p(lr_w), _p(partial), 1.0, *rl.args(), call.samples_per_block, _p(err_flag(dev)), _stream())
+            else:
+                _lib.call("rh_embed_bwd", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
+                          0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
+                          _p(lr_w), _p(partial), 1.0, sink, _p(rows), call.samples_per_block, _p(err_flag(dev)),
+                          _stream())
             if exchange is not None:
                 gathered = exchange(call, rows)
                 if gathered is not None:  # None: the exchange is deferred to after the backward (split-graph step)
                     scatter_rows(call, gathered[0], gathered[1])
             elif any_table:
-                _log_touch(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, call.idx)
+                _log_touch(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, call.idx, rl=rl)
             if any_table:
                 for w in {id(w): w for w in call.weights if w.requires_grad}.values():
                     _publish_grad(w)

@@ -101,6 +101,9 @@ class TableAdam(torch.optim.Adam):
                 self._ft_cache = {}
                 self._touch_log = []
                 self._table_ids = {id(p) for p in tables}
+                self._rl_cache = {}       # call-site key -> ops.RowList
+                self._rl_single = False   # the previous step had exactly one gather with table gradients
+                self._rl_pending = False  # a backward wrote a row list that no step has consumed yet
                 # Deferred sweep (default; RECHUB_SWEEP_OVERLAP=0 sweeps in line): the window sweep of step s (lazy tables)
                 # is launched on a side stream at the start of step s + 1, right after that step's rows were refreshed,
                 # with its step number BY VALUE; it then runs under the whole of step s + 1 (forward, backward, exchange,
@@ -239,13 +242,71 @@ class TableAdam(torch.optim.Adam):
         return ft
 
     def _touch(self, rec, groups, stream, refresh=False):
+        rl = rec.get("rl")
+        if refresh and rl is None:  # the pre-gather pass of a call site that writes row lists empties its hash
+            rl = self._rl_cache.get(self._rl_key(rec)) if rec.get("training", True) else None
         for grp in groups:
             if grp["D"] != rec["D"] or not any(id(w) in grp["local"] for w in rec["weights"]):
+                continue
+            if rl is not None:
+                _lib.call("rh_adam_lazy_touched_rows", ops._p(grp["ldesc"]), len(grp["members"]),
+                          ops._p(self._field_table(rec, grp)), ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"],
+                          rec["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64, 1 if refresh else 0,
+                          ops._p(ops.err_flag(self._tables[0].device)), *rl.args(), stream)
                 continue
             _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
                       ops._p(self._t_ring), self.RING, 64, 1 if refresh else 0,
                       ops._p(ops.err_flag(self._tables[0].device)), stream)
+
+    # -- row-list gradients (ops.RowList, rh_embed_bwd_rows) ---------------------------------------------------------
+    @staticmethod
+    def _rl_key(rec_or_call):
+        r = rec_or_call
+        if isinstance(r, dict):
+            return (id(r["idesc"]), r["B"], r["F"], r["D"])
+        return (id(r.idesc()), r.B, r.F, r.D)
+
+    def rowlist_for(self, call):
+        """Asked by the fused gather's backward while a trainer has armed ops.rowlist: an ops.RowList when this step's
+        table gradient of ``call`` may be handed over as per-lookup rows + duplicate chains, else None (dense buffers).
+        Conditions: blocked-lazy mode; the model's step has ONE gather with table gradients (learned from the previous
+        step: two call sites could put the same table row on two chains); all its tables in one launch group of this
+        optimizer; sizes within the hash's bit fields.
+
+        OPT-IN (RECHUB_ROWLIST=1), measured and not adopted: linking the lookups of a table row costs an
+        atomic load + compare-and-swap WITH return per lookup, against ONE fire-and-forget whole-row float atomic of the
+        dense-buffer path -- rh_embed_bwd_rows takes 21.9 / 47.0 / 159 us at B = 4096 / 16384 / 65536 where rh_embed_bwd
+        takes 11.9 / 30.2 / 103 us, and the optimizer side gains only ~1.5 us per step from dropping its claim atomics
+        and gradient-row traffic."""
+        if (self.lazy_k <= 1 or not self._tables or not self._rl_single or not self._k_decided or
+                os.environ.get("RECHUB_ROWLIST", "0") != "1"):
+            return None
+        if self._rl_pending:
+            raise RuntimeError("TableAdam: a second backward arrived before the optimizer step consumed the row-list "
+                               "gradient of the first; set RECHUB_ROWLIST=0 for gradient accumulation")
+        key = self._rl_key(call)
+        rl = self._rl_cache.get(key)
+        if rl is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # buffers are created by an eager step (the trainers warm up eagerly before capturing)
+            groups = self._lazy_setup()
+            if len(groups) != 1 or groups[0]["D"] != call.D or call.B * call.F >= (1 << 21):
+                return None
+            grp = groups[0]
+            field = []
+            for w in call.weights:
+                j = grp["local"].get(id(w), -1)
+                lazy = j >= 0 and w.requires_grad and self.table_k(w) != 1 and int(w.shape[0]) < (1 << 27)
+                if w.requires_grad and j < 0:
+                    return None  # a table of another optimizer / group: keep the dense path for the whole call
+                field.append(j + 1 if lazy else 0)
+            if not any(field):
+                return None
+            rl = self._rl_cache[key] = ops.RowList(call.B, call.F, call.D, field, call.device)
+        self._rl_pending = True
+        return rl
+
 
     def on_gather(self, rec):
         """Pre-gather event: replay the rows of this index batch up to the last completed step (their gradient rows are
@@ -396,6 +457,17 @@ class TableAdam(torch.optim.Adam):
             return False
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
         mode = SWEEP_DENSE_TABLES if self.overlap_sweep else SWEEP_WINDOW
+        rl = rec.get("rl")
+        if rl is not None:
+            if not self.overlap_sweep:
+                return False  # row list + in-line window sweep: touched pass, THEN the sweep (two launches, no claims)
+            _lib.call("rh_adam_lazy_step_rows", ops._p(grp["ldesc"]), len(grp["members"]),
+                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
+                      ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)),
+                      *rl.args(), stream)
+            self._sweep_pending = True
+            return True
         _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
                   ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
                   ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
@@ -437,6 +509,13 @@ class TableAdam(torch.optim.Adam):
         if not self._k_decided:
             self._decide_dense_by_volume()
         groups = self._lazy_setup()
+        n_rec = len(self._touch_log)
+        if n_rec > 1 and any(r.get("rl") is not None for r in self._touch_log):
+            raise RuntimeError("TableAdam: a step with several gathers received a row-list gradient (the model's number of "
+                               "gathers changed between steps); set RECHUB_ROWLIST=0")
+        if not torch.cuda.is_current_stream_capturing():
+            self._rl_single = (n_rec == 1)  # next step's backward may hand its table gradient over as a row list
+        self._rl_pending = False
         if self._merged_step(groups, stream):
             del self._touch_log[:]
             return

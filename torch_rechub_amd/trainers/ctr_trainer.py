@@ -188,9 +188,15 @@ class CTRTrainer(object):
         defer = packed and self.dp is None and os.environ.get("RECHUB_STEP_FUSION", "1") == "1"
         if defer:
             ops.deferred.arm(self.bucket.params)
+        if fast and self.dp is None:
+            # ONE backward per optimizer step and nobody reads weight.grad in between: the fused gather may hand the
+            # table gradient to the optimizer as per-lookup rows + duplicate chains (ops.RowList) instead of the
+            # vocab-sized scatter-add
+            ops.rowlist.arm(self.optimizer)
         try:
             loss.backward(self._grad_root(loss))
         finally:
+            ops.rowlist.disarm()
             items = ops.deferred.disarm() if defer else {}
         if fast and not self._bucket_attached:
             # first step: every dense parameter must receive a gradient for the packed one-launch optimizer path
@@ -382,7 +388,13 @@ class CTRTrainer(object):
         split = self.dp is not None
         if split and not isinstance(self.optimizer, TableAdam):
             raise RuntimeError("hipGraph + data parallel needs the default Adam optimizer (TableAdam)")
+        if self._graph is not None and getattr(self, "_graph_loader", loader) is not loader:
+            # the captured kernels read the static batch buffers of the loader they were captured with; the trainer
+            # keeps that loader alive, but batches of another loader would silently never be seen
+            raise RuntimeError("this trainer's hipGraph step was captured with another DeviceDataLoader; keep using that "
+                               "loader (reshuffle() / new epochs are fine) or build a new trainer")
         if self._graph is None:
+            self._graph_loader = loader
             if isinstance(self.optimizer, TableAdam):
                 self.optimizer.sync_hyper()
             total = torch.zeros((), dtype=torch.float32, device=self.device)
