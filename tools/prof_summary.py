@@ -10,6 +10,11 @@ from collections import defaultdict
 
 
 def short(name):
+    if "adam_lazy_sweep_kernel" in name:
+        # <LPR, MERGED>: false = the window sweep alone (in round 3: the DEFERRED side-stream sweep), true = the merged
+        # end-of-step launch (touched rows + dense tables / window)
+        tmpl = name[name.index("adam_lazy_sweep_kernel"):].split("(")[0]
+        return "rechub::" + tmpl
     for key in ("embed_fwd_kernel", "embed_bwd_kernel", "adam_dense_kernel", "adam_lazy_sweep_kernel",
                 "adam_lazy_touched_kernel", "adam_prepare_kernel", "batch_gather_kernel", "batch_advance_kernel",
                 "cross_fwd_kernel", "cross_bwd_kernel", "seq_pool_kernel", "fm_fwd_kernel", "fm_bwd_kernel"):
