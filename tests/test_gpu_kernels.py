@@ -1321,6 +1321,58 @@ def test_torch_library_ops_opcheck_and_values():
             assert torch.allclose(u, v, rtol=1e-6, atol=1e-7)
 
 
+def test_torch_library_functional_gather_and_adam_ops():
+    """torch.ops.rechub_hip.embedding_fm_lr (the fused gather + FM + LR as a FUNCTIONAL op: per-lookup gradient rows ->
+    one dense gradient per table in the autograd formula) and adam_step_ (mutated arguments declared in the schema):
+    opcheck on the device; values and every gradient equal to the trainers' autograd.Function path (ops.fused_embedding,
+    persistent gradient buffers) and to the oracle's Adam."""
+    import torch_rechub_amd.library  # noqa: F401
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(11)
+    vocabs, B, D, ND = [7, 300, 41, 300], 53, 16, 3
+    tabs = [(torch.randn(v, D, generator=g) * 0.3).to(dev()).requires_grad_() for v in vocabs[:3]]
+    tabs.append(tabs[1])  # a shared table (shared_with): field 3 indexes table 1
+    idx = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], 1).to(dev())
+    dense = torch.rand(B, ND, generator=g).to(dev()).requires_grad_()
+    lr_w = (torch.randn(1, 4 * D, generator=g) * 0.2).to(dev()).requires_grad_()
+    lr_b = torch.randn(1, generator=g).to(dev()).requires_grad_()
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(torch.ops.rechub_hip.embedding_fm_lr.default, (tabs, idx, dense, lr_w, lr_b), test_utils=tests)
+    out, fm, lr, _ = torch.ops.rechub_hip.embedding_fm_lr(tabs, idx, dense, lr_w, lr_b)
+    G = torch.randn(out.shape, generator=g).to(dev())
+    leaves = tabs[:3] + [dense, lr_w, lr_b]
+    ga = torch.autograd.grad((out * G).sum() + 0.7 * fm.sum() + (lr * lr).sum(), leaves)
+    # the trainers' path on twins of the same tensors
+    tw = [t.detach().clone().requires_grad_() for t in tabs[:3]]
+    tw.append(tw[1])
+    d2, w2, b2 = dense.detach().clone().requires_grad_(), lr_w.detach().clone().requires_grad_(), lr_b.detach().clone().requires_grad_()
+    call = ops.EmbedCall(tw, [None] * 4, [idx[:, f] for f in range(4)], dense=[d2[:, j] for j in range(ND)], want_fm=True,
+                         want_lr=True)
+    o2, f2, l2 = ops.fused_embedding(call, w2, b2)
+    assert torch.equal(out, o2) and torch.equal(fm, f2) and torch.equal(lr, l2)
+    ((o2 * G).sum() + 0.7 * f2.sum() + (l2 * l2).sum()).backward()
+    ops.check_errors()
+    for a, t in zip(ga[:3], tw[:3]):
+        close(a, t.grad.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="table gradient")
+    close(ga[3], d2.grad.cpu().numpy(), what="dense gradient")
+    close(ga[4], w2.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="lr weight gradient")
+    close(ga[5], b2.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="lr bias gradient")
+    # adam_step_: three steps of one tensor against the float64 oracle (coupled weight decay)
+    p = torch.randn(40, 16, generator=g).to(dev())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pr, mr, vr = p.cpu().numpy().astype(F64), np.zeros((40, 16)), np.zeros((40, 16))
+    torch.library.opcheck(torch.ops.rechub_hip.adam_step_.default,
+                          (p.clone(), torch.randn(40, 16, generator=g).to(dev()), m.clone(), v.clone(), 1, 1e-2, 0.9, 0.999, 1e-8,
+                           1e-3), test_utils=("test_schema", "test_faketensor"))
+    for t in range(1, 4):
+        gr = torch.randn(40, 16, generator=g)
+        gd = gr.to(dev())
+        torch.ops.rechub_hip.adam_step_(p, gd, m, v, t, 1e-2, 0.9, 0.999, 1e-8, 1e-3)
+        assert not gd.any()  # re-zeroed in the pass
+        pr, mr, vr = O.adam_step(pr, gr.numpy().astype(F64), mr, vr, t, lr=1e-2, weight_decay=1e-3)
+        close(p, pr, rtol=1e-5, atol_scale=1e-6, what=f"adam_step_ step {t}")
+
+
 @pytest.mark.parametrize("shapes", [
     [(1, 1000), (3, 429), (512, 429), (33, 64), (700, 1), (64, 7), (0, 50), (40, 300), (200, 5000)],
     [(2048, 65), (31, 31), (32, 256), (33, 256)] + [(1, 17)] * 40,  # > 32 items: two launches

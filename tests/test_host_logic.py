@@ -385,6 +385,17 @@ def test_torch_library_ops_trace_under_fake_tensors():
         out.sum().backward()  # the autograd formula traces too
         assert z.grad.shape == (64, 429) and W.grad.shape == (3, 429) and b.grad.shape == (3, 429)
         assert torch.ops.rechub_hip.dice(torch.empty(100, 36), torch.empty(1), 1e-9).shape == (100, 36)
+        # the functional form of the fused gather + FM + LR (shared table in fields 1 and 3) and its autograd formula
+        tabs = [torch.empty(7, 16, requires_grad=True), torch.empty(300, 16, requires_grad=True),
+                torch.empty(41, 16, requires_grad=True)]
+        tabs.append(tabs[1])
+        lw, lb = torch.empty(1, 64, requires_grad=True), torch.empty(1, requires_grad=True)
+        o, f, l, S = torch.ops.rechub_hip.embedding_fm_lr(tabs, torch.empty(53, 4, dtype=torch.int64), torch.empty(53, 3), lw, lb)
+        assert o.shape == (53, 67) and f.shape == (53, 1) and l.shape == (53, 1) and S.shape == (53, 16)
+        (o.sum() + f.sum() + l.sum()).backward()
+        assert tabs[1].grad.shape == (300, 16) and lw.grad.shape == (1, 64) and lb.grad.shape == (1,)
+        assert torch.ops.rechub_hip.adam_step_(torch.empty(8, 4), torch.empty(8, 4), torch.empty(8, 4), torch.empty(8, 4), 1,
+                                               1e-3, 0.9, 0.999, 1e-8, 0.0) is None
     with pytest.raises(RuntimeError, match="HIP device"):
         torch.ops.rechub_hip.fm(torch.zeros(2, 3, 4), True)
     schema = str(torch.ops.rechub_hip.cross_network.default._schema)

@@ -75,3 +75,58 @@ def test_model_and_trainer_level_patch(patched):
     with pytest.raises(RuntimeError, match="HIP"):  # the patched trainer drives the HIP path only
         RT.CTRTrainer(m, device="cpu")
     assert patched.enable() == []  # idempotent
+
+
+@pytest.mark.gpu
+def test_unmodified_reference_deepfm_runs_numerically_on_the_hip_layers(patched):
+    """INTEGRATION.md section B on a device: fires wherever a reference checkout is mounted next to a GPU
+    (RECHUB_REFERENCE=/path/to/torch-rechub; on the driver's GPU box there is none and the module-level skip applies).
+    The UNMODIFIED ``torch_rechub.models.ranking.DeepFM`` source, bound to the HIP layers by ``enable(models=False,
+    trainers=False)``, loaded with the reference fixture's weights: predictions, loss and every gradient against the vectors
+    the same class produced on the reference's own CPU layers (tests/golden/model_deepfm_tutorial.npz), then three steps of
+    the reference's OWN CTRTrainer (torch.optim.Adam reading the published ``weight.grad`` buffers) against its trajectory."""
+    import numpy as np
+    import torch_rechub.basic.features as RF
+    import torch_rechub.models.ranking.deepfm as ref_deepfm
+    import torch_rechub.trainers as RT
+    from conftest import golden_batch, golden_state, load_golden
+    import json
+    gold = load_golden("model_deepfm_tutorial.npz")
+    patched.enable(models=False, trainers=False)
+    spec = json.loads(str(gold["spec"]))
+    made = {}
+
+    def fea(d):
+        if d["name"] not in made:
+            made[d["name"]] = (RF.DenseFeature(d["name"]) if d["kind"] == "DenseFeature" else
+                               RF.SparseFeature(d["name"], vocab_size=d["vocab_size"], embed_dim=d["embed_dim"]))
+        return made[d["name"]]
+
+    deep, fm = [fea(d) for d in spec["deep_features"]], [fea(d) for d in spec["fm_features"]]
+    model = ref_deepfm.DeepFM(deep, fm, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"})
+    model.load_state_dict(golden_state(gold, "sd0."))
+    model = model.to("cuda:0")
+    x, y = golden_batch(gold, 0)
+    xd = {k: v.to("cuda:0") for k, v in x.items()}
+    model.train()
+    pred = model(xd)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), gold["pred_train"], rtol=1e-5, atol=2e-6)
+    loss = torch.nn.BCELoss()(pred, y.to("cuda:0").float())
+    assert abs(loss.item() - float(gold["loss"])) < 2e-6
+    loss.backward()
+    gmax = max(float(np.abs(gold["grad." + n]).max()) for n, _ in model.named_parameters())
+    for n, p_ in model.named_parameters():
+        if n.endswith("mlp.0.bias") or n.endswith("mlp.4.bias"):  # in front of BatchNorm: rounding noise on both sides
+            continue
+        np.testing.assert_allclose(p_.grad.detach().cpu().numpy(), gold["grad." + n], rtol=1e-4, atol=2e-6 * gmax, err_msg=n)
+    # the reference's own trainer loop over the three fixture batches
+    model.load_state_dict(golden_state(gold, "sd0."))
+    model.zero_grad()
+    trainer = RT.CTRTrainer(model, optimizer_params={"lr": float(gold["train.lr"]), "weight_decay": float(gold["train.wd"])},
+                            n_epoch=1, device="cuda:0")
+    mean_loss = trainer.train_one_epoch([golden_batch(gold, i) for i in range(3)])
+    assert abs(mean_loss - float(gold["train.mean_loss"])) < 5e-5
+    ref = golden_state(gold, "sd3.")
+    name = next(k for k in ref if "embed_dict" in k)
+    got = model.state_dict()[name].cpu().numpy()
+    assert np.abs(got - ref[name].numpy()).max() < 3e-4 + 1e-3 * np.abs(ref[name].numpy()).max()

@@ -6,11 +6,22 @@ boundary.  With these, ``FakeTensorMode`` / ``torch.export`` / ``torch.compile``
     torch.ops.rechub_hip.cross_network(x, W, b)                CrossNetwork.forward  basic/layers.py:412-420
     torch.ops.rechub_hip.dice(x, alpha, eps)                   Dice.forward          basic/activation.py:15-25
 
+    torch.ops.rechub_hip.embedding_fm_lr(tables, idx, dense, lr_w, lr_b, want_fm)
+                                                               EmbeddingLayer.forward + FM + LR  layers.py:77-127, :313-319, :185-189
+    torch.ops.rechub_hip.adam_step_(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay)
+                                                               torch.optim.Adam on one tensor    trainers/ctr_trainer.py:59-61, :99
+
 without running a kernel (shape / dtype propagation), and ``torch.library.opcheck`` validates schema, fake impl and
 autograd registration on the device (tests/test_gpu_kernels.py).  The layers of ``torch_rechub_amd.basic`` call the SAME
-C entry points through ``autograd.Function`` (no dispatcher hop per call in the eager / hipGraph step); the embedding
-gather, its backward and the optimizer are deliberately NOT pure ops -- they own persistent table-gradient buffers and
-claim words, i.e. hidden state a functional schema cannot express -- and stay ``autograd.Function`` + C ABI.
+C entry points through ``autograd.Function`` (no dispatcher hop per call in the eager / hipGraph step).
+
+The training fast path of the gather, its backward and the optimizer owns persistent table-gradient buffers and claim
+words -- hidden state a functional schema cannot express.  Their ``torch.library`` form is therefore the FUNCTIONAL
+restatement of the same kernels: ``embedding_fm_lr`` returns (flattened embeddings + dense block, fm, lr, S) from
+``rh_embed_fwd``; its backward op returns the per-lookup gradient rows (``rh_embed_bwd`` in row form, no buffer behind it)
+and the autograd formula turns them into one dense gradient per table with ``index_add`` -- exact, traceable, exportable
+(``export_onnx`` / ``torch.compile`` users of trainers/ctr_trainer.py:189-245), and O(vocab) per step, which is why the
+trainers do not use it.  ``adam_step_`` declares its mutated arguments in the schema (``Tensor(a!)``).
 
 The implementations refuse CPU tensors like every op of this package (no fallback).
 """
@@ -161,3 +172,136 @@ def _dice_bwd(ctx, g):
 
 
 dice.register_autograd(_dice_bwd, setup_context=_dice_setup)
+
+
+# ---- fused multi-field gather + FM + LR (functional form) -------------------------------------------------------------
+def _embed_call(tables, idx, dense):
+    F = len(tables)
+    if idx.dim() != 2 or idx.shape[1] != F or idx.dtype not in (torch.int64, torch.int32):
+        raise ValueError("rechub_hip::embedding_fm_lr: idx must be an integer (B, F) matrix, F = len(tables)")
+    idx = idx.contiguous()
+    cols = [idx[:, f] for f in range(F)]
+    dcols = [] if dense is None else [dense[:, j] for j in range(dense.shape[1])]
+    return ops.EmbedCall(list(tables), [None] * F, cols, dense=dcols, want_fm=True, want_lr=True), idx
+
+
+@torch.library.custom_op("rechub_hip::embedding_fm_lr", mutates_args=())
+def embedding_fm_lr(tables: list[torch.Tensor], idx: torch.Tensor, dense: torch.Tensor | None, lr_w: torch.Tensor,
+                    lr_b: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(out (B, F*D + n_dense), fm (B, 1), lr (B, 1), S (B, D)): sparse block first, dense values last (layers.py:120)."""
+    ops.require_hip(idx, lr_w, lr_b, *tables)
+    if dense is not None:
+        dense = dense.float().contiguous()
+    call, idx = _embed_call(tables, idx, dense)
+    B, F, D = call.B, call.F, call.D
+    dev = idx.device
+    out = torch.empty((B, call.width), dtype=torch.float32, device=dev)
+    fm_ = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    lr = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    s_sum = torch.empty((B, D), dtype=torch.float32, device=dev)
+    lw = lr_w.contiguous()
+    _lib.call("rh_embed_fwd", _p(call.fdesc(False)), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(call.ddesc()),
+              len(call.dense), call.dense_col, _p(out), out.stride(0), _p(lw), _p(lr_b), _p(lr), _p(fm_), _p(s_sum),
+              call.field_split, _p(ops.err_flag(dev)), _stream())
+    return out, fm_, lr, s_sum
+
+
+@embedding_fm_lr.register_fake
+def _(tables, idx, dense, lr_w, lr_b):
+    B, F = idx.shape
+    D = tables[0].shape[1]
+    nd = 0 if dense is None else dense.shape[1]
+    t = tables[0]
+    return t.new_empty((B, F * D + nd)), t.new_empty((B, 1)), t.new_empty((B, 1)), t.new_empty((B, D))
+
+
+@torch.library.custom_op("rechub_hip::embedding_fm_lr_backward", mutates_args=())
+def embedding_fm_lr_backward(tables: list[torch.Tensor], idx: torch.Tensor, out: torch.Tensor, s_sum: torch.Tensor,
+                             lr_w: torch.Tensor, g_out: torch.Tensor | None, g_fm: torch.Tensor | None,
+                             g_lr: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(rows (B, F, D) = the gradient of every looked-up row, g_lr_w, g_lr_b): rh_embed_bwd in its row form."""
+    ops.require_hip(idx, out, *tables)
+    call, idx = _embed_call(tables, idx, None)
+    B, F, D = call.B, call.F, call.D
+    dev = idx.device
+    rows = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+    nch = _lib.call("rh_embed_bwd_nchunks", B, call.samples_per_block)
+    partial = torch.zeros((nch, F * D), dtype=torch.float32, device=dev)
+    g_out = None if g_out is None else g_out.contiguous()
+    g_fm = None if g_fm is None else g_fm.reshape(-1).contiguous()
+    g_lr = None if g_lr is None else g_lr.reshape(-1).contiguous()
+    lw = lr_w.contiguous()
+    out = out.contiguous()
+    _lib.call("rh_embed_bwd", _p(call.fdesc(False)), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
+              0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
+              _p(lw), _p(partial if g_lr is not None else None), 1.0, 1, _p(rows), call.samples_per_block,
+              _p(ops.err_flag(dev)), _stream())
+    g_w = partial.sum(0).view_as(lr_w)
+    g_b = (g_lr.sum() if g_lr is not None else torch.zeros((), device=dev)).reshape(1)
+    return rows, g_w, g_b
+
+
+@embedding_fm_lr_backward.register_fake
+def _(tables, idx, out, s_sum, lr_w, g_out, g_fm, g_lr):
+    B, F = idx.shape
+    return out.new_empty((B, F, tables[0].shape[1])), torch.empty_like(lr_w), lr_w.new_empty((1,))
+
+
+def _embed_setup(ctx, inputs, output):
+    tables, idx, dense, lr_w, lr_b = inputs
+    out, fm_, lr, s_sum = output
+    ctx.tables = list(tables)
+    ctx.n_dense = 0 if dense is None else dense.shape[1]
+    ctx.has_dense = dense is not None
+    ctx.save_for_backward(idx, out, s_sum, lr_w)
+    ctx.set_materialize_grads(False)
+
+
+def _embed_bwd(ctx, g_out, g_fm, g_lr, g_s):
+    idx, out, s_sum, lr_w = ctx.saved_tensors
+    if g_s is not None:
+        raise RuntimeError("rechub_hip::embedding_fm_lr: S (the per-sample field sum) is an auxiliary output")
+    rows, g_w, g_b = torch.ops.rechub_hip.embedding_fm_lr_backward(ctx.tables, idx, out, s_sum, lr_w, g_out, g_fm, g_lr)
+    by_table = {}
+    for f, t in enumerate(ctx.tables):  # shared tables (shared_with): their fields' rows add up
+        g = by_table.get(id(t))
+        if g is None:
+            g = by_table[id(t)] = torch.zeros_like(t)
+        g.index_add_(0, idx[:, f].long(), rows[:, f])
+    seen, g_tables = set(), []
+    for t in ctx.tables:
+        g_tables.append(None if id(t) in seen else by_table[id(t)])
+        seen.add(id(t))
+    g_dense = None
+    if ctx.has_dense and g_out is not None:
+        g_dense = g_out[:, out.shape[1] - ctx.n_dense:]
+    return g_tables, None, g_dense, g_w, (g_b if g_lr is not None else None)
+
+
+embedding_fm_lr.register_autograd(_embed_bwd, setup_context=_embed_setup)
+
+
+# ---- torch.optim.Adam (coupled weight decay) on one tensor, in place -------------------------------------------------
+@torch.library.custom_op("rechub_hip::adam_step_", mutates_args=("p", "g", "m", "v"))
+def adam_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, beta1: float,
+               beta2: float, eps: float, weight_decay: float) -> None:
+    """One dense Adam step of ``p`` (step = the 1-based step count AFTER the increment); ``g`` is re-zeroed, as the
+    trainer's optimizer does instead of model.zero_grad() (ctr_trainer.py:97)."""
+    import ctypes
+    ops.require_hip(p, g, m, v)
+    if not all(t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel() for t in (p, g, m, v)) or \
+            p.numel() % 4:
+        raise ValueError("rechub_hip::adam_step_: contiguous float32 tensors of one size (numel % 4 == 0)")
+    dev = p.device
+    hyper = torch.zeros(16, dtype=torch.float64, device=dev)
+    hyper[:5] = torch.tensor([lr, beta1, beta2, eps, weight_decay], dtype=torch.float64)
+    cnt = torch.full((1,), int(step) - 1, dtype=torch.int64, device=dev)
+    _lib.call("rh_adam_prepare", _p(hyper), _p(cnt), _p(None), 0, _stream())
+    desc = torch.tensor([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()], dtype=torch.int64).to(dev)
+    numel = (ctypes.c_int64 * 1)(p.numel())
+    _lib.call("rh_adam_dense", _p(desc), 1, ctypes.cast(numel, ctypes.c_void_p), _p(hyper), 1, _stream())
+
+
+@adam_step_.register_fake
+def _(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
+    return None
