@@ -1354,7 +1354,8 @@ def test_torch_library_functional_gather_and_adam_ops():
     ops.check_errors()
     for a, t in zip(ga[:3], tw[:3]):
         close(a, t.grad.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="table gradient")
-    close(ga[3], d2.grad.cpu().numpy(), what="dense gradient")
+    assert d2.grad is None  # the trainers' op treats the dense values as data; the functional op differentiates them:
+    close(ga[3], G[:, 4 * D:].cpu().numpy(), what="dense gradient")  # out's dense block is a copy of `dense`
     close(ga[4], w2.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="lr weight gradient")
     close(ga[5], b2.grad.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="lr bias gradient")
     # adam_step_: three steps of one tensor against the float64 oracle (coupled weight decay)

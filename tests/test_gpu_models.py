@@ -462,6 +462,17 @@ def test_padded_width_embeddings_train_like_the_reference_op_chain():
         assert_trajectory_close(got, v.numpy(), 1e-2 * 3, k)
     for e in model.embedding.embed_dict.values():
         assert not e.weight[:, D:].any()  # the padding stayed zero through weight decay and Adam
+    # the optimizer checkpoint carries the tables' moments at the LOGICAL width (exchangeable with the reference
+    # optimizer's file) and loads back -- from its own file and from torch.optim.Adam's
+    osd, rsd = trainer.optimizer.state_dict(), opt.state_dict()
+    shapes = sorted(tuple(st["exp_avg"].shape) for st in osd["state"].values())
+    assert shapes == sorted(tuple(st["exp_avg"].shape) for st in rsd["state"].values())
+    before = {k: v["exp_avg_sq"].clone() for k, v in osd["state"].items()}
+    trainer.optimizer.load_state_dict(osd)
+    again = trainer.optimizer.state_dict()
+    assert all(torch.equal(before[k], again["state"][k]["exp_avg_sq"]) for k in before)
+    for p_ in trainer.optimizer._tables:
+        assert not trainer.optimizer.state[p_]["exp_avg"][:, D:].any()
     # sequence pooling and the plain layer call on padded tables
     feas = [SparseFeature("u", 30, 6), SequenceFeature("h", 50, 6, pooling="mean", padding_idx=0)]
     layer = EmbeddingLayer(feas).to(dev())

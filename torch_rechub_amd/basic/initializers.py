@@ -39,6 +39,7 @@ class PaddedEmbedding(nn.Embedding):
         self.embedding_dim = int(embedding_dim)
         with torch.no_grad():
             self.weight[:, self.logical_dim:].zero_()
+        self.weight._rh_logical_dim = self.logical_dim  # optim.TableAdam slices / pads this table's moments in checkpoints
         self._register_state_dict_hook(PaddedEmbedding._slice_hook)
         self._register_load_state_dict_pre_hook(self._pad_hook)
 

@@ -30,11 +30,23 @@ class RegularizationLoss(nn.Module):
             return 0.0
         return self.forward(model, _only_tables=True)
 
+    @staticmethod
+    def _exchanged_tables(model):
+        """ids of the embedding parameters whose gradient travels by the row exchange (not by the dense all-reduce): every
+        nn.Embedding except those a model flags ``_rh_dense`` (a small table read as a slice, BST's positional table) --
+        the same rule as distributed.table_parameters(), so a dense-bucket embedding is not added back world times."""
+        ids = set()
+        for m in model.modules():
+            if isinstance(m, (nn.Embedding, nn.EmbeddingBag)) and not getattr(m, "_rh_dense", False):
+                ids.update(id(p) for p in m.parameters())
+        return ids
+
     def forward(self, model, _only_tables=False):
         total = 0.0
         if not self.active():
             return total
         skip, tables = set(), set()
+        exchanged = self._exchanged_tables(model) if _only_tables else ()
         for m in model.modules():
             if isinstance(m, _NORMS):
                 skip.update(id(p) for p in m.parameters())
@@ -43,7 +55,7 @@ class RegularizationLoss(nn.Module):
         for p in model.parameters():
             if not p.requires_grad or id(p) in skip:
                 continue
-            if _only_tables and id(p) not in tables:
+            if _only_tables and id(p) not in exchanged:
                 continue
             l1, l2 = (self.embedding_l1, self.embedding_l2) if id(p) in tables else (self.dense_l1, self.dense_l2)
             if l1 > 0:

@@ -664,11 +664,50 @@ class TableAdam(torch.optim.Adam):
             t = float(self._t_step.item())
             for p in self._tables + (self._bucket.params if self._bucket is not None else []):
                 self.state[p]["step"] = torch.tensor(t)
-        return super().state_dict()
+        sd = super().state_dict()
+        # padded-width tables (basic.initializers.PaddedEmbedding): the moments leave with the table's LOGICAL width, like
+        # its weight in the model's state_dict -- the file is exchangeable with the reference optimizer's checkpoint
+        for idx, width in self._padded_state_indices().items():
+            st = sd["state"].get(idx)
+            if st is not None:
+                st = dict(st)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if torch.is_tensor(st.get(k)) and st[k].dim() == 2 and st[k].shape[1] > width:
+                        st[k] = st[k][:, :width].contiguous()
+                sd["state"][idx] = st
+        return sd
+
+    def _padded_state_indices(self):
+        """{index of the parameter in state_dict()['state']: logical width} for padded-width tables."""
+        out, i = {}, 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                w = getattr(p, "_rh_logical_dim", None)
+                if w is not None and p.dim() == 2 and int(w) < int(p.shape[1]):
+                    out[i] = int(w)
+                i += 1
+        return out
 
     def load_state_dict(self, state_dict):
         if self.lazy_k > 1 and self._tables:
             self._join_sweep()
+        padded = self._padded_state_indices()
+        if padded:  # moments saved at the logical width (by this class or by the reference's optimizer): pad with zeros
+            flat = [p for g in self.param_groups for p in g["params"]]
+            state = dict(state_dict["state"])
+            for idx, width in padded.items():
+                st = state.get(idx)
+                if st is None:
+                    continue
+                st = dict(st)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    t = st.get(k)
+                    if torch.is_tensor(t) and t.dim() == 2 and t.shape[1] == width:
+                        full = t.new_zeros((t.shape[0], flat[idx].shape[1]))
+                        full[:, :width] = t
+                        st[k] = full
+                state[idx] = st
+            state_dict = dict(state_dict, state=state)
         super().load_state_dict(state_dict)
         if self._tables:
             for i, p in enumerate(self._tables):

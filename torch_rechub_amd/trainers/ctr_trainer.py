@@ -578,13 +578,18 @@ class CTRTrainer(object):
                     self.model.load_state_dict(self.early_stopper.best_weights)
                     break
         # row-sharded tables are reassembled (a collective): the file has the reference's layout whatever the placement
-        weights = sharding.full_state_dict(self.model) if self.tables == "shard" else self.model.state_dict()
-        # (a padded-width table exposes its (vocab, embed_dim) view: save a compact copy, not the padded storage)
-        weights = {k: (v if not torch.is_tensor(v) or v.is_contiguous() else v.contiguous()) for k, v in weights.items()}
+        weights = self._checkpoint_weights()
         if self.rank == 0:
             torch.save(weights, os.path.join(self.model_path, "model.pth"))
         for logger in self._iter_loggers():
             logger.finish()
+
+    def _checkpoint_weights(self):
+        """The state_dict every trainer's fit() writes: row-sharded tables reassembled (a collective) into the reference's
+        layout, and compact tensors -- a padded-width table (PaddedEmbedding) exposes its (vocab, embed_dim) VIEW, and
+        torch.save of a view would write the whole padded storage behind it."""
+        weights = sharding.full_state_dict(self.model) if self.tables == "shard" else self.model.state_dict()
+        return {k: (v if not torch.is_tensor(v) or v.is_contiguous() else v.contiguous()) for k, v in weights.items()}
 
     def _iter_loggers(self):
         if self.model_logger is None or self.rank != 0:

@@ -121,7 +121,7 @@ class MTLTrainer(CTRTrainer):
                                                                            self.early_stopper.best_auc))
                 self.model.load_state_dict(self.early_stopper.best_weights)
                 break
-        weights = sharding.full_state_dict(self.model) if self.tables == "shard" else self.model.state_dict()
+        weights = self._checkpoint_weights()
         if self.rank == 0:
             torch.save(weights, os.path.join(self.model_path, "model_{}_{}.pth".format(mode, seed)))
         for logger in self._iter_loggers():
