@@ -532,7 +532,12 @@ class TableAdam(torch.optim.Adam):
         """A sweep that was not forked (no training-mode gather since the last step, or a plain hipGraph capture)
         runs in line, before the step counter moves."""
         if self._sweep_pending:
-            self._sweep(SWEEP_LAZY_TABLES, ops._stream())
+            # the step BY VALUE wherever the host knows it: with the step's scalar launch fused into the forward
+            # (fuse_prepare) the device-side step number may already belong to the coming step when this runs.  Only a
+            # plain hipGraph capture (no host code per replay) takes the device-side number -- can_fuse_prepare() keeps the
+            # early advance out of that case.
+            plain_capture = torch.cuda.is_current_stream_capturing() and graphs.active() is None
+            self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=-1 if plain_capture else self._host_step)
             self._sweep_pending = False
 
     def flush(self):
@@ -556,6 +561,8 @@ class TableAdam(torch.optim.Adam):
     def can_fuse_prepare(self):
         # (with the deferred sweep too: it takes its step number by value and its (A, E) from the ring entry of that
         # step, so the early advance of hyper[12..14] by this step's scalar launch does not reach it)
+        if getattr(self, "overlap_sweep", False) and torch.cuda.is_current_stream_capturing() and graphs.active() is None:
+            return False  # plain capture: a pending deferred sweep is finished in line with the DEVICE-side step number
         return (self._tables or self._bucket is not None) and not self._prepared
 
     def fuse_prepare(self):
@@ -566,6 +573,24 @@ class TableAdam(torch.optim.Adam):
             self.sync_hyper()  # lr / betas / eps / weight_decay must be on the device BEFORE the corrections are formed
         self._prepared = True
         return self._t_hyper, self._t_step, self._t_ring, self.RING
+
+    def rollback_abandoned_prepare(self):
+        """Called by the trainers at the start of a step.  ``fuse_prepare()`` advances the device step counter and the
+        bias corrections during the FORWARD (they ride in the step's scalar launch); if that step was then abandoned
+        (an exception in the backward, a caller that never stepped), ``_prepared`` is still set here and the counter is one
+        ahead of the last COMPLETED step -- the pre-gather refresh and ``flush()`` would replay a step that never
+        happened.  Take the early advance back; the coming forward prepares the same step number again."""
+        if self._prepared and not torch.cuda.is_current_stream_capturing():
+            # counter back to (last completed step - 1), then the ordinary prepare launch: it re-forms the corrections
+            # hyper[8..12] and the ring entry of the last completed step, bit for bit what they were
+            self._t_step.sub_(2)
+            _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
+                      ops._stream())
+            self._prepared = False
+            self._small_done = False
+            if self.lazy_k > 1 and self._tables:
+                self._gathers = 0  # the abandoned forward's gathers do not count towards the step's gather count
+                del self._touch_log[:]
 
     def small_adam_args(self):
         """(sdesc, hyper) for rh_pack_grads_adam when the dense parameters' step may ride on the packing launch of this

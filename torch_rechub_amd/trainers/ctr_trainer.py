@@ -137,6 +137,8 @@ class CTRTrainer(object):
                 type(self)._compute_loss is CTRTrainer._compute_loss and type(self)._criterion is CTRTrainer._criterion
                 and type(self.criterion) is torch.nn.BCELoss)
         counters, self._counters = self._counters, []
+        if isinstance(self.optimizer, TableAdam):
+            self.optimizer.rollback_abandoned_prepare()
         ops.fusion_begin(target=y if fuse else None, optimizer=self.optimizer if fuse else None, counters=counters)
         try:
             loss = self._compute_loss(x_dict, y)

@@ -23,7 +23,8 @@ class MatchTrainer(CTRTrainer):
     def __init__(self, model, mode=0, in_batch_neg=False, in_batch_neg_ratio=None, hard_negative=False,
                  sampler_seed=None, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
-                 model_path="./", model_logger=None, global_negatives=False, sampler_stream="fast", **kw):
+                 model_path="./", model_logger=None, global_negatives=False, sampler_stream="fast",
+                 deterministic_logits=None, **kw):
         if in_batch_neg and not (hasattr(model, "user_tower") and hasattr(model, "item_tower")):
             raise ValueError(f"Model {type(model).__name__} does not support in-batch negative sampling. "
                              "Only two-tower models with user_tower() and item_tower() methods are supported, "
@@ -42,6 +43,13 @@ class MatchTrainer(CTRTrainer):
         # all-gather of the (B, d) item embeddings; its backward is a reduce-scatter) -- the in-batch step of one
         # process on the global batch.  Off: each rank samples inside its own batch.
         self.global_negatives = bool(global_negatives)
+        # deterministic_logits: the direct in-batch logits (csrc/match.hip: no (B, C) score matrix) accumulate the item
+        # tower's gradient with row-wide float atomics, whose order -- hence the last bit of that gradient and of a whole
+        # training run -- is not fixed.  True keeps the reference's matmul + gather form (trainers/match_trainer.py:118-138,
+        # fixed summation order, ~9 % slower at configs[4]); default: env RECHUB_INBATCH_DIRECT=0 asks for the same.
+        if deterministic_logits is None:
+            deterministic_logits = os.environ.get("RECHUB_INBATCH_DIRECT", "1") != "1"
+        self.deterministic_logits = bool(deterministic_logits)
         # "fast": one HIP launch, own counter-based stream (distribution-preserving, hipGraph-replayable);
         # "reference": the reference's randperm-per-row draw, bit-identical indices for the same sampler_seed
         if sampler_stream not in ("fast", "reference"):
@@ -88,7 +96,7 @@ class MatchTrainer(CTRTrainer):
                 row0 = self.dp.rank * item_embedding.size(0)
                 item_embedding = sharding.gather_rows(item_embedding, self.dp.group)
             if (not self.hard_negative and ops.inbatch_logits_ok(user_embedding, item_embedding) and
-                    os.environ.get("RECHUB_INBATCH_DIRECT", "1") == "1"):
+                    not self.deterministic_logits):
                 # random negatives read 1 + K of a row's scores: the wanted dot products straight from the tower outputs
                 # (csrc/match.hip), no (B, C) score matrix and no (B, C)-sized gradients
                 neg_indices = random_inbatch_negatives(user_embedding.size(0), item_embedding.size(0),
