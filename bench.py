@@ -614,9 +614,10 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
     res["step_bytes"] = step_bytes
     res["overlap_sweep"] = bool(getattr(opt, "overlap_sweep", False))
     tune = getattr(trainer, "_tune", None) or {}
-    res["step_form"] = {"chosen": {"deferred_sweep": tune["chosen"][0], "deferred_sweep_workgroups": tune["chosen"][1]},
-                        "candidates": [{"deferred_sweep": c[0], "deferred_sweep_workgroups": c[1]} for c in tune["cands"]],
-                        "ms_per_step_during_tuning": tune.get("ms")} if tune.get("chosen") else None
+    res["step_form"] = {"chosen": {"form": tune["chosen"][0], "deferred_sweep_workgroups": tune["chosen"][1]},
+                        "candidates": [{"form": c[0], "deferred_sweep_workgroups": c[1]} for c in tune["cands"]],
+                        "ms_per_step_during_tuning": tune.get("ms")} if tune.get("chosen") else \
+        {"chosen": {"form": getattr(trainer, "_form", None), "pinned": True}}
     # the north-star kernels over batch sizes (same tables, same stream, HIP events): their bandwidth regime starts
     # where the launch is no longer three dependent memory round trips long.  Last: it leaves junk gradient rows behind.
     if profile and wl.name == "deepfm" and trainer.dp is None and not args.no_kernel_sweep:

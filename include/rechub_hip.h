@@ -506,6 +506,11 @@ int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
+/* rh_adam_lazy_touched, refresh argument: 0 = the touched-rows step (rows take their gradient); 1 = pre-gather refresh of
+ * every row of the batch; 2 = refresh of the rows OUTSIDE window (t - 2) mod K_t of their table; 3 = refresh of the rows
+ * INSIDE it.  2 / 3 serve the pipelined step (torch_rechub_amd/optim.py): the deferred sweep launched one step ago may
+ * still be writing exactly that window, so the bulk of the next batch's refresh (2) runs a step early BESIDE it and the
+ * few rows it had to leave out (3) follow once that sweep has been joined. */
 /* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
  * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,

@@ -216,6 +216,9 @@ struct LazyTouchedArgs {
   int ring_mask;
   int T, B, F, spb;
   int* err;
+  int win_mode;  // REFRESH only: 0 = every row of the batch; 1 = skip / 2 = only the rows inside window (t - 2) mod K of
+                 // their table -- the window a deferred sweep launched one step ago may still be writing (pipelined step:
+                 // the bulk of a batch's refresh runs a step early beside that sweep, the rest after it was joined)
   RhRowList rl;  // rows != nullptr: the gradient of the fields flagged in rl.field comes as a row list (common.h) -- the
                  // chain head of a table row owns its update, no claim word atomics, no dense gradient row; REFRESH clears
                  // the hash for the coming backward
@@ -408,7 +411,12 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     const int64_t b = base + slot;
     const bool ok = b < b1;
     const int64_t r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
-    const bool valid = ok && (uint64_t)r < (uint64_t)rows && r != pad;
+    bool valid = ok && (uint64_t)r < (uint64_t)rows && r != pad;
+    if (REFRESH && a.win_mode != 0 && valid) {
+      const int64_t wrows = a.ldesc[7 * T + ti];
+      const bool inwin = t >= 2 && (r / wrows) == (int64_t)((t - 2) % K);
+      valid = (a.win_mode == 2) ? inwin : !inwin;
+    }
     int old = t;
     if (valid && q == 0) {
       if (rl_tag != 0) {
@@ -904,7 +912,8 @@ static int lazy_touched_impl(const int64_t* ldesc, int T, const int64_t* field_t
              "rh_adam_lazy_touched: ring_size must be a power of two <= %d", kMaxRing);
   if (B == 0) return 0;
   int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag, rl};
+  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag,
+                    refresh == 2 ? 1 : (refresh == 3 ? 2 : 0), rl};
   const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)F);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define RH_LT(LPR)                                                                                             \
@@ -986,7 +995,7 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_step: ring_size must be a power of two <= %d", kMaxRing);
   const int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag, rl};
+  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag, 0, rl};
   LazySweepArgs a;
   a.ldesc = ldesc;
   a.hyper = hyper;

@@ -126,6 +126,18 @@ class TableAdam(torch.optim.Adam):
                 self.sweep_events = os.environ.get("RECHUB_SWEEP_EVENTS", "0") == "1"
                 self._ev_ref = self._ev_sweep = None
                 self._sidecar_seg = None
+                # Pipelined form of the captured step (trainers: RECHUB_STEP_FORM=pipelined / self-tuning): ONE graph
+                # segment per step and a sweep that is ALWAYS running.  unit(s) = [fixup(s): the rows of batch s inside the
+                # window sweep(s-2) was writing, after that sweep was joined] [forward .. touched rows of step s]
+                # [assembly of batch s+1] [refresh of batch s+1 EXCEPT the rows inside the window sweep(s-1) is writing];
+                # after every replay the host forks sweep(s) behind sweep(s-1) on the side stream.  No row is ever touched
+                # by two kernels at once: a deferred sweep writes only rows of its own window that are behind its step,
+                # every row of a batch outside that window was refreshed before the sweep after next starts, and the rows
+                # inside it wait for the join (rh_adam_lazy_touched refresh = 2 / 3).
+                self.pipelined = False
+                self._pipe_events = []
+                self._pipe_seg = None
+                self._step_recs, self._last_recs = [], []
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
                 self._side = None
@@ -251,12 +263,12 @@ class TableAdam(torch.optim.Adam):
             if rl is not None:
                 _lib.call("rh_adam_lazy_touched_rows", ops._p(grp["ldesc"]), len(grp["members"]),
                           ops._p(self._field_table(rec, grp)), ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"],
-                          rec["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64, 1 if refresh else 0,
+                          rec["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64, int(refresh),
                           ops._p(ops.err_flag(self._tables[0].device)), *rl.args(), stream)
                 continue
             _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
-                      ops._p(self._t_ring), self.RING, 64, 1 if refresh else 0,
+                      ops._p(self._t_ring), self.RING, 64, int(refresh),
                       ops._p(ops.err_flag(self._tables[0].device)), stream)
 
     # -- row-list gradients (ops.RowList, rh_embed_bwd_rows) ---------------------------------------------------------
@@ -316,6 +328,12 @@ class TableAdam(torch.optim.Adam):
             return
         seg = graphs.active()
         capturing = torch.cuda.is_current_stream_capturing()
+        training = rec.get("training", torch.is_grad_enabled())
+        if training:
+            self._step_recs.append({k: rec[k] for k in ("weights", "pads", "idesc", "idx_is_i64", "B", "F", "D")})
+        if capturing and seg is not None and self.overlap_sweep and self.pipelined and training:
+            self._gather_pipelined(rec, seg)
+            return
         if capturing and seg is not None and self.overlap_sweep and self.sweep_events:
             self._gather_sidecar(rec, seg)
             return
@@ -347,6 +365,43 @@ class TableAdam(torch.optim.Adam):
                 seg.cut(self._fork_sweep)
                 self._sweep_inflight = True
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
+
+    # -- pipelined form (see __init__) --------------------------------------------------------------------------------
+    def _gather_pipelined(self, rec, seg):
+        if self._pipe_seg is not seg:
+            seg.at_start(self._join_pipelined)
+            seg.after(self._fork_pipelined)
+            self._pipe_seg = seg
+        # the bulk of this batch was refreshed at the end of the previous unit; what is left are its rows inside the
+        # window of the sweep that was joined in front of this unit
+        self._touch(rec, self._lazy_setup(), ops._stream(), refresh=3)
+        self._gathers += 1
+
+    def prefetch_refresh(self, full=False):
+        """The pre-gather refresh of the NEXT batch (already assembled in the loader's static buffers), launched at the end
+        of a pipelined unit: every row of it except those inside the window the sweep in flight is writing (``full``: every
+        row -- the prologue in front of the first unit, when no sweep is in flight)."""
+        recs = self._last_recs
+        groups = self._lazy_setup()
+        for rec in recs:
+            self._touch(dict(rec, training=True), groups, ops._stream(), refresh=1 if full else 2)
+
+    def _join_pipelined(self):
+        if len(self._pipe_events) >= 2:  # the sweep forked after the unit before last (the last one may run on)
+            torch.cuda.current_stream().wait_event(self._pipe_events[-2])
+
+    def _fork_pipelined(self):
+        self._host_step += 1
+        if self._side is None:
+            self._side = self._make_side_stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pipe_events.append(ev)
+        del self._pipe_events[:-2]
+        self._sweep_pending, self._sweep_inflight = False, True
 
     def _events(self):
         if self._ev_ref is None:
@@ -395,6 +450,7 @@ class TableAdam(torch.optim.Adam):
         if self.lazy_k > 1 and self._tables and self.overlap_sweep:
             self._join_sweep()
             self._finish_sweep()
+            del self._pipe_events[:]
 
     def _sweep(self, mode, stream, t_value=-1):
         for grp in self._lazy_setup():
@@ -591,6 +647,7 @@ class TableAdam(torch.optim.Adam):
             if self.lazy_k > 1 and self._tables:
                 self._gathers = 0  # the abandoned forward's gathers do not count towards the step's gather count
                 del self._touch_log[:]
+                del self._step_recs[:]
 
     def small_adam_args(self):
         """(sdesc, hyper) for rh_pack_grads_adam when the dense parameters' step may ride on the packing launch of this
@@ -611,9 +668,11 @@ class TableAdam(torch.optim.Adam):
             self._finish_sweep()
             if self._gathers:
                 self._gathers_per_step, self._gathers = self._gathers, 0
+            if self._step_recs:
+                self._last_recs, self._step_recs = self._step_recs, []
             seg = graphs.active()
-            if seg is not None and self.overlap_sweep and self.sweep_events:
-                pass  # sidecar mode: _sidecar_after_replay counts the replayed steps
+            if seg is not None and self.overlap_sweep and (self.sweep_events or self.pipelined):
+                pass  # sidecar / pipelined form: their after-replay function counts the replayed steps
             elif seg is not None:
                 if getattr(self, "_advance_seg", None) is not seg:  # replays count their steps on the host too (the
                     seg.after(self._advance_host_step)              # deferred sweep takes its step by value), after the

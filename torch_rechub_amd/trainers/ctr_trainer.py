@@ -292,11 +292,17 @@ class CTRTrainer(object):
                 self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
         return self._main_stream
 
-    # Candidates of the step's self-tuning: (deferred sweep?, persistent workgroups of the side-stream sweep:
-    # RH_TUNE_DEFERRED_GRID, 512 / 256 = 2 / 1 per CU).  The in-line form (merged end-of-step launch) is always a candidate:
-    # the deferred sweep pays when the step's chain is latency-bound (DeepFM / DSSM at B = 4096: -17 %), less when its
-    # kernels are heavy themselves (DIN, B = 65536: the sweep slows them by what it hides).
-    TUNE_CANDIDATES = ((True, 512), (True, 256), (False, 0))
+    # Candidates of the step's self-tuning: (form of the captured step, persistent workgroups of the side-stream sweep:
+    # RH_TUNE_DEFERRED_GRID, 512 / 256 = 2 / 1 per CU).  Forms: "deferred" = join -> [assembly, refresh] -> fork sweep ->
+    # [rest of the step] (two graph segments); "pipelined" = one segment per step, the next batch assembled and refreshed at
+    # the END of the step so that the sweep never stops (optim.TableAdam.pipelined); "inline" = the merged end-of-step
+    # launch.  The in-line form is always a candidate: a deferred sweep pays when the step's chain is latency-bound (DeepFM /
+    # DSSM at B = 4096), less when its kernels are heavy themselves (DIN, B = 65536: the sweep slows them by what it hides).
+    # ("pipelined" is correct -- tests/test_gpu_models.py -- but not a candidate: measured 0.37-0.39 ms on the DeepFM step
+    # where "deferred" reaches 0.305: a sweep that is ALREADY fully resident when the step's GEMMs arrive costs them 3-4x
+    # (69 / 41 us instead of 18 / 14), whereas the deferred form forks it in the same instant as the first GEMM, whose
+    # workgroups then get their slots first; with the own tile GEMMs at raised priority 0.346.  RECHUB_STEP_FORM=pipelined.)
+    TUNE_CANDIDATES = (("deferred", 512), ("deferred", 256), ("inline", 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
     def _tune_step_form(self, loader):
@@ -304,8 +310,8 @@ class CTRTrainer(object):
         optimizer is in its steady state (lazy_k + 8 replays after the capture: the window sweeps have their full
         length), every candidate of TUNE_CANDIDATES runs TUNE_SETTLE + TUNE_STEPS steps bracketed by HIP events, then ONE
         event synchronisation picks the fastest.  The residency cap is a parameter of the EAGER side-stream launch and can
-        change between replays of one graph; the in-line form is a second capture of the same step (its own graph, same
-        arithmetic: the optimizer's bit-equality tests cover both).  RECHUB_STEP_FORM=overlap|inline and
+        change between replays of one graph; the other forms are further captures of the same step (their own graphs, same
+        arithmetic: the optimizer's bit-equality tests cover all of them).  RECHUB_STEP_FORM=pipelined|deferred|inline and
         RECHUB_SWEEP_GRID=workgroups pin the choice; data-parallel steps keep the configured form."""
         opt = self.optimizer
         st = getattr(self, "_tune", None)
@@ -313,23 +319,23 @@ class CTRTrainer(object):
             from .. import _lib
             lazy = isinstance(opt, TableAdam) and getattr(opt, "lazy_k", 0) > 1 and bool(opt._tables)
             form = os.environ.get("RECHUB_STEP_FORM", "")
-            pad = os.environ.get("RECHUB_SWEEP_GRID", "")
-            if pad:
-                _lib.call("rh_set_tuning", 8, int(pad))
-            cands = [c for c in self.TUNE_CANDIDATES if (form != "overlap" or c[0]) and (form != "inline" or not c[0]) and
-                     (not pad or not c[0] or c[1] == self.TUNE_CANDIDATES[0][1])]
+            form = {"overlap": "deferred"}.get(form, form)
+            grid = os.environ.get("RECHUB_SWEEP_GRID", "")
+            if grid:
+                _lib.call("rh_set_tuning", 8, int(grid))
+            cands = [c for c in self.TUNE_CANDIDATES if (not form or c[0] == form) and
+                     (not grid or c[0] == "inline" or c[1] == int(grid) or not any(k[1] == int(grid) for k in self.TUNE_CANDIDATES))]
             active = (lazy and self.dp is None and "RECHUB_SWEEP_OVERLAP" not in os.environ and len(cands) > 1 and
                       "8=" not in os.environ.get("RECHUB_TUNE", "") and "3=" not in os.environ.get("RECHUB_TUNE", ""))
             st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
                                "cands": cands}
-            if lazy and form == "inline" and opt.overlap_sweep:
-                self._switch_form(False, loader)
+            if lazy and self.dp is None and form and form != self._form:
+                self._switch_form(form, loader)
         if not st["active"]:
             return
         if st["wait"] > 0:
             st["wait"] -= 1
             return
-        from .. import _lib
         per = self.TUNE_SETTLE + self.TUNE_STEPS
         i, n = st["i"], st["n"]
         if n == 0:
@@ -356,22 +362,28 @@ class CTRTrainer(object):
 
     def _apply_candidate(self, cand, loader):
         from .. import _lib
-        overlap, grid = cand
-        if overlap:
+        form, grid = cand
+        if form != "inline":
             _lib.call("rh_set_tuning", 8, int(grid))
-        if bool(self.optimizer.overlap_sweep) != bool(overlap):
-            self._switch_form(overlap, loader)
+        if self._form != form:
+            self._switch_form(form, loader)
 
-    def _switch_form(self, overlap, loader):
-        """Continue with the other form of the captured step (deferred sweep <-> in-line sweep), capturing it on first
-        use.  The switch happens between two steps from a settled sweep state, so both graphs see the same invariants."""
+    def _switch_form(self, form, loader):
+        """Continue with another form of the captured step, capturing it on first use.  The switch happens between two
+        steps from a settled sweep state, so every graph sees the same invariants; a batch the pipelined form had already
+        assembled is assembled again by the form that takes over (its pending position advance is dropped)."""
         opt = self.optimizer
         opt.settle_sweep()
+        self._counters = []
         forms = self.__dict__.setdefault("_graph_forms", {})
-        forms[bool(opt.overlap_sweep)] = (self._graph, self._graph_loss)
-        opt.overlap_sweep = bool(overlap)
-        if bool(overlap) in forms:
-            self._graph, self._graph_loss = forms[bool(overlap)]
+        forms[self._form] = (self._graph, self._graph_loss)
+        self._form = form
+        opt.overlap_sweep = form != "inline"
+        opt.pipelined = form == "pipelined"
+        if form == "pipelined":
+            self._pipeline_prologue(loader)
+        if form in forms:
+            self._graph, self._graph_loss = forms[form]
             return
         g = graphs.SegmentedGraph()
 
@@ -379,8 +391,23 @@ class CTRTrainer(object):
             x, y = self._load(loader)
             return self.train_step(x, y)
 
-        self._graph_loss = g.capture(whole_step)
+        def pipelined_unit():
+            x, y = loader.current()
+            loss = self.train_step(x, y)
+            self._load(loader)  # the NEXT batch into the static buffers; its position advance rides in the next forward
+            opt.prefetch_refresh()
+            return loss
+
+        self._graph_loss = g.capture(pipelined_unit if form == "pipelined" else whole_step)
         self._graph = g
+
+    def _pipeline_prologue(self, loader):
+        """In front of the first pipelined unit (capture, switch of form, start of an epoch): the batch it computes on is
+        assembled and refreshed here, eagerly and in full -- no sweep is in flight at this point."""
+        self.optimizer.settle_sweep()
+        self._counters = []
+        self._load(loader)
+        self.optimizer.prefetch_refresh(full=True)
 
     def _graphed_step(self, loader):
         """Replay the captured (batch assembly + train_step); the first call warms up eagerly and captures.
@@ -418,6 +445,7 @@ class CTRTrainer(object):
                 x, y = self._load(loader)
                 return self._split_step(x, y) if split else self.train_step(x, y)
 
+            self._form = "deferred" if getattr(self.optimizer, "overlap_sweep", False) else "inline"
             if not split:
                 self._graph_loss = self._graph.capture(whole_step)
                 return total, self.GRAPH_WARMUP
@@ -503,6 +531,8 @@ class CTRTrainer(object):
                 ms.wait_stream(outer)
                 torch.cuda.set_stream(ms)
             data_loader.reshuffle()
+            if self._graph is not None and getattr(self, "_form", "") == "pipelined":
+                self._pipeline_prologue(data_loader)  # the position was reset: the prefetched batch is void
             rem = data_loader.N - full * data_loader.batch_size
             it = tqdm.tqdm(total=full, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
             since_log = 0
