@@ -536,6 +536,12 @@ int rh_adam_lazy_step_rows(const int64_t* ldesc, int T, const int64_t* h_rows, c
                            int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
+/* The deferred sweep as a BRANCH of a captured hipGraph (torch_rechub_amd/optim.py, form "branch"): rh_snapshot_step copies the
+ * current step number hyper[12] into the device word t_step at the fork (the step's scalar launch on the main branch waits
+ * for it before it advances hyper[12]); rh_adam_lazy_sweep_at is rh_adam_lazy_sweep with the step taken from that word. */
+int rh_adam_lazy_sweep_at(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                          const double* hyper, const float* ring, int ring_size, int mode, const int64_t* t_step, void* stream);
+int rh_snapshot_step(const double* hyper, int64_t* t_step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident minibatch assembly (columnar dataset already in HBM)

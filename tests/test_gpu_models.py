@@ -249,7 +249,7 @@ def _assert_no_row_behind(trainer):
     return t
 
 
-@pytest.mark.parametrize("overlap", ["0", "1", "auto", "pipelined", "0+rowlist", "1+rowlist"])
+@pytest.mark.parametrize("overlap", ["0", "1", "auto", "branch", "pipelined", "0+rowlist", "1+rowlist"])
 def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch):
     """Round-1 bug: TableAdam.flush() was driven by a host flag that hipGraph replays never set, so from the second
     epoch on state_dict() / checkpoints held table rows up to K-1 steps behind the dense-Adam semantics of the reference
@@ -289,6 +289,11 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
     if overlap == "auto":
         monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
         epochs = 9  # 3 eager + 105 replayed steps: past lazy_k + 8 + 3 candidates x 22 steps of tuning
+    elif overlap == "branch":
+        # the deferred sweep as a captured BRANCH of the step's one graph (device-side step snapshot at the fork)
+        monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
+        monkeypatch.setenv("RECHUB_STEP_FORM", "branch")
+        epochs = 3
     elif overlap == "pipelined":
         # one graph segment per step: the next batch assembled + refreshed (except the rows inside the window the sweep in
         # flight is writing) at the END of the step, those rows after the join; the prologue re-runs at every epoch start
@@ -317,6 +322,8 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
         assert ta._graph_forms  # the other form of the step was captured and replayed too
     if overlap == "pipelined":
         assert ta._form == "pipelined" and ta.optimizer.pipelined
+    if overlap == "branch":
+        assert ta._form == ("branch", 512) and ta.optimizer.branch_form
     if os.environ.get("RECHUB_ROWLIST") == "1":
         assert ta.optimizer._rl_cache, "the row-list path did not engage"
     steps = _assert_no_row_behind(ta)

@@ -131,6 +131,8 @@ SIGNATURES = {
     "rh_adam_lazy_step_rows": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                                c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr],
+    "rh_adam_lazy_sweep_at": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
+    "rh_snapshot_step": [c_ptr, c_ptr, c_ptr],
     "rh_adam_dense": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     "rh_batch_gather": [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],

@@ -232,6 +232,8 @@ struct LazySweepArgs {
   int T;
   int flush;  // 1: window = whole table
   int64_t t_value;  // >= 0: the step this sweep belongs to, by value (deferred sweep); < 0: hyper[12]
+  const int64_t* t_ptr;  // non-null: the step this sweep belongs to, read from a device word (a deferred sweep captured as a
+                         // graph branch: rh_snapshot_step wrote it before the step's scalar launch moved hyper[12] on)
   int64_t total_vblocks;
   int64_t vb_prefix[kMaxTensors + 1];
   // merged launch (rh_adam_lazy_step): the first touch_blocks workgroups run the touched-rows step of the batch, the rest
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     nblk = (int64_t)gridDim.x - a.touch_blocks;
   }
   AdamScalars h = load_scalars(a.hyper);
-  const int t = a.t_value >= 0 ? (int)a.t_value : (int)a.hyper[12];
-  if (a.t_value >= 0) {  // deferred: hyper[12..14] may already belong to the next step; the ring entry of t does not
+  const int t = a.t_ptr != nullptr ? (int)a.t_ptr[0] : (a.t_value >= 0 ? (int)a.t_value : (int)a.hyper[12]);
+  if (a.t_value >= 0 || a.t_ptr != nullptr) {  // deferred: hyper[12..14] may already belong to the next step; the ring entry of t does not
     h.A = a.ring[2 * (t & a.ring_mask)];
     h.E = a.ring[2 * (t & a.ring_mask) + 1];
   }
@@ -541,7 +543,7 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
   if (a.total_vblocks == 0 && a.touch_blocks == 0) return 0;
   // persistent-style grid: each workgroup walks several virtual blocks so the prefetch has something to overlap
   int64_t grid = a.total_vblocks;
-  const int64_t cap = (a.t_value >= 0 && touch == nullptr && g_deferred_grid > 0) ? g_deferred_grid
+  const int64_t cap = ((a.t_value >= 0 || a.t_ptr != nullptr) && touch == nullptr && g_deferred_grid > 0) ? g_deferred_grid
                       : (g_sweep_grid > 0 ? g_sweep_grid : 256 * 32);
   if (grid > cap) grid = cap;
   if (touch != nullptr) {
@@ -554,7 +556,7 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
     hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK), 0, s,
                        a);
   } else {
-    const int pad = a.t_value >= 0 ? (g_sweep_lds_pad < 0 ? kDeferredSweepPad : g_sweep_lds_pad) : 0;
+    const int pad = (a.t_value >= 0 || a.t_ptr != nullptr) ? (g_sweep_lds_pad < 0 ? kDeferredSweepPad : g_sweep_lds_pad) : 0;
     if (pad > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per workgroup is opt-in
       static int raised = 0;
       if (raised < pad) {
@@ -831,9 +833,39 @@ extern "C" int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel
   return 0;
 }
 
+static int lazy_sweep_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
+                           const int64_t* t_ptr, void* stream);
+
 extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                                   const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
                                   void* stream) {
+  return lazy_sweep_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, mode, t_value, nullptr, stream);
+}
+
+// A deferred sweep that can live INSIDE a captured hipGraph, as a branch beside the step's launch chain: its step number
+// comes from the device word t_step (written by rh_snapshot_step at the fork, before the step's scalar launch advances
+// hyper[12]) instead of a by-value argument, which a graph would freeze.  Residency-capped like every deferred sweep.
+extern "C" int rh_adam_lazy_sweep_at(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                     const double* hyper, const float* ring, int ring_size, int mode, const int64_t* t_step,
+                                     void* stream) {
+  RH_REQUIRE(t_step != nullptr, RH_E_BADARG, "rh_adam_lazy_sweep_at: t_step is null");
+  return lazy_sweep_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, mode, -1, t_step, stream);
+}
+
+__global__ void snapshot_step_kernel(const double* hyper, int64_t* out) {
+  if (threadIdx.x == 0) out[0] = (int64_t)hyper[12];
+}
+extern "C" int rh_snapshot_step(const double* hyper, int64_t* t_step, void* stream) {
+  RH_REQUIRE(hyper && t_step, RH_E_BADARG, "rh_snapshot_step: null pointer");
+  hipLaunchKernelGGL(snapshot_step_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), hyper, t_step);
+  RH_LAUNCH_CHECK("rh_snapshot_step");
+  return 0;
+}
+
+static int lazy_sweep_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
+                           const int64_t* t_ptr, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring, RH_E_BADARG, "rh_adam_lazy_sweep: null pointer");
   RH_REQUIRE(mode >= RH_SWEEP_WINDOW && mode <= RH_SWEEP_DENSE_TABLES, RH_E_BADARG, "rh_adam_lazy_sweep: mode %d", mode);
   RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
@@ -847,6 +879,7 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
   a.T = T;
   a.flush = mode == RH_SWEEP_FLUSH ? 1 : 0;
   a.t_value = t_value;
+  a.t_ptr = t_ptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
@@ -1004,6 +1037,7 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
   a.T = T;
   a.flush = 0;
   a.t_value = -1;
+  a.t_ptr = nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {

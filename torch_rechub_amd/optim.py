@@ -134,6 +134,18 @@ class TableAdam(torch.optim.Adam):
                 # by two kernels at once: a deferred sweep writes only rows of its own window that are behind its step,
                 # every row of a batch outside that window was refreshed before the sweep after next starts, and the rows
                 # inside it wait for the join (rh_adam_lazy_touched refresh = 2 / 3).
+                # "branch" form (opt-in, RECHUB_STEP_FORM=branch): the deferred sweep as a BRANCH of the step's one captured
+                # graph -- forked (captured event) after the last refresh, its step number from a device word snapshotted
+                # at the fork (rh_snapshot_step / rh_adam_lazy_sweep_at), joined at the end of the graph; no host work per
+                # replay.  Captured branches DO run concurrently on this runtime (tools/probe/branch_probe.cpp: 1.66 vs
+                # 3.25 ms for two long kernels; round 2's "they do not overlap" was the un-capped sweep starving the
+                # chain).  Measured 0.312 ms against 0.306 for the two-segment form: the runtime puts the two branches on
+                # two hardware queues, the chain pays the same ~17 us hand-over at the fork and ~20 us between two graph
+                # launches that the segment boundaries cost (profiles/r03_timeline_branch.txt).
+                self.branch_form = False
+                self._branch_open = False
+                self._snap_event = None
+                self._t_snap = torch.zeros(1, dtype=torch.int64, device=dev)
                 self.pipelined = False
                 self._pipe_events = []
                 self._pipe_seg = None
@@ -334,6 +346,9 @@ class TableAdam(torch.optim.Adam):
         if capturing and seg is not None and self.overlap_sweep and self.pipelined and training:
             self._gather_pipelined(rec, seg)
             return
+        if capturing and self.overlap_sweep and self.branch_form and training:
+            self._gather_branch(rec)
+            return
         if capturing and seg is not None and self.overlap_sweep and self.sweep_events:
             self._gather_sidecar(rec, seg)
             return
@@ -365,6 +380,41 @@ class TableAdam(torch.optim.Adam):
                 seg.cut(self._fork_sweep)
                 self._sweep_inflight = True
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
+
+    # -- branch form (see __init__) -----------------------------------------------------------------------------------
+    def _gather_branch(self, rec):
+        if self._sweep_inflight or self._sweep_pending:
+            raise RuntimeError("TableAdam: call optimizer.settle_sweep() before capturing a step in branch form")
+        stream = ops._stream()
+        self._touch(rec, self._lazy_setup(), stream, refresh=True)
+        self._gathers += 1
+        if self._gathers < (self._gathers_per_step or 1):
+            return
+        dev = self._tables[0].device
+        if self._side is None or isinstance(self._side, torch.cuda.ExternalStream):
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)  # the fork: every row of this step's batches is current
+        with torch.cuda.stream(self._side):
+            s2 = ops._stream()
+            _lib.call("rh_snapshot_step", ops._p(self._t_hyper), ops._p(self._t_snap), s2)
+            self._snap_event = torch.cuda.Event()
+            self._snap_event.record()  # the main branch's scalar launch waits for it before it moves hyper[12] on
+            for grp in self._lazy_setup():
+                _lib.call("rh_adam_lazy_sweep_at", ops._p(grp["ldesc"]), len(grp["members"]),
+                          ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                          ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, SWEEP_LAZY_TABLES, ops._p(self._t_snap), s2)
+        self._branch_open = True
+
+    def _wait_snapshot(self):
+        if self._snap_event is not None:
+            torch.cuda.current_stream().wait_event(self._snap_event)
+            self._snap_event = None
+
+    def _join_branch(self):
+        if self._branch_open:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._branch_open = False
 
     # -- pipelined form (see __init__) --------------------------------------------------------------------------------
     def _gather_pipelined(self, rec, seg):
@@ -627,6 +677,8 @@ class TableAdam(torch.optim.Adam):
         corrections) and before the optimizer kernels -- i.e. where the loss is computed."""
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()  # lr / betas / eps / weight_decay must be on the device BEFORE the corrections are formed
+        if self.lazy_k > 1 and self._tables:
+            self._wait_snapshot()
         self._prepared = True
         return self._t_hyper, self._t_step, self._t_ring, self.RING
 
@@ -683,6 +735,8 @@ class TableAdam(torch.optim.Adam):
         if self._prepared:
             self._prepared = False
         else:
+            if self.lazy_k > 1 and self._tables:
+                self._wait_snapshot()
             _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
                       stream)
         if self._bucket is not None and self._small_done:
@@ -701,6 +755,8 @@ class TableAdam(torch.optim.Adam):
             for desc, n, numel in self._desc():
                 _lib.call("rh_adam_dense", ops._p(desc), n, ctypes.cast(numel, ctypes.c_void_p),
                           ops._p(self._t_hyper), 1, stream)
+        if self.lazy_k > 1:
+            self._join_branch()  # branch form: the captured sweep rejoins the step here (the end of the graph)
         for p in self._tables:
             p._rh_dirty = False  # the kernels zeroed every non-zero gradient row
             if p.grad is None:

@@ -302,6 +302,9 @@ class CTRTrainer(object):
     # where "deferred" reaches 0.305: a sweep that is ALREADY fully resident when the step's GEMMs arrive costs them 3-4x
     # (69 / 41 us instead of 18 / 14), whereas the deferred form forks it in the same instant as the first GEMM, whose
     # workgroups then get their slots first; with the own tile GEMMs at raised priority 0.346.  RECHUB_STEP_FORM=pipelined.)
+    # ("branch" = the deferred sweep as a captured branch of the step's ONE graph, optim.TableAdam.branch_form; its
+    # residency cap is baked into the capture, so every (branch, grid) pair is its own graph.  Exact, 0.312 ms where
+    # "deferred" reaches 0.306: not a candidate, RECHUB_STEP_FORM=branch.)
     TUNE_CANDIDATES = (("deferred", 512), ("deferred", 256), ("inline", 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
@@ -311,7 +314,7 @@ class CTRTrainer(object):
         length), every candidate of TUNE_CANDIDATES runs TUNE_SETTLE + TUNE_STEPS steps bracketed by HIP events, then ONE
         event synchronisation picks the fastest.  The residency cap is a parameter of the EAGER side-stream launch and can
         change between replays of one graph; the other forms are further captures of the same step (their own graphs, same
-        arithmetic: the optimizer's bit-equality tests cover all of them).  RECHUB_STEP_FORM=pipelined|deferred|inline and
+        arithmetic: the optimizer's bit-equality tests cover all of them).  RECHUB_STEP_FORM=branch|deferred|pipelined|inline and
         RECHUB_SWEEP_GRID=workgroups pin the choice; data-parallel steps keep the configured form."""
         opt = self.optimizer
         st = getattr(self, "_tune", None)
@@ -324,13 +327,15 @@ class CTRTrainer(object):
             if grid:
                 _lib.call("rh_set_tuning", 8, int(grid))
             cands = [c for c in self.TUNE_CANDIDATES if (not form or c[0] == form) and
-                     (not grid or c[0] == "inline" or c[1] == int(grid) or not any(k[1] == int(grid) for k in self.TUNE_CANDIDATES))]
+                     (not grid or c[0] == "inline" or c[1] == int(grid))]
+            if form and (grid or not cands):  # fully pinned (also forms / grids that are not tuning candidates)
+                cands = [(form, int(grid or 512) if form != "inline" else 0)]
             active = (lazy and self.dp is None and "RECHUB_SWEEP_OVERLAP" not in os.environ and len(cands) > 1 and
                       "8=" not in os.environ.get("RECHUB_TUNE", "") and "3=" not in os.environ.get("RECHUB_TUNE", ""))
             st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
                                "cands": cands}
-            if lazy and self.dp is None and form and form != self._form:
-                self._switch_form(form, loader)
+            if lazy and self.dp is None and form and form != self._form and len(cands) == 1:
+                self._apply_candidate(cands[0], loader)
         if not st["active"]:
             return
         if st["wait"] > 0:
@@ -365,8 +370,9 @@ class CTRTrainer(object):
         form, grid = cand
         if form != "inline":
             _lib.call("rh_set_tuning", 8, int(grid))
-        if self._form != form:
-            self._switch_form(form, loader)
+        key = (form, int(grid)) if form == "branch" else form
+        if self._form != key:
+            self._switch_form(key, loader)
 
     def _switch_form(self, form, loader):
         """Continue with another form of the captured step, capturing it on first use.  The switch happens between two
@@ -378,12 +384,14 @@ class CTRTrainer(object):
         forms = self.__dict__.setdefault("_graph_forms", {})
         forms[self._form] = (self._graph, self._graph_loss)
         self._form = form
+        key, form = form, (form[0] if isinstance(form, tuple) else form)
         opt.overlap_sweep = form != "inline"
         opt.pipelined = form == "pipelined"
+        opt.branch_form = form == "branch"
         if form == "pipelined":
             self._pipeline_prologue(loader)
-        if form in forms:
-            self._graph, self._graph_loss = forms[form]
+        if key in forms:
+            self._graph, self._graph_loss = forms[key]
             return
         g = graphs.SegmentedGraph()
 
@@ -531,7 +539,7 @@ class CTRTrainer(object):
                 ms.wait_stream(outer)
                 torch.cuda.set_stream(ms)
             data_loader.reshuffle()
-            if self._graph is not None and getattr(self, "_form", "") == "pipelined":
+            if self._graph is not None and getattr(self, "_form", "") == "pipelined":  # (a string: branch keys are tuples)
                 self._pipeline_prologue(data_loader)  # the position was reset: the prefetched batch is void
             rem = data_loader.N - full * data_loader.batch_size
             it = tqdm.tqdm(total=full, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
