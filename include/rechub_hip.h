@@ -314,6 +314,22 @@ int rh_inbatch_logits_fwd(const float* u, int64_t ldu, const float* v, int64_t l
                           int K, int row0, float* logits, int32_t* err_flag, void* stream);
 int rh_inbatch_logits_bwd(const float* u, int64_t ldu, const float* v, int64_t ldv, const int64_t* neg, const float* g, int B,
                           int C, int D, int K, int row0, float* g_u, float* g_v, void* stream);
+
+/* Two-tower glue as single launches.
+ * rh_l2norm_fwd/bwd: F.normalize(x, p=2, dim=1) of the towers' outputs (torch_rechub/models/matching/dssm.py:56,66):
+ *   y = x / max(||x||_2, eps) row-wise, nrm (B,) = ||x|| saved; gx = (g - y (g . y)) / ||x||, or g / eps where the norm was
+ *   clamped.  x / g row stride ldx / ldg (multiples of 4), d % 4 == 0, d <= 4096; y, gx contiguous (B, d).
+ * rh_ce_fwd/bwd: torch.nn.CrossEntropyLoss() (mean) over the (B, C) in-batch logits (trainers/match_trainer.py:60,136;
+ *   target int64 (B,), null = class 0 for every row as the trainer's zero targets): lse (B,) = logsumexp per row, loss_partial
+ *   (rh_ce_nblocks(B),) per-block sums of lse - x[target] (the caller sums them and divides by B: rh_colsum);
+ *   g_logits = g_loss[0] / B * (softmax - onehot).  C <= 1024; an out-of-range target sets RH_FLAG_INDEX_OOB. */
+int rh_l2norm_fwd(const float* x, int64_t ldx, int B, int d, float eps, float* y, float* nrm, void* stream);
+int rh_l2norm_bwd(const float* y, const float* nrm, const float* g, int64_t ldg, int B, int d, float eps, float* gx, void* stream);
+int rh_ce_nblocks(int B);
+int rh_ce_fwd(const float* logits, const int64_t* target, int B, int C, float* lse, float* loss_partial, int32_t* err_flag,
+              void* stream);
+int rh_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* g_loss, int B, int C, float* g_logits,
+              void* stream);
 int rh_din_att_l1_supported(int D, int N);
 int rh_din_att_l1_chunk_rows(int64_t rows);
 int rh_din_att_l1_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* W,

@@ -1700,6 +1700,53 @@ def test_hidden_layer_and_prediction_with_two_consumers_each(fused_loss):
         close(p.grad, q.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what=f"g_{n}")
 
 
+@pytest.mark.parametrize("B,d", [(4096, 64), (37, 16), (5, 100), (300, 1024), (1, 4)])
+def test_l2_normalize_matches_functional_normalize(B, d):
+    """ops.l2_normalize (csrc/match.hip) == F.normalize(x, p=2, dim=1) of the reference towers (models/matching/dssm.py:56,66)
+    in float64: values and gradient, including rows whose norm is below eps (clamped denominator) and a strided input."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B + d)
+    big = torch.randn(B, d + 4, generator=g)
+    big[::7] *= 1e-3
+    if B > 2:
+        big[1] = 0.0          # zero row: y = 0, gradient g / eps
+        big[2] = 1e-14        # norm below eps
+    gy = torch.randn(B, d, generator=g).to(dev())
+    xs = big.to(dev())[:, :d].detach().requires_grad_()  # a view: row stride d + 4
+    assert ops.l2_normalize_ok(xs)
+    y = ops.l2_normalize(xs)
+    y.backward(gy)
+    xr = big[:, :d].double().requires_grad_()
+    yr = torch.nn.functional.normalize(xr, p=2, dim=1)
+    yr.backward(gy.double().cpu())
+    close(y, yr.detach().numpy(), rtol=1e-5, atol_scale=1e-6, what="normalised rows")
+    live = (big[:, :d].double().norm(dim=1) > 1e-12).numpy()
+    got, want = xs.grad.cpu().numpy(), xr.grad.numpy()
+    np.testing.assert_allclose(got[live], want[live], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(want[live]).max()) if live.any() else 1.0))
+    if (~live).any():  # clamped rows: g / eps (1e12-scale numbers)
+        np.testing.assert_allclose(got[~live], want[~live], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,with_target", [(4096, 21, False), (37, 5, True), (1, 1, False), (300, 64, True), (513, 130, True)])
+def test_cross_entropy_mean_matches_torch(B, C, with_target):
+    """ops.cross_entropy_mean == torch.nn.CrossEntropyLoss()(logits, target) in float64 (target None = the trainer's zero
+    targets, trainers/match_trainer.py:136): loss and gradient, large logits included (temperature 0.02 scales them by 50)."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(B * 3 + C)
+    logits = (torch.randn(B, C, generator=g) * 20).to(dev()).requires_grad_()
+    target = torch.randint(0, C, (B,), generator=g) if with_target else None
+    crit = torch.nn.CrossEntropyLoss()
+    assert ops.cross_entropy_ok(crit, logits, None if target is None else target.to(dev()))
+    loss = ops.cross_entropy_mean(logits, None if target is None else target.to(dev()))
+    (loss * 1.7).backward()
+    lr = logits.detach().double().cpu().requires_grad_()
+    ref = crit(lr, target if target is not None else torch.zeros(B, dtype=torch.long))
+    (ref * 1.7).backward()
+    ops.check_errors()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    close(logits.grad, lr.grad.numpy(), rtol=1e-5, atol_scale=1e-7, what="g_logits")
+
+
 @pytest.mark.parametrize("B,C,row0,D,K", [(4096, 4096, 0, 64, 20), (300, 900, 300, 16, 7), (5, 5, 0, 100, 4),
                                            (64, 64, 0, 300, 1), (33, 40, 7, 8, 0)])
 def test_inbatch_logits_without_the_score_matrix(B, C, row0, D, K):

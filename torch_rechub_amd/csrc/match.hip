@@ -133,3 +133,155 @@ extern "C" int rh_inbatch_logits_bwd(const float* u, int64_t ldu, const float* v
   RH_LAUNCH_CHECK("rh_inbatch_logits_bwd");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-wise L2 normalisation of the towers' outputs and the mean cross-entropy over the (B, 1 + K) in-batch logits: the
+// reference's F.normalize(.., p=2, dim=1) (models/matching/dssm.py:56,66: norm -> clamp_min(eps) -> expand -> div, and
+// its five-kernel backward) and torch.nn.CrossEntropyLoss() (trainers/match_trainer.py:60,136: log_softmax + nll_loss)
+// were ~30 ATen launches (~160 us of ~1.2 ms) in the configs[4] step.  One launch each way here.
+namespace {
+
+// 16 lanes per row (float4 each, d walked in chunks of 64 floats): y = x / max(||x||, eps); nrm saved for the backward
+__global__ __launch_bounds__(RH_BLOCK) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t ldx, int B, int d, float eps,
+                                                              float* __restrict__ y, float* __restrict__ nrm) {
+  RH_CHAIN_PRIO();
+  const int q = threadIdx.x % 16, slot = threadIdx.x / 16;
+  for (int64_t r = (int64_t)blockIdx.x * (RH_BLOCK / 16) + slot; r < B; r += (int64_t)gridDim.x * (RH_BLOCK / 16)) {
+    float ss = 0.f;
+    for (int c = q * 4; c < d; c += 64) {
+      const float4 v = gload<float4>(x + r * ldx + c);
+      ss += f4_dot(v, v);
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, RH_WAVE);
+    const float n = sqrtf(ss);
+    const float inv = 1.f / fmaxf(n, eps);
+    for (int c = q * 4; c < d; c += 64) gstore<float4>(y + r * (int64_t)d + c, f4_scale(gload<float4>(x + r * ldx + c), inv));
+    if (q == 0) nrm[r] = n;
+  }
+}
+
+// gx = (g - y (g . y)) / ||x||  where ||x|| > eps;  gx = g / eps where the norm was clamped (a constant denominator)
+__global__ __launch_bounds__(RH_BLOCK) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ nrm,
+                                                              const float* __restrict__ g, int64_t ldg, int B, int d, float eps,
+                                                              float* __restrict__ gx) {
+  RH_CHAIN_PRIO();
+  const int q = threadIdx.x % 16, slot = threadIdx.x / 16;
+  for (int64_t r = (int64_t)blockIdx.x * (RH_BLOCK / 16) + slot; r < B; r += (int64_t)gridDim.x * (RH_BLOCK / 16)) {
+    const float n = nrm[r];
+    const bool clamped = !(n > eps);
+    float dot = 0.f;
+    for (int c = q * 4; c < d; c += 64) dot += f4_dot(gload<float4>(g + r * ldg + c), gload<float4>(y + r * (int64_t)d + c));
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) dot += __shfl_xor(dot, m, RH_WAVE);
+    const float inv = 1.f / fmaxf(n, eps);
+    if (clamped) dot = 0.f;
+    for (int c = q * 4; c < d; c += 64) {
+      const float4 gv = gload<float4>(g + r * ldg + c), yv = gload<float4>(y + r * (int64_t)d + c);
+      gstore<float4>(gx + r * (int64_t)d + c, f4_scale(f4_fma(-dot, yv, gv), inv));
+    }
+  }
+}
+
+// one lane per row (C <= 64 classes: the in-batch logits have 1 + K columns): loss terms lse - x[target] summed per block
+__global__ __launch_bounds__(RH_BLOCK) void ce_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ target, int B,
+                                                          int C, float* __restrict__ lse, float* __restrict__ partial, int* err) {
+  RH_CHAIN_PRIO();
+  __shared__ float red[RH_BLOCK / RH_WAVE];
+  const int64_t r = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+  float term = 0.f;
+  if (r < B) {
+    const float* row = x + r * (int64_t)C;
+    float m = row[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+    const float l = m + logf(s);
+    lse[r] = l;
+    int64_t t = target ? target[r] : 0;
+    if ((uint64_t)t >= (uint64_t)C) {
+      if (err) atomicOr(err, RH_FLAG_INDEX_OOB);
+      t = 0;
+    }
+    term = l - row[t];
+  }
+  term = wave_sum(term);
+  if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < RH_BLOCK / RH_WAVE; ++w) tot += red[w];
+    partial[blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(RH_BLOCK) void ce_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ target,
+                                                          const float* __restrict__ lse, const float* __restrict__ g_loss, int B,
+                                                          int C, float* __restrict__ gx) {
+  RH_CHAIN_PRIO();
+  const float scale = g_loss[0] / (float)B;
+  for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < (int64_t)B * C; i += (int64_t)gridDim.x * RH_BLOCK) {
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    int64_t t = target ? target[r] : 0;
+    if ((uint64_t)t >= (uint64_t)C) t = 0;
+    gx[i] = scale * (expf(x[i] - lse[r]) - (c == t ? 1.f : 0.f));
+  }
+}
+
+}  // namespace
+
+extern "C" int rh_l2norm_fwd(const float* x, int64_t ldx, int B, int d, float eps, float* y, float* nrm, void* stream) {
+  RH_REQUIRE(x && y && nrm, RH_E_BADARG, "rh_l2norm_fwd: null pointer");
+  RH_REQUIRE(B >= 0 && d >= 4 && d % 4 == 0 && d <= 4096 && ldx >= d && ldx % 4 == 0, RH_E_UNSUPPORTED,
+             "rh_l2norm_fwd: B=%d d=%d ldx=%lld unsupported (d, ldx multiples of 4, d <= 4096)", B, d, (long long)ldx);
+  if (B == 0) return 0;
+  const int rows_per_block = RH_BLOCK / 16;
+  int64_t grid = ((int64_t)B + rows_per_block - 1) / rows_per_block;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                     B, d, eps, y, nrm);
+  RH_LAUNCH_CHECK("rh_l2norm_fwd");
+  return 0;
+}
+
+extern "C" int rh_l2norm_bwd(const float* y, const float* nrm, const float* g, int64_t ldg, int B, int d, float eps, float* gx,
+                             void* stream) {
+  RH_REQUIRE(y && nrm && g && gx, RH_E_BADARG, "rh_l2norm_bwd: null pointer");
+  RH_REQUIRE(B >= 0 && d >= 4 && d % 4 == 0 && d <= 4096 && ldg >= d && ldg % 4 == 0, RH_E_UNSUPPORTED,
+             "rh_l2norm_bwd: B=%d d=%d ldg=%lld unsupported", B, d, (long long)ldg);
+  if (B == 0) return 0;
+  const int rows_per_block = RH_BLOCK / 16;
+  int64_t grid = ((int64_t)B + rows_per_block - 1) / rows_per_block;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), y, nrm,
+                     g, ldg, B, d, eps, gx);
+  RH_LAUNCH_CHECK("rh_l2norm_bwd");
+  return 0;
+}
+
+extern "C" int rh_ce_nblocks(int B) { return (B + RH_BLOCK - 1) / RH_BLOCK; }
+
+extern "C" int rh_ce_fwd(const float* logits, const int64_t* target, int B, int C, float* lse, float* loss_partial,
+                         int32_t* err_flag, void* stream) {
+  RH_REQUIRE(logits && lse && loss_partial, RH_E_BADARG, "rh_ce_fwd: null pointer");
+  RH_REQUIRE(B >= 1 && C >= 1 && C <= 1024, RH_E_UNSUPPORTED, "rh_ce_fwd: B=%d C=%d unsupported (1 <= C <= 1024)", B, C);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)rh_ce_nblocks(B)), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                     logits, target, B, C, lse, loss_partial, err_flag);
+  RH_LAUNCH_CHECK("rh_ce_fwd");
+  return 0;
+}
+
+extern "C" int rh_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* g_loss, int B, int C,
+                         float* g_logits, void* stream) {
+  RH_REQUIRE(logits && lse && g_loss && g_logits, RH_E_BADARG, "rh_ce_bwd: null pointer");
+  RH_REQUIRE(B >= 1 && C >= 1 && C <= 1024, RH_E_UNSUPPORTED, "rh_ce_bwd: B=%d C=%d unsupported", B, C);
+  int64_t grid = ((int64_t)B * C + RH_BLOCK - 1) / RH_BLOCK;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), logits, target,
+                     lse, g_loss, B, C, g_logits);
+  RH_LAUNCH_CHECK("rh_ce_bwd");
+  return 0;
+}
+

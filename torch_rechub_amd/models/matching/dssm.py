@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ... import ops
 from ...basic.layers import MLP, EmbeddingLayer
 
 
@@ -26,7 +27,9 @@ class DSSM(nn.Module):
         self.mode = None
 
     def _tower(self, x, features, mlp):
-        return F.normalize(mlp(self.embedding(x, features, squeeze_dim=True)), p=2, dim=1)
+        h = mlp(self.embedding(x, features, squeeze_dim=True))
+        # F.normalize(h, p=2, dim=1) (dssm.py:56,66) as one HIP launch each way (csrc/match.hip)
+        return ops.l2_normalize(h) if ops.l2_normalize_ok(h) else F.normalize(h, p=2, dim=1)
 
     def user_tower(self, x):
         return None if self.mode == "item" else self._tower(x, self.user_features, self.user_mlp)

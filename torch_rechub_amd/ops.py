@@ -1261,6 +1261,84 @@ class _PReluFn(torch.autograd.Function):
         return gx, deferred.offer(ctx.param, partial.data_ptr(), nb, 1, 1, lambda: partial.sum().reshape(1), partial)
 
 
+class _L2NormFn(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=1, eps): one launch each way (csrc/match.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        require_hip(x)
+        if x.stride(1) != 1 or x.stride(0) % 4:
+            x = x.contiguous()
+        B, d = x.shape
+        y = torch.empty((B, d), dtype=torch.float32, device=x.device)
+        nrm = torch.empty((B,), dtype=torch.float32, device=x.device)
+        _lib.call("rh_l2norm_fwd", _p(x), x.stride(0), B, d, float(eps), _p(y), _p(nrm), _stream())
+        ctx.eps = float(eps)
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, nrm = ctx.saved_tensors
+        B, d = y.shape
+        if g.stride(1) != 1 or g.stride(0) % 4:
+            g = g.contiguous()
+        gx = torch.empty_like(y)
+        _lib.call("rh_l2norm_bwd", _p(y), _p(nrm), _p(g), g.stride(0), B, d, ctx.eps, _p(gx), _stream())
+        return gx, None
+
+
+def l2_normalize_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.shape[1] % 4 == 0 and \
+        4 <= x.shape[1] <= 4096
+
+
+def l2_normalize(x, eps=1e-12):
+    """torch.nn.functional.normalize(x, p=2, dim=1, eps=eps) for a float32 (B, d) HIP tensor, d % 4 == 0."""
+    return _L2NormFn.apply(x, eps)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss() (mean) over (B, C) logits, int64 targets (None = class 0 everywhere)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        require_hip(logits)
+        logits = logits.contiguous()
+        B, C = logits.shape
+        dev = logits.device
+        lse = torch.empty((B,), dtype=torch.float32, device=dev)
+        nb = _lib.call("rh_ce_nblocks", B)
+        partial = torch.empty((nb,), dtype=torch.float32, device=dev)
+        _lib.call("rh_ce_fwd", _p(logits), _p(target), B, C, _p(lse), _p(partial), _p(err_flag(dev)), _stream())
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        _lib.call("rh_colsum", _p(partial), nb, 1, _p(loss), _NULL, 0, _NULL, _stream())
+        ctx.save_for_backward(logits, lse) if target is None else ctx.save_for_backward(logits, lse, target)
+        ctx.has_target = target is not None
+        return (loss / B).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        logits, lse = saved[0], saved[1]
+        target = saved[2] if ctx.has_target else None
+        B, C = logits.shape
+        gx = torch.empty_like(logits)
+        _lib.call("rh_ce_bwd", _p(logits), _p(target), _p(lse), _p(g.contiguous().view(1)), B, C, _p(gx), _stream())
+        return gx, None
+
+
+def cross_entropy_ok(criterion, logits, target):
+    return (type(criterion) is torch.nn.CrossEntropyLoss and criterion.reduction == "mean" and criterion.weight is None and
+            criterion.label_smoothing == 0.0 and criterion.ignore_index == -100 and logits.is_cuda and
+            logits.dtype == torch.float32 and logits.dim() == 2 and 1 <= logits.shape[1] <= 1024 and logits.shape[0] > 0 and
+            (target is None or (target.dtype == torch.int64 and target.shape == (logits.shape[0],) and target.is_cuda)))
+
+
+def cross_entropy_mean(logits, target=None):
+    return _CrossEntropyFn.apply(logits, None if target is None else target.contiguous())
+
+
 def prelu_ok(mod, x):
     return (type(mod) is torch.nn.PReLU and mod.weight.numel() == 1 and x.is_cuda and x.dtype == torch.float32 and
             x.numel() >= 1)

@@ -113,6 +113,9 @@ class MatchTrainer(CTRTrainer):
                 logits = gather_inbatch_logits(scores, neg_indices, row_offset=row0)
             if self.mode == 1:
                 loss = self.criterion(logits[:, 0], logits[:, 1:], in_batch_neg=True)
+            elif ops.cross_entropy_ok(self.criterion, logits, None):
+                # CrossEntropyLoss()(logits, zeros) (match_trainer.py:136): logsumexp - logits[:, 0], one launch each way
+                loss = ops.cross_entropy_mean(logits)
             else:
                 loss = self.criterion(logits, self._zero_targets(logits.size(0)))
         elif self.mode == 1:
