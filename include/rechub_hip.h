@@ -446,6 +446,18 @@ int rh_bn_relu_dropout_bwd_pre(const float* h, const float* dy, int B, int C, co
 int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta,
                            float p_drop, const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat,
                            float* dx, float* dgamma, float* dbeta, int relu, void* stream);
+/* The same two passes with nn.PReLU() (ONE slope) in place of the ReLU: Linear -> BatchNorm1d -> PReLU -> Dropout of the
+ * two-tower MLPs (reference MLP(activation="prelu"), examples/matching/run_ml_dssm.py:69-80; basic/layers.py:276-292).
+ * y = bn > 0 ? bn : slope[0] * bn.  The backward also writes slope_partial (rh_bn_prelu_nblocks(B, C) floats): per-workgroup
+ * sums of dy * min(bn, 0), whose total is the slope's gradient.  Training mode only (eval: BatchNorm pass + rh_prelu_fwd). */
+int rh_bn_prelu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
+                            int training, int64_t* rng, int64_t* saved_ctr, float* partial, int partial_rows, float* stat,
+                            float* out, const float* slope, void* stream);
+int rh_bn_prelu_nblocks(int B, int C);
+int rh_bn_prelu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta, float p_drop,
+                            const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat, float* dx,
+                            float* dgamma, float* dbeta, const float* slope, float* slope_partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense Adam with coupled L2, torch.optim.Adam semantics over every row of every table

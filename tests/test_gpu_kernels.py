@@ -1700,6 +1700,64 @@ def test_hidden_layer_and_prediction_with_two_consumers_each(fused_loss):
         close(p.grad, q.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what=f"g_{n}")
 
 
+@pytest.mark.parametrize("B,dims,p", [(4096, [256, 128, 64], 0.0), (37, [33], 0.0), (9000, [64, 32], 0.0), (300, [48], 0.3),
+                                      (9000, [64], 0.5)])
+def test_mlp_batchnorm_prelu_dropout_epilogue(B, dims, p, monkeypatch):
+    """Linear -> BatchNorm1d -> nn.PReLU() -> Dropout of the two-tower MLPs (reference MLP(activation="prelu"),
+    basic/layers.py:276-292) through the fused epilogue (rh_bn_prelu_dropout_fwd/bwd: one launch pair per direction, the
+    slope gradient from the statistics pass).  p = 0: against the same modules in float64 on eager torch -- outputs, input
+    gradient, every parameter gradient (slopes included) and the running statistics.  p > 0 (one layer): the kernel's own
+    counter-based mask is read off the output (zeros), its rate is checked against p, and the float64 reference applies
+    exactly that mask."""
+    import copy
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import MLP
+    g = torch.Generator().manual_seed(B + len(dims))
+    x = torch.randn(B, 40, generator=g)
+    gy = torch.randn(B, dims[-1], generator=g)
+    torch.manual_seed(3)
+    mlp = MLP(40, output_layer=False, dims=dims, dropout=p, activation="prelu").train()
+    with torch.no_grad():
+        for m in mlp.mlp:
+            if isinstance(m, torch.nn.PReLU):
+                m.weight.uniform_(-0.4, 0.6)
+    calls = []
+    real = ops.bn_prelu_dropout
+    monkeypatch.setattr(ops, "bn_prelu_dropout", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    if p == 0.0:
+        ref = copy.deepcopy(mlp).double()
+        xr = x.double().requires_grad_()
+        yr = ref(xr)
+        yr.backward(gy.double())
+    else:
+        ref = copy.deepcopy(mlp).double()  # pristine copy: running statistics not yet updated
+        ref.mlp[3].p = 0.0               # the reference applies the kernel's own mask (read off the output below)
+    mlp = mlp.to(dev())
+    xd = x.to(dev()).requires_grad_()
+    y = mlp(xd)
+    y.backward(gy.to(dev()))
+    torch.cuda.synchronize()
+    if p > 0.0:
+        keep = (y.detach() != 0).double().cpu()  # the kernel's mask (an exact zero of prelu(bn) has measure zero)
+        rate = 1.0 - float(keep.mean())
+        assert abs(rate - p) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-3, f"dropout rate {rate} vs p = {p}"
+        xr = x.double().requires_grad_()
+        yr = ref(xr) * keep / (1.0 - p)
+        yr.backward(gy.double())
+    assert len(calls) == len(dims), "the fused BatchNorm + PReLU epilogue did not run"
+    close(y, yr.detach().cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what="outputs")
+    close(xd.grad, xr.grad.detach().cpu().numpy(), rtol=2e-4, atol_scale=2e-5, what="g_x")
+    gmax = max(float(q.grad.abs().max()) for q in ref.parameters())
+    for (n, a_), (_, b_) in zip(mlp.named_parameters(), ref.named_parameters()):
+        if n.endswith("bias") and "mlp." in n and isinstance(mlp.mlp[int(n.split(".")[1])], torch.nn.Linear):
+            continue  # a Linear bias in front of BatchNorm: exact gradient 0, rounding noise on both sides
+        got, want = a_.grad.detach().cpu().numpy(), b_.grad.detach().cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 2e-5 * gmax, f"grad of {n}"
+    for (n, a_), (_, b_) in zip(mlp.named_buffers(), ref.named_buffers()):
+        if not n.endswith("num_batches_tracked"):
+            close(a_, b_.detach().cpu().numpy(), rtol=1e-4, atol_scale=1e-5, what=f"buffer {n}")
+
+
 @pytest.mark.parametrize("B,d", [(4096, 64), (37, 16), (5, 100), (300, 1024), (1, 4)])
 def test_l2_normalize_matches_functional_normalize(B, d):
     """ops.l2_normalize (csrc/match.hip) == F.normalize(x, p=2, dim=1) of the reference towers (models/matching/dssm.py:56,66)

@@ -340,6 +340,13 @@ class MLP(nn.Module):
                 # Linear -> BatchNorm1d -> Dice (DIN's ActivationUnit): the normalisation is folded into the Dice passes
                 x = ops.bn_dice(self._linear(mods[i], x), mods[i + 1], mods[i + 2].alpha, mods[i + 2].epsilon)
                 i += 3
+            elif (i + 3 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and
+                  self._bn_ok(mods[i + 1], x) and isinstance(mods[i + 3], nn.Dropout) and
+                  ops.bn_prelu_dropout_ok(x, mods[i + 1], mods[i + 2])):
+                # Linear -> BatchNorm1d -> nn.PReLU() -> Dropout (the two-tower MLPs): ONE epilogue each way as for ReLU
+                drop = mods[i + 3]
+                x = ops.bn_prelu_dropout(self._linear(mods[i], x), mods[i + 1], mods[i + 2], drop.p if drop.training else 0.0)
+                i += 4
             elif (i + 1 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and
                   self._bn_ok(mods[i + 1], x)):
                 # Linear -> BatchNorm1d in front of Dice / PReLU / ...: the normalisation alone through the same kernels

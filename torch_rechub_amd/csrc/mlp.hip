@@ -42,8 +42,19 @@ struct BnArgs {
   float momentum, eps, p_drop;
   int training;
   int affine_out;      // forward finalize also writes stat rows 4, 5: scale = gamma*rstd, shift = beta - mean*scale
-  int relu;            // 1: ReLU after the normalisation (MLP hidden layer); 0: BatchNorm only (Dice / PReLU follow)
+  int relu;            // 1: ReLU after the normalisation (MLP hidden layer); 0: BatchNorm only (Dice follows);
+                       // 2: PReLU with ONE slope (nn.PReLU(), the two-tower MLPs): y = bn > 0 ? bn : slope * bn
+  const float* slope;  // relu == 2
+  float* slope_partial;  // relu == 2, backward: per-block sums of dy * min(bn, 0) (one per workgroup of bn_partial_kernel<1>)
 };
+
+// activation after the normalisation and its derivative factor (relu: 0 none, 1 ReLU, 2 PReLU)
+static __device__ __forceinline__ float bn_act(int relu, float sl, float bn) {
+  return relu == 1 ? fmaxf(bn, 0.f) : (relu == 2 ? (bn > 0.f ? bn : sl * bn) : bn);
+}
+static __device__ __forceinline__ float bn_act_grad(int relu, float sl, float bn, float dy) {
+  return relu == 1 ? (bn > 0.f ? dy : 0.f) : (relu == 2 ? (bn > 0.f ? dy : sl * dy) : dy);
+}
 
 static __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {
   return rh_drop_hash(seed, ctr, idx);
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
     a.rng[1] += 1;
     if (a.num_batches_tracked != nullptr) a.num_batches_tracked[0] += 1;
   }
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, sgs = 0.f;
   if (c < a.C) {
     if (MODE == 0) {
       const float shift = a.h[c];
@@ -81,16 +92,31 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_partial_kernel(const BnArgs a, in
       const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
       const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
       const uint64_t seed = (uint64_t)a.rng[0], ctr = (uint64_t)a.saved_ctr[0];
+      const float sl = a.relu == 2 ? a.slope[0] : 0.f;
 #pragma unroll 4
       for (int r = r0 + rsub; r < r1; r += RS) {
         const int64_t i = (int64_t)r * a.C + c;
         const float xhat = (a.h[i] - mean) * rstd;
         const float bn = fmaf(xhat, g, bt);
-        float g1 = (!a.relu || bn > 0.f) ? a.dy[i] : 0.f;
-        if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
+        float dyv = a.dy[i];
+        if (a.p_drop > 0.f) dyv = drop_hash(seed, ctr, (uint64_t)i) >= thr ? dyv * keep_scale : 0.f;
+        const float g1 = bn_act_grad(a.relu, sl, bn, dyv);
         s1 += g1;
         s2 = fmaf(g1, xhat, s2);
+        if (a.relu == 2) sgs = fmaf(dyv, fminf(bn, 0.f), sgs);  // d/d slope
       }
+    }
+  }
+  if (MODE == 1 && a.relu == 2) {  // block-uniform: the slope gradient of this workgroup's tile
+    __shared__ float sred[RH_BLOCK / RH_WAVE];
+    const float w = wave_sum(sgs);
+    if (threadIdx.x % RH_WAVE == 0) sred[threadIdx.x / RH_WAVE] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < RH_BLOCK / RH_WAVE; ++k) tot += sred[k];
+      a.slope_partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
     }
   }
   red[0][threadIdx.x] = s1;
@@ -270,13 +296,15 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_kernel(const BnArgs a) {
     const float g = a.gamma[c];
     const float xhat = (a.h[i] - mean) * rstd;
     const float bn = fmaf(xhat, g, a.beta[c]);
+    const float sl = a.relu == 2 ? a.slope[0] : 0.f;
     if (MODE == 1) {
-      float g1 = (!a.relu || bn > 0.f) ? a.dy[i] : 0.f;
-      if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
+      float dyv = a.dy[i];
+      if (a.p_drop > 0.f) dyv = drop_hash(seed, ctr, (uint64_t)i) >= thr ? dyv * keep_scale : 0.f;
+      const float g1 = bn_act_grad(a.relu, sl, bn, dyv);
       const float sg = a.stat[2 * a.C + c], sgx = a.stat[3 * a.C + c];
       a.out[i] = g * rstd * (g1 - sg * inv_n - xhat * (sgx * inv_n));
     } else {
-      float y = (!a.relu || bn > 0.f) ? bn : 0.f;
+      float y = bn_act(a.relu, sl, bn);
       if (MODE == 0 && a.p_drop > 0.f) y = drop_hash(seed, ctr, (uint64_t)i) >= thr ? y * keep_scale : 0.f;
       a.out[i] = y;
     }
@@ -359,17 +387,19 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_apply_fin_kernel(const BnArgs a, 
   }
   const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, a.B);
   const float sg = s1 * inv_n, sgx = s2 * inv_n;
+  const float sl = a.relu == 2 ? a.slope[0] : 0.f;
 #pragma unroll 4
   for (int r = r0 + grp; cok && r < r1; r += kSlabLanes) {
     const int64_t i = (int64_t)r * a.C + c;
     const float xhat = (a.h[i] - mean) * rstd;
     const float bn = fmaf(xhat, g, bt);
     if (MODE == 1) {
-      float g1 = (!a.relu || bn > 0.f) ? a.dy[i] : 0.f;
-      if (a.p_drop > 0.f) g1 = drop_hash(seed, ctr, (uint64_t)i) >= thr ? g1 * keep_scale : 0.f;
+      float dyv = a.dy[i];
+      if (a.p_drop > 0.f) dyv = drop_hash(seed, ctr, (uint64_t)i) >= thr ? dyv * keep_scale : 0.f;
+      const float g1 = bn_act_grad(a.relu, sl, bn, dyv);
       a.out[i] = g * rstd * (g1 - sg - xhat * sgx);
     } else {
-      float y = (!a.relu || bn > 0.f) ? bn : 0.f;
+      float y = bn_act(a.relu, sl, bn);
       if (a.p_drop > 0.f) y = drop_hash(seed, ctr, (uint64_t)i) >= thr ? y * keep_scale : 0.f;
       a.out[i] = y;
     }
@@ -425,11 +455,38 @@ static int big_chunk_rows(int B) {
 
 extern "C" int rh_bn_act_nchunks(int B) { return (B + kRowsPerChunk - 1) / kRowsPerChunk; }  // upper bound (workspace size)
 
+static int bn_fwd_impl(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
+                       int training, int64_t* rng, int64_t* saved_ctr, float* partial, int partial_rows, float* stat,
+                       float* out, int relu, const float* slope, void* stream);
+
 extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float momentum, float eps, float p_drop, int training, int64_t* rng,
                                       int64_t* saved_ctr, float* partial, int partial_rows, float* stat, float* out,
                                       int relu, void* stream) {
+  return bn_fwd_impl(h, B, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, training,
+                     rng, saved_ctr, partial, partial_rows, stat, out, relu != 0 ? 1 : 0, nullptr, stream);
+}
+
+// Linear -> BatchNorm1d -> nn.PReLU() -> Dropout of the two-tower MLPs (reference MLP with activation="prelu",
+// examples/matching/run_ml_dssm.py:69-80): rh_bn_relu_dropout_fwd / _bwd with y = bn > 0 ? bn : slope[0] * bn in place of
+// the ReLU; the backward also emits, per workgroup of its statistics pass, the partial sums of the slope's gradient
+// (slope_partial: rh_bn_prelu_nblocks(B, C) floats, summed by the caller / the step's packing launch).
+extern "C" int rh_bn_prelu_dropout_fwd(const float* h, int B, int C, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                       float momentum, float eps, float p_drop, int training, int64_t* rng,
+                                       int64_t* saved_ctr, float* partial, int partial_rows, float* stat, float* out,
+                                       const float* slope, void* stream) {
+  RH_REQUIRE(slope != nullptr, RH_E_BADARG, "rh_bn_prelu_dropout_fwd: slope is null");
+  return bn_fwd_impl(h, B, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, training,
+                     rng, saved_ctr, partial, partial_rows, stat, out, 2, slope, stream);
+}
+
+static int bn_fwd_impl(const float* h, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float p_drop,
+                       int training, int64_t* rng, int64_t* saved_ctr, float* partial, int partial_rows, float* stat,
+                       float* out, int relu, const float* slope, void* stream) {
   RH_REQUIRE(h && gamma && beta && out, RH_E_BADARG, "rh_bn_relu_dropout_fwd: null pointer");
   RH_REQUIRE(B >= 1 && C >= 1, RH_E_BADARG, "rh_bn_relu_dropout_fwd: bad shape B=%d C=%d", B, C);
   RH_REQUIRE(p_drop >= 0.f && p_drop < 1.f, RH_E_BADARG, "rh_bn_relu_dropout_fwd: p must be in [0, 1)");
@@ -440,7 +497,8 @@ extern "C" int rh_bn_relu_dropout_fwd(const float* h, int B, int C, const float*
   a.B = B; a.C = C; a.rows_per_chunk = big_chunk_rows(B); a.nchunks = (B + a.rows_per_chunk - 1) / a.rows_per_chunk;
   a.momentum = momentum; a.eps = eps; a.p_drop = p_drop;
   a.training = training;
-  a.relu = relu != 0;
+  a.relu = relu;
+  a.slope = slope;
   if (!training) {
     RH_REQUIRE(running_mean && running_var, RH_E_BADARG, "rh_bn_relu_dropout_fwd: eval mode needs running statistics");
     a.p_drop = 0.f;
@@ -564,10 +622,36 @@ extern "C" int rh_bn_relu_dropout_bwd_pre(const float* h, const float* dy, int B
   return 0;
 }
 
+static int bn_bwd_impl(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta, float p_drop,
+                       const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat, float* dx, float* dgamma,
+                       float* dbeta, int relu, const float* slope, float* slope_partial, void* stream);
+
 extern "C" int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma,
                                       const float* beta, float p_drop, const int64_t* rng, const int64_t* saved_ctr,
                                       float* partial, float* stat, float* dx, float* dgamma, float* dbeta, int relu,
                                       void* stream) {
+  return bn_bwd_impl(h, dy, B, C, gamma, beta, p_drop, rng, saved_ctr, partial, stat, dx, dgamma, dbeta, relu != 0 ? 1 : 0,
+                     nullptr, nullptr, stream);
+}
+
+// workgroups of the backward's statistics pass = entries of slope_partial
+extern "C" int rh_bn_prelu_nblocks(int B, int C) {
+  const int rows = fused_path_ok(B) ? kFusedRows : big_chunk_rows(B);
+  return ((C + kSlabCols - 1) / kSlabCols) * ((B + rows - 1) / rows);
+}
+
+extern "C" int rh_bn_prelu_dropout_bwd(const float* h, const float* dy, int B, int C, const float* gamma,
+                                       const float* beta, float p_drop, const int64_t* rng, const int64_t* saved_ctr,
+                                       float* partial, float* stat, float* dx, float* dgamma, float* dbeta,
+                                       const float* slope, float* slope_partial, void* stream) {
+  RH_REQUIRE(slope && slope_partial, RH_E_BADARG, "rh_bn_prelu_dropout_bwd: null slope pointer");
+  return bn_bwd_impl(h, dy, B, C, gamma, beta, p_drop, rng, saved_ctr, partial, stat, dx, dgamma, dbeta, 2, slope,
+                     slope_partial, stream);
+}
+
+static int bn_bwd_impl(const float* h, const float* dy, int B, int C, const float* gamma, const float* beta, float p_drop,
+                       const int64_t* rng, const int64_t* saved_ctr, float* partial, float* stat, float* dx, float* dgamma,
+                       float* dbeta, int relu, const float* slope, float* slope_partial, void* stream) {
   RH_REQUIRE(h && dy && gamma && beta && rng && saved_ctr && partial && stat && dx && dgamma && dbeta, RH_E_BADARG,
              "rh_bn_relu_dropout_bwd: null pointer");
   RH_REQUIRE(B >= 1 && C >= 1, RH_E_BADARG, "rh_bn_relu_dropout_bwd: bad shape B=%d C=%d", B, C);
@@ -577,7 +661,9 @@ extern "C" int rh_bn_relu_dropout_bwd(const float* h, const float* dy, int B, in
   a.dgamma = dgamma; a.dbeta = dbeta; a.rng = const_cast<int64_t*>(rng); a.saved_ctr = const_cast<int64_t*>(saved_ctr);
   a.B = B; a.C = C; a.rows_per_chunk = big_chunk_rows(B); a.nchunks = (B + a.rows_per_chunk - 1) / a.rows_per_chunk;
   a.p_drop = p_drop; a.training = 1;
-  a.relu = relu != 0;
+  a.relu = relu;
+  a.slope = slope;
+  a.slope_partial = slope_partial;
   if (fused_path_ok(B)) {
     launch_fused<1>(a, s);
     RH_LAUNCH_CHECK("rh_bn_relu_dropout_bwd(fused finalize)");

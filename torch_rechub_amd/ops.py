@@ -772,6 +772,56 @@ class _BnReluDropoutFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
+class _BnPreluDropoutFn(torch.autograd.Function):
+    """y = dropout(prelu(batch_norm(h))) for one hidden layer of a two-tower MLP (training mode; one slope, nn.PReLU())."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, p_drop, slope):
+        require_hip(h, gamma, beta, slope)
+        h = h.contiguous()
+        B, C = h.shape
+        dev = h.device
+        out = torch.empty_like(h)
+        partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
+        stat = torch.empty((4, C), dtype=torch.float32, device=dev)
+        saved_ctr = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.call("rh_bn_prelu_dropout_fwd", _p(h), B, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                  _p(num_batches_tracked), float(momentum), float(eps), float(p_drop), 1, _p(_dropout_rng(dev)), _p(saved_ctr),
+                  _p(partial), 0, _p(stat), _p(out), _p(slope), _stream())
+        ctx.p_drop = float(p_drop)
+        ctx.param = slope
+        ctx.save_for_backward(h, gamma, beta, stat, saved_ctr, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, gamma, beta, stat, saved_ctr, slope = ctx.saved_tensors
+        B, C = h.shape
+        dev = h.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(h)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        partial = torch.empty((_lib.call("rh_bn_act_nchunks", B), 2, C), dtype=torch.float32, device=dev)
+        nb = _lib.call("rh_bn_prelu_nblocks", B, C)
+        sp = torch.empty((nb,), dtype=torch.float32, device=dev)
+        _lib.call("rh_bn_prelu_dropout_bwd", _p(h), _p(dy), B, C, _p(gamma), _p(beta), ctx.p_drop, _p(_dropout_rng(dev)),
+                  _p(saved_ctr), _p(partial), _p(stat), _p(dx), _p(dgamma), _p(dbeta), _p(slope), _p(sp), _stream())
+        g_slope = deferred.offer(ctx.param, sp.data_ptr(), nb, 1, 1, lambda: sp.sum().reshape(1), sp)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, g_slope
+
+
+def bn_prelu_dropout_ok(h, bn, act):
+    return (bn.training and type(act) is torch.nn.PReLU and act.weight.numel() == 1 and h.is_cuda and
+            h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] > 1 and os.environ.get("RECHUB_BN_PRELU", "1") == "1")
+
+
+def bn_prelu_dropout(h, bn, act, p_drop):
+    """Fused BatchNorm1d + nn.PReLU() + Dropout of one hidden layer (training mode), driven by the modules."""
+    return _BnPreluDropoutFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                   bn.momentum, bn.eps, p_drop, act.weight)
+
+
 def bn_relu_dropout(h, bn, p_drop, stats=None, relu=True):
     """Fused BatchNorm1d + ReLU + Dropout of one MLP hidden layer, driven by the nn.BatchNorm1d module ``bn``
     (``relu=False``: BatchNorm1d + Dropout only, for layers whose activation is Dice / PReLU / ...).
