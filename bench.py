@@ -38,7 +38,7 @@ CRITEO_VOCABS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 56
                  10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 N_DENSE = 13
 EMBED_DIM = 16
-DEFERRED_SWEEP_PMC_TRAFFIC = 192.4e6  # bytes per launch: (2 * 33 448.6 + 121 038.3) KiB, profiles/r03_pmc_sweep_{FETCH,WRITE}_SIZE.txt
+DEFERRED_SWEEP_PMC_TRAFFIC = 208.8e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 508.6 + 100 852.2) KiB, profiles/r03_pmc_sweep_{FETCH,WRITE}_SIZE.txt
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a float4 copy
 
 # algorithmic bytes: F=26, D=16, fp32, int64 indices as the loader holds them
