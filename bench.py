@@ -535,7 +535,8 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
 
     # ---- the deferred window sweep in the GRAPH regime: it is launched eagerly on the side stream after every replay,
     # so HIP events on that stream bracket it while the captured chain runs beside it (what rocprofv3 shows for it) ----
-    if profile and graph_ok and lazy and getattr(opt, "overlap_sweep", False):
+    if profile and graph_ok and lazy and getattr(opt, "overlap_sweep", False) and trainer.dp is None and world == 1:
+        # (single process only: with a process group every step is a collective, and only rank 0 profiles)
         t2 = KernelTimer(["rh_adam_lazy_sweep"])
         t2.install()
         for _ in range(30):
