@@ -594,6 +594,48 @@ def test_adam_lazy_is_bit_identical_to_dense(lazy_k, small_rows, steps, flush_ev
     assert int(lazy._t_step.item()) == steps
 
 
+def test_refresh_skips_padding_lookups_but_keeps_a_nonzero_padding_row_exact():
+    """A post-padded history batch sends most of its lookups to padding_idx.  The pre-gather refresh skips those lookups
+    (one claim word would take them all) and keeps the padding row itself current with ONE lane group per field and
+    launch -- zero or not, dense Adam with coupled weight decay moves that row like every other (reference
+    trainers/ctr_trainer.py:59-61).  Checked after every refresh against a dense twin: the padding row and the
+    looked-up rows are bit-equal to what the dense optimizer holds at that step; the rows nobody looked up lag behind."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.optim import TableAdam
+    g = torch.Generator().manual_seed(17)
+    V, D, B, L, pad = 5000, 16, 64, 12, 0
+    w0 = torch.randn(V, D, generator=g) * 0.1  # padding row NOT zero
+    A, Bp = torch.nn.Parameter(w0.clone().to(dev())), torch.nn.Parameter(w0.clone().to(dev()))
+    dense = TableAdam([A], table_params=[A], lr=1e-2, weight_decay=1e-3)
+    lazy = TableAdam([Bp], table_params=[Bp], lr=1e-2, weight_decay=1e-3, lazy_k=8, lazy_small_rows=8)
+    lazy.overlap_sweep = False
+    for step in range(20):
+        idx = torch.randint(1, V, (B, L), generator=g)
+        lens = torch.randint(1, L + 1, (B,), generator=g)
+        idx[torch.arange(L)[None, :] >= lens[:, None]] = pad
+        idx = idx.to(dev())
+        flat = idx.view(-1)
+        idesc = ops.EmbedCall._icache.get((flat.data_ptr(), 1, 0), dev())
+        ops._pre_gather([Bp], [pad], idesc, 1, B * L, 1, D, training=True)  # what the sequence gather's forward does
+        torch.cuda.synchronize()
+        rows = torch.unique(flat)
+        assert torch.equal(Bp.detach()[rows], A.detach()[rows]), f"step {step}: looked-up rows (padding row included) stale"
+        assert torch.equal(Bp.detach()[pad], A.detach()[pad]) and bool(A.detach()[pad].abs().sum() > 0)
+        gr = torch.zeros(V, D)
+        live = flat.cpu()[flat.cpu() != pad]
+        gr.index_add_(0, live, torch.randn(live.numel(), D, generator=g))
+        for P in (A, Bp):
+            ops.grad_buffer(P).copy_(gr.to(dev()))
+            P._rh_dirty = True
+        ops._log_touch([Bp], [pad], idesc, 1, B * L, 1, D, [flat])
+        lazy.step()
+        dense.step()
+    assert not torch.equal(Bp.detach(), A.detach())  # lazy: rows outside the batches are behind until the flush
+    lazy.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(Bp.detach(), A.detach())
+
+
 def test_adam_lazy_moves_heavily_looked_up_tables_to_dense_stepping():
     """Default placement (no explicit lazy_small_rows): at the first step a table whose rows are looked up often enough
     (rows <= 4 x lookups per step; 1500 lookups here) is stepped densely like the small tables, the others stay lazy; the

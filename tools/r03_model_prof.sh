@@ -1,19 +1,12 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r03
-for m in ${MODELS:-dssm dcnv2}; do
+for m in ${MODELS:-dssm}; do
 (cd /tmp && rm -rf /tmp/${m}_prof && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/${m}_prof -o $m -- python $OLDPWD/bench.py --model $m --trace-inner --steps 10 --warmup 5 > /dev/null 2> $OLDPWD/gpurun_out/r03/${m}_prof.err)
-python - <<PY
-import csv,glob,os
-f=max(glob.glob('/tmp/${m}_prof/**/*kernel_trace.csv',recursive=True),key=os.path.getsize)
-rows=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"],r.get("Queue_Id","")) for r in csv.DictReader(open(f))]
-rows.sort()
-marks=[i for i,r in enumerate(rows) if "batch_gather_kernel" in r[2]]
-lo,hi=marks[-3],marks[-2]
-agg={}
-mainq=rows[lo][3]
-for st,en,n,q in rows[lo:hi]:
-    k=n.replace("void ","").replace("(anonymous namespace)::","").replace("rechub::","").split("(")[0][:64]+("" if q==mainq else " [side]")
-    a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=(en-st)/1e3
-print("== $m step wall us", (rows[hi][0]-rows[lo][0])/1e3, "main busy", sum(v[1] for k,v in agg.items() if "[side]" not in k))
-for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1])[:26]: print("%-72s %3d %9.1f"%(k,v[0],v[1]))
-PY
+python tools/timeline.py /tmp/${m}_prof 1 | grep -E "touched|seq_pool|embed_fwd|batch_gather" | cut -c1-140
 done
+(cd /tmp && rm -rf /tmp/rp_prof && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_prof -o rp -- python $OLDPWD/tools/refresh_probe.py > /tmp/rp.log 2>&1); head -3 /tmp/rp.log
+python - <<'PY'
+import csv,glob,os
+f=max(glob.glob('/tmp/rp_prof/**/*kernel_trace.csv',recursive=True),key=os.path.getsize)
+rows=[r for r in csv.DictReader(open(f)) if "adam_lazy_touched" in r["Kernel_Name"]]
+for r in rows[:7]: print((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3, r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"])
+PY

@@ -1,3 +1,5 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r3f
-timeout 300 python bench.py --steps 20 --warmup 10 --no-cpu-baseline --force-dp --tables both 2>gpurun_out/r3f/dp.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dp', d['ms_per_step'], {k:(v if not isinstance(v,dict) else (v.get('ms_per_step'), v.get('hipgraph'), v.get('comm_us_per_step'))) for k,v in d.get('scaling_modes',{}).items()})" || tail -5 gpurun_out/r3f/dp.err
-timeout 600 python -m pytest tests/test_gpu_world2.py tests/test_gpu_models.py -q -m gpu --timeout 300 -k "world2 or data_parallel or shard" 2>&1 | tail -3 | cut -c1-200
+timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_kernels.py -q -m gpu --timeout 300 -k "seq or din or dien or bst or dssm or match or graph_mode or lazy" 2>&1 | tail -4 | cut -c1-220
+run() { tag=$1; shift; env "$@" timeout 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --brief --no-kernel-sweep "${EXTRA[@]}" 2>gpurun_out/r3f/$tag.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['config']['step_form']['chosen'])" || tail -5 gpurun_out/r3f/$tag.err; }
+EXTRA=(--model dssm); run dssm RECHUB_X=1
+EXTRA=(--model din); run din RECHUB_X=1

@@ -584,7 +584,9 @@ class _SeqPoolFn(torch.autograd.Function):
         out = torch.empty((B, L, D) if mode == 2 else (B, D), dtype=torch.float32, device=weight.device)
         if _lazy_listeners:
             flat = idx.reshape(-1) if idx.is_contiguous() else idx.contiguous().view(-1)
-            _pre_gather([weight], [None], EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device),
+            # (the padding positions of a post-padded history all carry padding_idx: the refresh skips those lookups and
+            # keeps the padding row itself current once per launch -- csrc/optim.hip)
+            _pre_gather([weight], [padding_idx], EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device),
                         1 if idx.dtype == torch.int64 else 0, B * L, 1, D, training=any(ctx.needs_input_grad))
         _lib.call("rh_seq_pool_fwd", _p(weight), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
                   idx.stride(1), B, L, D, mode, sentinel, _p(out), out.stride(0), _p(err_flag(weight.device)),
