@@ -359,6 +359,8 @@ class TableAdam(torch.optim.Adam):
                 seg.at_start(self._join_sweep)
                 self._join_seg = seg
             self._sweep_inflight = False
+            if training and self._refresh_ahead(rec, seg):
+                return
         elif self._sweep_inflight:  # the previous step's sweep must be done before rows are refreshed again
             if capturing:
                 raise RuntimeError("TableAdam: a deferred table sweep is in flight on the side stream; call "
@@ -380,6 +382,37 @@ class TableAdam(torch.optim.Adam):
                 seg.cut(self._fork_sweep)
                 self._sweep_inflight = True
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
+
+    def _refresh_ahead(self, rec, seg):
+        """Deferred form, a step with SEVERAL gathers (two-tower / sequence models): the sweep may only start once the rows
+        of every gather of the step are current, i.e. after the LAST refresh -- in the configs[4] step that is a third of
+        the way in, and the sweep (0.65 ms there) then outlasts the chain.  The index buffers of all the step's gathers are
+        static and assembled before the first one, so the first gather refreshes the rows of ALL of them (the records of
+        the previous step's gathers, checked one by one against this step's) and forks the sweep at once; the later gathers
+        find their rows done.  Returns True when this gather needs no refresh of its own any more."""
+        def same(a, b):
+            return a["idesc"] is b["idesc"] and (a["B"], a["F"], a["D"], a["idx_is_i64"]) == (b["B"], b["F"], b["D"], b["idx_is_i64"]) \
+                and len(a["weights"]) == len(b["weights"]) and all(x is y for x, y in zip(a["weights"], b["weights"])) \
+                and list(a["pads"]) == list(b["pads"])
+        k = self._gathers
+        recs = self._last_recs
+        if k == 0:
+            self._ahead = 0
+            if len(recs) < 2 or (self._gathers_per_step or 0) != len(recs) or not same(rec, recs[0]) or \
+                    os.environ.get("RECHUB_REFRESH_AHEAD", "1") != "1":
+                return False
+            groups = self._lazy_setup()
+            for r in recs:
+                self._touch(dict(r, training=True), groups, ops._stream(), refresh=True)
+            self._ahead = len(recs)
+            self._gathers = 1
+            seg.cut(self._fork_sweep)  # every replay: the side-stream launch, after the refreshes above
+            self._sweep_pending, self._sweep_inflight = False, True
+            return True
+        if k < getattr(self, "_ahead", 0) and same(rec, recs[k]):
+            self._gathers += 1
+            return True
+        return False  # not the gather the record announced: refresh it in the ordinary way (a second pass is harmless)
 
     # -- branch form (see __init__) -----------------------------------------------------------------------------------
     def _gather_branch(self, rec):
