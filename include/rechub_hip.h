@@ -287,6 +287,19 @@ int rh_bn_dice_bwd_stats(const float* h, const float* g, const float* alpha, flo
                          const float* stat, const float* gamma, float* col_partial, float* alpha_partial, void* stream);
 int rh_bn_dice_bwd_apply(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
                          const float* stat, const float* gamma, float* dh, void* stream);
+/* BatchNorm1d -> Dice -> [Dropout(0)] -> Linear(C, 1): the tail of the ActivationUnit's MLP (basic/layers.py:281-288, the
+ * output layer of MLP(4 * emb_dim, dims=...), models/ranking/din.py:74).  The Dice output has ONE consumer, a C -> 1 dot
+ * product, so it is never written: forward out (N,) = Dice(bn(h)) . head_w + head_b; backward g (N,) = dL/d out, the
+ * gradient of the Dice output is g[r] * head_w[c] in registers.  rh_bn_dice_head_bwd_stats writes, besides col_partial
+ * (blocks, 2, C), alpha_partial (2, blocks) = [d alpha partials | dL/d head_b partials] and head_partial (blocks, C) =
+ * partial dL/d head_w (Dice output recomputed); blocks = rh_bn_dice_stats_blocks(N); the caller sums over blocks. */
+int rh_bn_dice_head_fwd(const float* h, const float* alpha, float eps, int64_t N, int C, const float* bn_scale,
+                        const float* bn_shift, const float* head_w, const float* head_b, float* out, void* stream);
+int rh_bn_dice_head_bwd_stats(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                              const float* stat, const float* gamma, const float* head_w, float* col_partial,
+                              float* alpha_partial, float* head_partial, void* stream);
+int rh_bn_dice_head_bwd_apply(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                              const float* stat, const float* gamma, const float* head_w, float* dh, void* stream);
 int rh_din_att_input_fwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, int B, int L,
                          int D, float* out, void* stream);
 int rh_din_att_input_bwd(const float* hist, int64_t hist_stride, const float* tgt, int64_t tgt_stride, const float* g,

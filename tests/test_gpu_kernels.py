@@ -1089,6 +1089,53 @@ def test_bn_dice_folded_vs_modules(N, C):
               rtol=2e-4, atol_scale=5e-6, what="eval")
 
 
+@pytest.mark.parametrize("N,C,bias", [(25600, 128, True), (1000, 64, True), (77, 36, False), (409600, 128, True), (300, 256, True)])
+def test_bn_dice_head_vs_modules(N, C, bias):
+    """BatchNorm1d -> Dice -> Linear(C, 1) (the tail of the ActivationUnit's MLP) with the Dice output never written ==
+    the three modules one after the other (float64 Dice and dot product on torch's BatchNorm output): output, every
+    gradient (h, gamma, beta, alpha, head weight, head bias), running statistics, eval mode."""
+    from torch_rechub_amd import ops
+    torch.manual_seed(N + C)
+    h0 = (torch.randn(N, C) * 1.5 + torch.randn(C)).to(dev())
+    bn_ref, bn_mine = torch.nn.BatchNorm1d(C).to(dev()), torch.nn.BatchNorm1d(C).to(dev())
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5)
+        bn_ref.bias.normal_()
+    bn_mine.load_state_dict(bn_ref.state_dict())
+    lin = torch.nn.Linear(C, 1, bias=bias).to(dev())
+    w64 = lin.weight.detach().double().clone().requires_grad_(True)
+    b64 = lin.bias.detach().double().clone().requires_grad_(True) if bias else None
+    alpha0 = torch.randn(1)
+    gy = torch.randn(N, 1, device=dev())
+    ha = h0.clone().requires_grad_(True)
+    al_a = alpha0.double().to(dev()).requires_grad_(True)
+    ya = _dice_ref(bn_ref(ha).double(), al_a) @ w64.t()
+    if bias:
+        ya = ya + b64
+    ya.backward(gy.double())
+    hb = h0.clone().requires_grad_(True)
+    al_b = alpha0.to(dev()).requires_grad_(True)
+    yb = ops.bn_dice_head(hb, bn_mine, al_b, 1e-3, lin)
+    assert yb.shape == (N, 1)
+    yb.backward(gy)
+    close(yb, ya.detach().cpu().numpy(), rtol=2e-4, atol_scale=5e-6, what="out")
+    close(hb.grad, ha.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dh")
+    close(bn_mine.weight.grad, bn_ref.weight.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dgamma")
+    close(bn_mine.bias.grad, bn_ref.bias.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="dbeta")
+    close(al_b.grad, al_a.grad.cpu().numpy(), rtol=1e-3, atol_scale=1e-4, what="dalpha")
+    close(lin.weight.grad, w64.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="d head weight")
+    if bias:
+        close(lin.bias.grad, b64.grad.cpu().numpy(), rtol=1e-3, atol_scale=2e-5, what="d head bias")
+    close(bn_mine.running_var, bn_ref.running_var.cpu().numpy(), rtol=2e-5, what="running_var")
+    bn_ref.eval(), bn_mine.eval()
+    with torch.no_grad():
+        want = _dice_ref(bn_ref(h0).double(), al_a.detach()) @ w64.detach().t()
+        if bias:
+            want = want + b64.detach()
+        close(ops.bn_dice_head(h0, bn_mine, al_b.detach(), 1e-3, lin), want.cpu().numpy(), rtol=2e-4, atol_scale=5e-6,
+              what="eval")
+
+
 # -- row-sharded tables (csrc/shard.hip) and the rectangular in-batch sampler -----------------------------------------
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])

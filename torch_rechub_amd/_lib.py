@@ -71,6 +71,9 @@ SIGNATURES = {
     "rh_bn_dice_stats_blocks": [c_i64],
     "rh_bn_dice_bwd_stats": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_bn_dice_bwd_apply": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_dice_head_fwd": [c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_dice_head_bwd_stats": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_dice_head_bwd_apply": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_din_att_input_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_din_att_input_bwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "rh_din_pool_fwd": [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],

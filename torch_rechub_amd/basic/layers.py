@@ -319,6 +319,15 @@ class MLP(nn.Module):
     def _linear(lin, x):
         return ops.linear(x, lin.weight, lin.bias) if type(lin) is nn.Linear and ops.linear_ok(x, lin.weight) else lin(x)
 
+    @staticmethod
+    def head_after(mods, j, width, bn, dice_mod):
+        """The output Linear(width, 1) when mods[j:] is nothing but inactive Dropouts and that Linear, else None."""
+        while j < len(mods) - 1 and isinstance(mods[j], nn.Dropout) and (mods[j].p == 0 or not mods[j].training):
+            j += 1
+        if j == len(mods) - 1 and ops.bn_dice_head_ok(width, bn, dice_mod, mods[j]):
+            return mods[j]
+        return None
+
     def _run(self, mods, x):
         # [Linear, BatchNorm1d, ReLU, Dropout] blocks: library GEMM + ONE fused epilogue (csrc/mlp.hip); any other
         # activation (dice, prelu, sigmoid ...) runs the modules as they are.  Every Linear's weight / bias gradient
@@ -338,6 +347,10 @@ class MLP(nn.Module):
                   type(mods[i + 2]) is Dice and self._bn_ok(mods[i + 1], x) and mods[i].out_features <= 512 and
                   not (torch.is_grad_enabled() and not mods[i + 1].training)):
                 # Linear -> BatchNorm1d -> Dice (DIN's ActivationUnit): the normalisation is folded into the Dice passes
+                head = self.head_after(mods, i + 3, mods[i].out_features, mods[i + 1], mods[i + 2])
+                if head is not None:
+                    # ... -> Linear(C, 1) at the end of the stack: the Dice output is never written (ops.bn_dice_head)
+                    return ops.bn_dice_head(self._linear(mods[i], x), mods[i + 1], mods[i + 2].alpha, mods[i + 2].epsilon, head)
                 x = ops.bn_dice(self._linear(mods[i], x), mods[i + 1], mods[i + 2].alpha, mods[i + 2].epsilon)
                 i += 3
             elif (i + 3 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and

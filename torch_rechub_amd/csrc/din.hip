@@ -40,13 +40,20 @@ struct DiceArgs {
   const float* stat;       // MODE 2/3: (>= 4, C) mean, rstd, sum g_x, sum g_x * xhat
   const float* gamma;
   float* col_partial;      // MODE 2: (blocks, 2, C)
+  // HEAD: the Dice output feeds a Linear(C -> 1) (last layer of the ActivationUnit's MLP, layers.py:288) and nothing else.
+  // forward: out is (N,) = Dice(x) . w + b, the Dice output itself is never written; backward: g is (N,) = dL/d out and the
+  // gradient of the Dice output is the rank-1 g[r] * w[c], formed in registers; MODE 2 also accumulates dL/dw per column.
+  const float* head_w;     // (C,)
+  const float* head_b;     // (1,) or null
+  float* head_partial;     // MODE 2: (blocks, C) partial dL/dw;  alpha_partial is (2, blocks): d alpha, then dL/db
 };
 
-template <int EPL, int MODE>
+template <int EPL, int MODE, bool HEAD>
 __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
   RH_CHAIN_PRIO();
   __shared__ float red[kWaves];
-  extern __shared__ float colred[];  // MODE 2: kWaves * 2 * EPL * 64 floats
+  extern __shared__ float colred[];  // MODE 2: kWaves * (2 + HEAD) * EPL * 64 floats
+  constexpr int NCS = HEAD ? 3 : 2;
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int64_t nw = (int64_t)gridDim.x * kWaves;
   const int C = a.C;
@@ -56,13 +63,16 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
   float sc[EPL], sh[EPL];                       // folded BatchNorm affine of the lane's columns
   float mu[EPL], rsd[EPL], gm[EPL], sg[EPL], sgx[EPL];  // MODE 2 / 3
   float cs1[EPL], cs2[EPL];                     // MODE 2: column sums over this wavefront's rows
+  float hw[EPL], cs3[EPL];                      // HEAD: the lane's weights of the Linear(C -> 1); MODE 2: its dL/dw sums
+  float acc_b = 0.f;                            // HEAD, MODE 2: sum of g over this wavefront's rows (same in every lane)
 #pragma unroll
   for (int k = 0; k < EPL; ++k) {
     const int e = lane + RH_WAVE * k;
     const bool ok = e < C;
     sc[k] = (bn && ok) ? a.scale[e] : 1.f;
     sh[k] = (bn && ok) ? a.shift[e] : 0.f;
-    cs1[k] = cs2[k] = 0.f;
+    cs1[k] = cs2[k] = cs3[k] = 0.f;
+    hw[k] = (HEAD && ok) ? a.head_w[e] : 0.f;
     if (MODE >= 2) {
       mu[k] = ok ? a.stat[e] : 0.f;
       rsd[k] = ok ? a.stat[C + e] : 0.f;
@@ -79,12 +89,14 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
   // the second pass over the row (measured: -0.5 % of the DIN step; the statistics pass stays at ~3.5 TB/s of its two input
   // streams -- its bound is the per-row chain of reductions and transcendentals, not the loads in flight)
   float hn[EPL], gn[EPL];
+  float gsn = 0.f;
   auto fetch = [&](int64_t r) {
+    if (HEAD && MODE != 0) gsn = r < a.N ? a.g[r] : 0.f;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
       hn[k] = (r < a.N && e < C) ? a.x[r * C + e] : 0.f;
-      if (MODE != 0) gn[k] = (r < a.N && e < C) ? a.g[r * C + e] : 0.f;
+      if (MODE != 0 && !HEAD) gn[k] = (r < a.N && e < C) ? a.g[r * C + e] : 0.f;
     }
   };
   fetch((int64_t)blockIdx.x * kWaves + wave);
@@ -94,8 +106,9 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       hraw[k] = hn[k];
-      if (MODE != 0) gin[k] = gn[k];
+      if (MODE != 0) gin[k] = HEAD ? gsn * hw[k] : gn[k];
     }
+    const float gs = gsn;
     fetch(r + nw);
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
@@ -114,13 +127,20 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
     const float var = wave_sum(q) + a.eps * (float)C;
     const float rs = rsqrtf(var);
     if (MODE == 0) {
+      float dot = 0.f;
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         const int e = lane + RH_WAVE * k;
         if (e < C) {
           const float ps = 1.f / (1.f + expf(-(v[k] - avg) * rs));
-          a.out[r * C + e] = ps * v[k] + (1.f - ps) * alpha * v[k];
+          const float o = ps * v[k] + (1.f - ps) * alpha * v[k];
+          if (HEAD) dot = fmaf(o, hw[k], dot);
+          else a.out[r * C + e] = o;
         }
+      }
+      if (HEAD) {
+        dot = wave_sum(dot);
+        if (lane == 0) a.out[r] = dot + (a.head_b ? a.head_b[0] : 0.f);
       }
     } else {
       // out = x * (alpha + (1-alpha) ps),  ps = sigmoid(z),  z = c * rs
@@ -136,7 +156,9 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
         st += tk[k];
         stc = fmaf(tk[k], c, stc);
         if (MODE != 3) acc_alpha += e < C ? gk[k] * v[k] * (1.f - psk[k]) : 0.f;
+        if (HEAD && MODE == 2) cs3[k] = fmaf(gs, e < C ? v[k] * (alpha + (1.f - alpha) * psk[k]) : 0.f, cs3[k]);
       }
+      if (HEAD && MODE == 2) acc_b += gs;
       st = wave_sum(st);
       stc = wave_sum(stc);
       const float rs3 = rs * rs * rs;
@@ -170,21 +192,33 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
       for (int w = 0; w < kWaves; ++w) t += red[w];
       a.alpha_partial[blockIdx.x] = t;
     }
+    if (HEAD) {
+      __syncthreads();
+      if (lane == 0) red[wave] = acc_b;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kWaves; ++w) t += red[w];
+        a.alpha_partial[gridDim.x + blockIdx.x] = t;
+      }
+    }
   }
   if (MODE == 2) {
     // the wavefronts of the block are summed in wavefront order: deterministic per-block partial rows
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      colred[(wave * 2 + 0) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs1[k];
-      colred[(wave * 2 + 1) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs2[k];
+      colred[(wave * NCS + 0) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs1[k];
+      colred[(wave * NCS + 1) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs2[k];
+      if (HEAD) colred[(wave * NCS + 2) * EPL * RH_WAVE + k * RH_WAVE + lane] = cs3[k];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * EPL * RH_WAVE; i += RH_BLOCK) {
+    for (int i = threadIdx.x; i < NCS * EPL * RH_WAVE; i += RH_BLOCK) {
       const int which = i / (EPL * RH_WAVE), e = i % (EPL * RH_WAVE);
       if (e < C) {
         float t = 0.f;
-        for (int w = 0; w < kWaves; ++w) t += colred[(w * 2 + which) * EPL * RH_WAVE + e];
-        a.col_partial[((int64_t)blockIdx.x * 2 + which) * C + e] = t;
+        for (int w = 0; w < kWaves; ++w) t += colred[(w * NCS + which) * EPL * RH_WAVE + e];
+        if (which < 2) a.col_partial[((int64_t)blockIdx.x * 2 + which) * C + e] = t;
+        else a.head_partial[(int64_t)blockIdx.x * C + e] = t;
       }
     }
   }
@@ -204,23 +238,23 @@ unsigned dice_grid(int64_t N, int cap = 256 * 16) {
 }
 constexpr int kStatsBlocks = 2048;  // MODE 2: few enough partial rows for the column finalize to combine quickly
 
-template <int MODE>
+template <int MODE, bool HEAD = false>
 int dice_dispatch(const DiceArgs& a, hipStream_t s) {
   const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : dice_grid(a.N);
 #define RH_DICE(E)                                                                                          \
-  hipLaunchKernelGGL((dice_kernel<E, MODE>), dim3(grid), dim3(RH_BLOCK),                                    \
-                     MODE == 2 ? (size_t)kWaves * 2 * E * RH_WAVE * sizeof(float) : 0, s, a)
+  hipLaunchKernelGGL((dice_kernel<E, MODE, HEAD>), dim3(grid), dim3(RH_BLOCK),                              \
+                     MODE == 2 ? (size_t)kWaves * (HEAD ? 3 : 2) * E * RH_WAVE * sizeof(float) : 0, s, a)
   switch (dice_epl(a.C)) {
     case 1: RH_DICE(1); break;
     case 2: RH_DICE(2); break;
     case 4: RH_DICE(4); break;
     case 8: RH_DICE(8); break;
     case 16:
-      if (MODE >= 2) return RH_E_UNSUPPORTED;  // the folded-BatchNorm modes keep 9 values per owned column in registers
+      if (MODE >= 2 || HEAD) return RH_E_UNSUPPORTED;  // the folded-BatchNorm modes keep 9 values per owned column in registers
       RH_DICE(16);
       break;
     case 32:
-      if (MODE >= 2) return RH_E_UNSUPPORTED;
+      if (MODE >= 2 || HEAD) return RH_E_UNSUPPORTED;
       RH_DICE(32);
       break;
     default: return RH_E_UNSUPPORTED;
@@ -432,7 +466,7 @@ extern "C" int rh_dice_fwd(const float* x, const float* alpha, float eps, int64_
   RH_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), RH_E_BADARG, "rh_dice_fwd: scale and shift go together");
   RH_REQUIRE(C <= 2048, RH_E_UNSUPPORTED, "rh_dice_fwd: %d neurons unsupported (max 2048)", C);
   if (N == 0) return 0;
-  DiceArgs a{x, nullptr, alpha, eps, N, C, out, nullptr, bn_scale, bn_shift, nullptr, nullptr, nullptr};
+  DiceArgs a{x, nullptr, alpha, eps, N, C, out, nullptr, bn_scale, bn_shift, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int rc = dice_dispatch<0>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_dice_fwd");
@@ -443,7 +477,7 @@ extern "C" int rh_dice_bwd(const float* x, const float* g, const float* alpha, f
                            float* alpha_partial, void* stream) {
   RH_REQUIRE(x && g && alpha && gx && alpha_partial && N >= 0 && C >= 1, RH_E_BADARG, "rh_dice_bwd: bad arguments");
   RH_REQUIRE(C <= 2048, RH_E_UNSUPPORTED, "rh_dice_bwd: %d neurons unsupported (max 2048)", C);
-  DiceArgs a{x, g, alpha, eps, N, C, gx, alpha_partial, nullptr, nullptr, nullptr, nullptr, nullptr};
+  DiceArgs a{x, g, alpha, eps, N, C, gx, alpha_partial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int rc = dice_dispatch<1>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_dice_bwd");
@@ -457,7 +491,7 @@ extern "C" int rh_bn_dice_bwd_stats(const float* h, const float* g, const float*
              "rh_bn_dice_bwd_stats: bad arguments");
   RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_bwd_stats: %d neurons unsupported (max 512)", C);
   DiceArgs a{h, g, alpha, eps, N, C, nullptr, alpha_partial, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma,
-             col_partial};
+             col_partial, nullptr, nullptr, nullptr};
   int rc = dice_dispatch<2>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_bn_dice_bwd_stats");
@@ -468,10 +502,53 @@ extern "C" int rh_bn_dice_bwd_apply(const float* h, const float* g, const float*
                                     const float* stat, const float* gamma, float* dh, void* stream) {
   RH_REQUIRE(h && g && alpha && stat && gamma && dh && N >= 1 && C >= 1, RH_E_BADARG, "rh_bn_dice_bwd_apply: bad arguments");
   RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_bwd_apply: %d neurons unsupported (max 512)", C);
-  DiceArgs a{h, g, alpha, eps, N, C, dh, nullptr, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma, nullptr};
+  DiceArgs a{h, g, alpha, eps, N, C, dh, nullptr, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma, nullptr, nullptr, nullptr, nullptr};
   int rc = dice_dispatch<3>(a, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   RH_LAUNCH_CHECK("rh_bn_dice_bwd_apply");
+  return 0;
+}
+
+extern "C" int rh_bn_dice_head_fwd(const float* h, const float* alpha, float eps, int64_t N, int C, const float* bn_scale,
+                                   const float* bn_shift, const float* head_w, const float* head_b, float* out,
+                                   void* stream) {
+  RH_REQUIRE(h && alpha && bn_scale && bn_shift && head_w && out && N >= 0 && C >= 1, RH_E_BADARG,
+             "rh_bn_dice_head_fwd: bad arguments");
+  RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_head_fwd: %d neurons unsupported (max 512)", C);
+  if (N == 0) return 0;
+  DiceArgs a{h, nullptr, alpha, eps, N, C, out, nullptr, bn_scale, bn_shift, nullptr, nullptr, nullptr, head_w, head_b,
+             nullptr};
+  int rc = dice_dispatch<0, true>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_bn_dice_head_fwd");
+  return 0;
+}
+
+extern "C" int rh_bn_dice_head_bwd_stats(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                                         const float* stat, const float* gamma, const float* head_w, float* col_partial,
+                                         float* alpha_partial, float* head_partial, void* stream) {
+  RH_REQUIRE(h && g && alpha && stat && gamma && head_w && col_partial && alpha_partial && head_partial && N >= 1 && C >= 1,
+             RH_E_BADARG, "rh_bn_dice_head_bwd_stats: bad arguments");
+  RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_head_bwd_stats: %d neurons unsupported (max 512)", C);
+  DiceArgs a{h, g, alpha, eps, N, C, nullptr, alpha_partial, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma,
+             col_partial, head_w, nullptr, head_partial};
+  int rc = dice_dispatch<2, true>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_bn_dice_head_bwd_stats");
+  return 0;
+}
+
+extern "C" int rh_bn_dice_head_bwd_apply(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
+                                         const float* stat, const float* gamma, const float* head_w, float* dh,
+                                         void* stream) {
+  RH_REQUIRE(h && g && alpha && stat && gamma && head_w && dh && N >= 1 && C >= 1, RH_E_BADARG,
+             "rh_bn_dice_head_bwd_apply: bad arguments");
+  RH_REQUIRE(C <= 512, RH_E_UNSUPPORTED, "rh_bn_dice_head_bwd_apply: %d neurons unsupported (max 512)", C);
+  DiceArgs a{h, g, alpha, eps, N, C, dh, nullptr, stat + 4 * (int64_t)C, stat + 5 * (int64_t)C, stat, gamma, nullptr, head_w,
+             nullptr, nullptr};
+  int rc = dice_dispatch<3, true>(a, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  RH_LAUNCH_CHECK("rh_bn_dice_head_bwd_apply");
   return 0;
 }
 

@@ -75,8 +75,13 @@ class ActivationUnit(nn.Module):
             # the (B*L, 4D) tensor of din.py:81-85 never exists in the forward
             z, stats = ops.din_att_l1(history, target, mods[0].weight, mods[0].bias, mods[1].training)
             rows = ops._lib.call("rh_din_att_l1_chunk_rows", B * L) if stats is not None else 0
-            x = ops.bn_dice(z, mods[1], mods[2].alpha, mods[2].epsilon, chunk_stats=stats, chunk_rows=rows)
-            att_weight = self.attention._run(mods[3:], x).view(-1, L)
+            head = self.attention.head_after(mods, 3, mods[0].out_features, mods[1], mods[2])
+            if head is not None:  # one hidden layer: its Dice output only feeds the Linear(., 1)
+                att_weight = ops.bn_dice_head(z, mods[1], mods[2].alpha, mods[2].epsilon, head, chunk_stats=stats,
+                                              chunk_rows=rows).view(-1, L)
+            else:
+                x = ops.bn_dice(z, mods[1], mods[2].alpha, mods[2].epsilon, chunk_stats=stats, chunk_rows=rows)
+                att_weight = self.attention._run(mods[3:], x).view(-1, L)
         else:
             att_input = ops.din_att_input(history, target)  # (B*L, 4D) = [t, h, t-h, t*h], one kernel
             att_weight = self.attention(att_input).view(-1, L)

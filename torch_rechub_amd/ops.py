@@ -1466,6 +1466,80 @@ def bn_dice(h, bn, alpha, eps, chunk_stats=None, chunk_rows=0):
     return out
 
 
+class _BnDiceHeadFn(torch.autograd.Function):
+    """Linear(C, 1)(Dice(BatchNorm1d(h))) -- the tail of the ActivationUnit's MLP (layers.py:281-288) -- without the Dice
+    output: forward one pass over h writing (N, 1); backward two passes over h with the rank-1 gradient g[r] * w[c] formed in
+    registers, the head's weight / bias gradients as per-block partials of the statistics pass (csrc/din.hip, HEAD)."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, alpha, eps, head_w,
+                head_b, chunk_stats=None, chunk_rows=0):
+        require_hip(h, gamma, beta, alpha, head_w)
+        h = h.contiguous()
+        N, C = h.shape
+        dev = h.device
+        stat = torch.empty((6, C), dtype=torch.float32, device=dev)
+        if chunk_stats is not None:
+            _lib.call("rh_bn_stats_from_partial", _p(chunk_stats), int(chunk_rows), N, C, _p(gamma), _p(beta),
+                      _p(running_mean), _p(running_var), _p(num_batches_tracked), float(momentum), float(bn_eps), _p(stat),
+                      _stream())
+        else:
+            partial = torch.empty((_lib.call("rh_bn_act_nchunks", N), 2, C), dtype=torch.float32, device=dev)
+            _lib.call("rh_bn_stats_fwd", _p(h), N, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                      _p(num_batches_tracked), float(momentum), float(bn_eps), 1, _p(partial), _p(stat), _stream())
+        head_w = head_w.contiguous()
+        out = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        _lib.call("rh_bn_dice_head_fwd", _p(h), _p(alpha), float(eps), N, C, _p(stat[4]), _p(stat[5]), _p(head_w),
+                  _p(head_b), _p(out), _stream())
+        ctx.eps = float(eps)
+        ctx.has_bias = head_b is not None
+        ctx.save_for_backward(h, gamma, alpha, stat, head_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, gamma, alpha, stat, head_w = ctx.saved_tensors
+        N, C = h.shape
+        dev = h.device
+        g = g.contiguous()
+        nb = _lib.call("rh_bn_dice_stats_blocks", N)
+        col_partial = torch.empty((nb, 2, C), dtype=torch.float32, device=dev)
+        scalar_partial = torch.empty((2, nb), dtype=torch.float32, device=dev)
+        head_partial = torch.empty((nb, C), dtype=torch.float32, device=dev)
+        _lib.call("rh_bn_dice_head_bwd_stats", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(head_w),
+                  _p(col_partial), _p(scalar_partial), _p(head_partial), _stream())
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        _lib.call("rh_bn_finalize_bwd", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _stream())
+        dh = torch.empty_like(h)
+        _lib.call("rh_bn_dice_head_bwd_apply", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(head_w),
+                  _p(dh), _stream())
+        scalars = scalar_partial.sum(1)
+        return (dh, dgamma, dbeta, None, None, None, None, None, scalars[0:1], None, head_partial.sum(0, keepdim=True),
+                scalars[1:2] if ctx.has_bias else None, None, None)
+
+
+def bn_dice_head_ok(h_cols, bn, dice_mod, lin):
+    return (type(lin) is torch.nn.Linear and lin.out_features == 1 and lin.in_features == h_cols and h_cols <= 512 and
+            lin.weight.dtype == torch.float32 and os.environ.get("RECHUB_DICE_HEAD", "1") == "1")
+
+
+def bn_dice_head(h, bn, alpha, eps, lin, chunk_stats=None, chunk_rows=0):
+    """lin(Dice(bn(h))) for Linear -> BatchNorm1d -> Dice -> Linear(C, 1); (N, 1)."""
+    if bn.training:
+        return _BnDiceHeadFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                   bn.momentum, bn.eps, alpha, eps, lin.weight, lin.bias, chunk_stats, chunk_rows)
+    require_hip(h)
+    h = h.contiguous()
+    N, C = h.shape
+    stat = torch.empty((6, C), dtype=torch.float32, device=h.device)
+    _lib.call("rh_bn_stats_fwd", _p(h), N, C, _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(None),
+              0.0, float(bn.eps), 0, _p(None), _p(stat), _stream())
+    out = torch.empty((N, 1), dtype=torch.float32, device=h.device)
+    _lib.call("rh_bn_dice_head_fwd", _p(h), _p(alpha), float(eps), N, C, _p(stat[4]), _p(stat[5]),
+              _p(lin.weight.detach().contiguous()), _p(None if lin.bias is None else lin.bias.detach()), _p(out), _stream())
+    return out
+
+
 def _hist_layout(history):
     """(B, L, D) view whose rows are contiguous over (L, D); returns (tensor, batch stride in floats)."""
     if history.stride(2) != 1 or history.stride(1) != history.shape[2]:
