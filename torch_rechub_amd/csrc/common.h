@@ -11,6 +11,7 @@
 
 void rh_set_error(const char* fmt, ...);
 extern "C" int rh_optim_set_tuning(int key, int value);
+extern "C" int rh_linear_set_tuning(int key, int value);
 
 #define RH_REQUIRE(cond, code, ...)  \
   do {                               \
@@ -85,6 +86,25 @@ static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, RH_WAVE);
   return v;
+}
+// the same total as a wavefront-uniform value, without LDS traffic: four DPP steps inside each row of 16 lanes, one
+// v_readlane per row (wave_sum above is six dependent ds_bpermute).  For the kernels whose per-row chain of reductions is
+// what bounds them (Dice: up to five reductions per row).  EVERY lane of the wavefront must be active; summation order
+// differs from wave_sum's butterfly (last-bit differences).
+static __device__ __forceinline__ float wave_sum_dpp(float v) {
+#define RH_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+  RH_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+  RH_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+  RH_DPP_ADD(0x141);  // row_half_mirror
+  RH_DPP_ADD(0x140);  // row_mirror
+#undef RH_DPP_ADD
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 // minimum over all 64 lanes as a wavefront-uniform (SGPR) value: DPP within each row of 16 lanes (no LDS traffic, unlike
 // __shfl_xor = ds_bpermute), then one readlane per row

@@ -48,13 +48,15 @@ struct DiceArgs {
   float* head_partial;     // MODE 2: (blocks, C) partial dL/dw;  alpha_partial is (2, blocks): d alpha, then dL/db
 };
 
-template <int EPL, int MODE, bool HEAD>
+// FULL: C == 64 * EPL, no column guards (the widths of the ActivationUnit's MLP are multiples of 64).
+template <int EPL, int MODE, bool HEAD, bool FULL>
 __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
   RH_CHAIN_PRIO();
   __shared__ float red[kWaves];
   extern __shared__ float colred[];  // MODE 2: kWaves * (2 + HEAD) * EPL * 64 floats
   constexpr int NCS = HEAD ? 3 : 2;
-  const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
+  const int lane = threadIdx.x % RH_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / RH_WAVE);  // rows and their guards are wavefront-uniform
   const int64_t nw = (int64_t)gridDim.x * kWaves;
   const int C = a.C;
   const float alpha = a.alpha[0];
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
 #pragma unroll
   for (int k = 0; k < EPL; ++k) {
     const int e = lane + RH_WAVE * k;
-    const bool ok = e < C;
+    const bool ok = (FULL || e < C);
     sc[k] = (bn && ok) ? a.scale[e] : 1.f;
     sh[k] = (bn && ok) ? a.shift[e] : 0.f;
     cs1[k] = cs2[k] = cs3[k] = 0.f;
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
-      hn[k] = (r < a.N && e < C) ? a.x[r * C + e] : 0.f;
-      if (MODE != 0 && !HEAD) gn[k] = (r < a.N && e < C) ? a.g[r * C + e] : 0.f;
+      hn[k] = (r < a.N && (FULL || e < C)) ? a.x[r * C + e] : 0.f;
+      if (MODE != 0 && !HEAD) gn[k] = (r < a.N && (FULL || e < C)) ? a.g[r * C + e] : 0.f;
     }
   };
   fetch((int64_t)blockIdx.x * kWaves + wave);
@@ -113,33 +115,33 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
-      v[k] = e < C ? fmaf(hraw[k], sc[k], sh[k]) : 0.f;
+      v[k] = (FULL || e < C) ? fmaf(hraw[k], sc[k], sh[k]) : 0.f;
       s += v[k];
     }
-    const float avg = wave_sum(s) * invC;
+    const float avg = wave_sum_dpp(s) * invC;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const int e = lane + RH_WAVE * k;
-      const float c = e < C ? v[k] - avg : 0.f;
+      const float c = (FULL || e < C) ? v[k] - avg : 0.f;
       q = fmaf(c, c, q);
     }
-    const float var = wave_sum(q) + a.eps * (float)C;
+    const float var = wave_sum_dpp(q) + a.eps * (float)C;
     const float rs = rsqrtf(var);
     if (MODE == 0) {
       float dot = 0.f;
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         const int e = lane + RH_WAVE * k;
-        if (e < C) {
-          const float ps = 1.f / (1.f + expf(-(v[k] - avg) * rs));
+        if ((FULL || e < C)) {
+          const float ps = __builtin_amdgcn_rcpf(1.f + expf(-(v[k] - avg) * rs));  // v_rcp_f32: 1 ulp
           const float o = ps * v[k] + (1.f - ps) * alpha * v[k];
           if (HEAD) dot = fmaf(o, hw[k], dot);
           else a.out[r * C + e] = o;
         }
       }
       if (HEAD) {
-        dot = wave_sum(dot);
+        dot = wave_sum_dpp(dot);
         if (lane == 0) a.out[r] = dot + (a.head_b ? a.head_b[0] : 0.f);
       }
     } else {
@@ -151,21 +153,21 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
         const int e = lane + RH_WAVE * k;
         gk[k] = gin[k];
         const float c = v[k] - avg;
-        psk[k] = 1.f / (1.f + expf(-c * rs));
-        tk[k] = e < C ? gk[k] * v[k] * (1.f - alpha) * psk[k] * (1.f - psk[k]) : 0.f;  // dL/dz
+        psk[k] = __builtin_amdgcn_rcpf(1.f + expf(-c * rs));
+        tk[k] = (FULL || e < C) ? gk[k] * v[k] * (1.f - alpha) * psk[k] * (1.f - psk[k]) : 0.f;  // dL/dz
         st += tk[k];
         stc = fmaf(tk[k], c, stc);
-        if (MODE != 3) acc_alpha += e < C ? gk[k] * v[k] * (1.f - psk[k]) : 0.f;
-        if (HEAD && MODE == 2) cs3[k] = fmaf(gs, e < C ? v[k] * (alpha + (1.f - alpha) * psk[k]) : 0.f, cs3[k]);
+        if (MODE != 3) acc_alpha += (FULL || e < C) ? gk[k] * v[k] * (1.f - psk[k]) : 0.f;
+        if (HEAD && MODE == 2) cs3[k] = fmaf(gs, (FULL || e < C) ? v[k] * (alpha + (1.f - alpha) * psk[k]) : 0.f, cs3[k]);
       }
       if (HEAD && MODE == 2) acc_b += gs;
-      st = wave_sum(st);
-      stc = wave_sum(stc);
+      st = wave_sum_dpp(st);
+      stc = wave_sum_dpp(stc);
       const float rs3 = rs * rs * rs;
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         const int e = lane + RH_WAVE * k;
-        if (e < C) {
+        if ((FULL || e < C)) {
           const float c = v[k] - avg;
           const float gx = gk[k] * (alpha + (1.f - alpha) * psk[k]) + rs * tk[k] - rs * invC * st - rs3 * c * stc;
           if (MODE == 1) {
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
     __syncthreads();
     for (int i = threadIdx.x; i < NCS * EPL * RH_WAVE; i += RH_BLOCK) {
       const int which = i / (EPL * RH_WAVE), e = i % (EPL * RH_WAVE);
-      if (e < C) {
+      if ((FULL || e < C)) {
         float t = 0.f;
         for (int w = 0; w < kWaves; ++w) t += colred[(w * NCS + which) * EPL * RH_WAVE + e];
         if (which < 2) a.col_partial[((int64_t)blockIdx.x * 2 + which) * C + e] = t;
@@ -238,28 +240,32 @@ unsigned dice_grid(int64_t N, int cap = 256 * 16) {
 }
 constexpr int kStatsBlocks = 2048;  // MODE 2: few enough partial rows for the column finalize to combine quickly
 
+template <int E, int MODE, bool HEAD>
+void dice_launch(const DiceArgs& a, unsigned grid, hipStream_t s) {
+  const size_t lds = MODE == 2 ? (size_t)kWaves * (HEAD ? 3 : 2) * E * RH_WAVE * sizeof(float) : 0;
+  if (a.C == E * RH_WAVE) hipLaunchKernelGGL((dice_kernel<E, MODE, HEAD, true>), dim3(grid), dim3(RH_BLOCK), lds, s, a);
+  else hipLaunchKernelGGL((dice_kernel<E, MODE, HEAD, false>), dim3(grid), dim3(RH_BLOCK), lds, s, a);
+}
+
 template <int MODE, bool HEAD = false>
 int dice_dispatch(const DiceArgs& a, hipStream_t s) {
   const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : dice_grid(a.N);
-#define RH_DICE(E)                                                                                          \
-  hipLaunchKernelGGL((dice_kernel<E, MODE, HEAD>), dim3(grid), dim3(RH_BLOCK),                              \
-                     MODE == 2 ? (size_t)kWaves * (HEAD ? 3 : 2) * E * RH_WAVE * sizeof(float) : 0, s, a)
   switch (dice_epl(a.C)) {
-    case 1: RH_DICE(1); break;
-    case 2: RH_DICE(2); break;
-    case 4: RH_DICE(4); break;
-    case 8: RH_DICE(8); break;
+    case 1: dice_launch<1, MODE, HEAD>(a, grid, s); break;
+    case 2: dice_launch<2, MODE, HEAD>(a, grid, s); break;
+    case 4: dice_launch<4, MODE, HEAD>(a, grid, s); break;
+    case 8: dice_launch<8, MODE, HEAD>(a, grid, s); break;
     case 16:
-      if (MODE >= 2 || HEAD) return RH_E_UNSUPPORTED;  // the folded-BatchNorm modes keep 9 values per owned column in registers
-      RH_DICE(16);
+      // the folded-BatchNorm modes keep 9 values per owned column in registers
+      if constexpr (MODE >= 2 || HEAD) return RH_E_UNSUPPORTED;
+      else dice_launch<16, MODE, HEAD>(a, grid, s);
       break;
     case 32:
-      if (MODE >= 2 || HEAD) return RH_E_UNSUPPORTED;
-      RH_DICE(32);
+      if constexpr (MODE >= 2 || HEAD) return RH_E_UNSUPPORTED;
+      else dice_launch<32, MODE, HEAD>(a, grid, s);
       break;
     default: return RH_E_UNSUPPORTED;
   }
-#undef RH_DICE
   return 0;
 }
 

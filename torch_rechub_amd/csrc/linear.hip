@@ -41,13 +41,17 @@ struct WgradArgs {
   int direct;          // 1: S == 1 and the block writes dW / db itself
 };
 
-__global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
+// LONG: the build for long reductions (see the two kernels below): simple prefetch loop and ONE LDS tile; otherwise the
+// round-1 form (ping-pong register sets, one LDS tile per wavefront).  Same sums in the same order either way.
+template <bool LONG>
+__device__ __forceinline__ void linear_wgrad_body(const WgradArgs& a, float* red) {
   RH_CHAIN_PRIO();
-  extern __shared__ float red[];  // kWaves * kPartStride floats
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int half = lane >> 5, c = lane & 31;
-  const int k0 = blockIdx.x * kTile, n0 = blockIdx.y * kTile, s = blockIdx.z;
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x, tiles = gridDim.x * gridDim.y;
+  // (Measured and dropped: a 1-D launch that puts the tiles of one split on ONE XCD, so that its L2 serves the rows they
+  // share -- 945 us against 884 for DIN's four long launches; with x-fastest tiles each XCD streams its own column range.)
+  const int bx = blockIdx.x, by = blockIdx.y, s = blockIdx.z;
+  const int k0 = bx * kTile, n0 = by * kTile;
   const int b_lo = s * a.rows_per_split;
   const int b_hi = min(a.B, b_lo + a.rows_per_split);
 
@@ -90,23 +94,39 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
   const int last_full = b_hi - (2 * kWaves * (kUnroll - 1) + 2);  // p <= last_full: every row of the iteration exists
   if (p <= last_full) {
     fetch(p, fa0, fa1, fb0, fb1);
-    while (true) {  // ping-pong between the two register sets; the branch conditions are wave-uniform
-      if (p + kStep > last_full) {
+    if (LONG) {
+      for (; p + kStep <= last_full; p += kStep) {
+        fetch(p + kStep, qa0, qa1, qb0, qb1);
         issue(fa0, fa1, fb0, fb1);
-        p += kStep;
-        break;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          fa0[u] = qa0[u];
+          fa1[u] = qa1[u];
+          fb0[u] = qb0[u];
+          fb1[u] = qb1[u];
+        }
       }
-      fetch(p + kStep, qa0, qa1, qb0, qb1);
       issue(fa0, fa1, fb0, fb1);
       p += kStep;
-      if (p + kStep > last_full) {
+    } else {
+      while (true) {  // ping-pong between the two register sets; the branch conditions are wave-uniform
+        if (p + kStep > last_full) {
+          issue(fa0, fa1, fb0, fb1);
+          p += kStep;
+          break;
+        }
+        fetch(p + kStep, qa0, qa1, qb0, qb1);
+        issue(fa0, fa1, fb0, fb1);
+        p += kStep;
+        if (p + kStep > last_full) {
+          issue(qa0, qa1, qb0, qb1);
+          p += kStep;
+          break;
+        }
+        fetch(p + kStep, fa0, fa1, fb0, fb1);
         issue(qa0, qa1, qb0, qb1);
         p += kStep;
-        break;
       }
-      fetch(p + kStep, fa0, fa1, fb0, fb1);
-      issue(qa0, qa1, qb0, qb1);
-      p += kStep;
     }
   }
   // ragged end of the last split: fewer than kStep rows, guarded per row
@@ -124,40 +144,90 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
     bs1 += t1;
   }
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float* mine = red + wave * kPartStride;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-    mine[row * kTile + c] = acc00[r];
-    mine[row * kTile + 32 + c] = acc01[r];
-    mine[(32 + row) * kTile + c] = acc10[r];
-    mine[(32 + row) * kTile + 32 + c] = acc11[r];
-  }
+  // LONG: the four wavefronts add their tiles into ONE LDS tile, one after the other in wavefront order (deterministic, and the
+  // same sum ((w0 + w1) + w2) + w3 as four separate tiles summed afterwards).  Four tiles were 66.5 KB per workgroup = two
+  // workgroups per CU = two wavefronts per SIMD, too few to hide the operand loads of a long reduction (DIN: 409 600 rows,
+  // ~70 TF); one tile is 16.6 KB.
   bs0 += __shfl_xor(bs0, 32);
   bs1 += __shfl_xor(bs1, 32);
-  if (half == 0) {
-    mine[kTileElems + c] = bs0;
-    mine[kTileElems + 32 + c] = bs1;
+  if (!LONG) {
+    float* mine = red + wave * kPartStride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      mine[row * kTile + c] = acc00[r];
+      mine[row * kTile + 32 + c] = acc01[r];
+      mine[(32 + row) * kTile + c] = acc10[r];
+      mine[(32 + row) * kTile + 32 + c] = acc11[r];
+    }
+    if (half == 0) {
+      mine[kTileElems + c] = bs0;
+      mine[kTileElems + 32 + c] = bs1;
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  for (int w = 0; LONG && w < kWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float* q = red + row * kTile + c;
+        if (w == 0) {
+          q[0] = acc00[r];
+          q[32] = acc01[r];
+          q[32 * kTile] = acc10[r];
+          q[32 * kTile + 32] = acc11[r];
+        } else {
+          q[0] += acc00[r];
+          q[32] += acc01[r];
+          q[32 * kTile] += acc10[r];
+          q[32 * kTile + 32] += acc11[r];
+        }
+      }
+      if (half == 0) {
+        if (w == 0) {
+          red[kTileElems + c] = bs0;
+          red[kTileElems + 32 + c] = bs1;
+        } else {
+          red[kTileElems + c] += bs0;
+          red[kTileElems + 32 + c] += bs1;
+        }
+      }
+    }
+    __syncthreads();
+  }
   // Partial results of split s in the layout of the outputs themselves -- (N, K) and (N,) slabs, one per split -- so
   // that summing the splits is a plain slab sum for whoever does it (wgrad_reduce_kernel, or rh_pack_grads fused with
   // the packing of the step's dense gradients).
-  (void)tile;
-  (void)tiles;
   float* outW = a.direct ? a.dW : a.partial + (int64_t)s * a.N * a.K;
   float* outB = a.direct ? a.db : a.partial + (int64_t)a.S * a.N * a.K + (int64_t)s * a.N;
   for (int e = threadIdx.x; e < kPartStride; e += RH_BLOCK) {
     float v = red[e];
+    if (!LONG) {
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) v += red[w * kPartStride + e];
+      for (int w = 1; w < kWaves; ++w) v += red[w * kPartStride + e];
+    }
     if (e < kTileElems) {
       const int n = n0 + e / kTile, k = k0 + e % kTile;
       if (n < a.N && k < a.K) outW[(int64_t)n * a.K + k] = v;
-    } else if (outB && blockIdx.x == 0 && n0 + e - kTileElems < a.N) {
+    } else if (outB && bx == 0 && n0 + e - kTileElems < a.N) {
       outB[n0 + e - kTileElems] = v;
     }
   }
+}
+
+// Two builds of the same body: the default (the compiler takes 78 VGPRs + 128 AGPRs: two wavefronts per SIMD, what a
+// B = 4096 launch of ~500 workgroups fills anyway) and one held to 128 registers = four wavefronts per SIMD for the long
+// reductions, where the latency of the operand loads is hidden by the other wavefronts (DIN, B * L = 409 600 rows).
+__global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ float red[];  // kWaves * kPartStride floats
+  linear_wgrad_body<false>(a, red);
+}
+
+__global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void linear_wgrad_long_kernel(
+    const WgradArgs a) {
+  extern __shared__ float red[];  // kPartStride floats: the block's tile + its db slice
+  linear_wgrad_body<true>(a, red);
 }
 
 // Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
@@ -183,11 +253,17 @@ __global__ __launch_bounds__(RH_BLOCK) void wgrad_reduce_kernel(const WgradArgs 
   else a.dW[i] = v;
 }
 
+// Workgroups a launch aims for.  Short batches (B = 4096): 512, two per CU -- every further split is another (N, K) slab
+// written and summed.  Long reductions (DIN's B * L = 409 600 rows): g_long_blocks, so that every SIMD holds enough
+// wavefronts to cover the latency of the operand loads (tuning knob RH_TUNE_WGRAD_BLOCKS).
+int g_long_blocks = 1024;   // negative: -value workgroups with the default build of the kernel (A/B)
+constexpr int kLongRows = 32768;
+
 void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
   *tiles_n = (N + kTile - 1) / kTile;
   *tiles_k = (K + kTile - 1) / kTile;
   const int tiles = *tiles_n * *tiles_k;
-  int s = 512 / tiles;
+  int s = (B >= kLongRows ? abs(g_long_blocks) : 512) / tiles;
   const int max_s = (B + 63) / 64;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -629,21 +705,33 @@ static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, 
   int tn, tk;
   wgrad_plan(B, N, K, &tn, &tk, &a.S, &a.rows_per_split);
   a.direct = (reduce && a.S == 1) ? 1 : 0;
+  const bool long_form = B >= kLongRows && g_long_blocks > 0;
+  const size_t lds = (size_t)(long_form ? 1 : kWaves) * kPartStride * sizeof(float);
   static bool attr_set = false;
-  const size_t lds = (size_t)kWaves * kPartStride * sizeof(float);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    RH_REQUIRE(e == hipSuccess, (int)e, "rh_linear_wgrad: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kWaves * kPartStride * sizeof(float)));
+    RH_REQUIRE(e == hipSuccess, (int)e, "rh_linear_wgrad: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
+  if (long_form)
+    hipLaunchKernelGGL(linear_wgrad_long_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
+  else
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
   if (reduce && a.S > 1)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)N * K + N + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK),
                        0, st, a);
   RH_LAUNCH_CHECK("rh_linear_wgrad");
   return 0;
+}
+
+extern "C" int rh_linear_set_tuning(int key, int value) {
+  if (key == RH_TUNE_WGRAD_BLOCKS) {
+    g_long_blocks = value;
+    return 0;
+  }
+  return RH_E_BADARG;
 }
 
 extern "C" int rh_head_nblocks(int B) { return head_grid(B); }
