@@ -58,6 +58,8 @@ const char* rh_last_error(void);
 #define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
                                   the residency cap that lets the step's chain keep its wave slots and issue cycles */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
+#define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront
+                                  kernel (C = 64 / 128 / 256); default 16 | 32 */
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
 #define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
 #define RH_TUNE_FWD_PATH 7      /* rh_embed_fwd: 0 auto (by batch size), 1 lane-split kernel only, 2 field-uniform kernel only */

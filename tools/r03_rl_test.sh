@@ -1,5 +1,7 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r3g
-timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "wgrad or linear or dice" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "dice" 2>&1 | tail -3
+RECHUB_TUNE=10=112 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "dice" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "din" 2>&1 | tail -3
 run() { tag=$1; shift; env "$@" timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --brief --no-kernel-sweep "${EXTRA[@]}" 2>gpurun_out/r3g/$tag.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['config']['step_form']['chosen'])" || tail -5 gpurun_out/r3g/$tag.err; }
-EXTRA=(--model din); run din RECHUB_X=1; run din_2048 RECHUB_TUNE=9=2048; run din_old RECHUB_TUNE=9=-1024
-bash tools/r03_din_prof.sh 2>&1 | tail -36 | head -8
+EXTRA=(--model din); run din RECHUB_X=1; run din_vec256 RECHUB_TUNE=10=112; run din_novec RECHUB_TUNE=10=0
+bash tools/r03_din_prof.sh 2>&1 | tail -36 | head -14

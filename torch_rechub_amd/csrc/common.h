@@ -12,6 +12,7 @@
 void rh_set_error(const char* fmt, ...);
 extern "C" int rh_optim_set_tuning(int key, int value);
 extern "C" int rh_linear_set_tuning(int key, int value);
+extern "C" int rh_din_set_tuning(int key, int value);
 
 #define RH_REQUIRE(cond, code, ...)  \
   do {                               \

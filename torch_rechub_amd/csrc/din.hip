@@ -226,6 +226,222 @@ __global__ __launch_bounds__(RH_BLOCK) void dice_kernel(const DiceArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same four passes for C = 64 / 128 / 256 with LPR = C / 4 lanes per row and 64 / LPR rows per wavefront pass: one
+// 16-byte load per lane and row, and the per-row reductions (2 forward, 4-5 backward) run for all rows of the pass in the
+// same instructions.  dice_kernel above spends one wavefront per row whatever C is: at C = 128 its fixed per-row work
+// (reductions, loop, addressing) bounded it at 1.8 - 2.9 TB/s of its streams.  Rows r = (wavefront pass) * RPW + lane / LPR;
+// lane l of a row owns columns 4l .. 4l + 3.
+template <int LPR>
+static __device__ __forceinline__ float group_sum(float v) {
+#define RH_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+  RH_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+  RH_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+  RH_DPP_ADD(0x141);  // row_half_mirror
+  RH_DPP_ADD(0x140);  // row_mirror
+#undef RH_DPP_ADD
+  if (LPR == 16) return v;
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  if (LPR == 64) return (r0 + r1) + (r2 + r3);
+  return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+}
+
+static __device__ __forceinline__ void unpack4(const float4 q, float* v) {
+  v[0] = q.x;
+  v[1] = q.y;
+  v[2] = q.z;
+  v[3] = q.w;
+}
+
+template <int LPR, int MODE, bool HEAD>
+__global__ __launch_bounds__(RH_BLOCK) void dice_vec_kernel(const DiceArgs a) {
+  RH_CHAIN_PRIO();
+  constexpr int RPW = RH_WAVE / LPR;  // rows per wavefront pass
+  constexpr int C = 4 * LPR;
+  constexpr int NCS = HEAD ? 3 : 2;
+  __shared__ float red[2 * kWaves];
+  extern __shared__ float colred[];  // MODE 2: kWaves * NCS * C floats
+  const int lane = threadIdx.x % RH_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / RH_WAVE);
+  const int l = lane % LPR, sub = lane / LPR;
+  const int64_t np = (int64_t)gridDim.x * kWaves;  // wavefront passes in flight
+  const float alpha = a.alpha[0];
+  constexpr float invC = 1.f / (float)C;
+  const bool bn = a.scale != nullptr;
+  float sc[4], sh[4], mu[4], rsd[4], gm[4], sg[4], sgx[4], hw[4];
+  float cs1[4], cs2[4], cs3[4];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  auto col4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + 4 * l); };
+  unpack4(bn ? col4(a.scale) : one4, sc);
+  unpack4(bn ? col4(a.shift) : z4, sh);
+  unpack4(HEAD ? col4(a.head_w) : z4, hw);
+  if (MODE >= 2) {
+    unpack4(col4(a.stat), mu);
+    unpack4(col4(a.stat + C), rsd);
+    unpack4(col4(a.gamma), gm);
+    if (MODE == 3) {
+      const float inv_n = 1.f / (float)a.N;
+      unpack4(col4(a.stat + 2 * C), sg);
+      unpack4(col4(a.stat + 3 * C), sgx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sg[k] *= inv_n;
+        sgx[k] *= inv_n;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cs1[k] = cs2[k] = cs3[k] = 0.f;
+  float acc_alpha = 0.f, acc_b = 0.f;
+
+  float4 hn = z4, gn = z4;
+  float gsn = 0.f;
+  auto fetch = [&](int64_t pass) {
+    const int64_t r = pass * RPW + sub;
+    const bool ok = r < a.N;
+    hn = ok ? *reinterpret_cast<const float4*>(a.x + r * C + 4 * l) : z4;
+    if (MODE != 0) {
+      if (HEAD) gsn = ok ? a.g[r] : 0.f;
+      else gn = ok ? *reinterpret_cast<const float4*>(a.g + r * C + 4 * l) : z4;
+    }
+  };
+  const int64_t first = (int64_t)blockIdx.x * kWaves + wave;
+  fetch(first);
+  for (int64_t pass = first; pass * RPW < a.N; pass += np) {
+    const int64_t r = pass * RPW + sub;
+    const bool ok = r < a.N;
+    float hraw[4], gin[4], v[4];
+    unpack4(hn, hraw);
+    const float gs = gsn;
+    if (MODE != 0) {
+      if (HEAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gin[k] = gs * hw[k];
+      } else {
+        unpack4(gn, gin);
+      }
+    }
+    fetch(pass + np);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = fmaf(hraw[k], sc[k], sh[k]);
+      s += v[k];
+    }
+    const float avg = group_sum<LPR>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = v[k] - avg;
+      q = fmaf(c, c, q);
+    }
+    const float var = group_sum<LPR>(q) + a.eps * (float)C;
+    const float rs = rsqrtf(var);
+    if (MODE == 0) {
+      float o[4], dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float ps = __builtin_amdgcn_rcpf(1.f + expf(-(v[k] - avg) * rs));
+        o[k] = ps * v[k] + (1.f - ps) * alpha * v[k];
+        dot = fmaf(o[k], hw[k], dot);
+      }
+      if (HEAD) {
+        dot = group_sum<LPR>(dot);
+        if (ok && l == 0) a.out[r] = dot + (a.head_b ? a.head_b[0] : 0.f);
+      } else if (ok) {
+        *reinterpret_cast<float4*>(a.out + r * C + 4 * l) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    } else {
+      float tk[4], psk[4];
+      float st = 0.f, stc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float c = v[k] - avg;
+        psk[k] = __builtin_amdgcn_rcpf(1.f + expf(-c * rs));
+        tk[k] = gin[k] * v[k] * (1.f - alpha) * psk[k] * (1.f - psk[k]);  // dL/dz
+        st += tk[k];
+        stc = fmaf(tk[k], c, stc);
+        if (MODE != 3) acc_alpha += gin[k] * v[k] * (1.f - psk[k]);
+        if (HEAD && MODE == 2) cs3[k] = fmaf(gs, v[k] * (alpha + (1.f - alpha) * psk[k]), cs3[k]);
+      }
+      if (HEAD && MODE == 2) acc_b += gs;
+      st = group_sum<LPR>(st);
+      stc = group_sum<LPR>(stc);
+      const float rs3 = rs * rs * rs;
+      float gx[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float c = v[k] - avg;
+        gx[k] = gin[k] * (alpha + (1.f - alpha) * psk[k]) + rs * tk[k] - rs * invC * st - rs3 * c * stc;
+        if (MODE >= 2) {
+          const float xhat = (hraw[k] - mu[k]) * rsd[k];
+          if (MODE == 2) {
+            // a row past N has h = 0 and g = 0: tk = 0, st = stc = 0, gx = 0 -- nothing to mask
+            cs1[k] += gx[k];
+            cs2[k] = fmaf(gx[k], xhat, cs2[k]);
+          } else {
+            gx[k] = gm[k] * rsd[k] * (gx[k] - sg[k] - xhat * sgx[k]);
+          }
+        }
+      }
+      if ((MODE == 1 || MODE == 3) && ok)
+        *reinterpret_cast<float4*>(a.out + r * C + 4 * l) = make_float4(gx[0], gx[1], gx[2], gx[3]);
+    }
+  }
+  if (MODE == 1 || MODE == 2) {
+    acc_alpha = wave_sum_dpp(acc_alpha);
+    if (HEAD) acc_b = wave_sum_dpp(l == 0 ? acc_b : 0.f);  // one lane per row carries that row's g
+    if (lane == 0) {
+      red[wave] = acc_alpha;
+      red[kWaves + wave] = acc_b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f, u = 0.f;
+      for (int w = 0; w < kWaves; ++w) {
+        t += red[w];
+        u += red[kWaves + w];
+      }
+      a.alpha_partial[blockIdx.x] = t;
+      if (HEAD) a.alpha_partial[gridDim.x + blockIdx.x] = u;
+    }
+  }
+  if (MODE == 2) {
+    // rows of the wavefront pass first (fixed order), then the wavefronts in order: deterministic per-block partial rows
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      for (int m = LPR; m < RH_WAVE; m <<= 1) {
+        cs1[k] += __shfl_xor(cs1[k], m, RH_WAVE);
+        cs2[k] += __shfl_xor(cs2[k], m, RH_WAVE);
+        if (HEAD) cs3[k] += __shfl_xor(cs3[k], m, RH_WAVE);
+      }
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        colred[(wave * NCS + 0) * C + 4 * l + k] = cs1[k];
+        colred[(wave * NCS + 1) * C + 4 * l + k] = cs2[k];
+        if (HEAD) colred[(wave * NCS + 2) * C + 4 * l + k] = cs3[k];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NCS * C; i += RH_BLOCK) {
+      const int which = i / C, e = i % C;
+      float t = 0.f;
+      for (int w = 0; w < kWaves; ++w) t += colred[(w * NCS + which) * C + e];
+      if (which < 2) a.col_partial[((int64_t)blockIdx.x * 2 + which) * C + e] = t;
+      else a.head_partial[(int64_t)blockIdx.x * C + e] = t;
+    }
+  }
+}
+
+int g_dice_vec = 16 | 32;  // tuning knob RH_TUNE_DICE_VEC: bit mask of the LPR values dice_vec_kernel serves (C = 4 * LPR)
+
 int dice_epl(int C) {
   int e = 1;
   while (e * RH_WAVE < C) e *= 2;
@@ -247,8 +463,27 @@ void dice_launch(const DiceArgs& a, unsigned grid, hipStream_t s) {
   else hipLaunchKernelGGL((dice_kernel<E, MODE, HEAD, false>), dim3(grid), dim3(RH_BLOCK), lds, s, a);
 }
 
+template <int LPR, int MODE, bool HEAD>
+void dice_vec_launch(const DiceArgs& a, hipStream_t s) {
+  // MODE 2: the caller sized its partial rows by rh_bn_dice_stats_blocks(N); blocks without rows write zeros
+  const int64_t passes = (a.N + RH_WAVE / LPR - 1) / (RH_WAVE / LPR);
+  const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : dice_grid(passes);
+  const size_t lds = MODE == 2 ? (size_t)kWaves * (HEAD ? 3 : 2) * 4 * LPR * sizeof(float) : 0;
+  hipLaunchKernelGGL((dice_vec_kernel<LPR, MODE, HEAD>), dim3(grid), dim3(RH_BLOCK), lds, s, a);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <int MODE, bool HEAD = false>
 int dice_dispatch(const DiceArgs& a, hipStream_t s) {
+  if ((a.C == 64 || a.C == 128 || a.C == 256) && (g_dice_vec & (a.C / 4)) && aligned16(a.x) && aligned16(a.out) &&
+      (HEAD || aligned16(a.g)) && aligned16(a.scale) && aligned16(a.shift) && aligned16(a.stat) && aligned16(a.gamma) &&
+      aligned16(a.head_w)) {
+    if (a.C == 64) dice_vec_launch<16, MODE, HEAD>(a, s);
+    else if (a.C == 128) dice_vec_launch<32, MODE, HEAD>(a, s);
+    else dice_vec_launch<64, MODE, HEAD>(a, s);
+    return 0;
+  }
   const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : dice_grid(a.N);
   switch (dice_epl(a.C)) {
     case 1: dice_launch<1, MODE, HEAD>(a, grid, s); break;
@@ -461,6 +696,14 @@ extern "C" int rh_prelu_bwd(const float* x, const float* g, const float* slope, 
                      slope, n / 4, n, gx, partial);
   RH_LAUNCH_CHECK("rh_prelu_bwd");
   return 0;
+}
+
+extern "C" int rh_din_set_tuning(int key, int value) {
+  if (key == RH_TUNE_DICE_VEC) {
+    g_dice_vec = value;
+    return 0;
+  }
+  return RH_E_BADARG;
 }
 
 extern "C" int rh_dice_nblocks(int64_t N) { return (int)dice_grid(N); }

@@ -771,6 +771,7 @@ extern "C" int rh_set_tuning(int key, int value) {
   if (key == RH_TUNE_BWD_SPLIT || key == RH_TUNE_BWD_SLABS) return 0;  // retired knobs (kept so old probes still run)
   if (rh_optim_set_tuning(key, value) == 0) return 0;
   if (rh_linear_set_tuning(key, value) == 0) return 0;
+  if (rh_din_set_tuning(key, value) == 0) return 0;
   rh_set_error("rh_set_tuning: unknown key %d", key);
   return RH_E_BADARG;
 }
