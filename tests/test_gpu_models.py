@@ -650,6 +650,27 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
         assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-5, rtol=1e-4)
 
 
+def test_dssm_towers_side_by_side_are_the_sequential_towers(monkeypatch):
+    """DSSM.towers with RECHUB_TOWER_BRANCHES=1 (item tower's MLP on a second stream, forward and backward) == the two tower
+    calls one after the other, bit for bit: same kernels on the same inputs, only their streams differ."""
+    got = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RECHUB_TOWER_BRANCHES", flag)
+        gold, model = load_model("dssm")
+        xd = to_dev(golden_batch(gold, 0)[0])
+        model.train()
+        u, v = model.towers(xd)
+        (u * v).sum().backward()
+        torch.cuda.synchronize()
+        got.append((u.detach().clone(), v.detach().clone(),
+                    {n: p.grad.detach().clone() for n, p in model.named_parameters()
+                     if p.grad is not None and "mlp" in n}))  # (table gradients are float atomics: order not fixed)
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    assert got[0][2].keys() == got[1][2].keys() and len(got[0][2]) > 4
+    for n in got[0][2]:
+        assert torch.equal(got[0][2][n], got[1][2][n]), n
+
+
 def test_dssm_towers_and_inbatch_sampling():
     """Config 5 pieces: tower embeddings against the reference, in-batch sampler invariants (reference
     tests/test_inbatch_sampling.py:12-30) on the device."""

@@ -1,9 +1,7 @@
+# kernel timeline of one traced step: bash tools/r03_tl.sh MODEL [ENV=VALUE ...]
 mkdir -p gpurun_out/r3c; export TMPDIR=/tmp
-cd /tmp
-for cfg in "branch RECHUB_STEP_FORM=branch RECHUB_SWEEP_GRID=512"; do
-  set -- $cfg; tag=$1; shift
-  rm -rf /tmp/tl_$tag
-  env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$tag -o t -- python $OLDPWD/bench.py --trace-inner --steps 30 --warmup 10 --rows 4000000 > /dev/null 2> $OLDPWD/gpurun_out/r3c/tl_$tag.err
-  python $OLDPWD/tools/timeline.py /tmp/tl_$tag 1 > $OLDPWD/gpurun_out/r3c/timeline_$tag.txt
-  echo "== $tag"; cat $OLDPWD/gpurun_out/r3c/timeline_$tag.txt
-done
+m=$1; shift
+cd /tmp; rm -rf /tmp/tl_$m
+env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$m -o t -- python $OLDPWD/bench.py --model $m --trace-inner --steps 10 --warmup 5 > /dev/null 2> $OLDPWD/gpurun_out/r3c/tl_$m.err
+python $OLDPWD/tools/timeline.py /tmp/tl_$m 1 > $OLDPWD/gpurun_out/r3c/timeline_$m.txt
+cat $OLDPWD/gpurun_out/r3c/timeline_$m.txt

@@ -6,6 +6,8 @@ embedding when ``mode`` is "user" / "item" (the other tower then yields None).  
 kernels (sequence history features on the gather+pool kernel), the towers' BatchNorm through csrc/mlp.hip, their GEMMs
 are library calls.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -30,6 +32,26 @@ class DSSM(nn.Module):
         h = mlp(self.embedding(x, features, squeeze_dim=True))
         # F.normalize(h, p=2, dim=1) (dssm.py:56,66) as one HIP launch each way (csrc/match.hip)
         return ops.l2_normalize(h) if ops.l2_normalize_ok(h) else F.normalize(h, p=2, dim=1)
+
+    def _mlp_norm(self, h, mlp):
+        h = mlp(h)
+        return ops.l2_normalize(h) if ops.l2_normalize_ok(h) else F.normalize(h, p=2, dim=1)
+
+    def towers(self, x):
+        """(user_tower(x), item_tower(x)) with the two MLPs side by side (extension; the reference runs them one after the
+        other, trainers/match_trainer.py:112-113).  Both gathers stay on the calling stream -- they refresh optimizer state
+        in order -- then the item tower's MLP + normalisation run on a second stream beside the user tower's: each of their
+        ~12 launches per direction fills a fraction of the chip.  Opt-in (RECHUB_TOWER_BRANCHES=1): at configs[4] the step is
+        bounded by the deferred window sweep, not by the chain (0.823 ms either way); with the chain as the bound (sweep at
+        1024 workgroups) the branches take 1.04 -> 0.92 ms."""
+        if self.mode is not None or os.environ.get("RECHUB_TOWER_BRANCHES", "0") != "1":
+            return self.user_tower(x), self.item_tower(x)
+        hu = self.embedding(x, self.user_features, squeeze_dim=True)
+        hi = self.embedding(x, self.item_features, squeeze_dim=True)
+        if not hu.is_cuda:
+            return self._mlp_norm(hu, self.user_mlp), self._mlp_norm(hi, self.item_mlp)
+        return ops.run_beside(lambda: self._mlp_norm(hu, self.user_mlp), lambda: self._mlp_norm(hi, self.item_mlp),
+                              side_inputs=(hi,))
 
     def user_tower(self, x):
         return None if self.mode == "item" else self._tower(x, self.user_features, self.user_mlp)

@@ -43,6 +43,33 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_BRANCH_STREAMS = {}
+
+
+def run_beside(fn_main, fn_side, side_inputs=()):
+    """(fn_main(), fn_side()) with fn_side on a second HIP stream: fork after everything enqueued so far, join before
+    returning.  Inside a hipGraph capture the two become concurrent branches of the graph (tools/probe/branch_probe.cpp:
+    captured branches do run side by side on this runtime); autograd runs each op's backward on the stream of its forward,
+    so the backward forks and joins the same way.  For two independent chains of small kernels (the towers of a two-tower
+    model: each launch fills a fraction of the 256 CUs)."""
+    cur = torch.cuda.current_stream()
+    key = cur.device.index
+    side = _BRANCH_STREAMS.get(key)
+    if side is None:
+        side = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    for t in side_inputs:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        b = fn_side()
+    a = fn_main()
+    cur.wait_stream(side)
+    for t in (b if isinstance(b, (tuple, list)) else (b,)):
+        if torch.is_tensor(t):
+            t.record_stream(cur)
+    return a, b
+
+
 def require_hip(*tensors):
     """Fail loudly for anything that is not a HIP tensor (there is no CPU fallback)."""
     for t in tensors:

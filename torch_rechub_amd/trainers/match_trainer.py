@@ -80,8 +80,11 @@ class MatchTrainer(CTRTrainer):
 
     def _compute_loss(self, x_dict, y):
         if self.in_batch_neg:
-            user_embedding = self.model.user_tower(x_dict)
-            item_embedding = self.model.item_tower(x_dict)
+            if hasattr(self.model, "towers"):  # both towers, their MLPs side by side on two streams (models/matching/dssm.py)
+                user_embedding, item_embedding = self.model.towers(x_dict)
+            else:
+                user_embedding = self.model.user_tower(x_dict)
+                item_embedding = self.model.item_tower(x_dict)
             if user_embedding is None or item_embedding is None:
                 raise ValueError("Model must return user/item embeddings when in_batch_neg is True.")
             if user_embedding.dim() > 2 and user_embedding.size(1) == 1:
