@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def poison_free_device_memory(request):
+    """Before every GPU test: fill what the caching allocator will hand out next with NaN bit patterns, so that a kernel
+    that leaves part of a ``torch.empty`` partial / workspace buffer unwritten produces NaN instead of whatever the
+    previous test left there (found that way: a launch with fewer workgroups than the caller's partial rows)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        junk = [torch.full((64 * 1024,), float("nan"), device="cuda") for _ in range(48)]  # small-block pool (256 KB each)
+        junk.append(torch.full((16 * 1024 * 1024,), float("nan"), device="cuda"))         # large-block pool (64 MB)
+        del junk
+    yield
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -467,7 +467,8 @@ template <int LPR, int MODE, bool HEAD>
 void dice_vec_launch(const DiceArgs& a, hipStream_t s) {
   // MODE 2: the caller sized its partial rows by rh_bn_dice_stats_blocks(N); blocks without rows write zeros
   const int64_t passes = (a.N + RH_WAVE / LPR - 1) / (RH_WAVE / LPR);
-  const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : dice_grid(passes);
+  // MODE 1 likewise: alpha_partial has rh_dice_nblocks(N) entries, every one of them must be written
+  const unsigned grid = MODE == 2 ? dice_grid(a.N, kStatsBlocks) : MODE == 1 ? dice_grid(a.N) : dice_grid(passes);
   const size_t lds = MODE == 2 ? (size_t)kWaves * (HEAD ? 3 : 2) * 4 * LPR * sizeof(float) : 0;
   hipLaunchKernelGGL((dice_vec_kernel<LPR, MODE, HEAD>), dim3(grid), dim3(RH_BLOCK), lds, s, a);
 }
