@@ -1,5 +1,4 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r3g
-run() { tag=$1; shift; env "$@" timeout 300 python bench.py --steps 20 --warmup 10 --no-cpu-baseline --brief 2>gpurun_out/r3g/$tag.err | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step']); print(json.dumps(d.get('gather_kernel_sweep') or d.get('roofline_north_star'))[:1500])" || tail -5 gpurun_out/r3g/$tag.err; }
-run base RECHUB_X=1
-run store RECHUB_TUNE=6=5
+timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "din or dien or bst" 2>&1 | tail -3
+run() { tag=$1; shift; env "$@" timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --brief --no-kernel-sweep "${EXTRA[@]}" 2>gpurun_out/r3g/$tag.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['config']['step_form']['chosen'])" || tail -5 gpurun_out/r3g/$tag.err; }
+EXTRA=(--model din); run din RECHUB_X=1

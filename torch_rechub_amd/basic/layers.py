@@ -210,7 +210,15 @@ class EmbeddingLayer(nn.Module):
         """(B, F*D) rows of row-sharded tables for the local batch (index all-gather, shard gather, reduce-scatter)."""
         return sharding.lookup([self.table_of(f) for f in sparse_feas], [_as_index(x[f.name]) for f in sparse_feas])
 
-    def forward(self, x, features, squeeze_dim=False):
+    def pieces(self, x, features):
+        """The per-feature tensors of ``forward(x, features)`` as a list -- (B, D) per sparse feature, (B, L, D) per
+        concat-pooled sequence feature -- for callers that take the (B, n, ...) result apart again feature by feature
+        (DIN: din.py:40-47).  Saves the concatenation and, in the backward, a zero-filled (B, n, L, D) buffer, a copy and
+        an add per slice."""
+        out = self.forward(x, features, as_list=True)
+        return list(out.unbind(1)) if torch.is_tensor(out) else out
+
+    def forward(self, x, features, squeeze_dim=False, as_list=False):
         table_feas = [f for f in features if isinstance(f, (SparseFeature, SequenceFeature))]
         dense_feas = [f for f in features if not isinstance(f, (SparseFeature, SequenceFeature))]
         for fea in table_feas:
@@ -269,6 +277,8 @@ class EmbeddingLayer(nn.Module):
                 if pooled.shape[-1] != fea.embed_dim:  # PaddedEmbedding: cut the zero padding columns off
                     pooled = pooled[..., :fea.embed_dim]
                 pieces[i] = pooled.unsqueeze(1)
+        if as_list and not squeeze_dim:
+            return [p.squeeze(1) for p in pieces]
         sparse_emb = torch.cat(pieces, dim=1)
         if not squeeze_dim:
             return sparse_emb

@@ -28,18 +28,12 @@ class DIN(nn.Module):
 
     def forward(self, x):
         embed_x_features = self.embedding(x, self.features)  # (B, n_feat, D)
-        embed_x_history = self.embedding(x, self.history_features)  # (B, n_hist, L, D)
-        embed_x_target = self.embedding(x, self.target_features)  # (B, n_tgt, D)
-        pooled = [
-            self.attention_layers[i](embed_x_history[:, i, :, :], embed_x_target[:, i, :]).unsqueeze(1)
-            for i in range(self.num_history_features)
-        ]
-        attention_pooling = torch.cat(pooled, dim=1)
-        mlp_in = torch.cat([
-            attention_pooling.flatten(start_dim=1),
-            embed_x_target.flatten(start_dim=1),
-            embed_x_features.flatten(start_dim=1)
-        ], dim=1)
+        # per-feature tensors instead of the reference's (B, n_hist, L, D) / (B, n_tgt, D) stacks that din.py:40-47 takes
+        # apart again: same values, no concatenation here and no zero-fill + copy + add per slice in the backward
+        hist = self.embedding.pieces(x, self.history_features)  # n_hist x (B, L, D)
+        tgt = self.embedding.pieces(x, self.target_features)  # n_tgt x (B, D)
+        pooled = [self.attention_layers[i](hist[i], tgt[i]) for i in range(self.num_history_features)]
+        mlp_in = torch.cat(pooled + tgt + [embed_x_features.flatten(start_dim=1)], dim=1)
         return torch.sigmoid(self.mlp(mlp_in).squeeze(1))
 
 
