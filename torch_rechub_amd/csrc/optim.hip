@@ -409,37 +409,23 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     __syncthreads();
   }
   const float* ring = REFRESH ? ring_t : a.ring;
-  if (REFRESH && pad >= 0 && pad < rows && bx == 0 && slot == 0) {
-    // The lookups that carry the field's padding_idx are skipped below (a padded history batch would send a hundred
-    // thousand of them to ONE claim word: 221 us instead of 81 for the 204 800 history lookups of configs[4]).  The
-    // padding row itself is still kept exact -- zero or not, dense Adam moves it like every other row -- by this one
-    // lane group per field, once per launch.
-    bool mine = true;
-    if (a.win_mode != 0) {
-      const int64_t wrows = a.ldesc[7 * T + ti];
-      const bool inwin = t >= 2 && (pad / wrows) == (int64_t)((t - 2) % K);
-      mine = (a.win_mode == 2) ? inwin : !inwin;
-    }
-    int old = t;
-    if (mine && q == 0) {
-      old = gload<int>(last + pad);
-      if (old < t) old = atomicMax(last + pad, t);
-    }
-    old = __shfl(old, lane - q, RH_WAVE);
-    if (old < t) {
-      float4 P = gload<float4>(p + pad * D + q * 4), M = gload<float4>(m + pad * D + q * 4), V = gload<float4>(v + pad * D + q * 4);
-      for (int jj = old + 1; jj < t; ++jj) adam_f4_zero_g(P, M, V, h, ring[2 * (jj & a.ring_mask)], ring[2 * (jj & a.ring_mask) + 1]);
-      adam_f4_zero_g(P, M, V, h, h.A, h.E);
-      gstore<float4>(p + pad * D + q * 4, P);
-      gstore<float4>(m + pad * D + q * 4, M);
-      gstore<float4>(v + pad * D + q * 4, V);
-    }
-  }
-  for (int64_t base = b0; base < b1; base += LPP) {  // uniform trip count: the claim is broadcast by shuffle
+  // The lookups that carry the field's padding_idx are skipped below (a padded history batch would send a hundred thousand
+  // of them to ONE claim word: 221 us instead of 81 for the 204 800 history lookups of configs[4]).  The padding row itself
+  // is still kept exact -- zero or not, dense Adam moves it like every other row -- by ONE more pass of the first workgroup
+  // of the field whose only live lookup is that row.  (As a separate block of code with its own replay loop in front of
+  // this loop it cost the pass 26 -> 48 us in the DeepFM step, where no field has a padding row at all.)
+  const bool pad_pass = REFRESH && pad >= 0 && pad < rows && bx == 0;  // block-uniform
+  const int64_t b_end = b1 + (pad_pass ? LPP : 0);
+  for (int64_t base = b0; base < b_end; base += LPP) {  // uniform trip count: the claim is broadcast by shuffle
+    const bool extra = base >= b1;
     const int64_t b = base + slot;
-    const bool ok = b < b1;
-    const int64_t r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
+    const bool ok = !extra && b < b1;
+    int64_t r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
     bool valid = ok && (uint64_t)r < (uint64_t)rows && r != pad;
+    if (extra) {
+      r = pad;
+      valid = slot == 0;
+    }
     if (REFRESH && a.win_mode != 0 && valid) {
       const int64_t wrows = a.ldesc[7 * T + ti];
       const bool inwin = t >= 2 && (r / wrows) == (int64_t)((t - 2) % K);
