@@ -458,6 +458,9 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       if (q == 0) s_key[slot] = lag;
       __syncthreads();
       int rank = 0;
+      // (unrolled by 4, not completely: with all 64 keys of a pass preloaded the LPR = 4 kernel took 110 VGPRs = 4 wavefronts
+      // per SIMD, and the 6.5 wavefronts per SIMD of the DeepFM launch ran as two rounds of a latency-bound replay)
+#pragma unroll 4
       for (int j = 0; j < LPP; ++j) {
         const int kj = s_key[j];
         rank += (kj > lag || (kj == lag && j < slot)) ? 1 : 0;
