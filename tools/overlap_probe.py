@@ -64,7 +64,7 @@ def main():
         with torch.cuda.graph(gph, stream=sa):
             fwd_bwd()
     tables = [torch.nn.Parameter(torch.randn(v, 16, device=dev, generator=g) * 1e-2) for v in CRITEO_VOCABS]
-    lazy = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5, lazy_k=32)
+    lazy = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5, lazy_k=64)
     lazy.sync_hyper()
     if a.grid:
         _lib.call("rh_set_tuning", 2, a.grid)
