@@ -400,3 +400,28 @@ def test_torch_library_ops_trace_under_fake_tensors():
         torch.ops.rechub_hip.fm(torch.zeros(2, 3, 4), True)
     schema = str(torch.ops.rechub_hip.cross_network.default._schema)
     assert schema.startswith("rechub_hip::cross_network(Tensor x, Tensor W, Tensor b) -> Tensor")
+
+
+def test_mlp_head_after_finds_only_a_lone_output_layer_behind_inactive_dropouts(monkeypatch):
+    """MLP.head_after (the host-side pattern match for BatchNorm1d -> Dice -> Linear(C, 1), ops.bn_dice_head): the output
+    Linear(width, 1) is taken only when nothing but inactive Dropouts stand between the Dice and it and it ends the stack."""
+    import torch
+    from torch_rechub_amd.basic.layers import MLP
+    mlp = MLP(64, dims=[32, 16], activation="dice")  # reference default dropout = 0 (layers.py:269)
+    mods = list(mlp.mlp)
+    assert [type(m).__name__ for m in mods] == ["Linear", "BatchNorm1d", "Dice", "Dropout"] * 2 + ["Linear"]
+    assert MLP.head_after(mods, 7, 16, mods[5], mods[6]) is mods[8]   # behind the LAST hidden block
+    assert MLP.head_after(mods, 3, 32, mods[1], mods[2]) is None      # another hidden block follows the first
+    assert MLP.head_after(mods, 7, 32, mods[5], mods[6]) is None      # width of the producer does not match
+    active = list(MLP(64, dims=[16], activation="dice", dropout=0.5).mlp)
+    assert MLP.head_after(active, 3, 16, active[1], active[2]) is None   # training-mode dropout with p > 0 stays a kernel
+    for m in active:
+        m.eval()
+    assert MLP.head_after(active, 3, 16, active[1], active[2]) is active[4]
+    no_out = list(MLP(64, output_layer=False, dims=[16], activation="dice").mlp)
+    assert MLP.head_after(no_out, 3, 16, no_out[1], no_out[2]) is None
+    wide = list(MLP(64, dims=[16], activation="dice").mlp)
+    wide[-1] = torch.nn.Linear(16, 2)
+    assert MLP.head_after(wide, 3, 16, wide[1], wide[2]) is None
+    monkeypatch.setenv("RECHUB_DICE_HEAD", "0")
+    assert MLP.head_after(mods, 7, 16, mods[5], mods[6]) is None
