@@ -306,6 +306,7 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
         epochs = 3
     else:
         monkeypatch.setenv("RECHUB_SWEEP_OVERLAP", overlap)
+    epochs = int(os.environ.get("RECHUB_SOAK_EPOCHS", epochs))  # soak runs: thousands of replayed steps, same bits demanded
     kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, device="cuda:0", show_progress=False, use_graph=True)
     ma, names, dnames = build()
     mb, _, _ = build()
@@ -430,17 +431,18 @@ def test_graph_mode_flush_leaves_no_row_behind_match_trainer(monkeypatch):
               optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, use_graph=True)
     ma, mb = build(), build()
     mb.load_state_dict(ma.state_dict())
+    epochs = int(os.environ.get("RECHUB_SOAK_EPOCHS", 2))  # soak runs: thousands of replayed steps, same bits demanded
     results = []
     for m, extra in ((ma, dict(table_update="lazy", lazy_k=4, lazy_small_rows=8)), (mb, dict(table_update="dense"))):
         ops._sample_rng.clear()  # both twins draw the same negatives: same seed, call counter from 0
         t = MatchTrainer(m, **extra, **kw)
         dl = DeviceDataLoader(sparse.to(dev()), ["user_id", "item_id", ("hist_item_id", L)], None, [], label.to(dev()), B,
                               shuffle=False)
-        results.append((t, [t.train_one_epoch(dl) for _ in range(2)]))
+        results.append((t, [t.train_one_epoch(dl) for _ in range(epochs)]))
         assert t._graph is not None
     (ta, la), (tb, lb) = results
     assert la == lb
-    assert _assert_no_row_behind(ta) == 2 * nb
+    assert _assert_no_row_behind(ta) == epochs * nb
     sa, sb = ma.state_dict(), mb.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
