@@ -339,26 +339,12 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     // (one exec mask) and the step counter is scalar.  The per-iteration form (`if (j >= first)` inside one loop) cost
     // ~22 of 158 cycles per iteration in v_cmp / s_and_saveexec / s_or exec / counter VALU ops.
     int j = wave_min_uniform(first);
-    // (Known loss: the first use of the row's values below waits with s_waitcnt vmcnt(0), i.e. also for the loads of the
-    // NEXT unit issued just before -- the waitcnt pass gives up across fetch()'s control flow -- so a unit costs one memory
-    // latency + its replay instead of the larger of the two; other wavefronts cover it at 4 per SIMD, partly at 2.)
     while (j < t) {  // wavefront-uniform
       const int nxt = wave_min_uniform(first > j ? first : t);  // the next joining step, > j
       if (first <= j) {
-        // two steps per iteration, both ring entries read (LDS) before the first step's arithmetic: at the 2 wavefronts per
-        // SIMD of the deferred form the read's latency is otherwise exposed once per replayed step (deferred sweep alone at
-        // 512 workgroups: 188 -> 172 us; at 8192: 152 -> 147 us; same operations in the same order)
-        int jj = j;
-        for (; jj + 2 <= nxt; jj += 2) {
-          const float2 ae0 = *reinterpret_cast<const float2*>(ring_s + 2 * (jj & a.ring_mask));
-          const float2 ae1 = *reinterpret_cast<const float2*>(ring_s + 2 * ((jj + 1) & a.ring_mask));
-          __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the second read to its use)
-          adam_f4_zero_g(u.P, u.M, u.V, h, ae0.x, ae0.y);
-          adam_f4_zero_g(u.P, u.M, u.V, h, ae1.x, ae1.y);
-        }
-        if (jj < nxt) {
-          const float2 ae = *reinterpret_cast<const float2*>(ring_s + 2 * (jj & a.ring_mask));
-          adam_f4_zero_g(u.P, u.M, u.V, h, ae.x, ae.y);
+        for (int jj = j; jj < nxt; ++jj) {
+          const float A = ring_s[2 * (jj & a.ring_mask)], E = ring_s[2 * (jj & a.ring_mask) + 1];
+          adam_f4_zero_g(u.P, u.M, u.V, h, A, E);
         }
       }
       j = nxt;
