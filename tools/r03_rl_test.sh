@@ -1,4 +1,4 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/r3g
-ROOT=$PWD
-(cd /tmp && rm -rf /tmp/tl_new && cd $ROOT && RECHUB_OWN_GEMM=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_new -o t -- python bench.py --trace-inner --steps 30 --warmup 10 > /dev/null 2> $ROOT/gpurun_out/r3g/tl_new.err)
-python tools/timeline.py /tmp/tl_new 1 | cut -c1-120
+run() { tag=$1; shift; env "$@" timeout 200 python bench.py --steps 300 --warmup 10 --no-cpu-baseline --brief --no-kernel-sweep "${EXTRA[@]}" 2>gpurun_out/r3g/$tag.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['config']['step_form']['chosen'])" || tail -5 gpurun_out/r3g/$tag.err; }
+EXTRA=(--model dssm); run dssm X=1; run dssm X=1
+EXTRA=(); run deepfm X=1
