@@ -2,6 +2,7 @@
 """bench.py — CTR train samples/sec, DeepFM on Criteo-shape synthetic data, N x MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -82,7 +83,50 @@ def parse():
                     help="cpu_baseline: full = SURVEY 8(d)'s 3 warm-up + 10 timed steps per leg (~90 s at the Criteo shape); "
                          "bounded = about --cpu-budget seconds of steps; auto = full unless a step is too slow on this host")
     ap.add_argument("--trace-inner", action="store_true", help=argparse.SUPPRESS)  # child of the step_accounting pass
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="exercise ONLY the rank launcher + rendezvous on CPU (gloo): every rank joins the group, one "
+                         "all-reduce, rank 0 prints a JSON line with n_gpus = N and dry_run = true (tests/test_host_logic.py)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks here (one process per GPU,
+    replacement of the reference's single-process nn.DataParallel, trainers/ctr_trainer.py:53-55) by re-executing this
+    file under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 and a free port.  The
+    children's stdout (rank 0's ONE JSON line) is this process's stdout; the exit code is theirs.  Fewer than N visible
+    devices is an error, never a silent one-rank measurement."""
+    import socket
+    import subprocess
+    if not args.launch_dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"[bench] --gpus {args.gpus} but only {have} HIP device(s) are visible: refusing to measure fewer "
+                     "ranks than asked for")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a torchrun environment: launching {args.gpus} ranks: {' '.join(cmd)}",
+          file=sys.stderr)
+    sys.stdout.flush()
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def launch_dry_run(args, world, rank, result_fd):
+    """The launcher path on CPU: gloo rendezvous of the ranks `self_launch` (or torchrun) started, one all-reduce."""
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    assert t.item() == world * (world + 1) / 2, (t.item(), world)
+    if rank == 0:
+        os.write(result_fd, (json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": 0, "gloo_ranks": dist.get_world_size(),
+                                         "gpus_asked": args.gpus, "steps": args.steps, "warmup": args.warmup}) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def criteo_columns(rows, vocabs, device, seed, dist_kind):
@@ -787,6 +831,8 @@ def trace_inner(args, device, rank):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     # stdout carries exactly ONE line, the result JSON: RCCL / the runtime print banners on fd 1 (seen: "RCCL version :
     # ..." after the collectives), so everything else is sent to stderr for the lifetime of the process.
     sys.stdout.flush()
@@ -795,6 +841,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a "
+                 "line whose n_gpus differs from what was asked for")
+    if args.launch_dry_run:
+        launch_dry_run(args, world, rank, result_fd)
+        return
+    if world > 1 and torch.cuda.device_count() < world:
+        sys.exit(f"[bench] WORLD_SIZE={world} but only {torch.cuda.device_count()} HIP device(s) are visible")
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -803,8 +857,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     if args.force_dp:
         os.environ["RECHUB_FORCE_DP"] = "1"
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
@@ -1099,6 +1151,8 @@ def main():
                     "flush_ms": v["flush_ms"], "comm_us_per_step": v.get("comm_us_per_step")}
                 for k, v in results.items()}
             line["scaling_modes"]["headline"] = best
+            line["rccl_ranks"] = dist.get_world_size()
+            line["comm_us_per_step"] = head.get("comm_us_per_step")
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()

@@ -98,3 +98,42 @@ def test_world2_gradients_equal_global_batch(tmp_path):
     b = O.embedding_backward(shapes, torch.cat(idxs).numpy(), torch.cat(rows).numpy().astype(np.float64))
     for ga, gb in zip(a, b):
         np.testing.assert_array_equal(ga, gb)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_dry_run_on_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks by itself (round-3 verdict: it ran ONE
+    rank and printed n_gpus = 1).  The launcher + rendezvous path is exercised on CPU with gloo; stdout is exactly one
+    JSON line from rank 0 with n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--launch-dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gloo_ranks"] == 2 and line["dry_run"] is True
+    assert "launching 2 ranks" in r.stderr
+
+
+def test_bench_refuses_to_measure_fewer_ranks_than_asked_for():
+    """Without enough visible devices `--gpus N` is an error, not a one-rank line (no GPU in the CPU container: 0 < 2);
+    a torchrun environment whose WORLD_SIZE differs from --gpus is refused too."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "refusing to measure fewer" in r.stderr and r.stdout.strip() == ""
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--launch-dry-run"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
