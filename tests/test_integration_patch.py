@@ -130,3 +130,115 @@ def test_unmodified_reference_deepfm_runs_numerically_on_the_hip_layers(patched)
     name = next(k for k in ref if "embed_dict" in k)
     got = model.state_dict()[name].cpu().numpy()
     assert np.abs(got - ref[name].numpy()).max() < 3e-4 + 1e-3 * np.abs(ref[name].numpy()).max()
+
+
+def _reference_features(RF, spec_json):
+    """Feature objects of the (patched) reference module from a fixture's json spec, shared by name (Q2)."""
+    import json
+    spec, made, groups = json.loads(str(spec_json)), {}, {}
+    for gname, feas in spec.items():
+        lst = []
+        for d in feas:
+            key = (d["kind"], d["name"])
+            if key not in made:
+                if d["kind"] == "DenseFeature":
+                    made[key] = RF.DenseFeature(d["name"])
+                elif d["kind"] == "SparseFeature":
+                    made[key] = RF.SparseFeature(d["name"], vocab_size=d["vocab_size"], embed_dim=d["embed_dim"],
+                                                 shared_with=d["shared_with"], padding_idx=d["padding_idx"])
+                else:
+                    made[key] = RF.SequenceFeature(d["name"], vocab_size=d["vocab_size"], embed_dim=d["embed_dim"],
+                                                   pooling=d["pooling"], shared_with=d["shared_with"],
+                                                   padding_idx=d["padding_idx"])
+            lst.append(made[key])
+        groups[gname] = lst
+    return groups
+
+
+def _unmodified_reference_model(cfg, groups):
+    """The reference's OWN model classes (their source untouched; enable(models=False) only rebinds the layer names they
+    import), built with the constructor calls of oracle/gen_golden.py::build_model."""
+    import torch_rechub.models.ranking.dcn as ref_dcn
+    import torch_rechub.models.ranking.dcn_v2 as ref_dcn_v2
+    import torch_rechub.models.ranking.din as ref_din
+    from torch_rechub_amd.models.ranking import DCN, DIN, DCNv2
+    mlp = {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}
+    if cfg.startswith("din"):
+        from conftest import DIN_ATTENTION_DIMS
+        assert ref_din.DIN is not DIN
+        return ref_din.DIN(groups["features"], groups["history_features"], groups["target_features"],
+                           mlp_params={"dims": [32, 16], "dropout": 0.0},
+                           attention_mlp_params={"dims": DIN_ATTENTION_DIMS.get(cfg, [16, 8]),
+                                                 "use_softmax": cfg.endswith("softmax")})
+    if cfg == "dcn":
+        assert ref_dcn.DCN is not DCN
+        return ref_dcn.DCN(groups["features"], 3, {"dims": [32, 16]})
+    if cfg == "dcnv2_mix":
+        assert ref_dcn_v2.DCNv2 is not DCNv2
+        return ref_dcn_v2.DCNv2(groups["features"], 3, mlp, low_rank=8, num_experts=3)
+    if cfg == "dcnv2_full_stacked":
+        return ref_dcn_v2.DCNv2(groups["features"], 2, mlp, model_structure="stacked", use_low_rank_mixture=False)
+    raise ValueError(cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["din", "din_wide", "din_softmax", "dcn", "dcnv2_mix", "dcnv2_full_stacked"])
+def test_unmodified_reference_din_dcn_dcnv2_run_numerically_on_the_hip_layers(patched, cfg):
+    """Same as the DeepFM run above for the UNMODIFIED reference DIN (its own ``ActivationUnit`` composed of the patched
+    ``MLP`` / ``Dice``, models/ranking/din.py:38-92), DCN (models/ranking/dcn.py:32-38) and DCNv2
+    (models/ranking/dcn_v2.py:47-59, CrossNetMix / CrossNetV2 from the patched layers): predictions (eval + train), loss,
+    every gradient against the reference's CPU vectors, then three steps of the reference's own CTRTrainer."""
+    import numpy as np
+    import torch_rechub.basic.features as RF
+    import torch_rechub.trainers as RT
+    from conftest import golden_batch, golden_state, load_golden
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic import layers as H
+    gold = load_golden(f"model_{cfg}.npz")
+    patched.enable(models=False, trainers=False)
+    model = _unmodified_reference_model(cfg, _reference_features(RF, gold["spec"]))
+    assert type(model.embedding) is H.EmbeddingLayer
+    model.load_state_dict(golden_state(gold, "sd0."))
+    model = model.to("cuda:0")
+    x, y = golden_batch(gold, 0)
+    xd = {k: v.to("cuda:0") for k, v in x.items()}
+    model.eval()
+    with torch.no_grad():
+        pe = model(xd)
+    np.testing.assert_allclose(pe.cpu().numpy(), gold["pred_eval"], rtol=1e-5, atol=2e-6)
+    model.train()
+    pred = model(xd)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), gold["pred_train"], rtol=1e-5, atol=2e-6)
+    loss = torch.nn.BCELoss()(pred, y.to("cuda:0").float())
+    assert abs(loss.item() - float(gold["loss"])) < 2e-6
+    loss.backward()
+    ops.check_errors()
+    gmax = max(float(np.abs(gold["grad." + n]).max()) for n, _ in model.named_parameters())
+    noise = set()
+    for mn, m in model.named_modules():
+        if isinstance(m, torch.nn.Sequential):
+            mods = list(m)
+            noise |= {f"{mn}.{i}.bias" for i in range(len(mods) - 1)
+                      if isinstance(mods[i], torch.nn.Linear) and isinstance(mods[i + 1], torch.nn.BatchNorm1d)}
+    for n, p_ in model.named_parameters():
+        ref = gold["grad." + n]
+        got = p_.grad.detach().cpu().numpy() if p_.grad is not None else np.zeros_like(ref)
+        if n in noise:
+            assert np.abs(got).max() <= 1e-5 * max(gmax, 1e-3) + 1e-6, n
+            continue
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * gmax, err_msg=f"{cfg}: grad of {n}")
+    model.load_state_dict(golden_state(gold, "sd0."))
+    model.zero_grad()
+    trainer = RT.CTRTrainer(model, optimizer_params={"lr": float(gold["train.lr"]), "weight_decay": float(gold["train.wd"])},
+                            n_epoch=1, device="cuda:0")
+    nb = sum(1 for k in gold.files if k.startswith("y") and k[1:].isdigit())
+    mean_loss = trainer.train_one_epoch([golden_batch(gold, i) for i in range(nb)])
+    assert abs(mean_loss - float(gold["train.mean_loss"])) < 5e-5
+    ref = golden_state(gold, "sd3.")
+    sd = model.state_dict()
+    for name in ref:
+        if not ref[name].dtype.is_floating_point:
+            continue
+        got, want = sd[name].cpu().numpy(), ref[name].numpy()
+        close = np.abs(got - want) <= 3e-4 + 1e-3 * np.abs(want)
+        assert close.mean() >= 0.995, f"{cfg}: {name}: {100 * (1 - close.mean()):.2f} % of elements off the reference trajectory"
