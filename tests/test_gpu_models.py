@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import AUX_LOSS_CONFIGS, DIN_ATTENTION_DIMS, MODEL_CONFIGS, MTL_CONFIGS, build_amd_model, build_mtl_model, features_from_spec, golden_batch, golden_state, load_golden
+from conftest import (AUX_LOSS_CONFIGS, DIN_ATTENTION_DIMS, MODEL_CONFIGS, MTL_CONFIGS, assert_state_follows_reference_trajectory,
+                      assert_trajectory_close, build_amd_model, build_mtl_model, features_from_spec, golden_batch, golden_state, load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -22,16 +23,6 @@ def dev():
 
 def to_dev(x):
     return {k: v.to(dev()) for k, v in x.items()}
-
-
-def assert_trajectory_close(got, want, travel, what, atol=3e-4, rtol=1e-3, outlier_frac=5e-3):
-    """Adam divides by sqrt(v): an element whose gradient nearly cancels amplifies fp32 summation-order noise, so a
-    handful of elements may drift by a fraction of lr per step.  >= 99.5 % of the elements must agree to atol/rtol
-    and every element to within a quarter of the distance Adam can travel in these steps."""
-    diff = np.abs(got - want)
-    bad = diff > atol + rtol * np.abs(want)
-    assert bad.mean() <= outlier_frac, f"{what}: {bad.sum()} / {bad.size} elements off (max {diff.max():.3e})"
-    assert diff.max() <= 0.25 * travel + atol, f"{what}: max diff {diff.max():.3e}"
 
 
 def load_model(cfg):
@@ -122,32 +113,8 @@ def test_three_step_training_matches_reference_trainer(cfg, mode, monkeypatch):
     assert abs(mean_loss - float(gold["train.mean_loss"])) < 5e-5
     if cfg in DIN_ATTENTION_DIMS:
         assert len(fused_calls) >= 6, f"{cfg}: fused first attention layer ran {len(fused_calls)} times in 3 steps"
-    ref = golden_state(gold, "sd3.")
     mine = model.state_dict()
-    gmax = max(float(np.abs(gold[k]).max()) for k in gold.files if k.startswith("grad."))
-    lr, steps = float(gold["train.lr"]), 3
-    for k, v in ref.items():
-        got = mine[k].detach().cpu().numpy()
-        if k.endswith("num_batches_tracked"):
-            assert int(got) == int(v)
-            continue
-        if "grad." + k in gold.files and float(np.abs(gold["grad." + k]).max()) < 1e-5 * gmax:
-            # gradient is pure rounding noise (e.g. a bias in front of BatchNorm): Adam turns the SIGN of that noise
-            # into +-lr steps, so the trajectory of this tensor is not defined by the model; only bound it
-            assert np.abs(got - v.numpy()).max() <= 2.1 * lr * steps, k
-            continue
-        if k.endswith("running_mean"):
-            # the batch mean of (W x + b) carries the noise-driven drift of the bias b above one-for-one
-            assert np.abs(got - v.numpy()).max() <= 0.5 * lr * steps, k
-            continue
-        want = v.numpy()
-        if k.endswith("self_attn.in_proj_bias"):
-            # the KEY bias shifts every score of a softmax row by the same q . b: its gradient is zero mathematically and
-            # rounding noise in practice, which Adam turns into +-lr steps; only the query / value thirds are defined
-            d = got.shape[0] // 3
-            assert np.abs(got[d:2 * d] - want[d:2 * d]).max() <= 2.1 * lr * steps, k
-            got, want = np.delete(got, np.s_[d:2 * d]), np.delete(want, np.s_[d:2 * d])
-        assert_trajectory_close(got, want, lr * steps, f"{cfg}: {k} after 3 steps")
+    ref = assert_state_follows_reference_trajectory(gold, mine, cfg)
     # rows never touched by the three batches still moved (dense Adam + coupled L2)
     name = next(k for k in ref if "embed_dict" in k)
     before = gold["sd0." + name]
