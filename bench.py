@@ -420,37 +420,16 @@ def gather_sweep(model, wl, device, batches=(4096, 16384, 65536), rounds=8):
                       ops._p(emb), emb.stride(0), ops._p(s_sum), ops._p(g_fm), ops._p(g_lr), ops._p(w), ops._p(partial),
                       1.0, 0, ops._p(None), c[0].samples_per_block, ops._p(err), ops._stream())
 
-        # row-list form of the backward (what the single-GPU trainer step runs, ops.RowList): the tables the optimizer
-        # steps lazily (> 4096 rows) take per-lookup rows + duplicate chains, the small ones the dense buffers.  Every timed
-        # launch gets its own all-zero hash (in the step the next forward's refresh pass empties it).
-        from torch_rechub_amd.ops import RowList
-        rl_field = [(j + 1 if int(w_.shape[0]) > 4096 else 0) for j, w_ in enumerate(c0.weights)]
-        rls = [RowList(B, F, D, rl_field, device) for _ in range(rounds * nsets)] if B * F < (1 << 21) else []
-        rl_iter = [0]
-
-        def bwd_rows(c):
-            rl = rls[rl_iter[0] % len(rls)]
-            rl_iter[0] += 1
-            _lib.call("rh_embed_bwd_rows", ops._p(c[2]), ops._p(c[3]), c[0].idx_is_i64, B, F, D, ops._p(g_out), g_out.stride(0),
-                      ops._p(emb), emb.stride(0), ops._p(s_sum), ops._p(g_fm), ops._p(g_lr), ops._p(w), ops._p(partial),
-                      1.0, *rl.args(), c[0].samples_per_block, ops._p(err), ops._stream())
-
         for w_ in c0.weights:  # the table-gradient buffers the backward scatters into
             ops.grad_buffer(w_)
         ent = {}
         side = torch.cuda.Stream(device=device)
         variants = [("rh_embed_fwd", fwd, FWD_BYTES_PER_SAMPLE), ("rh_embed_bwd", bwd, BWD_BYTES_PER_SAMPLE)]
-        if rls:
-            variants.append(("rh_embed_bwd_rows", bwd_rows, BWD_BYTES_PER_SAMPLE))
         for name, fn, nbytes in variants:
             with torch.cuda.stream(side):
                 for c in calls:
                     fn(c)
                 side.synchronize()
-                if name == "rh_embed_bwd_rows":
-                    for rl in rls:
-                        rl.hash.zero_()
-                    rl_iter[0] = 0
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):
                     for _ in range(rounds):
@@ -460,10 +439,6 @@ def gather_sweep(model, wl, device, batches=(4096, 16384, 65536), rounds=8):
                 side.synchronize()
                 best = None
                 for _ in range(3):
-                    if name == "rh_embed_bwd_rows":
-                        for rl in rls:
-                            rl.hash.zero_()  # outside the timed region: every launch starts from an empty hash
-                        side.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(side)
                     graph.replay()
@@ -503,17 +478,7 @@ def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     flush (timed separately) and the no-row-behind check.  Returns a dict."""
     from torch_rechub_amd import ops
     model, trainer, loader = wl.build(placement, use_graph, batch=args.batch)
-    ms = trainer.main_stream() if use_graph else None  # RECHUB_MAIN_CUS: the replayed steps on their share of the CUs
-    outer = torch.cuda.current_stream()
-    if ms is not None:
-        ms.wait_stream(outer)
-        torch.cuda.set_stream(ms)
-    try:
-        return _run_mode(args, wl, placement, use_graph, world, rank, device, profile, model, trainer, loader)
-    finally:
-        if ms is not None:
-            torch.cuda.synchronize()
-            torch.cuda.set_stream(outer)
+    return _run_mode(args, wl, placement, use_graph, world, rank, device, profile, model, trainer, loader)
 
 
 def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, model, trainer, loader):

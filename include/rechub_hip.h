@@ -53,8 +53,7 @@ const char* rh_last_error(void);
 /* tuning knobs (process-wide; defaults are the measured winners) */
 #define RH_TUNE_WIDE_ATOMICS 1 /* 1: table-gradient atomics carry whole rows per request (default), 0: 16 B pieces */
 #define RH_TUNE_SWEEP_GRID 2   /* workgroups of rh_adam_lazy_sweep (0 = default 8192) */
-#define RH_TUNE_SWEEP_LDS_PAD 3 /* extra LDS bytes per workgroup of a DEFERRED sweep (rh_adam_lazy_sweep with t_value >= 0; <= 150
-                                  KiB, -1 = default 0): one way of capping its residency beside the step's launch chain */
+/* key 3 (an LDS-padding residency cap of the deferred sweep) was measured in round 3 and removed: rh_set_tuning(3, .) fails */
 #define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
                                   the residency cap that lets the step's chain keep its wave slots and issue cycles */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
@@ -65,26 +64,6 @@ const char* rh_last_error(void);
 #define RH_TUNE_FWD_PATH 7      /* rh_embed_fwd: 0 auto (by batch size), 1 lane-split kernel only, 2 field-uniform kernel only */
 #define RH_TUNE_BWD_PATH 6      /* rh_embed_bwd experiments: 0 auto, 1 global atomics for every table, 3 no sink */
 int rh_set_tuning(int key, int value);
-
-/* ---------------------------------------------------------------------------------------------
- * Streams with a compute-unit mask (hipExtStreamCreateWithCUMask) and external events, for running the optimizer's
- * window sweep BESIDE the step's launch chain on its own share of the 256 CUs (torch_rechub_amd/optim.py; the
- * reference's optimizer.step() is one serial call, trainers/ctr_trainer.py:99).
- * rh_stream_create_cumask: *out = a new HIP stream restricted to the first `cus_per_xcd` CUs (1..32) of every XCD
- *   (MI355X: mask bit i = XCD i % 8, CU i / 8 -- measured, tools/probe/cumask_probe.cpp; a mask that empties an XCD is
- *   ignored by the runtime); `from_top` != 0 takes the LAST cus_per_xcd CUs of every XCD instead.
- * rh_stream_destroy: releases it.  Events: plain hipEvent handles as void*; rh_event_record / rh_stream_wait_event with
- *   external != 0 use hipEventRecordExternal / hipEventWaitExternal, i.e. inside a stream capture they become event
- *   nodes of the graph that synchronise with work OUTSIDE it on every replay. */
-int rh_stream_create_cumask(int cus_per_xcd, int from_top, void** out);
-/* *out = a new non-blocking HIP stream of the given priority (hipStreamCreateWithPriority: lower number = higher priority,
- * clamped by the runtime to the device's range). */
-int rh_stream_create_priority(int priority, void** out);
-int rh_stream_destroy(void* stream);
-int rh_event_create(void** out);
-int rh_event_destroy(void* event);
-int rh_event_record(void* event, void* stream, int external);
-int rh_stream_wait_event(void* stream, void* event, int external);
 
 /* ---------------------------------------------------------------------------------------------
  * K1+K2+K3  fused multi-field gather + FM second order + LR first order (+ dense concat)
@@ -136,22 +115,6 @@ int rh_embed_bwd_nchunks(int B, int samples_per_block);
 int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F,
                           int D, const float* rows, float scale, int samples_per_block,
                           int32_t* err_flag, void* stream);
-/* Row-list form of the table gradient (the single-GPU fused step; the reference's loss.backward() + optimizer.step(),
- * trainers/ctr_trainer.py:97-99, never needs the vocab-sized .grad tensor in between): rh_embed_bwd with the gradient rows
- * of the flagged fields written where they are produced -- rl_rows (B * F, D), coalesced plain stores -- and the lookups
- * that hit the same table row linked into a chain (rl_next (B * F) int32: next lookup of the row, -1 end, -2 dead lookup)
- * through an open-addressing hash rl_hash (rl_slots uint64, a power of two >= 2 * B * F, all zero on entry; slot = key
- * 34 bits | chain head 21 bits).  rl_field (F, device int64): 0 = the field keeps the dense gradient buffer of its fdesc
- * entry (small / densely stepped tables: LDS pre-reduction or atomics as in rh_embed_bwd), t + 1 = row list for table t.
- * The chain head owns the row's update: rh_adam_lazy_touched_rows / rh_adam_lazy_step_rows sum the chain and apply ONE
- * Adam step; the next forward's pre-gather pass (rh_adam_lazy_touched_rows, refresh = 1) empties the hash.
- * No memory-side read-modify-write into a vocab-sized buffer, no re-read / re-zero of gradient rows by the optimizer.
- * Limits: B * F < 2^21 lookups, rows per row-list table < 2^27; indices and upstream gradients as rh_embed_bwd. */
-int rh_embed_bwd_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F, int D, const float* g_out,
-                      int64_t g_stride, const float* emb, int64_t emb_stride, const float* s_sum, const float* g_fm,
-                      const float* g_lr, const float* lr_w, float* lr_wgrad, float scale, float* rl_rows, int32_t* rl_next,
-                      uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, int samples_per_block, int32_t* err_flag,
-                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FM on an arbitrary (B, F, D) tensor (row stride x_stride floats per sample, fields contiguous)
@@ -551,10 +514,7 @@ int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
 /* rh_adam_lazy_touched, refresh argument: 0 = the touched-rows step (rows take their gradient); 1 = pre-gather refresh of
- * every row of the batch; 2 = refresh of the rows OUTSIDE window (t - 2) mod K_t of their table; 3 = refresh of the rows
- * INSIDE it.  2 / 3 serve the pipelined step (torch_rechub_amd/optim.py): the deferred sweep launched one step ago may
- * still be writing exactly that window, so the bulk of the next batch's refresh (2) runs a step early BESIDE it and the
- * few rows it had to leave out (3) follow once that sweep has been joined. */
+ * every row of the batch (no gradient traffic). */
 /* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
  * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
@@ -566,26 +526,8 @@ int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, c
                            const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                            const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
                            void* stream);
-/* Optimizer side of the row-list gradient (rh_embed_bwd_rows; same rl_* arguments): rh_adam_lazy_touched with the chain
- * head of every table row as the owner of its update (refresh = 0), or with the hash emptied for the coming backward
- * (refresh = 1, the pre-gather pass); rh_adam_lazy_step_rows = that touched pass + the sweep of the dense (K = 1) tables in
- * one launch (the lazy tables' window sweep is its own launch: rh_adam_lazy_sweep, RH_SWEEP_LAZY_TABLES). */
-int rh_adam_lazy_touched_rows(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc, int idx_is_i64,
-                              int B, int F, int D, const double* hyper, const float* ring, int ring_size,
-                              int samples_per_block, int refresh, int32_t* err_flag, float* rl_rows, int32_t* rl_next,
-                              uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, void* stream);
-int rh_adam_lazy_step_rows(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, float* rl_rows,
-                           int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots, const int64_t* rl_field, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
-/* The deferred sweep as a BRANCH of a captured hipGraph (torch_rechub_amd/optim.py, form "branch"): rh_snapshot_step copies the
- * current step number hyper[12] into the device word t_step at the fork (the step's scalar launch on the main branch waits
- * for it before it advances hyper[12]); rh_adam_lazy_sweep_at is rh_adam_lazy_sweep with the step taken from that word. */
-int rh_adam_lazy_sweep_at(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                          const double* hyper, const float* ring, int ring_size, int mode, const int64_t* t_step, void* stream);
-int rh_snapshot_step(const double* hyper, int64_t* t_step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident minibatch assembly (columnar dataset already in HBM)

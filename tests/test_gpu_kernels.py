@@ -1708,7 +1708,7 @@ def test_prelu_single_slope_vs_torch(shape):
 def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monkeypatch):
     """Linear -> BatchNorm1d -> ReLU -> Dropout -> Linear(K, 1) + sigmoid head: with the head as the only consumer of the hidden
     layer its backward also emits the BatchNorm-backward column sums (rh_head_bwd_bn + rh_bn_relu_dropout_bwd_pre); every
-    gradient must agree with the separate statistics launch (RECHUB_HEAD_BN=0) -- same mask, same arithmetic per element,
+    gradient must agree with the separate statistics launch (ops.FUSE_HEAD_BN = False) -- same mask, same arithmetic per element,
     only the summation partition differs."""
     from torch_rechub_amd import ops
     from torch_rechub_amd.basic.layers import MLP
@@ -1717,8 +1717,8 @@ def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monk
     gy = torch.randn(B, generator=g).to(dev())
     grads = {}
     rng = dev() if isinstance(dev(), torch.device) else torch.device(dev())
-    for flag in ("1", "0"):
-        monkeypatch.setenv("RECHUB_HEAD_BN", flag)
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "FUSE_HEAD_BN", flag)
         torch.manual_seed(5)
         mlp = MLP(40, output_layer=True, dims=[K], dropout=p, activation="relu").to(dev()).train()
         ops._dropout_rng(rng).copy_(torch.tensor([1234, 0, 0, 0], device=rng))  # same dropout stream for both runs
@@ -1727,7 +1727,7 @@ def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monk
         y.backward(gy)
         grads[flag] = [xi.grad.clone()] + [q.grad.clone() for q in mlp.parameters()]
     torch.cuda.synchronize()
-    for a, b in zip(grads["1"], grads["0"]):
+    for a, b in zip(grads[True], grads[False]):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-4 * float(b.abs().max())
 

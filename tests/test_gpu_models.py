@@ -220,7 +220,7 @@ def _assert_no_row_behind(trainer):
     return t
 
 
-@pytest.mark.parametrize("overlap", ["0", "1", "auto", "branch", "pipelined", "0+rowlist", "1+rowlist"])
+@pytest.mark.parametrize("overlap", ["0", "1", "auto"])
 def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch):
     """Round-1 bug: TableAdam.flush() was driven by a host flag that hipGraph replays never set, so from the second
     epoch on state_dict() / checkpoints held table rows up to K-1 steps behind the dense-Adam semantics of the reference
@@ -252,27 +252,11 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
     # overlap = "auto": nothing pinned -- the trainer's self-tuning alternates between the forms of the step (deferred sweep
     # at two residency caps, in-line sweep: two captured graphs of the same step) over real steps and settles on one
     epochs = 2
-    if overlap.endswith("+rowlist"):
-        # opt-in row-list form of the table gradient (rh_embed_bwd_rows: per-lookup rows + duplicate chains, the chain head
-        # owns the row's update): B = 64 lookups into tables of 65 .. 20000 rows = many duplicate chains; same bits demanded
-        monkeypatch.setenv("RECHUB_ROWLIST", "1")
-        overlap = overlap[0]
     if overlap == "auto":
-        monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
+        monkeypatch.delenv("RECHUB_STEP_FORM", raising=False)
         epochs = 9  # 3 eager + 105 replayed steps: past lazy_k + 8 + 3 candidates x 22 steps of tuning
-    elif overlap == "branch":
-        # the deferred sweep as a captured BRANCH of the step's one graph (device-side step snapshot at the fork)
-        monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
-        monkeypatch.setenv("RECHUB_STEP_FORM", "branch")
-        epochs = 3
-    elif overlap == "pipelined":
-        # one graph segment per step: the next batch assembled + refreshed (except the rows inside the window the sweep in
-        # flight is writing) at the END of the step, those rows after the join; the prologue re-runs at every epoch start
-        monkeypatch.delenv("RECHUB_SWEEP_OVERLAP", raising=False)
-        monkeypatch.setenv("RECHUB_STEP_FORM", "pipelined")
-        epochs = 3
     else:
-        monkeypatch.setenv("RECHUB_SWEEP_OVERLAP", overlap)
+        monkeypatch.setenv("RECHUB_STEP_FORM", {"0": "inline", "1": "deferred"}[overlap])
     epochs = int(os.environ.get("RECHUB_SOAK_EPOCHS", epochs))  # soak runs: thousands of replayed steps, same bits demanded
     kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, device="cuda:0", show_progress=False, use_graph=True)
     ma, names, dnames = build()
@@ -292,12 +276,8 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
         assert ta._tune["active"] is False and ta._tune["chosen"] in ta.TUNE_CANDIDATES
         assert len(ta._tune["ms"]) == len(ta.TUNE_CANDIDATES)
         assert ta._graph_forms  # the other form of the step was captured and replayed too
-    if overlap == "pipelined":
-        assert ta._form == "pipelined" and ta.optimizer.pipelined
-    if overlap == "branch":
-        assert ta._form == ("branch", 512) and ta.optimizer.branch_form
-    if os.environ.get("RECHUB_ROWLIST") == "1":
-        assert ta.optimizer._rl_cache, "the row-list path did not engage"
+    if overlap != "auto":
+        assert ta._form == {"0": "inline", "1": "deferred"}[overlap] and ta.optimizer.overlap_sweep == (overlap == "1")
     steps = _assert_no_row_behind(ta)
     assert steps == epochs * nb
     sa, sb = ma.state_dict(), mb.state_dict()
@@ -369,7 +349,6 @@ def test_graph_mode_flush_leaves_no_row_behind_match_trainer(monkeypatch):
     The twins take the score-matrix form of the in-batch logits: the direct form (ops.inbatch_logits, the default)
     accumulates the item-tower gradient with float atomics, whose order -- hence last bit -- is not fixed, and this test
     isolates the OPTIMIZER's exactness by demanding bit-equal trajectories."""
-    monkeypatch.setenv("RECHUB_INBATCH_DIRECT", "0")
     from torch_rechub_amd import ops
     from torch_rechub_amd.basic.features import SequenceFeature, SparseFeature
     from torch_rechub_amd.models.matching import DSSM
@@ -395,7 +374,7 @@ def test_graph_mode_flush_leaves_no_row_behind_match_trainer(monkeypatch):
         return m
 
     kw = dict(mode=0, in_batch_neg=True, in_batch_neg_ratio=5, sampler_seed=4, device="cuda:0", show_progress=False,
-              optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, use_graph=True)
+              optimizer_params={"lr": 1e-2, "weight_decay": 1e-3}, use_graph=True, deterministic_logits=True)
     ma, mb = build(), build()
     mb.load_state_dict(ma.state_dict())
     epochs = int(os.environ.get("RECHUB_SOAK_EPOCHS", 2))  # soak runs: thousands of replayed steps, same bits demanded
@@ -620,12 +599,12 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
 
 
 def test_dssm_towers_side_by_side_are_the_sequential_towers(monkeypatch):
-    """DSSM.towers with RECHUB_TOWER_BRANCHES=1 (item tower's MLP on a second stream, forward and backward) == the two tower
+    """DSSM.towers with ``model.tower_branches = True`` (item tower's MLP on a second stream, forward and backward) == the two tower
     calls one after the other, bit for bit: same kernels on the same inputs, only their streams differ."""
     got = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RECHUB_TOWER_BRANCHES", flag)
+    for flag in (False, True):
         gold, model = load_model("dssm")
+        model.tower_branches = flag
         xd = to_dev(golden_batch(gold, 0)[0])
         model.train()
         u, v = model.towers(xd)

@@ -423,5 +423,6 @@ def test_mlp_head_after_finds_only_a_lone_output_layer_behind_inactive_dropouts(
     wide = list(MLP(64, dims=[16], activation="dice").mlp)
     wide[-1] = torch.nn.Linear(16, 2)
     assert MLP.head_after(wide, 3, 16, wide[1], wide[2]) is None
-    monkeypatch.setenv("RECHUB_DICE_HEAD", "0")
+    from torch_rechub_amd import ops as _ops
+    monkeypatch.setattr(_ops, "FUSE_DICE_HEAD", False)
     assert MLP.head_after(mods, 7, 16, mods[5], mods[6]) is None

@@ -21,19 +21,10 @@ SIGNATURES = {
     "rh_abi_version": [],
     "rh_last_error": [],
     "rh_set_tuning": [c_int, c_int],
-    "rh_stream_create_cumask": [c_int, c_int, c_ptr],
-    "rh_stream_create_priority": [c_int, c_ptr],
-    "rh_stream_destroy": [c_ptr],
-    "rh_event_create": [c_ptr],
-    "rh_event_destroy": [c_ptr],
-    "rh_event_record": [c_ptr, c_ptr, c_int],
-    "rh_stream_wait_event": [c_ptr, c_ptr, c_int],
     "rh_embed_fwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
                      c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
     "rh_embed_bwd": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
                      c_ptr, c_ptr, c_f32, c_int, c_ptr, c_int, c_ptr, c_ptr],
-    "rh_embed_bwd_rows": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
-                          c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_ptr],
     "rh_embed_bwd_nchunks": [c_int, c_int],
     "rh_embed_scatter_rows": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_f32, c_int, c_ptr, c_ptr],
     "rh_fm_fwd": [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
@@ -134,18 +125,12 @@ SIGNATURES = {
                                c_ptr, c_int, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
-    "rh_adam_lazy_touched_rows": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
-                                  c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
-    "rh_adam_lazy_step_rows": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
-                               c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr],
     "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr],
     "rh_l2norm_fwd": [c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr, c_ptr],
     "rh_l2norm_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr],
     "rh_ce_nblocks": [c_int],
     "rh_ce_fwd": [c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_ce_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
-    "rh_adam_lazy_sweep_at": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
-    "rh_snapshot_step": [c_ptr, c_ptr, c_ptr],
     "rh_adam_dense": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr],
     "rh_batch_gather": [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_batch_advance": [c_ptr, c_i64, c_i64, c_ptr],

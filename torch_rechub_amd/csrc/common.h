@@ -139,60 +139,6 @@ static __device__ __forceinline__ void gatomic_add_f4(float* p, float4 v) {
     unsafeAtomicAdd(&(base)[(off) + 3], (v).w); \
   } while (0)
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Row-list gradients (single-GPU fused step): instead of scatter-adding every lookup's gradient row into a vocab-sized
-// dense buffer (a memory-side read-modify-write per row, re-read and re-zeroed by the optimizer), rh_embed_bwd_rows writes
-// the rows where they are produced -- rows (B*F, D), coalesced, plain stores -- and links the lookups that hit the same
-// table row through a small open-addressing hash (2 slots per lookup: L2 / MALL resident): slot = [key 34 bits | head 21
-// bits], key = (table id + 1) << 27 | row, head = the LAST lookup linked so far; next[lookup] = the head it replaced.
-// After the kernel, the head of a row's chain is its owner: the optimizer's touched pass (rh_adam_lazy_*_rows) lets the
-// owner sum the chain (duplicates are rare for the tables that are lazy: >= ~1e4 rows) and apply ONE Adam step.
-// The pre-gather refresh pass of the next step clears the hash.
-struct RhRowList {
-  float* rows;               // (B * F, D) per-lookup gradient rows; nullptr = feature off
-  int* next;                 // (B * F): next lookup of the same table row, -1 = end of the chain, -2 = dead lookup
-  unsigned long long* hash;  // mask + 1 slots, 0 = empty
-  unsigned int mask;         // slots - 1 (power of two)
-  const int64_t* field;      // (F): 0 = the field's table keeps the dense gradient buffer, t + 1 = row list, table id t
-};
-constexpr int kRlHeadBits = 21;   // B * F < 2^21 lookups per call
-constexpr int kRlRowBits = 27;    // rows per table < 2^27
-static __device__ __forceinline__ unsigned long long rl_key(int64_t field_tag, int64_t row) {
-  return ((unsigned long long)field_tag << kRlRowBits) | (unsigned long long)row;
-}
-static __device__ __forceinline__ unsigned int rl_slot(unsigned long long key, unsigned int mask) {
-  unsigned long long z = key * 0x9E3779B97F4A7C15ull;
-  z ^= z >> 29;
-  return (unsigned int)(z * 0xBF58476D1CE4E5B9ull >> 40) & mask;
-}
-// link lookup `id` into the chain of `key`; returns the previous head (-1: first lookup of this row)
-static __device__ __forceinline__ int rl_link(const RhRowList& rl, unsigned long long key, unsigned int id) {
-  unsigned int h = rl_slot(key, rl.mask);
-  const unsigned long long mine = (key << kRlHeadBits) | id;
-  for (;;) {
-    unsigned long long w = __hip_atomic_load(rl.hash + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w == 0ull) {
-      if (atomicCAS(rl.hash + h, 0ull, mine) == 0ull) return -1;
-      continue;  // someone took the slot: look at it again
-    }
-    if ((w >> kRlHeadBits) == key) {
-      if (atomicCAS(rl.hash + h, w, mine) == w) return (int)(w & ((1u << kRlHeadBits) - 1));
-      continue;
-    }
-    h = (h + 1) & rl.mask;
-  }
-}
-// head of the chain of `key`, -1 when the key is not in the table
-static __device__ __forceinline__ int rl_head(const RhRowList& rl, unsigned long long key) {
-  unsigned int h = rl_slot(key, rl.mask);
-  for (;;) {
-    const unsigned long long w = gload<unsigned long long>(rl.hash + h);
-    if (w == 0ull) return -1;
-    if ((w >> kRlHeadBits) == key) return (int)(w & ((1u << kRlHeadBits) - 1));
-    h = (h + 1) & rl.mask;
-  }
-}
-
 // Counter-based dropout hash of csrc/mlp.hip (seed, call counter, element index) -> 32 random bits; shared with the head
 // backward of csrc/linear.hip, which forms the BatchNorm-backward column sums of the layer below from the same mask.
 static __device__ __forceinline__ uint32_t rh_drop_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {

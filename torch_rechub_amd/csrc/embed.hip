@@ -391,15 +391,14 @@ struct EmbedBwdArgs {
   int path;  // experiment knob: 0 auto, 1 global atomics for every table, 3 no sink, 4 chunk-fastest block order
   int nchunks8;  // sample chunks rounded up to a multiple of 8
   int* err;
-  RhRowList rl;  // SINK 2: per-lookup gradient rows + duplicate chains for the fields flagged in rl.field
 };
 
 constexpr int kSweeps = 2;  // phase-B sweeps of the small-table path: covers kSweeps * 4 * (64 / D) rows (32 at D = 16)
 
 // grid = (sample chunks, fields).  SRC 0: compute the gradient row from the upstream gradients,
-// 1: read it from rows_in.  SINK 0: scatter-add into the table gradient, 1: write to rows_out, 2: per field -- row list
-// (a.rl: plain coalesced store of the row + a link into the chain of its table row, common.h) for the fields flagged in
-// a.rl.field, the SINK 0 paths for the others (the small / densely stepped tables).
+// 1: read it from rows_in.  SINK 0: scatter-add into the table gradient, 1: write to rows_out.  (Round 3 also built a
+// row-list sink -- plain stores of every lookup's row + a hash-linked chain per table row -- and measured it slower at every
+// batch size, 21.9 / 47.0 / 159 us against 11.9 / 30.2 / 103 us: removed, DESIGN 3.2 keeps the numbers.)
 //
 // Small tables (Criteo has vocab 3, 4, 10, 15, 18, 24, 27, 105): every lookup of the batch lands on a few rows, and what
 // is expensive on MI355X is contention, measured at B = 65536 (tools/bwd_field_probe.py):
@@ -458,11 +457,10 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
   const int col = (int)a.idesc[2 * F + f] * D;  // column of this field in g_out / emb
   const bool has_tab = gtab != nullptr;  // frozen tables (requires_grad = False) carry no gradient buffer
   constexpr bool kSmallOk = (SINK != 1) && (LPR <= 16);
-  const int64_t rl_tag = (SINK == 2) ? a.rl.field[f] : 0;  // block-uniform: != 0 = this field writes the row list
   constexpr int RG = kSmallOk ? RH_WAVE / (4 * LPR) : 1;  // row groups of phase B
   constexpr int NL = LPP * U;                            // lookups per pass
   constexpr int RPS = (RH_BLOCK / RH_WAVE) * RG;         // rows per phase-B sweep
-  const bool small = kSmallOk && rl_tag == 0 && has_tab && a.path != 1 && vocab <= (int64_t)kSweeps * RPS;  // block-uniform
+  const bool small = kSmallOk && has_tab && a.path != 1 && vocab <= (int64_t)kSweeps * RPS;  // block-uniform
   float* park = lds;                                                 // [NL][D] gradient rows of the pass
   int* park_row = reinterpret_cast<int*>(lds + NL * 4 * LPR);       // [NL] row id, -1 = dead lookup
   float acc[kSweeps];
@@ -520,13 +518,7 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
         const bool oob = (uint64_t)row[u] >= (uint64_t)vocab;
         oob_any |= (oob && ok[u]);
         const bool live = ok[u] && has_tab && !oob && row[u] != pad && a.path != 3;
-        if (SINK == 2 && rl_tag != 0) {
-          if (ok[u]) {  // (the clamped tail lanes repeat the last sample: one store / link per lookup)
-            const int64_t id = bc[u] * F + f;
-            gstore<float4>(a.rl.rows + id * D + q * 4, gr);
-            if (q == 0) a.rl.next[id] = live ? rl_link(a.rl, rl_key(rl_tag, row[u]), (unsigned int)id) : -2;
-          }
-        } else if (kSmallOk && small) {
+        if (kSmallOk && small) {
           const int j = u * LPP + slot;
           *reinterpret_cast<float4*>(park + j * (4 * LPR) + q * 4) = gr;
           if (q == 0) park_row[j] = live ? (int)row[u] : -1;
@@ -604,15 +596,9 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
 
 int g_bwd_path = 0;        // tuning knob RH_TUNE_BWD_PATH (experiments)
 
-int g_wide_atomics = -1;  // tuning knob RH_TUNE_WIDE_ATOMICS (env RECHUB_WIDE_ATOMICS), default on
+int g_wide_atomics = 1;  // tuning knob RH_TUNE_WIDE_ATOMICS (rh_set_tuning / RECHUB_TUNE=1=0), default on
 
-int wide_atomics_default() {
-  if (g_wide_atomics < 0) {
-    const char* e = getenv("RECHUB_WIDE_ATOMICS");
-    g_wide_atomics = (e != nullptr) ? (atoi(e) != 0) : 1;
-  }
-  return g_wide_atomics;
-}
+int wide_atomics_default() { return g_wide_atomics; }
 
 template <int LPR, typename IdxT, int SRC, int SINK>
 int launch_bwd(EmbedBwdArgs a, hipStream_t s) {
@@ -710,7 +696,7 @@ extern "C" int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_
              "rh_embed_bwd: lr_wgrad needs emb and g_lr");
   if (B == 0) return 0;
   EmbedBwdArgs a{fdesc, idesc, B, F, D, g_out, g_stride, emb, emb_stride, s_sum, g_fm, g_lr, lr_w,
-                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, 0, 0, err_flag, RhRowList{}};
+                 lr_wgrad, scale, rows_out, nullptr, pick_spb(samples_per_block), 0, 0, 0, err_flag};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (sink == 0)
@@ -719,39 +705,6 @@ extern "C" int rh_embed_bwd(const int64_t* fdesc, const int64_t* idesc, int idx_
     rc = idx_is_i64 ? dispatch_bwd<int64_t, 0, 1>(a, s) : dispatch_bwd<int32_t, 0, 1>(a, s);
   if (rc != 0) return rc;
   RH_LAUNCH_CHECK("rh_embed_bwd");
-  return 0;
-}
-
-// rh_embed_bwd with the table gradient of the flagged fields as a ROW LIST (common.h, RhRowList): rl_rows (B * F, D)
-// receives every lookup's gradient row where it is produced, rl_next (B * F) the duplicate chains, rl_hash (rl_slots, a
-// power of two >= 2 * B * F, all zero on entry) the chain heads; rl_field (F, device) = 0 for fields that keep the dense
-// gradient buffer of their fdesc entry (small / densely stepped tables: LDS pre-reduction or atomics as rh_embed_bwd),
-// t + 1 for fields whose table t takes the row list.  B * F < 2^21, rows per row-list table < 2^27.
-extern "C" int rh_embed_bwd_rows(const int64_t* fdesc, const int64_t* idesc, int idx_is_i64, int B, int F, int D,
-                                 const float* g_out, int64_t g_stride, const float* emb, int64_t emb_stride,
-                                 const float* s_sum, const float* g_fm, const float* g_lr, const float* lr_w,
-                                 float* lr_wgrad, float scale, float* rl_rows, int32_t* rl_next, uint64_t* rl_hash,
-                                 int64_t rl_slots, const int64_t* rl_field, int samples_per_block, int32_t* err_flag,
-                                 void* stream) {
-  if (int rc = check_common("rh_embed_bwd_rows", fdesc, idesc, B, F, D)) return rc;
-  RH_REQUIRE(rl_rows && rl_next && rl_hash && rl_field, RH_E_BADARG, "rh_embed_bwd_rows: null row-list pointer");
-  RH_REQUIRE(rl_slots >= 2 && (rl_slots & (rl_slots - 1)) == 0 && rl_slots >= 2 * (int64_t)B * F && rl_slots <= (1ll << 31),
-             RH_E_BADARG, "rh_embed_bwd_rows: rl_slots = %lld must be a power of two >= 2 * B * F", (long long)rl_slots);
-  RH_REQUIRE((int64_t)B * F < (1ll << kRlHeadBits), RH_E_UNSUPPORTED, "rh_embed_bwd_rows: B * F = %lld lookups (max 2^21 - 1)",
-             (long long)B * F);
-  RH_REQUIRE(g_fm == nullptr || (emb != nullptr && s_sum != nullptr), RH_E_BADARG,
-             "rh_embed_bwd_rows: g_fm needs emb and s_sum");
-  RH_REQUIRE(lr_wgrad == nullptr || (emb != nullptr && g_lr != nullptr), RH_E_BADARG,
-             "rh_embed_bwd_rows: lr_wgrad needs emb and g_lr");
-  if (B == 0) return 0;
-  EmbedBwdArgs a{fdesc, idesc, B, F, D, g_out, g_stride, emb, emb_stride, s_sum, g_fm, g_lr, lr_w,
-                 lr_wgrad, scale, nullptr, nullptr, pick_spb(samples_per_block), 0, 0, 0, err_flag,
-                 RhRowList{rl_rows, rl_next, reinterpret_cast<unsigned long long*>(rl_hash), (unsigned int)(rl_slots - 1),
-                           rl_field}};
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int rc = idx_is_i64 ? dispatch_bwd<int64_t, 0, 2>(a, s) : dispatch_bwd<int32_t, 0, 2>(a, s);
-  if (rc != 0) return rc;
-  RH_LAUNCH_CHECK("rh_embed_bwd_rows");
   return 0;
 }
 
@@ -788,7 +741,7 @@ extern "C" int rh_embed_scatter_rows(const int64_t* fdesc, const int64_t* idesc,
   RH_REQUIRE(rows != nullptr, RH_E_BADARG, "rh_embed_scatter_rows: rows is null");
   if (B == 0) return 0;
   EmbedBwdArgs a{fdesc, idesc, B, F, D, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, 0, 0, err_flag, RhRowList{}};
+                 nullptr, scale, nullptr, rows, pick_spb(samples_per_block), 0, 0, 0, err_flag};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = idx_is_i64 ? dispatch_bwd<int64_t, 1, 0>(a, s) : dispatch_bwd<int32_t, 1, 0>(a, s);
   if (rc != 0) return rc;

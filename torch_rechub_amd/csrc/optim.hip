@@ -20,15 +20,10 @@ int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workg
 // step, the chain's kernels ran 2.6x slower under it and the overlap gained nothing.  Its residency is therefore capped:
 //   RH_TUNE_DEFERRED_GRID  persistent workgroups of a deferred sweep (default 512 = 2 per CU = 2 wavefronts per SIMD; the
 //                          trainer's self-tuning also tries 256 = 1 per CU, which wins under long chains: DCN-v2, B >= 8192)
-//   RH_TUNE_SWEEP_LDS_PAD  extra dynamic LDS bytes per workgroup of a deferred sweep (default 0).  The first cap tried:
-//                          8 KB ring + 58 KB pad = 2 workgroups per CU of 160 KB.  It works (0.365 -> 0.311 ms) but the
-//                          padding also keeps LDS-hungry kernels of the chain (library GEMMs) off the CU; the grid cap
-//                          reaches the same residency without that: 0.302 ms.
-// Step time by cap (DeepFM, B = 4096, same box): pad 0 / 48 / 58 / 64 / 88 KB at grid 8192: 0.365 / 0.353 / 0.311 / 0.35 /
-// 0.42 ms; grid 256 / 384 / 448 / 512 / 576 / 640 / 1024 at pad 0: 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.
-int g_sweep_lds_pad = -1;
+// Step time by cap (DeepFM, B = 4096, same box, round 3): grid 256 / 384 / 448 / 512 / 576 / 640 / 1024:
+// 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.  (An LDS-padding cap reached 0.311 ms and was removed: it also
+// kept LDS-hungry kernels of the chain off the CU.)
 int g_deferred_grid = 512;
-static const int kDeferredSweepPad = 0;
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -216,12 +211,6 @@ struct LazyTouchedArgs {
   int ring_mask;
   int T, B, F, spb;
   int* err;
-  int win_mode;  // REFRESH only: 0 = every row of the batch; 1 = skip / 2 = only the rows inside window (t - 2) mod K of
-                 // their table -- the window a deferred sweep launched one step ago may still be writing (pipelined step:
-                 // the bulk of a batch's refresh runs a step early beside that sweep, the rest after it was joined)
-  RhRowList rl;  // rows != nullptr: the gradient of the fields flagged in rl.field comes as a row list (common.h) -- the
-                 // chain head of a table row owns its update, no claim word atomics, no dense gradient row; REFRESH clears
-                 // the hash for the coming backward
 };
 
 struct LazySweepArgs {
@@ -232,8 +221,6 @@ struct LazySweepArgs {
   int T;
   int flush;  // 1: window = whole table
   int64_t t_value;  // >= 0: the step this sweep belongs to, by value (deferred sweep); < 0: hyper[12]
-  const int64_t* t_ptr;  // non-null: the step this sweep belongs to, read from a device word (a deferred sweep captured as a
-                         // graph branch: rh_snapshot_step wrote it before the step's scalar launch moved hyper[12] on)
   int64_t total_vblocks;
   int64_t vb_prefix[kMaxTensors + 1];
   // merged launch (rh_adam_lazy_step): the first touch_blocks workgroups run the touched-rows step of the batch, the rest
@@ -264,8 +251,8 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
     nblk = (int64_t)gridDim.x - a.touch_blocks;
   }
   AdamScalars h = load_scalars(a.hyper);
-  const int t = a.t_ptr != nullptr ? (int)a.t_ptr[0] : (a.t_value >= 0 ? (int)a.t_value : (int)a.hyper[12]);
-  if (a.t_value >= 0 || a.t_ptr != nullptr) {  // deferred: hyper[12..14] may already belong to the next step; the ring entry of t does not
+  const int t = a.t_value >= 0 ? (int)a.t_value : (int)a.hyper[12];
+  if (a.t_value >= 0) {  // deferred: hyper[12..14] may already belong to the next step; the ring entry of t does not
     h.A = a.ring[2 * (t & a.ring_mask)];
     h.E = a.ring[2 * (t & a.ring_mask) + 1];
   }
@@ -394,7 +381,6 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   const int64_t st = a.idesc[F + f];
   const AdamScalars h = load_scalars(a.hyper);
   const int t = (int)a.hyper[12];
-  const int64_t rl_tag = (!REFRESH && a.rl.rows != nullptr) ? a.rl.field[f] : 0;  // block-uniform
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
   const int lane = threadIdx.x % RH_WAVE;
@@ -426,20 +412,10 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       r = pad;
       valid = slot == 0;
     }
-    if (REFRESH && a.win_mode != 0 && valid) {
-      const int64_t wrows = a.ldesc[7 * T + ti];
-      const bool inwin = t >= 2 && (r / wrows) == (int64_t)((t - 2) % K);
-      valid = (a.win_mode == 2) ? inwin : !inwin;
-    }
     int old = t;
     if (valid && q == 0) {
-      if (rl_tag != 0) {
-        // row list: the head of the row's chain owns the update (exactly one lookup per table row and step)
-        if (rl_head(a.rl, rl_key(rl_tag, r)) == (int)(b * F + f)) old = gload<int>(last + r);
-      } else {
-        old = gload<int>(last + r);
-        if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
-      }
+      old = gload<int>(last + r);
+      if (old < t) old = atomicMax(last + r, t);  // exactly one claimant sees a value < t
     }
     old = __shfl(old, lane - q, RH_WAVE);
     bool act = valid && old < t;  // this lane group claimed the row
@@ -483,17 +459,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       P = gload<float4>(p + rr * D + q * 4);
       M = gload<float4>(m + rr * D + q * 4);
       V = gload<float4>(v + rr * D + q * 4);
-      if (!REFRESH) {
-        if (rl_tag != 0) {  // sum of the chain's gradient rows (one row unless the batch looked the table row up twice)
-          int j = (int)(b * F + f);
-          do {
-            G = f4_add(G, gload<float4>(a.rl.rows + (int64_t)j * D + q * 4));
-            j = gload<int>(a.rl.next + j);
-          } while (j >= 0);
-        } else {
-          G = gload<float4>(g + rr * D + q * 4);
-        }
-      }
+      if (!REFRESH) G = gload<float4>(g + rr * D + q * 4);
     }
     // replay in segments between the steps at which rows of the wavefront join (see adam_lazy_sweep_kernel): fixed exec
     // mask and a scalar step counter inside a segment (the ring entry becomes a scalar load)
@@ -515,23 +481,13 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     gstore<float4>(p + rr * D + q * 4, P);
     gstore<float4>(m + rr * D + q * 4, M);
     gstore<float4>(v + rr * D + q * 4, V);
-    if (!REFRESH) {
-      if (rl_tag == 0) gstore<float4>(g + rr * D + q * 4, f4_zero());
-      else if (q == 0) last[rr] = t;  // (the claim of the dense-buffer path wrote it with its atomicMax)
-    }
+    if (!REFRESH) gstore<float4>(g + rr * D + q * 4, f4_zero());
   }
 }
 
 template <int LPR, typename IdxT, bool REFRESH>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
   RH_CHAIN_PRIO();
-  if (REFRESH && a.rl.hash != nullptr) {
-    // the pre-gather pass of a step also empties the duplicate-chain hash of the row list for the coming backward
-    const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * RH_BLOCK;
-    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * RH_BLOCK + threadIdx.x; i <= (int64_t)a.rl.mask;
-         i += nthreads)
-      a.rl.hash[i] = 0ull;
-  }
   lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -558,7 +514,7 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
   if (a.total_vblocks == 0 && a.touch_blocks == 0) return 0;
   // persistent-style grid: each workgroup walks several virtual blocks so the prefetch has something to overlap
   int64_t grid = a.total_vblocks;
-  const int64_t cap = ((a.t_value >= 0 || a.t_ptr != nullptr) && touch == nullptr && g_deferred_grid > 0) ? g_deferred_grid
+  const int64_t cap = (a.t_value >= 0 && touch == nullptr && g_deferred_grid > 0) ? g_deferred_grid
                       : (g_sweep_grid > 0 ? g_sweep_grid : 256 * 32);
   if (grid > cap) grid = cap;
   if (touch != nullptr) {
@@ -571,16 +527,7 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
     hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK), 0, s,
                        a);
   } else {
-    const int pad = (a.t_value >= 0 || a.t_ptr != nullptr) ? (g_sweep_lds_pad < 0 ? kDeferredSweepPad : g_sweep_lds_pad) : 0;
-    if (pad > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; more than 64 KB per workgroup is opt-in
-      static int raised = 0;
-      if (raised < pad) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_lazy_sweep_kernel<LPR, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-        raised = pad;
-      }
-    }
-    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, false>), dim3((unsigned)grid), dim3(RH_BLOCK), (size_t)pad, s, a);
+    hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, false>), dim3((unsigned)grid), dim3(RH_BLOCK), 0, s, a);
   }
   return 0;
 }
@@ -802,10 +749,6 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     g_deferred_grid = value;
     return 0;
   }
-  if (key == RH_TUNE_SWEEP_LDS_PAD) {
-    g_sweep_lds_pad = value < 0 ? -1 : (value > 150 * 1024 ? 150 * 1024 : value);
-    return 0;
-  }
   return RH_E_BADARG;
 }
 
@@ -848,39 +791,9 @@ extern "C" int rh_adam_dense(const int64_t* tdesc, int T, const int64_t* h_numel
   return 0;
 }
 
-static int lazy_sweep_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                           const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
-                           const int64_t* t_ptr, void* stream);
-
 extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                                   const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
                                   void* stream) {
-  return lazy_sweep_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, mode, t_value, nullptr, stream);
-}
-
-// A deferred sweep that can live INSIDE a captured hipGraph, as a branch beside the step's launch chain: its step number
-// comes from the device word t_step (written by rh_snapshot_step at the fork, before the step's scalar launch advances
-// hyper[12]) instead of a by-value argument, which a graph would freeze.  Residency-capped like every deferred sweep.
-extern "C" int rh_adam_lazy_sweep_at(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                                     const double* hyper, const float* ring, int ring_size, int mode, const int64_t* t_step,
-                                     void* stream) {
-  RH_REQUIRE(t_step != nullptr, RH_E_BADARG, "rh_adam_lazy_sweep_at: t_step is null");
-  return lazy_sweep_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, mode, -1, t_step, stream);
-}
-
-__global__ void snapshot_step_kernel(const double* hyper, int64_t* out) {
-  if (threadIdx.x == 0) out[0] = (int64_t)hyper[12];
-}
-extern "C" int rh_snapshot_step(const double* hyper, int64_t* t_step, void* stream) {
-  RH_REQUIRE(hyper && t_step, RH_E_BADARG, "rh_snapshot_step: null pointer");
-  hipLaunchKernelGGL(snapshot_step_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), hyper, t_step);
-  RH_LAUNCH_CHECK("rh_snapshot_step");
-  return 0;
-}
-
-static int lazy_sweep_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                           const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
-                           const int64_t* t_ptr, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring, RH_E_BADARG, "rh_adam_lazy_sweep: null pointer");
   RH_REQUIRE(mode >= RH_SWEEP_WINDOW && mode <= RH_SWEEP_DENSE_TABLES, RH_E_BADARG, "rh_adam_lazy_sweep: mode %d", mode);
   RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
@@ -894,7 +807,6 @@ static int lazy_sweep_impl(const int64_t* ldesc, int T, const int64_t* h_rows, c
   a.T = T;
   a.flush = mode == RH_SWEEP_FLUSH ? 1 : 0;
   a.t_value = t_value;
-  a.t_ptr = t_ptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
@@ -911,57 +823,17 @@ static int lazy_sweep_impl(const int64_t* ldesc, int T, const int64_t* h_rows, c
   return 0;
 }
 
-static int lazy_touched_impl(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
-                             int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
-                             int ring_size, int samples_per_block, int refresh, int32_t* err_flag, const RhRowList& rl,
-                             void* stream);
-
 extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                                     int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                                     int ring_size, int samples_per_block, int refresh, int32_t* err_flag,
                                     void* stream) {
-  return lazy_touched_impl(ldesc, T, field_table, idesc, idx_is_i64, B, F, D, hyper, ring, ring_size, samples_per_block,
-                           refresh, err_flag, RhRowList{}, stream);
-}
-
-static int rl_check(const char* who, const float* rl_rows, const int32_t* rl_next, const uint64_t* rl_hash, int64_t rl_slots,
-                    const int64_t* rl_field, int B, int F) {
-  RH_REQUIRE(rl_rows && rl_next && rl_hash && rl_field, RH_E_BADARG, "%s: null row-list pointer", who);
-  RH_REQUIRE(rl_slots >= 2 && (rl_slots & (rl_slots - 1)) == 0 && rl_slots >= 2 * (int64_t)B * F && rl_slots <= (1ll << 31),
-             RH_E_BADARG, "%s: rl_slots = %lld must be a power of two >= 2 * B * F", who, (long long)rl_slots);
-  RH_REQUIRE((int64_t)B * F < (1ll << kRlHeadBits), RH_E_UNSUPPORTED, "%s: B * F = %lld lookups (max 2^21 - 1)", who,
-             (long long)B * F);
-  return 0;
-}
-
-// rh_adam_lazy_touched for a step whose table gradients came from rh_embed_bwd_rows (same row-list arguments).
-// refresh = 1 (the pre-gather pass of the NEXT forward): as rh_adam_lazy_touched, and the hash is emptied for the coming
-// backward.  refresh = 0: the head of every table row's chain sums the chain's gradient rows and applies the step.
-extern "C" int rh_adam_lazy_touched_rows(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
-                                         int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
-                                         int ring_size, int samples_per_block, int refresh, int32_t* err_flag,
-                                         float* rl_rows, int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots,
-                                         const int64_t* rl_field, void* stream) {
-  if (int rc = rl_check("rh_adam_lazy_touched_rows", rl_rows, rl_next, rl_hash, rl_slots, rl_field, B, F)) return rc;
-  return lazy_touched_impl(ldesc, T, field_table, idesc, idx_is_i64, B, F, D, hyper, ring, ring_size, samples_per_block,
-                           refresh, err_flag,
-                           RhRowList{rl_rows, rl_next, reinterpret_cast<unsigned long long*>(rl_hash),
-                                     (unsigned int)(rl_slots - 1), rl_field},
-                           stream);
-}
-
-static int lazy_touched_impl(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
-                             int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
-                             int ring_size, int samples_per_block, int refresh, int32_t* err_flag, const RhRowList& rl,
-                             void* stream) {
   RH_REQUIRE(ldesc && field_table && idesc && hyper && ring, RH_E_BADARG, "rh_adam_lazy_touched: null pointer");
   RH_REQUIRE(T >= 1 && F >= 1 && F <= 65535 && B >= 0, RH_E_BADARG, "rh_adam_lazy_touched: bad shape");
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_touched: ring_size must be a power of two <= %d", kMaxRing);
   if (B == 0) return 0;
   int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag,
-                    refresh == 2 ? 1 : (refresh == 3 ? 2 : 0), rl};
+  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
   const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)F);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define RH_LT(LPR)                                                                                             \
@@ -993,57 +865,14 @@ static int lazy_touched_impl(const int64_t* ldesc, int T, const int64_t* field_t
 static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                          const RhRowList& rl, void* stream);
-
-extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                                 const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                                 const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
-                                 void* stream) {
-  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, RH_SWEEP_WINDOW, RhRowList{}, stream);
-}
-
-// rh_adam_lazy_step with the sweep part restricted as rh_adam_lazy_sweep's `mode`: RH_SWEEP_DENSE_TABLES = the touched-rows
-// step + the dense (K = 1) tables only -- the end of a step whose window sweep of the lazy tables is deferred to a side
-// stream (torch_rechub_amd/optim.py, overlap mode).
-extern "C" int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
-                                      int sweep_mode, void* stream) {
-  RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
-             "rh_adam_lazy_step_mode: sweep_mode %d", sweep_mode);
-  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, sweep_mode, RhRowList{}, stream);
-}
-
-// rh_adam_lazy_step_mode for a step whose table gradients came from rh_embed_bwd_rows.  Only RH_SWEEP_DENSE_TABLES: the
-// sweep part of this launch claims window rows of the lazy tables by their last-step word and expects their gradient
-// in the dense buffer, which a row-list step does not fill -- the lazy tables' window is swept by its own launch
-// (rh_adam_lazy_sweep, RH_SWEEP_LAZY_TABLES: deferred to a side stream, or in line after this one).
-extern "C" int rh_adam_lazy_step_rows(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
-                                      float* rl_rows, int32_t* rl_next, uint64_t* rl_hash, int64_t rl_slots,
-                                      const int64_t* rl_field, void* stream) {
-  if (int rc = rl_check("rh_adam_lazy_step_rows", rl_rows, rl_next, rl_hash, rl_slots, rl_field, B, F)) return rc;
-  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, RH_SWEEP_DENSE_TABLES,
-                        RhRowList{rl_rows, rl_next, reinterpret_cast<unsigned long long*>(rl_hash),
-                                  (unsigned int)(rl_slots - 1), rl_field},
-                        stream);
-}
-
-static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                          const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                          const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                          const RhRowList& rl, void* stream) {
+                          void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc, RH_E_BADARG,
              "rh_adam_lazy_step: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1, RH_E_BADARG, "rh_adam_lazy_step: bad shape");
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_step: ring_size must be a power of two <= %d", kMaxRing);
   const int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag, 0, rl};
+  LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
   LazySweepArgs a;
   a.ldesc = ldesc;
   a.hyper = hyper;
@@ -1052,7 +881,6 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
   a.T = T;
   a.flush = 0;
   a.t_value = -1;
-  a.t_ptr = nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
@@ -1093,4 +921,25 @@ extern "C" int rh_adam_small(const int64_t* sdesc, int T, const int64_t* h_numel
                      a);
   RH_LAUNCH_CHECK("rh_adam_small");
   return 0;
+}
+
+extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                 const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                 const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
+                                 void* stream) {
+  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
+                        err_flag, RH_SWEEP_WINDOW, stream);
+}
+
+// rh_adam_lazy_step with the sweep part restricted as rh_adam_lazy_sweep's `mode`: RH_SWEEP_DENSE_TABLES = the touched-rows
+// step + the dense (K = 1) tables only -- the end of a step whose window sweep of the lazy tables is deferred to a side
+// stream (torch_rechub_amd/optim.py, deferred form).
+extern "C" int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
+                                      int sweep_mode, void* stream) {
+  RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
+             "rh_adam_lazy_step_mode: sweep_mode %d", sweep_mode);
+  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
+                        err_flag, sweep_mode, stream);
 }

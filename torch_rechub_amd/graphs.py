@@ -77,9 +77,7 @@ class SegmentedGraph(object):
 
     def after(self, fn):
         """``fn`` runs eagerly after the last segment of every replay -- i.e. after the WHOLE step has been enqueued.
-        Where in stream order its launches land is up to ``fn`` itself: the sidecar sweep of optim.TableAdam waits on an
-        EXTERNAL event recorded by a node in the middle of the graph (hipEventRecordExternal), so it starts when that
-        node has run, not when the graph has finished -- without cutting the graph into segments."""
+        (optim.TableAdam counts the replayed steps on the host this way: its deferred sweep takes the step by value)."""
         self.after_fns.append(fn)
 
     # -- replay ----------------------------------------------------------------------------

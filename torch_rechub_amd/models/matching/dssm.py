@@ -6,7 +6,6 @@ embedding when ``mode`` is "user" / "item" (the other tower then yields None).  
 kernels (sequence history features on the gather+pool kernel), the towers' BatchNorm through csrc/mlp.hip, their GEMMs
 are library calls.
 """
-import os
 
 import torch
 import torch.nn.functional as F
@@ -41,10 +40,10 @@ class DSSM(nn.Module):
         """(user_tower(x), item_tower(x)) with the two MLPs side by side (extension; the reference runs them one after the
         other, trainers/match_trainer.py:112-113).  Both gathers stay on the calling stream -- they refresh optimizer state
         in order -- then the item tower's MLP + normalisation run on a second stream beside the user tower's: each of their
-        ~12 launches per direction fills a fraction of the chip.  Opt-in (RECHUB_TOWER_BRANCHES=1): at configs[4] the step is
+        ~12 launches per direction fills a fraction of the chip.  Opt-in (``model.tower_branches = True``): at configs[4] the step is
         bounded by the deferred window sweep, not by the chain (0.823 ms either way); with the chain as the bound (sweep at
         1024 workgroups) the branches take 1.04 -> 0.92 ms."""
-        if self.mode is not None or os.environ.get("RECHUB_TOWER_BRANCHES", "0") != "1":
+        if self.mode is not None or not getattr(self, "tower_branches", False):
             return self.user_tower(x), self.item_tower(x)
         hu = self.embedding(x, self.user_features, squeeze_dim=True)
         hi = self.embedding(x, self.item_features, squeeze_dim=True)

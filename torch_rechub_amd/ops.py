@@ -244,6 +244,14 @@ class EmbedCall(object):
         return EmbedCall._dcache.get(key, self.device)
 
 
+# Fusions that have an unfused twin kept for A/B parity tests (tests flip these module attributes; they are not
+# environment switches): the head's backward forming the BatchNorm sums of the layer below, the Dice + output-layer pass of
+# DIN's attention MLP, BatchNorm + PReLU + Dropout as one launch pair.
+FUSE_HEAD_BN = True
+FUSE_DICE_HEAD = True
+FUSE_BN_PRELU = True
+
+
 # Lazy optimizers (optim.TableAdam(lazy_k > 1)) listen to two events, through weak references:
 #   on_gather(record): rows are about to be READ -> bring them up to date first (a row that was not in recent batches
 #                      lags behind the dense semantics until someone looks at it);
@@ -264,60 +272,22 @@ def _listeners():
     return [r() for r in live]
 
 
-def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep, rl=None):
+def _log_touch(weights, pads, idesc, idx_is_i64, B, F, D, keep):
     for lst in _listeners():
         lst.on_touch(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
-                          keep=keep, rl=rl))
+                          keep=keep))
 
 
-def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D, training=None):
+def _pre_gather(weights, pads, idesc, idx_is_i64, B, F, D, training=None, keep=None):
     """``training``: the lookup is part of a differentiated forward (a backward / optimizer step follows).  Inside an
-    autograd.Function.forward grad mode is off, so the callers pass ctx.needs_input_grad; None = ask grad mode."""
+    autograd.Function.forward grad mode is off, so the callers pass ctx.needs_input_grad; None = ask grad mode.
+    ``keep``: the index tensor(s) behind ``idesc`` -- a listener that keeps the record (TableAdam's refresh-ahead replays the
+    previous step's records) keeps the memory the descriptor points at alive with it."""
     if training is None:
         training = torch.is_grad_enabled()
     for lst in _listeners():
         lst.on_gather(dict(weights=list(weights), pads=list(pads), idesc=idesc, idx_is_i64=idx_is_i64, B=B, F=F, D=D,
-                           training=bool(training)))
-
-
-class RowList(object):
-    """Buffers of one call site's row-list gradient (include/rechub_hip.h, rh_embed_bwd_rows): per-lookup gradient rows,
-    duplicate chains, the chain-head hash (zero on creation; emptied by every pre-gather refresh pass afterwards) and
-    the per-field flags chosen by the optimizer (0 = dense gradient buffer, t + 1 = row list of table t)."""
-
-    def __init__(self, B, F, D, field, device):
-        slots = 1
-        while slots < 2 * B * F:
-            slots *= 2
-        self.B, self.F, self.D, self.slots = B, F, D, max(slots, 2)
-        self.rows = torch.empty((B * F, D), dtype=torch.float32, device=device)
-        self.next = torch.empty((B * F,), dtype=torch.int32, device=device)
-        self.hash = torch.zeros((self.slots,), dtype=torch.int64, device=device)
-        self.field_host = list(field)
-        self.field = torch.tensor(self.field_host, dtype=torch.int64).to(device)
-
-    def args(self):
-        return (_p(self.rows), _p(self.next), _p(self.hash), self.slots, _p(self.field))
-
-
-class _RowListArm(object):
-    """Armed by a trainer around the ONE backward of its training step (never by user code): the fused gather's backward
-    may then hand the table gradient to ``provider`` (optim.TableAdam) as a row list instead of scatter-adding into the
-    vocab-sized ``weight.grad`` buffers, which nobody else reads inside that step."""
-
-    def __init__(self):
-        self.provider = None
-
-    def arm(self, provider):
-        self.provider = provider
-        if hasattr(provider, "_rl_pending"):
-            provider._rl_pending = False  # a new step: whatever an abandoned backward left behind is dropped
-
-    def disarm(self):
-        self.provider = None
-
-
-rowlist = _RowListArm()
+                           training=bool(training), keep=keep))
 
 
 # data-parallel exchange hook: set by torch_rechub_amd.distributed when world_size > 1
@@ -369,7 +339,8 @@ class _EmbedFused(torch.autograd.Function):
                 raise ValueError("fused LR weight must be contiguous float32 with F*D elements")
             require_hip(lr_w, lr_b)
         ddesc = call.ddesc()
-        _pre_gather(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, training=any(ctx.needs_input_grad))
+        _pre_gather(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, training=any(ctx.needs_input_grad),
+                    keep=call.idx)
         _lib.call("rh_embed_fwd", _p(call.fdesc(False)), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(ddesc),
                   len(call.dense), call.dense_col, _p(out), out.stride(0), _p(lr_w if call.want_lr else None),
                   _p(lr_b if call.want_lr else None), _p(lr), _p(fm), _p(s_sum), call.field_split,
@@ -400,32 +371,24 @@ class _EmbedFused(torch.autograd.Function):
         # local_grads: a lookup over row-sharded tables already holds the gradient rows of the global batch
         exchange = _sparse_exchange if (any_table and not call.local_grads) else None
         if any_table or want_wgrad:
-            rl = None
             if exchange is None:
                 fdesc = call.fdesc(True)
                 rows = None
                 sink = 0
-                if any_table and rowlist.provider is not None and not call.local_grads and B > 0:
-                    rl = rowlist.provider.rowlist_for(call)  # optim.TableAdam: RowList, or None = dense buffers
             else:
                 fdesc = call.fdesc(False)
                 rows = torch.empty((B, F, D), dtype=torch.float32, device=dev)
                 sink = 1
-            if rl is not None:
-                _lib.call("rh_embed_bwd_rows", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
-                          0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
-                          _p(lr_w), _p(partial), 1.0, *rl.args(), call.samples_per_block, _p(err_flag(dev)), _stream())
-            else:
-                _lib.call("rh_embed_bwd", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
-                          0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
-                          _p(lr_w), _p(partial), 1.0, sink, _p(rows), call.samples_per_block, _p(err_flag(dev)),
-                          _stream())
+            _lib.call("rh_embed_bwd", _p(fdesc), _p(call.idesc()), call.idx_is_i64, B, F, D, _p(g_out),
+                      0 if g_out is None else g_out.stride(0), _p(out), out.stride(0), _p(s_sum), _p(g_fm), _p(g_lr),
+                      _p(lr_w), _p(partial), 1.0, sink, _p(rows), call.samples_per_block, _p(err_flag(dev)),
+                      _stream())
             if exchange is not None:
                 gathered = exchange(call, rows)
                 if gathered is not None:  # None: the exchange is deferred to after the backward (split-graph step)
                     scatter_rows(call, gathered[0], gathered[1])
             elif any_table:
-                _log_touch(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, call.idx, rl=rl)
+                _log_touch(call.weights, call.pads, call.idesc(), call.idx_is_i64, B, F, D, call.idx)
             if any_table:
                 for w in {id(w): w for w in call.weights if w.requires_grad}.values():
                     _publish_grad(w)
@@ -614,7 +577,7 @@ class _SeqPoolFn(torch.autograd.Function):
             # (the padding positions of a post-padded history all carry padding_idx: the refresh skips those lookups and
             # keeps the padding row itself current once per launch -- csrc/optim.hip)
             _pre_gather([weight], [padding_idx], EmbedCall._icache.get((flat.data_ptr(), 1, 0), weight.device),
-                        1 if idx.dtype == torch.int64 else 0, B * L, 1, D, training=any(ctx.needs_input_grad))
+                        1 if idx.dtype == torch.int64 else 0, B * L, 1, D, training=any(ctx.needs_input_grad), keep=[flat])
         _lib.call("rh_seq_pool_fwd", _p(weight), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0),
                   idx.stride(1), B, L, D, mode, sentinel, _p(out), out.stride(0), _p(err_flag(weight.device)),
                   _stream())
@@ -842,7 +805,7 @@ class _BnPreluDropoutFn(torch.autograd.Function):
 
 def bn_prelu_dropout_ok(h, bn, act):
     return (bn.training and type(act) is torch.nn.PReLU and act.weight.numel() == 1 and h.is_cuda and
-            h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] > 1 and os.environ.get("RECHUB_BN_PRELU", "1") == "1")
+            h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] > 1 and FUSE_BN_PRELU)
 
 
 def bn_prelu_dropout(h, bn, act, p_drop):
@@ -1129,7 +1092,7 @@ class _HeadFn(torch.autograd.Function):
         # also forms that layer's BatchNorm-backward column sums (one statistics launch less per step)
         node = h.grad_fn
         ctx.bn_node = node if (node is not None and type(node).__name__ == "_BnReluDropoutFnBackward" and
-                               os.environ.get("RECHUB_HEAD_BN", "1") == "1") else None
+                               FUSE_HEAD_BN) else None
         return y
 
     @staticmethod
@@ -1547,7 +1510,7 @@ class _BnDiceHeadFn(torch.autograd.Function):
 
 def bn_dice_head_ok(h_cols, bn, dice_mod, lin):
     return (type(lin) is torch.nn.Linear and lin.out_features == 1 and lin.in_features == h_cols and h_cols <= 512 and
-            lin.weight.dtype == torch.float32 and os.environ.get("RECHUB_DICE_HEAD", "1") == "1")
+            lin.weight.dtype == torch.float32 and FUSE_DICE_HEAD)
 
 
 def bn_dice_head(h, bn, alpha, eps, lin, chunk_stats=None, chunk_rows=0):

@@ -101,10 +101,7 @@ class TableAdam(torch.optim.Adam):
                 self._ft_cache = {}
                 self._touch_log = []
                 self._table_ids = {id(p) for p in tables}
-                self._rl_cache = {}       # call-site key -> ops.RowList
-                self._rl_single = False   # the previous step had exactly one gather with table gradients
-                self._rl_pending = False  # a backward wrote a row list that no step has consumed yet
-                # Deferred sweep (default; RECHUB_SWEEP_OVERLAP=0 sweeps in line): the window sweep of step s (lazy tables)
+                # Deferred sweep (default; RECHUB_STEP_FORM=inline sweeps in line): the window sweep of step s (lazy tables)
                 # is launched on a side stream at the start of step s + 1, right after that step's rows were refreshed,
                 # with its step number BY VALUE; it then runs under the whole of step s + 1 (forward, backward, exchange,
                 # optimizer: none of them touches a row that is behind step s) and is joined before step s + 2
@@ -113,42 +110,14 @@ class TableAdam(torch.optim.Adam):
                 # after flush(): tests/test_gpu_properties.py, tests/test_gpu_models.py::test_graph_mode_flush_*).
                 # Round 2 measured no gain (the VALU-saturating sweep starved the step's small dependent kernels: they
                 # ran 2.6x slower under it).  What makes it pay (round 3): the sweep's residency capped at
-                # two workgroups per CU (RH_TUNE_SWEEP_LDS_PAD), the chain's kernels at wave priority 3
+                # two workgroups per CU (RH_TUNE_DEFERRED_GRID), the chain's kernels at wave priority 3
                 # (RH_CHAIN_PRIO), the step's scalar / packing fusions kept, and only two graph segments:
                 # DeepFM 0.365 -> 0.310 ms, DSSM 1.43 -> 1.22 ms per step.
-                self.overlap_sweep = os.environ.get("RECHUB_SWEEP_OVERLAP", "1") == "1"
-                # Sidecar form of the deferred sweep under hipGraph replay (RECHUB_SWEEP_EVENTS=1, opt-in with the
-                # overlap): the step stays ONE graph.  A captured hipStreamWaitEvent(hipEventWaitExternal) in front of
-                # the first refresh waits for the previous sidecar sweep, a captured hipEventRecordWithFlags(
-                # hipEventRecordExternal) after the last refresh marks where the sweep may start, and after every replay
-                # the host enqueues  wait(e_ref) -> sweep(step by value) -> record(e_sweep)  on the side stream
-                # (graphs.SegmentedGraph.after).  No graph boundary, no host synchronisation.
-                self.sweep_events = os.environ.get("RECHUB_SWEEP_EVENTS", "0") == "1"
-                self._ev_ref = self._ev_sweep = None
-                self._sidecar_seg = None
-                # Pipelined form of the captured step (trainers: RECHUB_STEP_FORM=pipelined / self-tuning): ONE graph
-                # segment per step and a sweep that is ALWAYS running.  unit(s) = [fixup(s): the rows of batch s inside the
-                # window sweep(s-2) was writing, after that sweep was joined] [forward .. touched rows of step s]
-                # [assembly of batch s+1] [refresh of batch s+1 EXCEPT the rows inside the window sweep(s-1) is writing];
-                # after every replay the host forks sweep(s) behind sweep(s-1) on the side stream.  No row is ever touched
-                # by two kernels at once: a deferred sweep writes only rows of its own window that are behind its step,
-                # every row of a batch outside that window was refreshed before the sweep after next starts, and the rows
-                # inside it wait for the join (rh_adam_lazy_touched refresh = 2 / 3).
-                # "branch" form (opt-in, RECHUB_STEP_FORM=branch): the deferred sweep as a BRANCH of the step's one captured
-                # graph -- forked (captured event) after the last refresh, its step number from a device word snapshotted
-                # at the fork (rh_snapshot_step / rh_adam_lazy_sweep_at), joined at the end of the graph; no host work per
-                # replay.  Captured branches DO run concurrently on this runtime (tools/probe/branch_probe.cpp: 1.66 vs
-                # 3.25 ms for two long kernels; round 2's "they do not overlap" was the un-capped sweep starving the
-                # chain).  Measured 0.312 ms against 0.306 for the two-segment form: the runtime puts the two branches on
-                # two hardware queues, the chain pays the same ~17 us hand-over at the fork and ~20 us between two graph
-                # launches that the segment boundaries cost (profiles/r03_timeline_branch.txt).
-                self.branch_form = False
-                self._branch_open = False
-                self._snap_event = None
-                self._t_snap = torch.zeros(1, dtype=torch.int64, device=dev)
-                self.pipelined = False
-                self._pipe_events = []
-                self._pipe_seg = None
+                # Forms measured in round 3 and removed in round 4 (DESIGN 4.3 keeps the numbers): "pipelined" (one segment
+                # per step, the refresh of the next batch beside the sweep: 0.37 ms), "branch" (the sweep as a captured
+                # branch of the step's graph: 0.312 ms), external-event nodes (1.66 ms), CU-masked streams (0.350 ms), the
+                # row-list table gradient (backward 159 vs 103 us at B = 65536).
+                self.overlap_sweep = os.environ.get("RECHUB_STEP_FORM", "deferred") != "inline"
                 self._step_recs, self._last_recs = [], []
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
@@ -266,71 +235,13 @@ class TableAdam(torch.optim.Adam):
         return ft
 
     def _touch(self, rec, groups, stream, refresh=False):
-        rl = rec.get("rl")
-        if refresh and rl is None:  # the pre-gather pass of a call site that writes row lists empties its hash
-            rl = self._rl_cache.get(self._rl_key(rec)) if rec.get("training", True) else None
         for grp in groups:
             if grp["D"] != rec["D"] or not any(id(w) in grp["local"] for w in rec["weights"]):
-                continue
-            if rl is not None:
-                _lib.call("rh_adam_lazy_touched_rows", ops._p(grp["ldesc"]), len(grp["members"]),
-                          ops._p(self._field_table(rec, grp)), ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"],
-                          rec["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64, int(refresh),
-                          ops._p(ops.err_flag(self._tables[0].device)), *rl.args(), stream)
                 continue
             _lib.call("rh_adam_lazy_touched", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
                       ops._p(self._t_ring), self.RING, 64, int(refresh),
                       ops._p(ops.err_flag(self._tables[0].device)), stream)
-
-    # -- row-list gradients (ops.RowList, rh_embed_bwd_rows) ---------------------------------------------------------
-    @staticmethod
-    def _rl_key(rec_or_call):
-        r = rec_or_call
-        if isinstance(r, dict):
-            return (id(r["idesc"]), r["B"], r["F"], r["D"])
-        return (id(r.idesc()), r.B, r.F, r.D)
-
-    def rowlist_for(self, call):
-        """Asked by the fused gather's backward while a trainer has armed ops.rowlist: an ops.RowList when this step's
-        table gradient of ``call`` may be handed over as per-lookup rows + duplicate chains, else None (dense buffers).
-        Conditions: blocked-lazy mode; the model's step has ONE gather with table gradients (learned from the previous
-        step: two call sites could put the same table row on two chains); all its tables in one launch group of this
-        optimizer; sizes within the hash's bit fields.
-
-        OPT-IN (RECHUB_ROWLIST=1), measured and not adopted: linking the lookups of a table row costs an
-        atomic load + compare-and-swap WITH return per lookup, against ONE fire-and-forget whole-row float atomic of the
-        dense-buffer path -- rh_embed_bwd_rows takes 21.9 / 47.0 / 159 us at B = 4096 / 16384 / 65536 where rh_embed_bwd
-        takes 11.9 / 30.2 / 103 us, and the optimizer side gains only ~1.5 us per step from dropping its claim atomics
-        and gradient-row traffic."""
-        if (self.lazy_k <= 1 or not self._tables or not self._rl_single or not self._k_decided or
-                os.environ.get("RECHUB_ROWLIST", "0") != "1"):
-            return None
-        if self._rl_pending:
-            raise RuntimeError("TableAdam: a second backward arrived before the optimizer step consumed the row-list "
-                               "gradient of the first; set RECHUB_ROWLIST=0 for gradient accumulation")
-        key = self._rl_key(call)
-        rl = self._rl_cache.get(key)
-        if rl is None:
-            if torch.cuda.is_current_stream_capturing():
-                return None  # buffers are created by an eager step (the trainers warm up eagerly before capturing)
-            groups = self._lazy_setup()
-            if len(groups) != 1 or groups[0]["D"] != call.D or call.B * call.F >= (1 << 21):
-                return None
-            grp = groups[0]
-            field = []
-            for w in call.weights:
-                j = grp["local"].get(id(w), -1)
-                lazy = j >= 0 and w.requires_grad and self.table_k(w) != 1 and int(w.shape[0]) < (1 << 27)
-                if w.requires_grad and j < 0:
-                    return None  # a table of another optimizer / group: keep the dense path for the whole call
-                field.append(j + 1 if lazy else 0)
-            if not any(field):
-                return None
-            rl = self._rl_cache[key] = ops.RowList(call.B, call.F, call.D, field, call.device)
-        self._rl_pending = True
-        return rl
-
 
     def on_gather(self, rec):
         """Pre-gather event: replay the rows of this index batch up to the last completed step (their gradient rows are
@@ -342,16 +253,8 @@ class TableAdam(torch.optim.Adam):
         capturing = torch.cuda.is_current_stream_capturing()
         training = rec.get("training", torch.is_grad_enabled())
         if training:
-            self._step_recs.append({k: rec[k] for k in ("weights", "pads", "idesc", "idx_is_i64", "B", "F", "D")})
-        if capturing and seg is not None and self.overlap_sweep and self.pipelined and training:
-            self._gather_pipelined(rec, seg)
-            return
-        if capturing and self.overlap_sweep and self.branch_form and training:
-            self._gather_branch(rec)
-            return
-        if capturing and seg is not None and self.overlap_sweep and self.sweep_events:
-            self._gather_sidecar(rec, seg)
-            return
+            # "keep": the index tensors behind idesc stay alive as long as the record does (refresh-ahead replays it)
+            self._step_recs.append({k: rec.get(k) for k in ("weights", "pads", "idesc", "idx_is_i64", "B", "F", "D", "keep")})
         if capturing and seg is not None and self.overlap_sweep:
             # segmented replay: EVERY replay joins the sweep forked by the previous one before its first segment (the
             # refresh below must not meet a row the sweep is still writing), whatever the state at capture time was
@@ -361,6 +264,14 @@ class TableAdam(torch.optim.Adam):
             self._sweep_inflight = False
             if training and self._refresh_ahead(rec, seg):
                 return
+            if training and getattr(self, "_ahead", 0) > 0:
+                # this step's first gather already refreshed the recorded gathers and FORKED the sweep, and this gather is
+                # not the one its record announced (other index tensor, order or count): its ordinary refresh below would
+                # run while the sweep -- which claims no rows -- may be writing the same rows.  Every replay joins the
+                # sweep here first (it is not forked a second time in this step); the refresh-ahead records are dropped,
+                # so the next capture of this model starts from the fork-after-the-last-refresh form.
+                seg.cut(self._join_forked_sweep)
+                self._ahead_broken = True
         elif self._sweep_inflight:  # the previous step's sweep must be done before rows are refreshed again
             if capturing:
                 raise RuntimeError("TableAdam: a deferred table sweep is in flight on the side stream; call "
@@ -371,6 +282,8 @@ class TableAdam(torch.optim.Adam):
         self._touch(rec, self._lazy_setup(), ops._stream(), refresh=True)
         if rec.get("training", torch.is_grad_enabled()):
             self._gathers += 1
+            if getattr(self, "_ahead_broken", False) and capturing:
+                return  # the sweep of this step ran (and was joined) already
             if self._sweep_pending and self._gathers >= (self._gathers_per_step or 1):
                 if not capturing:
                     self._fork_sweep()
@@ -398,8 +311,8 @@ class TableAdam(torch.optim.Adam):
         recs = self._last_recs
         if k == 0:
             self._ahead = 0
-            if len(recs) < 2 or (self._gathers_per_step or 0) != len(recs) or not same(rec, recs[0]) or \
-                    os.environ.get("RECHUB_REFRESH_AHEAD", "1") != "1":
+            self._ahead_broken = False
+            if len(recs) < 2 or (self._gathers_per_step or 0) != len(recs) or not same(rec, recs[0]):
                 return False
             groups = self._lazy_setup()
             for r in recs:
@@ -412,128 +325,19 @@ class TableAdam(torch.optim.Adam):
         if k < getattr(self, "_ahead", 0) and same(rec, recs[k]):
             self._gathers += 1
             return True
-        return False  # not the gather the record announced: refresh it in the ordinary way (a second pass is harmless)
+        return False  # not the gather the record announced: on_gather joins the forked sweep, then refreshes it
 
-    # -- branch form (see __init__) -----------------------------------------------------------------------------------
-    def _gather_branch(self, rec):
-        if self._sweep_inflight or self._sweep_pending:
-            raise RuntimeError("TableAdam: call optimizer.settle_sweep() before capturing a step in branch form")
-        stream = ops._stream()
-        self._touch(rec, self._lazy_setup(), stream, refresh=True)
-        self._gathers += 1
-        if self._gathers < (self._gathers_per_step or 1):
-            return
-        dev = self._tables[0].device
-        if self._side is None or isinstance(self._side, torch.cuda.ExternalStream):
-            self._side = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)  # the fork: every row of this step's batches is current
-        with torch.cuda.stream(self._side):
-            s2 = ops._stream()
-            _lib.call("rh_snapshot_step", ops._p(self._t_hyper), ops._p(self._t_snap), s2)
-            self._snap_event = torch.cuda.Event()
-            self._snap_event.record()  # the main branch's scalar launch waits for it before it moves hyper[12] on
-            for grp in self._lazy_setup():
-                _lib.call("rh_adam_lazy_sweep_at", ops._p(grp["ldesc"]), len(grp["members"]),
-                          ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
-                          ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, SWEEP_LAZY_TABLES, ops._p(self._t_snap), s2)
-        self._branch_open = True
-
-    def _wait_snapshot(self):
-        if self._snap_event is not None:
-            torch.cuda.current_stream().wait_event(self._snap_event)
-            self._snap_event = None
-
-    def _join_branch(self):
-        if self._branch_open:
+    def _join_forked_sweep(self):
+        if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-            self._branch_open = False
-
-    # -- pipelined form (see __init__) --------------------------------------------------------------------------------
-    def _gather_pipelined(self, rec, seg):
-        if self._pipe_seg is not seg:
-            seg.at_start(self._join_pipelined)
-            seg.after(self._fork_pipelined)
-            self._pipe_seg = seg
-        # the bulk of this batch was refreshed at the end of the previous unit; what is left are its rows inside the
-        # window of the sweep that was joined in front of this unit
-        self._touch(rec, self._lazy_setup(), ops._stream(), refresh=3)
-        self._gathers += 1
-
-    def prefetch_refresh(self, full=False):
-        """The pre-gather refresh of the NEXT batch (already assembled in the loader's static buffers), launched at the end
-        of a pipelined unit: every row of it except those inside the window the sweep in flight is writing (``full``: every
-        row -- the prologue in front of the first unit, when no sweep is in flight)."""
-        recs = self._last_recs
-        groups = self._lazy_setup()
-        for rec in recs:
-            self._touch(dict(rec, training=True), groups, ops._stream(), refresh=1 if full else 2)
-
-    def _join_pipelined(self):
-        if len(self._pipe_events) >= 2:  # the sweep forked after the unit before last (the last one may run on)
-            torch.cuda.current_stream().wait_event(self._pipe_events[-2])
-
-    def _fork_pipelined(self):
-        self._host_step += 1
-        if self._side is None:
-            self._side = self._make_side_stream()
-        self._side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side):
-            self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
-            ev = torch.cuda.Event()
-            ev.record()
-        self._pipe_events.append(ev)
-        del self._pipe_events[:-2]
-        self._sweep_pending, self._sweep_inflight = False, True
-
-    def _events(self):
-        if self._ev_ref is None:
-            a, b = ctypes.c_void_p(), ctypes.c_void_p()
-            _lib.call("rh_event_create", ctypes.byref(a))
-            _lib.call("rh_event_create", ctypes.byref(b))
-            self._ev_ref, self._ev_sweep = a, b
-        return self._ev_ref, self._ev_sweep
-
-    def _gather_sidecar(self, rec, seg):
-        """Pre-gather hook while a SegmentedGraph captures the step in sidecar mode (see __init__)."""
-        if self._sweep_inflight or self._sweep_pending:
-            raise RuntimeError("TableAdam: call optimizer.settle_sweep() before capturing a step in sidecar mode")
-        e_ref, e_sweep = self._events()
-        stream = ops._stream()
-        training = rec.get("training", torch.is_grad_enabled())
-        if training and self._gathers == 0:
-            _lib.call("rh_stream_wait_event", stream, e_sweep, 1)  # graph node: the previous replay's sidecar sweep is done
-        self._touch(rec, self._lazy_setup(), stream, refresh=True)
-        if training:
-            self._gathers += 1
-            if self._gathers >= (self._gathers_per_step or 1):
-                _lib.call("rh_event_record", e_ref, stream, 1)  # graph node: every row of this step's batches is current
-                if self._sidecar_seg is not seg:
-                    seg.after(self._sidecar_after_replay)
-                    self._sidecar_seg = seg
-
-    def _sidecar_after_replay(self):
-        """Runs on the host after every replay of a step captured in sidecar mode: the window sweep of the step that was
-        complete BEFORE this replay goes to the side stream, behind the replay's refresh marker; the replay's own step then
-        counts as completed (its sweep is launched by the next replay, or by whatever eager call comes first)."""
-        e_ref, e_sweep = self._events()
-        if self._side is None:
-            self._side = self._make_side_stream()
-        side = ctypes.c_void_p(self._side.cuda_stream)
-        _lib.call("rh_stream_wait_event", side, e_ref, 0)
-        if self._host_step > 0:
-            self._sweep(SWEEP_LAZY_TABLES, side, t_value=self._host_step)
-        _lib.call("rh_event_record", e_sweep, side, 0)
-        self._host_step += 1
-        self._sweep_pending, self._sweep_inflight = True, True
+        self._sweep_inflight = False
 
     def settle_sweep(self):
         """Bring the deferred-sweep state to rest (nothing in flight, nothing pending) without a full flush: what a
-        capture in sidecar mode starts from."""
+        switch between the forms of the captured step starts from."""
         if self.lazy_k > 1 and self._tables and self.overlap_sweep:
             self._join_sweep()
             self._finish_sweep()
-            del self._pipe_events[:]
 
     def _sweep(self, mode, stream, t_value=-1):
         for grp in self._lazy_setup():
@@ -552,23 +356,8 @@ class TableAdam(torch.optim.Adam):
         self._sweep_pending, self._sweep_inflight = False, True
 
     def _make_side_stream(self):
-        """The sweep's stream.  RECHUB_SWEEP_CUS=n (1..31) restricts it to n compute units of every XCD
-        (rh_stream_create_cumask): the VALU-saturating sweep then leaves the other 8 * (32 - n) CUs to the step's chain of
-        small dependent kernels instead of competing with them for wave slots on every CU."""
-        dev = self._tables[0].device
-        n = int(os.environ.get("RECHUB_SWEEP_CUS", "0") or 0)
-        if 1 <= n <= 31:
-            ptr = ctypes.c_void_p()
-            _lib.call("rh_stream_create_cumask", n, 0, ctypes.byref(ptr))
-            self._side_raw = ptr.value  # never destroyed: lives as long as the process
-            return torch.cuda.ExternalStream(ptr.value, device=dev)
-        prio = os.environ.get("RECHUB_SWEEP_PRIO")
-        if prio not in (None, ""):  # experiment: the sweep's queue below (positive) / above (negative) the step's
-            ptr = ctypes.c_void_p()
-            _lib.call("rh_stream_create_priority", int(prio), ctypes.byref(ptr))
-            self._side_raw = ptr.value
-            return torch.cuda.ExternalStream(ptr.value, device=dev)
-        return torch.cuda.Stream(device=dev)
+        """The sweep's stream (a plain stream: CU-masked and priority streams were measured in round 3 and bought nothing)."""
+        return torch.cuda.Stream(device=self._tables[0].device)
 
     def _join_sweep(self):
         if self._sweep_inflight:
@@ -588,7 +377,7 @@ class TableAdam(torch.optim.Adam):
         """The touched-rows step of the batch and the window sweep as ONE launch (rh_adam_lazy_step) when the step has a
         single index batch over a single table group with int64 indices -- the DeepFM / DCN / WideDeep step.  The short,
         latency-bound touched pass then runs under the ALU-bound sweep instead of in front of it."""
-        if os.environ.get("RECHUB_MERGE_STEP", "1") != "1" or len(self._touch_log) != 1 or len(groups) != 1:
+        if len(self._touch_log) != 1 or len(groups) != 1:
             return False
         rec, grp = self._touch_log[0], groups[0]
         if grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or \
@@ -596,17 +385,6 @@ class TableAdam(torch.optim.Adam):
             return False
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
         mode = SWEEP_DENSE_TABLES if self.overlap_sweep else SWEEP_WINDOW
-        rl = rec.get("rl")
-        if rl is not None:
-            if not self.overlap_sweep:
-                return False  # row list + in-line window sweep: touched pass, THEN the sweep (two launches, no claims)
-            _lib.call("rh_adam_lazy_step_rows", ops._p(grp["ldesc"]), len(grp["members"]),
-                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
-                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
-                      ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)),
-                      *rl.args(), stream)
-            self._sweep_pending = True
-            return True
         _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
                   ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
                   ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
@@ -648,13 +426,6 @@ class TableAdam(torch.optim.Adam):
         if not self._k_decided:
             self._decide_dense_by_volume()
         groups = self._lazy_setup()
-        n_rec = len(self._touch_log)
-        if n_rec > 1 and any(r.get("rl") is not None for r in self._touch_log):
-            raise RuntimeError("TableAdam: a step with several gathers received a row-list gradient (the model's number of "
-                               "gathers changed between steps); set RECHUB_ROWLIST=0")
-        if not torch.cuda.is_current_stream_capturing():
-            self._rl_single = (n_rec == 1)  # next step's backward may hand its table gradient over as a row list
-        self._rl_pending = False
         if self._merged_step(groups, stream):
             del self._touch_log[:]
             return
@@ -689,9 +460,13 @@ class TableAdam(torch.optim.Adam):
         if self.lazy_k > 1 and self._tables:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("TableAdam.flush() inside a hipGraph capture")
+            self.rollback_abandoned_prepare()  # a forward that never reached its optimizer step advanced the counter
             self._join_sweep()
             self._sweep_pending = False  # subsumed: the flush visits every row
             t = int(self._t_step.item())
+            # plain hipGraph replays run no host code: the host mirror of the step (by-value argument of deferred sweeps)
+            # is re-read from the device counter wherever the host synchronises anyway
+            self._host_step = t
             if t != self._flushed_at:
                 self._sweep(SWEEP_FLUSH, ops._stream())
                 self._flushed_at = t
@@ -710,8 +485,6 @@ class TableAdam(torch.optim.Adam):
         corrections) and before the optimizer kernels -- i.e. where the loss is computed."""
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()  # lr / betas / eps / weight_decay must be on the device BEFORE the corrections are formed
-        if self.lazy_k > 1 and self._tables:
-            self._wait_snapshot()
         self._prepared = True
         return self._t_hyper, self._t_step, self._t_ring, self.RING
 
@@ -722,15 +495,27 @@ class TableAdam(torch.optim.Adam):
         ahead of the last COMPLETED step -- the pre-gather refresh and ``flush()`` would replay a step that never
         happened.  Take the early advance back; the coming forward prepares the same step number again."""
         if self._prepared and not torch.cuda.is_current_stream_capturing():
-            # counter back to (last completed step - 1), then the ordinary prepare launch: it re-forms the corrections
-            # hyper[8..12] and the ring entry of the last completed step, bit for bit what they were
-            self._t_step.sub_(2)
-            _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
-                      ops._stream())
+            if int(self._t_step.item()) <= 1:
+                # the very first step was the abandoned one: "last completed step" is step 0, for which no corrections exist
+                # (1 - b1^0 = 0).  Restore the initial state instead of running prepare with t = 0.
+                self._t_step.zero_()
+                self._t_hyper[8:15].zero_()
+                self._t_ring[:4].zero_()
+            else:
+                # counter back to (last completed step - 1), then the ordinary prepare launch: it re-forms the corrections
+                # hyper[8..12] and the ring entry of the last completed step, bit for bit what they were
+                self._t_step.sub_(2)
+                _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
+                          ops._stream())
             self._prepared = False
             self._small_done = False
             if self.lazy_k > 1 and self._tables:
                 self._gathers = 0  # the abandoned forward's gathers do not count towards the step's gather count
+                if self._touch_log:
+                    # the abandoned backward scattered gradient rows that no optimizer step will consume (and re-zero)
+                    for p in self._tables:
+                        ops.grad_buffer(p).zero_()
+                        p._rh_dirty = False
                 del self._touch_log[:]
                 del self._step_recs[:]
 
@@ -738,8 +523,7 @@ class TableAdam(torch.optim.Adam):
         """(sdesc, hyper) for rh_pack_grads_adam when the dense parameters' step may ride on the packing launch of this
         step -- i.e. when this step's Adam scalars are already on the device (fuse_prepare ran in the forward, so
         step_tables() would not launch rh_adam_prepare) -- else None.  The following step_tables() then skips rh_adam_small."""
-        if (self._bucket is None or not self._prepared or not self._groups_agree() or
-                os.environ.get("RECHUB_PACK_ADAM", "1") != "1"):
+        if self._bucket is None or not self._prepared or not self._groups_agree():
             return None
         self._small_done = True
         return self._s_desc, self._t_hyper
@@ -755,10 +539,10 @@ class TableAdam(torch.optim.Adam):
                 self._gathers_per_step, self._gathers = self._gathers, 0
             if self._step_recs:
                 self._last_recs, self._step_recs = self._step_recs, []
+                if getattr(self, "_ahead_broken", False):
+                    self._last_recs = []
             seg = graphs.active()
-            if seg is not None and self.overlap_sweep and (self.sweep_events or self.pipelined):
-                pass  # sidecar / pipelined form: their after-replay function counts the replayed steps
-            elif seg is not None:
+            if seg is not None:
                 if getattr(self, "_advance_seg", None) is not seg:  # replays count their steps on the host too (the
                     seg.after(self._advance_host_step)              # deferred sweep takes its step by value), after the
                     self._advance_seg = seg                         # last segment -- in-line captures as well: a trainer
@@ -768,8 +552,6 @@ class TableAdam(torch.optim.Adam):
         if self._prepared:
             self._prepared = False
         else:
-            if self.lazy_k > 1 and self._tables:
-                self._wait_snapshot()
             _lib.call("rh_adam_prepare", ops._p(self._t_hyper), ops._p(self._t_step), ops._p(self._t_ring), self.RING,
                       stream)
         if self._bucket is not None and self._small_done:
@@ -788,8 +570,6 @@ class TableAdam(torch.optim.Adam):
             for desc, n, numel in self._desc():
                 _lib.call("rh_adam_dense", ops._p(desc), n, ctypes.cast(numel, ctypes.c_void_p),
                           ops._p(self._t_hyper), 1, stream)
-        if self.lazy_k > 1:
-            self._join_branch()  # branch form: the captured sweep rejoins the step here (the end of the graph)
         for p in self._tables:
             p._rh_dirty = False  # the kernels zeroed every non-zero gradient row
             if p.grad is None:
@@ -832,6 +612,7 @@ class TableAdam(torch.optim.Adam):
                 p._rh_dirty = False
 
     def state_dict(self):
+        self.rollback_abandoned_prepare()
         self.flush()
         if self._tables or self._bucket is not None:
             t = float(self._t_step.item())
@@ -862,6 +643,7 @@ class TableAdam(torch.optim.Adam):
         return out
 
     def load_state_dict(self, state_dict):
+        self.rollback_abandoned_prepare()
         if self.lazy_k > 1 and self._tables:
             self._join_sweep()
         padded = self._padded_state_indices()

@@ -132,8 +132,7 @@ class CTRTrainer(object):
         """_compute_loss under an armed ops.StepFusion: head + BCE terms in one launch, the loss mean / Adam bias
         corrections / device counters in ONE scalar launch (ops.StepFusion).  Anything the fusion did not absorb is
         launched here."""
-        fuse = (os.environ.get("RECHUB_STEP_FUSION", "1") == "1" and isinstance(self.optimizer, TableAdam) and
-                self.loss_mode and
+        fuse = (isinstance(self.optimizer, TableAdam) and self.loss_mode and
                 type(self)._compute_loss is CTRTrainer._compute_loss and type(self)._criterion is CTRTrainer._criterion
                 and type(self.criterion) is torch.nn.BCELoss)
         counters, self._counters = self._counters, []
@@ -187,18 +186,12 @@ class CTRTrainer(object):
         packed = fast and self.optimizer._bucket is not None
         # single GPU, packed optimizer: the weight-gradient / head / LR backward kernels leave their partial slabs to the
         # step's ONE packing launch (ops.DeferredGrads) instead of reducing them one by one
-        defer = packed and self.dp is None and os.environ.get("RECHUB_STEP_FUSION", "1") == "1"
+        defer = packed and self.dp is None
         if defer:
             ops.deferred.arm(self.bucket.params)
-        if fast and self.dp is None:
-            # ONE backward per optimizer step and nobody reads weight.grad in between: the fused gather may hand the
-            # table gradient to the optimizer as per-lookup rows + duplicate chains (ops.RowList) instead of the
-            # vocab-sized scatter-add
-            ops.rowlist.arm(self.optimizer)
         try:
             loss.backward(self._grad_root(loss))
         finally:
-            ops.rowlist.disarm()
             items = ops.deferred.disarm() if defer else {}
         if fast and not self._bucket_attached:
             # first step: every dense parameter must receive a gradient for the packed one-launch optimizer path
@@ -270,41 +263,13 @@ class CTRTrainer(object):
 
     GRAPH_WARMUP = 3
 
-    def main_stream(self):
-        """The stream hipGraph-replayed steps run on: None (the current stream) unless RECHUB_MAIN_CUS=n (1..31) asks for
-        the step's launch chain on the LAST n compute units of every XCD (rh_stream_create_cumask) -- the counterpart of
-        RECHUB_SWEEP_CUS, which puts the optimizer's deferred window sweep on the FIRST n: with disjoint shares the
-        VALU-saturating sweep and the chain of small dependent kernels run side by side instead of contending for wave
-        slots on every CU.  ``train_one_epoch`` switches to it around its replay loop."""
-        if not hasattr(self, "_main_stream"):
-            import ctypes
-            self._main_stream = None
-            n = int(os.environ.get("RECHUB_MAIN_CUS", "0") or 0)
-            if 1 <= n <= 31 and torch.device(self.device).type == "cuda":
-                from .. import _lib
-                ptr = ctypes.c_void_p()
-                _lib.call("rh_stream_create_cumask", n, 1, ctypes.byref(ptr))
-                self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
-            elif os.environ.get("RECHUB_MAIN_PRIO") not in (None, "") and torch.device(self.device).type == "cuda":
-                from .. import _lib  # experiment: the replayed steps on a queue of another priority than the sweep's
-                ptr = ctypes.c_void_p()
-                _lib.call("rh_stream_create_priority", int(os.environ["RECHUB_MAIN_PRIO"]), ctypes.byref(ptr))
-                self._main_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device(self.device))
-        return self._main_stream
-
     # Candidates of the step's self-tuning: (form of the captured step, persistent workgroups of the side-stream sweep:
     # RH_TUNE_DEFERRED_GRID, 512 / 256 = 2 / 1 per CU).  Forms: "deferred" = join -> [assembly, refresh] -> fork sweep ->
-    # [rest of the step] (two graph segments); "pipelined" = one segment per step, the next batch assembled and refreshed at
-    # the END of the step so that the sweep never stops (optim.TableAdam.pipelined); "inline" = the merged end-of-step
-    # launch.  The in-line form is always a candidate: a deferred sweep pays when the step's chain is latency-bound (DeepFM /
-    # DSSM at B = 4096), less when its kernels are heavy themselves (DIN, B = 65536: the sweep slows them by what it hides).
-    # ("pipelined" is correct -- tests/test_gpu_models.py -- but not a candidate: measured 0.37-0.39 ms on the DeepFM step
-    # where "deferred" reaches 0.305: a sweep that is ALREADY fully resident when the step's GEMMs arrive costs them 3-4x
-    # (69 / 41 us instead of 18 / 14), whereas the deferred form forks it in the same instant as the first GEMM, whose
-    # workgroups then get their slots first; with the own tile GEMMs at raised priority 0.346.  RECHUB_STEP_FORM=pipelined.)
-    # ("branch" = the deferred sweep as a captured branch of the step's ONE graph, optim.TableAdam.branch_form; its
-    # residency cap is baked into the capture, so every (branch, grid) pair is its own graph.  Exact, 0.312 ms where
-    # "deferred" reaches 0.306: not a candidate, RECHUB_STEP_FORM=branch.)
+    # [rest of the step] (two graph segments); "inline" = the merged end-of-step launch.  The in-line form is always a
+    # candidate: a deferred sweep pays when the step's chain is latency-bound (DeepFM / DSSM at B = 4096), less when its
+    # kernels are heavy themselves (DIN, B = 65536: the sweep slows them by what it hides).  Round 3 also built a
+    # "pipelined" form (0.37-0.39 ms where "deferred" reaches 0.305) and a "branch" form (0.312 ms); both were removed
+    # in round 4, DESIGN 4.3 keeps their numbers and timelines.
     TUNE_CANDIDATES = (("deferred", 512), ("deferred", 256), ("inline", 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
@@ -314,7 +279,7 @@ class CTRTrainer(object):
         length), every candidate of TUNE_CANDIDATES runs TUNE_SETTLE + TUNE_STEPS steps bracketed by HIP events, then ONE
         event synchronisation picks the fastest.  The residency cap is a parameter of the EAGER side-stream launch and can
         change between replays of one graph; the other forms are further captures of the same step (their own graphs, same
-        arithmetic: the optimizer's bit-equality tests cover all of them).  RECHUB_STEP_FORM=branch|deferred|pipelined|inline and
+        arithmetic: the optimizer's bit-equality tests cover all of them).  RECHUB_STEP_FORM=deferred|inline and
         RECHUB_SWEEP_GRID=workgroups pin the choice; data-parallel steps keep the configured form."""
         opt = self.optimizer
         st = getattr(self, "_tune", None)
@@ -322,7 +287,9 @@ class CTRTrainer(object):
             from .. import _lib
             lazy = isinstance(opt, TableAdam) and getattr(opt, "lazy_k", 0) > 1 and bool(opt._tables)
             form = os.environ.get("RECHUB_STEP_FORM", "")
-            form = {"overlap": "deferred"}.get(form, form)
+            if form not in ("", "deferred", "inline"):
+                raise ValueError(f"RECHUB_STEP_FORM={form!r}: 'deferred' or 'inline' (the round-3 forms 'pipelined' and "
+                                 "'branch' were removed)")
             grid = os.environ.get("RECHUB_SWEEP_GRID", "")
             if grid:
                 _lib.call("rh_set_tuning", 8, int(grid))
@@ -330,8 +297,9 @@ class CTRTrainer(object):
                      (not grid or c[0] == "inline" or c[1] == int(grid))]
             if form and (grid or not cands):  # fully pinned (also forms / grids that are not tuning candidates)
                 cands = [(form, int(grid or 512) if form != "inline" else 0)]
-            active = (lazy and self.dp is None and "RECHUB_SWEEP_OVERLAP" not in os.environ and len(cands) > 1 and
-                      "8=" not in os.environ.get("RECHUB_TUNE", "") and "3=" not in os.environ.get("RECHUB_TUNE", ""))
+            # a user who pinned the deferred sweep's grid through RECHUB_TUNE (key 8, exact match) keeps it
+            pinned = {kv.split("=")[0].strip() for kv in os.environ.get("RECHUB_TUNE", "").split(",") if "=" in kv}
+            active = lazy and self.dp is None and len(cands) > 1 and "8" not in pinned
             st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
                                "cands": cands}
             if lazy and self.dp is None and form and form != self._form and len(cands) == 1:
@@ -370,28 +338,21 @@ class CTRTrainer(object):
         form, grid = cand
         if form != "inline":
             _lib.call("rh_set_tuning", 8, int(grid))
-        key = (form, int(grid)) if form == "branch" else form
-        if self._form != key:
-            self._switch_form(key, loader)
+        if self._form != form:
+            self._switch_form(form, loader)
 
     def _switch_form(self, form, loader):
         """Continue with another form of the captured step, capturing it on first use.  The switch happens between two
-        steps from a settled sweep state, so every graph sees the same invariants; a batch the pipelined form had already
-        assembled is assembled again by the form that takes over (its pending position advance is dropped)."""
+        steps from a settled sweep state, so every graph sees the same invariants."""
         opt = self.optimizer
         opt.settle_sweep()
         self._counters = []
         forms = self.__dict__.setdefault("_graph_forms", {})
         forms[self._form] = (self._graph, self._graph_loss)
         self._form = form
-        key, form = form, (form[0] if isinstance(form, tuple) else form)
         opt.overlap_sweep = form != "inline"
-        opt.pipelined = form == "pipelined"
-        opt.branch_form = form == "branch"
-        if form == "pipelined":
-            self._pipeline_prologue(loader)
-        if key in forms:
-            self._graph, self._graph_loss = forms[key]
+        if form in forms:
+            self._graph, self._graph_loss = forms[form]
             return
         g = graphs.SegmentedGraph()
 
@@ -399,23 +360,8 @@ class CTRTrainer(object):
             x, y = self._load(loader)
             return self.train_step(x, y)
 
-        def pipelined_unit():
-            x, y = loader.current()
-            loss = self.train_step(x, y)
-            self._load(loader)  # the NEXT batch into the static buffers; its position advance rides in the next forward
-            opt.prefetch_refresh()
-            return loss
-
-        self._graph_loss = g.capture(pipelined_unit if form == "pipelined" else whole_step)
+        self._graph_loss = g.capture(whole_step)
         self._graph = g
-
-    def _pipeline_prologue(self, loader):
-        """In front of the first pipelined unit (capture, switch of form, start of an epoch): the batch it computes on is
-        assembled and refreshed here, eagerly and in full -- no sweep is in flight at this point."""
-        self.optimizer.settle_sweep()
-        self._counters = []
-        self._load(loader)
-        self.optimizer.prefetch_refresh(full=True)
 
     def _graphed_step(self, loader):
         """Replay the captured (batch assembly + train_step); the first call warms up eagerly and captures.
@@ -443,8 +389,7 @@ class CTRTrainer(object):
                     total += self._split_step(x, y) if split else self.train_step(x, y)
             torch.cuda.current_stream().wait_stream(side)
             # Segmented capture: the optimizer cuts the step where it launches the deferred table sweep eagerly on
-            # its side stream (graphs.SegmentedGraph); without cuts this is one ordinary hipGraph.  In sidecar mode the
-            # step stays one graph with two external-event nodes and starts from a settled sweep state.
+            # its side stream (graphs.SegmentedGraph); without cuts this is one ordinary hipGraph.
             if hasattr(self.optimizer, "settle_sweep"):
                 self.optimizer.settle_sweep()
             self._graph = graphs.SegmentedGraph()
@@ -533,14 +478,7 @@ class CTRTrainer(object):
         batch_count = 0
         full = data_loader.N // data_loader.batch_size if device_loader else 0
         if device_loader and self.use_graph and (self._graph is not None or full > self.GRAPH_WARMUP):
-            ms = self.main_stream()
-            if ms is not None:  # CU-masked stream for the replay loop; everything before / after stays ordered with it
-                outer = torch.cuda.current_stream()
-                ms.wait_stream(outer)
-                torch.cuda.set_stream(ms)
             data_loader.reshuffle()
-            if self._graph is not None and getattr(self, "_form", "") == "pipelined":  # (a string: branch keys are tuples)
-                self._pipeline_prologue(data_loader)  # the position was reset: the prefetched batch is void
             rem = data_loader.N - full * data_loader.batch_size
             it = tqdm.tqdm(total=full, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
             since_log = 0
@@ -564,9 +502,6 @@ class CTRTrainer(object):
                 x, y = self._load(data_loader, rem)
                 epoch += self.train_step(x, y)
                 batch_count += 1
-            if ms is not None:
-                outer.wait_stream(ms)
-                torch.cuda.set_stream(outer)
         else:
             it = tqdm.tqdm(data_loader, desc="train", smoothing=0, mininterval=1.0, disable=not self.show_progress)
             for i, (x_dict, y) in enumerate(it):

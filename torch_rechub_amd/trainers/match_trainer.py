@@ -46,9 +46,7 @@ class MatchTrainer(CTRTrainer):
         # deterministic_logits: the direct in-batch logits (csrc/match.hip: no (B, C) score matrix) accumulate the item
         # tower's gradient with row-wide float atomics, whose order -- hence the last bit of that gradient and of a whole
         # training run -- is not fixed.  True keeps the reference's matmul + gather form (trainers/match_trainer.py:118-138,
-        # fixed summation order, ~9 % slower at configs[4]); default: env RECHUB_INBATCH_DIRECT=0 asks for the same.
-        if deterministic_logits is None:
-            deterministic_logits = os.environ.get("RECHUB_INBATCH_DIRECT", "1") != "1"
+        # fixed summation order, ~9 % slower at configs[4]); default False.
         self.deterministic_logits = bool(deterministic_logits)
         # "fast": one HIP launch, own counter-based stream (distribution-preserving, hipGraph-replayable);
         # "reference": the reference's randperm-per-row draw, bit-identical indices for the same sampler_seed

@@ -301,12 +301,6 @@ class DeviceDataLoader(object):
             dst.copy_(src)
         return x, y
 
-    def current(self, B=None):
-        """(x, y) views of the static batch buffers WITHOUT assembling anything: the batch a previous ``load_next`` put
-        there (the pipelined trainer step computes on it while the next one is being assembled at its end)."""
-        x, y = self._buffers(self.batch_size if B is None else B)[:2]
-        return x, y
-
     def counter(self, B=None):
         """(device counter, increment, modulus) of the batch position: pos = (pos + B) % N."""
         return self.pos, int(self.batch_size if B is None else B), int(self.N)
