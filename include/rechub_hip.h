@@ -347,6 +347,35 @@ int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
                   void* stream);
 int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
                     int64_t ldgx, void* stream);
+/* The fused MLP chain (round 4): the reference's hidden-layer tail  BatchNorm1d -> ReLU -> Dropout
+ * (torch_rechub/basic/layers.py:283-286) is never run as a pass of its own -- it is applied where its output is consumed.
+ * rh_linear_bnact_fwd: layer l + 1 as ONE launch, y = dropout(relu(batch_norm(h))) W^T + b with h (M, K) the PRE-BatchNorm
+ *   output of layer l.  pro_stats (ceil(M / pro_rows), 2, K): the per-slab (sum, M2) the producing GEMM wrote as `stats`
+ *   (pro_rows = rh_gemm_stats_rows(M, K)); gamma / beta / running_* / momentum / eps: layer l's nn.BatchNorm1d; p_drop, rng,
+ *   ctr: its nn.Dropout and the counter the producing GEMM drew for it (that call's bn_saved_ctr).  Written besides y:
+ *   stat_out (>= 2, K) = mean, rstd of layer l; its running statistics; act_out (M, K) or NULL = the activations (this
+ *   layer's weight gradient reads them); stats / bn_rng / bn_saved_ctr / bn_batches: as rh_linear_fwd, for y and the NEXT
+ *   BatchNorm.  K % 4 == 0, K <= 1024, ldh % 4 == 0.  Same per-element arithmetic as rh_bn_relu_dropout_fwd.
+ * rh_linear_dgrad_bnbwd: rh_linear_dgrad whose epilogue also forms the BatchNorm-backward column sums of the hidden layer
+ *   that produced this Linear's input: gx (M, K) = gradient of a = dropout(relu(batch_norm(h))), h (M, K) that layer's
+ *   pre-BatchNorm activations, stat (>= 2, K) its mean / rstd, ctr its dropout counter.  bwd_partial (ceil(M / R), 2, K),
+ *   R = rh_gemm_stats_rows(M, K): per R-row slab (sum g1, sum g1 * xhat) -- rh_bn_relu_dropout_bwd_pre's `partial` with
+ *   nchunks_pre = ceil(M / R) (replaces the statistics launch of the BatchNorm backward).
+ * rh_head_bnact_fwd: the output head of such a chain, y = sigmoid(dropout(relu(batch_norm(z))) . w + b + e0 + e1), z (B, K)
+ *   pre-BatchNorm, stats / stats_rows / ctr as above; t / loss_partial as rh_head_loss_fwd (both NULL: no loss terms).
+ *   K % 4 == 0, K <= 256.  Its backward is rh_head_bwd_bn with h = NULL (the head's input is recomputed from z). */
+int rh_linear_bnact_fwd(const float* h, int64_t ldh, int M, int K, const float* pro_stats, int pro_rows, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, float momentum, float eps, float p_drop,
+                        const int64_t* rng, const int64_t* ctr, float* stat_out, float* act_out, const float* w, int64_t ldw,
+                        const float* bias, int N, float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr,
+                        int64_t* bn_batches, void* stream);
+int rh_linear_dgrad_bnbwd(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
+                          int64_t ldgx, const float* h, int64_t ldh, const float* stat, const float* gamma, const float* beta,
+                          float p_drop, const int64_t* rng, const int64_t* ctr, float* bwd_partial, void* stream);
+int rh_head_bnact_fwd(const float* z, int64_t ldz, const float* stats, int stats_rows, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float p_drop, const int64_t* rng,
+                      const int64_t* ctr, float* stat_out, const float* w, const float* bias, const float* e0, const float* e1,
+                      int B, int K, float* y, const float* t, float* loss_partial, void* stream);
 int64_t rh_linear_wgrad_workspace(int B, int N, int K);
 int rh_linear_wgrad_tiles(int N, int K);
 int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* dW, float* db,

@@ -1717,6 +1717,7 @@ def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monk
     gy = torch.randn(B, generator=g).to(dev())
     grads = {}
     rng = dev() if isinstance(dev(), torch.device) else torch.device(dev())
+    monkeypatch.setattr(ops, "FUSE_MLP_CHAIN", False)  # this test is about the layer-by-layer kernels
     for flag in (True, False):
         monkeypatch.setattr(ops, "FUSE_HEAD_BN", flag)
         torch.manual_seed(5)
@@ -1730,6 +1731,64 @@ def test_head_backward_forms_the_batchnorm_sums_of_the_layer_below(B, K, p, monk
     for a, b in zip(grads[True], grads[False]):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-4 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("B,K0,dims,p", [(4096, 429, [256, 128], 0.2), (4096, 429, [256, 128], 0.0), (1000, 40, [64], 0.3),
+                                         (77, 33, [128, 64, 32], 0.5), (2, 16, [8, 4], 0.0), (3000, 432, [1024, 256], 0.1)])
+def test_mlp_chain_equals_the_layer_by_layer_kernels(B, K0, dims, p, monkeypatch):
+    """ops._MlpChainFn (round 4: BatchNorm + ReLU + Dropout of a hidden layer applied on the operand load of the next GEMM /
+    of the head, BatchNorm-backward sums from the head's backward / the input-gradient GEMM's epilogue; csrc/gemm.hip PRO /
+    BNBWD, csrc/linear.hip head_bnact_fwd_kernel) against the layer-by-layer path it replaces (library GEMM -> rh_bn_relu_
+    dropout_fwd -> ... -> rh_head_fwd and their backwards), reference torch_rechub/basic/layers.py:276-292 + deepfm.py:39-43:
+    same dropout stream (same counters in the same order), so predictions, every gradient, the running statistics and
+    num_batches_tracked must agree up to the summation order of the GEMMs and of the column sums."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import MLP
+    g = torch.Generator().manual_seed(B + K0)
+    pitch = (K0 + 15) // 16 * 16
+    x = torch.randn(B, pitch, generator=g).to(dev())[:, :K0]  # a row-padded view, as the fused gather hands over
+    e0, e1 = torch.randn(B, 1, generator=g).to(dev()), torch.randn(B, generator=g).to(dev())
+    gy = torch.randn(B, generator=g).to(dev())
+    rng = dev() if isinstance(dev(), torch.device) else torch.device(dev())
+    out, calls = {}, []
+    real = ops.mlp_chain_sigmoid
+    monkeypatch.setattr(ops, "mlp_chain_sigmoid", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "FUSE_MLP_CHAIN", flag)
+        torch.manual_seed(5)
+        mlp = MLP(K0, output_layer=True, dims=dims, dropout=p, activation="relu").to(dev()).train()
+        with torch.no_grad():
+            for m in mlp.mlp:
+                if isinstance(m, torch.nn.BatchNorm1d):  # non-trivial affine, so that gamma / beta matter
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.5, 0.5)
+        ops._dropout_rng(rng).copy_(torch.tensor([1234, 0, 0, 0], device=rng))  # same dropout stream for both runs
+        xi, a0, a1 = x.clone().requires_grad_(), e0.clone().requires_grad_(), e1.clone().requires_grad_()
+        for _ in range(2):  # two steps: the running statistics / counters advance the same way
+            y = mlp.sigmoid_head(xi, a0, a1)
+            y.backward(gy)
+        ops.check_errors()
+        out[flag] = dict(y=y.detach().clone(), gx=xi.grad.clone(), g0=a0.grad.clone(), g1=a1.grad.clone(),
+                         params={n: q.grad.clone() for n, q in mlp.named_parameters()},
+                         bufs={n: b_.clone() for n, b_ in mlp.named_buffers()})
+    torch.cuda.synchronize()
+    assert len(calls) == 2, "the fused chain did not run"
+    A, R = out[True], out[False]
+    np.testing.assert_allclose(A["y"].cpu().numpy(), R["y"].cpu().numpy(), rtol=1e-5, atol=2e-6)
+    for k in ("gx", "g0", "g1"):
+        scale = max(1e-6, float(R[k].abs().max()))
+        assert float((A[k] - R[k]).abs().max()) <= 2e-5 * scale, k
+    for n in R["params"]:
+        scale = max(1e-3, float(R["params"][n].abs().max()))
+        # (a Linear bias in front of BatchNorm has a mathematically zero gradient: rounding noise on both sides)
+        noise = n.endswith(".bias") and any(n == f"mlp.{4 * i}.bias" for i in range(len(dims)))
+        tol = 1e-4 * max(scale, float(R["gx"].abs().max()) * B ** 0.5) if noise else 2e-5 * scale
+        assert float((A["params"][n] - R["params"][n]).abs().max()) <= tol, n
+    for n in R["bufs"]:
+        if n.endswith("num_batches_tracked"):
+            assert int(A["bufs"][n]) == int(R["bufs"][n]) == 2, n
+        else:
+            np.testing.assert_allclose(A["bufs"][n].cpu().numpy(), R["bufs"][n].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
 
 
 @pytest.mark.parametrize("fused_loss", [False, True])

@@ -83,6 +83,12 @@ SIGNATURES = {
     "rh_linear_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                       c_ptr],
     "rh_linear_dgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr],
+    "rh_linear_bnact_fwd": [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr,
+                            c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_linear_dgrad_bnbwd": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                              c_f32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_head_bnact_fwd": [c_ptr, c_i64, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr,
+                          c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_linear_wgrad_workspace": [c_int, c_int, c_int],
     "rh_linear_wgrad_tiles": [c_int, c_int],
     "rh_linear_wgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],

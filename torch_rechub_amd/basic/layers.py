@@ -338,6 +338,19 @@ class MLP(nn.Module):
             return mods[j]
         return None
 
+    @staticmethod
+    def _chain_blocks(mods):
+        """[(Linear, BatchNorm1d, p_drop)] when ``mods`` is nothing but [Linear, BatchNorm1d, ReLU, Dropout] groups, else None."""
+        if not mods or len(mods) % 4:
+            return None
+        out = []
+        for i in range(0, len(mods), 4):
+            lin, bn, act, drop = mods[i:i + 4]
+            if not (type(lin) is nn.Linear and type(bn) is nn.BatchNorm1d and type(act) is nn.ReLU and type(drop) is nn.Dropout):
+                return None
+            out.append((lin, bn, float(drop.p) if drop.training else 0.0))
+        return out
+
     def _run(self, mods, x):
         # [Linear, BatchNorm1d, ReLU, Dropout] blocks: library GEMM + ONE fused epilogue (csrc/mlp.hip); any other
         # activation (dice, prelu, sigmoid ...) runs the modules as they are.  Every Linear's weight / bias gradient
@@ -394,6 +407,11 @@ class MLP(nn.Module):
         (deepfm.py:39-43, widedeep.py:35-39) and the sigmoid as ONE kernel (ops.head_sigmoid) when the shapes allow."""
         mods = list(self.mlp)
         if mods and type(mods[-1]) is nn.Linear and mods[-1].out_features == 1:
+            blocks = self._chain_blocks(mods[:-1])
+            if blocks and ops.mlp_chain_ok(x, blocks, mods[-1], extras):
+                # every hidden layer is Linear -> BatchNorm1d -> ReLU -> Dropout (training): ONE autograd node, the
+                # BatchNorm / ReLU / Dropout of a layer applied where the next GEMM / the head reads it (ops._MlpChainFn)
+                return ops.mlp_chain_sigmoid(x, blocks, mods[-1], *extras)
             h = self._run(mods[:-1], x)
             if ops.head_ok(h, mods[-1], extras):
                 return ops.head_sigmoid(h, mods[-1].weight, mods[-1].bias, *extras)

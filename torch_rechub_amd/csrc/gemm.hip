@@ -19,6 +19,17 @@
 //   slab's sum and its M2 = sum (x - slab mean)^2 computed from the accumulators in registers (two passes, no
 //   cancellation) -- the BatchNorm statistics then need no separate pass over h (csrc/mlp.hip combines the slabs with
 //   Chan's formula, in slab order: deterministic).
+//   PRO (round 4, forward of layer l + 1 of an MLP): A is not read as it is but as the OUTPUT of the hidden layer in front,
+//   a = dropout(relu(batch_norm(h))) (torch_rechub/basic/layers.py:281-286), formed on the way from global memory to LDS:
+//   every workgroup first combines the per-slab (sum, M2) statistics the producing GEMM's STATS epilogue left behind
+//   (Chan's formula in slab order, one column per thread, all loads in flight at once) into mean / rstd of all K
+//   columns (LDS), then applies normalisation, ReLU and the counter-hash dropout mask to each float4 it parks in LDS.
+//   The BatchNorm + ReLU + Dropout pass of csrc/mlp.hip (read h, write a) and its launch are gone; the workgroups of the
+//   first tile column also write a (the weight gradient of this layer needs it) and workgroup 0 the statistics the
+//   backward needs and the running statistics.  Same per-element arithmetic as bn_apply_fin_kernel<0>.
+//   BNBWD (round 4, input gradient of layer l + 1): the epilogue also forms, per tile-row slab and column, the
+//   BatchNorm-backward sums (sum g1, sum g1 * xhat) of layer l from the accumulators (g1 = the tile's gradient under
+//   layer l's ReLU / dropout mask, recomputed from h_l) -- what bn_partial_kernel<1> read g and h again for.
 // Roofline: f32 MFMA (157 TF); 0.9 GFLOP for the 4096 x 429 x 256 layer = 5.7 us at peak.
 #include <type_traits>
 
@@ -48,7 +59,26 @@ struct GemmArgs {
   int64_t* bn_rng;        // STATS, optional: the consumer's (seed, call counter) -- see rh_linear_fwd
   int64_t* bn_saved_ctr;
   int64_t* bn_batches;
+  // PRO: A = dropout(relu(bn(A))) of the hidden layer in front (K columns); BNBWD: the same layer's description for the
+  // epilogue sums (then over the N output columns, h = pro_h)
+  const float* pro_stats;   // PRO: (ceil(M / pro_rows), 2, K) per-slab (sum, M2) of A
+  int pro_rows;
+  const float* pro_gamma;
+  const float* pro_beta;
+  float* pro_running_mean;  // PRO, optional
+  float* pro_running_var;
+  float pro_momentum, pro_eps, pro_p;
+  const int64_t* pro_rng;   // (seed, .)
+  const int64_t* pro_ctr;   // the dropout counter of that layer's call
+  float* pro_stat_out;      // PRO: (>= 2, K) mean, rstd (written by workgroup 0); BNBWD: read
+  float* pro_act_out;       // PRO, optional: (M, K) the activations a, written by the workgroups of tile column 0
+  const float* pro_h;       // BNBWD: (M, N) pre-BatchNorm activations of the layer whose gradient the tile holds
+  int64_t ldh;
+  float* bwd_partial;       // BNBWD: (ceil(M / BM), 2, N)
 };
+
+constexpr int kProMaxSlabs = 64;  // PRO: slabs combined from registers in one round of loads (more: a second, looped round)
+constexpr int kProMaxK = 1024;
 
 static __device__ __forceinline__ float4 load4_guard(const float* row, int k, int K, bool row_ok) {
   if (!row_ok || k >= K) return f4_zero();
@@ -60,7 +90,7 @@ static __device__ __forceinline__ float4 load4_guard(const float* row, int k, in
   return v;
 }
 
-template <int WM, int WN, bool B_KMAJOR, bool STATS>
+template <int WM, int WN, bool B_KMAJOR, bool STATS, bool PRO = false, bool BNBWD = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a) {
   RH_CHAIN_PRIO();
   constexpr int NT = 64 * WM * WN;      // threads
@@ -71,6 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   constexpr int A_TILE = BM * kLd;
   constexpr int B_TILE = B_KMAJOR ? BN * kLd : kBK * kLdN;
   __shared__ float lds[2 * (A_TILE + B_TILE)];
+  __shared__ float pro_c[PRO ? 4 * kProMaxK : 1];  // PRO: mean, rstd, gamma, beta of the K columns of A (zero past K)
   const int tid = threadIdx.x, lane = tid % RH_WAVE, wave = tid / RH_WAVE;
   const int wm = wave / WN, wn = wave % WN;
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber them so that the tiles_n
@@ -107,6 +138,88 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   bool bfull[B_V4];
 #pragma unroll
   for (int v = 0; v < B_V4; ++v) bfull[v] = B_KMAJOR || n0 + ((tid + v * NT) % (BN / 4)) * 4 + 3 < a.N;
+  float keep_scale = 1.f;
+  uint32_t thr = 0;
+  uint64_t seed = 0, ctr = 0;
+  if (PRO || BNBWD) {
+    if (a.pro_p > 0.f) {
+      keep_scale = 1.f / (1.f - a.pro_p);
+      thr = (uint32_t)(a.pro_p * 4294967296.0);
+      seed = (uint64_t)a.pro_rng[0];
+      ctr = (uint64_t)a.pro_ctr[0];
+    }
+  }
+  if (PRO) {
+    // statistics of the K columns of A: Chan's combination of the per-slab (sum, M2) pairs in slab order (the arithmetic
+    // of csrc/mlp.hip::chan_combine with one thread per column), every load of a column in flight at once
+    const int nslab = (a.M + a.pro_rows - 1) / a.pro_rows;
+    const float full = (float)a.pro_rows, inv_full = 1.f / full;
+    const float tail = (float)(a.M - (nslab - 1) * a.pro_rows), inv_tail = 1.f / tail;
+    for (int c = tid; c < ((a.K + kBK - 1) / kBK) * kBK; c += NT) {
+      float mean = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
+      if (c < a.K) {
+        float ps[kProMaxSlabs], pm[kProMaxSlabs];
+#pragma unroll
+        for (int k = 0; k < kProMaxSlabs; ++k) {
+          const bool ok = k < nslab;
+          ps[k] = ok ? a.pro_stats[((int64_t)k * 2 + 0) * a.K + c] : 0.f;
+          pm[k] = ok ? a.pro_stats[((int64_t)k * 2 + 1) * a.K + c] : 0.f;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < kProMaxSlabs; ++k) sum += ps[k];
+        for (int k = kProMaxSlabs; k < nslab; ++k) sum += a.pro_stats[((int64_t)k * 2 + 0) * a.K + c];
+        mean = sum / (float)a.M;
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kProMaxSlabs; ++k) {
+          if (k < nslab) {
+            const float d = ps[k] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
+            m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, pm[k]);
+          }
+        }
+        for (int k = kProMaxSlabs; k < nslab; ++k) {
+          const float d = a.pro_stats[((int64_t)k * 2 + 0) * a.K + c] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
+          m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, a.pro_stats[((int64_t)k * 2 + 1) * a.K + c]);
+        }
+        const float var = fmaxf(m2 / (float)a.M, 0.f);
+        rstd = rsqrtf(var + a.pro_eps);
+        gam = a.pro_gamma[c];
+        bet = a.pro_beta[c];
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+          a.pro_stat_out[c] = mean;
+          a.pro_stat_out[a.K + c] = rstd;
+          if (a.pro_running_mean != nullptr) {
+            const float n = (float)a.M;
+            const float unbiased = a.M > 1 ? var * (n / (n - 1.f)) : var;
+            a.pro_running_mean[c] = fmaf(a.pro_momentum, mean - a.pro_running_mean[c], a.pro_running_mean[c]);
+            a.pro_running_var[c] = fmaf(a.pro_momentum, unbiased - a.pro_running_var[c], a.pro_running_var[c]);
+          }
+        }
+      }
+      pro_c[c] = mean;
+      pro_c[kProMaxK + c] = rstd;
+      pro_c[2 * kProMaxK + c] = gam;
+      pro_c[3 * kProMaxK + c] = bet;
+    }
+    __syncthreads();
+  }
+  // PRO: one float4 of A (row `row`, columns k .. k + 3) -> the hidden layer's output; columns past K come out as 0
+  auto pro_apply = [&](float4 v, int row, int k) -> float4 {
+    const float4 mean = *reinterpret_cast<const float4*>(pro_c + k);
+    const float4 rstd = *reinterpret_cast<const float4*>(pro_c + kProMaxK + k);
+    const float4 gam = *reinterpret_cast<const float4*>(pro_c + 2 * kProMaxK + k);
+    const float4 bet = *reinterpret_cast<const float4*>(pro_c + 3 * kProMaxK + k);
+    const uint64_t e = (uint64_t)row * (uint64_t)a.K + (uint64_t)k;
+    auto one = [&](float x, float m, float r, float g, float b, uint64_t idx) -> float {
+      const float xhat = (x - m) * r;
+      float y = fmaxf(fmaf(xhat, g, b), 0.f);
+      if (a.pro_p > 0.f) y = rh_drop_hash(seed, ctr, idx) >= thr ? y * keep_scale : 0.f;
+      return y;
+    };
+    return make_float4(one(v.x, mean.x, rstd.x, gam.x, bet.x, e), one(v.y, mean.y, rstd.y, gam.y, bet.y, e + 1),
+                       one(v.z, mean.z, rstd.z, gam.z, bet.z, e + 2), one(v.w, mean.w, rstd.w, gam.w, bet.w, e + 3));
+  };
   auto bload = [&](int v, int k0) -> float4 {
     if (B_KMAJOR) return gload<float4>(pb[v] + k0);
     if (bfull[v]) return gload<float4>(pb[v] + (int64_t)k0 * a.ldb);
@@ -138,14 +251,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
       }
     }
   };
-  auto lstore = [&](int buf, const float4* ra, const float4* rb) {
+  auto lstore = [&](int buf, const float4* ra, const float4* rb, int k0) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
 #pragma unroll
     for (int v = 0; v < A_V4; ++v) {
       const int e = tid + v * NT;
       const int r = e / 8, c = (e % 8) * 4;
-      *reinterpret_cast<float4*>(As + r * kLd + c) = ra[v];
+      float4 av = ra[v];
+      if (PRO) {
+        av = pro_apply(av, m0 + r, k0 + c);
+        if (a.pro_act_out != nullptr && n0 == 0 && m0 + r < a.M && k0 + c < a.K)
+          gstore<float4>(a.pro_act_out + (int64_t)(m0 + r) * a.K + k0 + c, av);
+      }
+      *reinterpret_cast<float4*>(As + r * kLd + c) = av;
     }
 #pragma unroll
     for (int v = 0; v < B_V4; ++v) {
@@ -189,11 +308,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   // MFMAs of tile t under them, parks tile t+2 in the LDS buffer tile t came from and fetches tile t+4.
   v16f acc = {};
   const int ntiles = (a.K + kBK - 1) / kBK;
+  // BNBWD: this lane's 16 elements of h (the tile of the layer whose gradient the accumulators will hold) are requested
+  // now and consumed in the epilogue
+  float zpre[BNBWD ? 16 : 1];
+  if (BNBWD) {
+    const int colz = n0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + 4 * kk + (r & 3) + 8 * (r >> 2);
+      zpre[r] = (colz < a.N && row < a.M) ? a.pro_h[(int64_t)row * a.ldh + colz] : 0.f;
+    }
+  }
   float fa0[16], fb0[16], fa1[16], fb1[16];
   gfetch(0, ra0, rb0);
   if (ntiles > 1) gfetch(kBK, ra1, rb1);
-  lstore(0, ra0, rb0);
-  if (ntiles > 1) lstore(1, ra1, rb1);
+  lstore(0, ra0, rb0, 0);
+  if (ntiles > 1) lstore(1, ra1, rb1, kBK);
   if (RH_PROBE != 1 && ntiles > 2) gfetch(2 * kBK, ra0, rb0);
   if (RH_PROBE != 1 && ntiles > 3) gfetch(3 * kBK, ra1, rb1);
   __syncthreads();
@@ -213,7 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
       else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
       if (RH_PROBE != 1 && s == 3) {
         __builtin_amdgcn_sched_barrier(0);
-        if (FULL || t + 2 < ntiles) lstore(t & 1, ra, rb);
+        if (FULL || t + 2 < ntiles) lstore(t & 1, ra, rb, (t + 2) * kBK);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (RH_PROBE != 1 && s == 7) {
@@ -311,17 +441,67 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
       }
     }
   }
+  if (BNBWD) {
+    // BatchNorm-backward sums of the layer whose output gradient this tile is: g1 = g under that layer's ReLU / dropout
+    // mask (the arithmetic of bn_partial_kernel<1>), summed over the BM rows of the tile per column; slab order and the
+    // order inside a slab are fixed -> deterministic
+    float s1 = 0.f, s2 = 0.f;
+    if (cok) {
+      const float mean = a.pro_stat_out[col], rstd = a.pro_stat_out[a.N + col];
+      const float gam = a.pro_gamma[col], bet = a.pro_beta[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < a.M) {
+          const float xhat = (zpre[r] - mean) * rstd;
+          const float bn = fmaf(xhat, gam, bet);
+          float g1 = acc[r];
+          if (a.pro_p > 0.f) g1 = rh_drop_hash(seed, ctr, (uint64_t)row * (uint64_t)a.N + (uint64_t)col) >= thr ? g1 * keep_scale : 0.f;
+          g1 = bn > 0.f ? g1 : 0.f;
+          s1 += g1;
+          s2 = fmaf(g1, xhat, s2);
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (WM == 1) {
+      if (kk == 0 && cok) {
+        a.bwd_partial[((int64_t)(m0 / BM) * 2 + 0) * a.N + col] = s1;
+        a.bwd_partial[((int64_t)(m0 / BM) * 2 + 1) * a.N + col] = s2;
+      }
+    } else {
+      float* ex = lds;  // [WM][WN * 32][2] (the K-loop buffers are free: the loop ended with a barrier)
+      if (kk == 0) {
+        ex[((wm * WN + wn) * 32 + li) * 2 + 0] = s1;
+        ex[((wm * WN + wn) * 32 + li) * 2 + 1] = s2;
+      }
+      __syncthreads();
+      if (wm == 0 && kk == 0 && cok) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          t1 += ex[((w * WN + wn) * 32 + li) * 2];
+          t2 += ex[((w * WN + wn) * 32 + li) * 2 + 1];
+        }
+        a.bwd_partial[((int64_t)(m0 / BM) * 2 + 0) * a.N + col] = t1;
+        a.bwd_partial[((int64_t)(m0 / BM) * 2 + 1) * a.N + col] = t2;
+      }
+    }
+  }
 }
 
 // one tile per workgroup; 64x64 tiles unless that leaves most of the 256 CUs idle
 bool big_tiles(int M, int N) { return (int64_t)((M + 63) / 64) * ((N + 63) / 64) >= 192; }
 
-template <bool B_KMAJOR, bool STATS>
+template <bool B_KMAJOR, bool STATS, bool PRO = false, bool BNBWD = false>
 void launch(const GemmArgs& a, hipStream_t s) {
   if (big_tiles(a.M, a.N)) {
-    hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), 0,
+                       s, a);
   } else {
-    hipLaunchKernelGGL((gemm_f32_kernel<1, 2, B_KMAJOR, STATS>), dim3((a.N + 63) / 64, (a.M + 31) / 32), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<1, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 31) / 32), dim3(128), 0,
+                       s, a);
   }
 }
 
@@ -337,11 +517,49 @@ extern "C" int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_
              "rh_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
   RH_REQUIRE(bn_rng == nullptr || (stats != nullptr && bn_saved_ctr != nullptr), RH_E_BADARG,
              "rh_linear_fwd: the BatchNorm call counter needs stats and saved_ctr");
-  GemmArgs a{x, ldx, w, ldw, bias, y, ldy, M, N, K, stats, bn_rng, bn_saved_ctr, bn_batches};
+  GemmArgs a{};
+  a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.bias = bias; a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+  a.stats = stats; a.bn_rng = bn_rng; a.bn_saved_ctr = bn_saved_ctr; a.bn_batches = bn_batches;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats) launch<true, true>(a, s);
   else launch<true, false>(a, s);
   RH_LAUNCH_CHECK("rh_linear_fwd");
+  return 0;
+}
+
+// Layer l + 1 of an MLP in ONE launch: y = dropout(relu(batch_norm(h))) W^T + b, where h (M, K) is the PRE-BatchNorm output
+// of layer l and pro_stats its per-slab (sum, M2) pairs (the `stats` of the rh_linear_fwd / rh_linear_bnact_fwd call that
+// produced h; pro_rows = rh_gemm_stats_rows(M, K)), ctr the dropout counter that call drew for layer l.
+// Replaces, per hidden layer: rh_bn_relu_dropout_fwd (BatchNorm1d + ReLU + Dropout, torch_rechub/basic/layers.py:283-286)
+// and the read of its output by the next nn.Linear (:282).  Also written: stat_out (>= 2, K) = mean, rstd of layer l (its
+// backward reads them), layer l's running statistics, act_out (M, K) = the activations (optional: the weight gradient of
+// THIS layer reads them), and -- as rh_linear_fwd -- y's own slab statistics / the next BatchNorm's bookkeeping.
+extern "C" int rh_linear_bnact_fwd(const float* h, int64_t ldh, int M, int K, const float* pro_stats, int pro_rows,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float p_drop, const int64_t* rng, const int64_t* ctr,
+                                   float* stat_out, float* act_out, const float* w, int64_t ldw, const float* bias, int N,
+                                   float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr,
+                                   int64_t* bn_batches, void* stream) {
+  RH_REQUIRE(h && pro_stats && gamma && beta && rng && ctr && stat_out && w && y, RH_E_BADARG,
+             "rh_linear_bnact_fwd: null pointer");
+  RH_REQUIRE(M >= 2 && N >= 1 && K >= 4 && K % 4 == 0 && K <= kProMaxK && ldh >= K && ldh % 4 == 0 && ldw >= K && ldy >= N &&
+                 pro_rows >= 1,
+             RH_E_UNSUPPORTED, "rh_linear_bnact_fwd: bad shape M=%d N=%d K=%d (K %% 4 == 0, K <= %d)", M, N, K, kProMaxK);
+  RH_REQUIRE(p_drop >= 0.f && p_drop < 1.f, RH_E_BADARG, "rh_linear_bnact_fwd: p must be in [0, 1)");
+  RH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), RH_E_BADARG,
+             "rh_linear_bnact_fwd: running_mean and running_var go together");
+  RH_REQUIRE(bn_rng == nullptr || (stats != nullptr && bn_saved_ctr != nullptr), RH_E_BADARG,
+             "rh_linear_bnact_fwd: the BatchNorm call counter needs stats and saved_ctr");
+  GemmArgs a{};
+  a.A = h; a.lda = ldh; a.B = w; a.ldb = ldw; a.bias = bias; a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+  a.stats = stats; a.bn_rng = bn_rng; a.bn_saved_ctr = bn_saved_ctr; a.bn_batches = bn_batches;
+  a.pro_stats = pro_stats; a.pro_rows = pro_rows; a.pro_gamma = gamma; a.pro_beta = beta;
+  a.pro_running_mean = running_mean; a.pro_running_var = running_var; a.pro_momentum = momentum; a.pro_eps = eps;
+  a.pro_p = p_drop; a.pro_rng = rng; a.pro_ctr = ctr; a.pro_stat_out = stat_out; a.pro_act_out = act_out;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stats) launch<true, true, true>(a, s);
+  else launch<true, false, true>(a, s);
+  RH_LAUNCH_CHECK("rh_linear_bnact_fwd");
   return 0;
 }
 
@@ -351,8 +569,32 @@ extern "C" int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int6
   RH_REQUIRE(g && w && gx, RH_E_BADARG, "rh_linear_dgrad: null pointer");
   RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldg >= N && ldw >= K && ldgx >= K, RH_E_BADARG,
              "rh_linear_dgrad: bad shape M=%d N=%d K=%d", M, N, K);
-  GemmArgs a{g, ldg, w, ldw, nullptr, gx, ldgx, M, /*N=*/K, /*K=*/N, nullptr, nullptr, nullptr, nullptr};
+  GemmArgs a{};
+  a.A = g; a.lda = ldg; a.B = w; a.ldb = ldw; a.C = gx; a.ldc = ldgx; a.M = M; a.N = K; a.K = N;
   launch<false, false>(a, reinterpret_cast<hipStream_t>(stream));
   RH_LAUNCH_CHECK("rh_linear_dgrad");
+  return 0;
+}
+
+// rh_linear_dgrad whose epilogue also forms the BatchNorm-backward column sums of the hidden layer that produced this
+// Linear's input: gx (M, K) is the gradient of a = dropout(relu(batch_norm(h))), h (M, K) that layer's pre-BatchNorm
+// activations, stat (>= 2, K) its mean / rstd, ctr its dropout counter.  bwd_partial (ceil(M / R), 2, K), R =
+// rh_gemm_stats_rows(M, K): per R-row slab (sum g1, sum g1 * xhat) -- what rh_bn_relu_dropout_bwd_pre takes as `partial`
+// with nchunks_pre = ceil(M / R).  Replaces the statistics launch of the BatchNorm backward (bn_partial_kernel<1>).
+extern "C" int rh_linear_dgrad_bnbwd(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
+                                     int64_t ldgx, const float* h, int64_t ldh, const float* stat, const float* gamma,
+                                     const float* beta, float p_drop, const int64_t* rng, const int64_t* ctr,
+                                     float* bwd_partial, void* stream) {
+  RH_REQUIRE(g && w && gx && h && stat && gamma && beta && rng && ctr && bwd_partial, RH_E_BADARG,
+             "rh_linear_dgrad_bnbwd: null pointer");
+  RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldg >= N && ldw >= K && ldgx >= K && ldh >= K, RH_E_BADARG,
+             "rh_linear_dgrad_bnbwd: bad shape M=%d N=%d K=%d", M, N, K);
+  RH_REQUIRE(p_drop >= 0.f && p_drop < 1.f, RH_E_BADARG, "rh_linear_dgrad_bnbwd: p must be in [0, 1)");
+  GemmArgs a{};
+  a.A = g; a.lda = ldg; a.B = w; a.ldb = ldw; a.C = gx; a.ldc = ldgx; a.M = M; a.N = K; a.K = N;
+  a.pro_h = h; a.ldh = ldh; a.pro_stat_out = const_cast<float*>(stat); a.pro_gamma = gamma; a.pro_beta = beta;
+  a.pro_p = p_drop; a.pro_rng = rng; a.pro_ctr = ctr; a.bwd_partial = bwd_partial;
+  launch<false, false, false, true>(a, reinterpret_cast<hipStream_t>(stream));
+  RH_LAUNCH_CHECK("rh_linear_dgrad_bnbwd");
   return 0;
 }

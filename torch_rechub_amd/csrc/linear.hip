@@ -333,6 +333,144 @@ __global__ __launch_bounds__(RH_BLOCK) void head_fwd_kernel(const float* __restr
   }
 }
 
+// The output head on the PRE-BatchNorm activations of the last hidden layer (fused MLP chain, round 4):
+//   y = sigmoid(dropout(relu(batch_norm(z))) . w + b + e0 + e1)
+// Every workgroup combines the per-slab (sum, M2) statistics the GEMM that produced z left behind (Chan's formula, slab
+// order, one column per thread, all loads in flight) into mean / rstd in LDS, then walks its rows as head_fwd_kernel does,
+// applying normalisation, ReLU and the dropout hash on the way into the dot product: the BatchNorm + ReLU + Dropout pass
+// over the last hidden layer and its output tensor are gone.  Workgroup 0 writes mean / rstd (the backward reads them) and
+// the running statistics.  Same per-element arithmetic as bn_apply_fin_kernel<0> (csrc/mlp.hip) followed by head_fwd_kernel.
+struct HeadBnFwdArgs {
+  const float* z;
+  int64_t ldz;
+  const float* stats;  // (ceil(B / rows), 2, K)
+  int rows;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  float momentum, eps, p;
+  const int64_t *rng, *ctr;
+  float* stat_out;  // (>= 2, K)
+  const float *w, *bias, *e0, *e1;
+  int B, K;
+  float* y;
+  const float* t;
+  float* loss_partial;
+};
+constexpr int kHeadBnMaxK = 256;
+constexpr int kHeadBnMaxSlabs = 64;
+
+__global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFwdArgs a) {
+  RH_CHAIN_PRIO();
+  __shared__ float lred[kHeadRows];
+  __shared__ float cst[4 * kHeadBnMaxK];  // mean, rstd, gamma, beta
+  const int K = a.K, B = a.B;
+  {
+    const int c = threadIdx.x;
+    const int nslab = (B + a.rows - 1) / a.rows;
+    const float full = (float)a.rows, inv_full = 1.f / full;
+    const float tail = (float)(B - (nslab - 1) * a.rows), inv_tail = 1.f / tail;
+    if (c < K) {
+      float ps[kHeadBnMaxSlabs], pm[kHeadBnMaxSlabs];
+#pragma unroll
+      for (int k = 0; k < kHeadBnMaxSlabs; ++k) {
+        const bool ok = k < nslab;
+        ps[k] = ok ? a.stats[((int64_t)k * 2 + 0) * K + c] : 0.f;
+        pm[k] = ok ? a.stats[((int64_t)k * 2 + 1) * K + c] : 0.f;
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < kHeadBnMaxSlabs; ++k) sum += ps[k];
+      for (int k = kHeadBnMaxSlabs; k < nslab; ++k) sum += a.stats[((int64_t)k * 2 + 0) * K + c];
+      const float mean = sum / (float)B;
+      float m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < kHeadBnMaxSlabs; ++k) {
+        if (k < nslab) {
+          const float d = ps[k] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
+          m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, pm[k]);
+        }
+      }
+      for (int k = kHeadBnMaxSlabs; k < nslab; ++k) {
+        const float d = a.stats[((int64_t)k * 2 + 0) * K + c] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
+        m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, a.stats[((int64_t)k * 2 + 1) * K + c]);
+      }
+      const float var = fmaxf(m2 / (float)B, 0.f);
+      const float rstd = rsqrtf(var + a.eps);
+      cst[c] = mean;
+      cst[kHeadBnMaxK + c] = rstd;
+      cst[2 * kHeadBnMaxK + c] = a.gamma[c];
+      cst[3 * kHeadBnMaxK + c] = a.beta[c];
+      if (blockIdx.x == 0) {
+        a.stat_out[c] = mean;
+        a.stat_out[K + c] = rstd;
+        if (a.running_mean != nullptr) {
+          const float n = (float)B;
+          const float unbiased = B > 1 ? var * (n / (n - 1.f)) : var;
+          a.running_mean[c] = fmaf(a.momentum, mean - a.running_mean[c], a.running_mean[c]);
+          a.running_var[c] = fmaf(a.momentum, unbiased - a.running_var[c], a.running_var[c]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float keep_scale = 1.f;
+  uint32_t thr = 0;
+  uint64_t seed = 0, ctr = 0;
+  if (a.p > 0.f) {
+    keep_scale = 1.f / (1.f - a.p);
+    thr = (uint32_t)(a.p * 4294967296.0);
+    seed = (uint64_t)a.rng[0];
+    ctr = (uint64_t)a.ctr[0];
+  }
+  const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
+  const int nv = K / 4;
+  const float b0 = a.bias ? a.bias[0] : 0.f;
+  float lacc = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < B; row += (int64_t)gridDim.x * kHeadRows) {
+    float acc = 0.f;
+    for (int v = sub; v < nv; v += kHeadLanes) {
+      const float4 zv = gload<float4>(a.z + row * a.ldz + 4 * v);
+      const float4 wv = gload<float4>(a.w + 4 * v);
+      const float4 mean = *reinterpret_cast<const float4*>(cst + 4 * v);
+      const float4 rstd = *reinterpret_cast<const float4*>(cst + kHeadBnMaxK + 4 * v);
+      const float4 gam = *reinterpret_cast<const float4*>(cst + 2 * kHeadBnMaxK + 4 * v);
+      const float4 bet = *reinterpret_cast<const float4*>(cst + 3 * kHeadBnMaxK + 4 * v);
+      const uint64_t e = (uint64_t)row * (uint64_t)K + (uint64_t)(4 * v);
+      auto one = [&](float x, float m, float r, float g, float b, uint64_t idx) -> float {
+        float y_ = fmaxf(fmaf((x - m) * r, g, b), 0.f);
+        if (a.p > 0.f) y_ = rh_drop_hash(seed, ctr, idx) >= thr ? y_ * keep_scale : 0.f;
+        return y_;
+      };
+      acc = fmaf(one(zv.x, mean.x, rstd.x, gam.x, bet.x, e), wv.x, acc);
+      acc = fmaf(one(zv.y, mean.y, rstd.y, gam.y, bet.y, e + 1), wv.y, acc);
+      acc = fmaf(one(zv.z, mean.z, rstd.z, gam.z, bet.z, e + 2), wv.z, acc);
+      acc = fmaf(one(zv.w, mean.w, rstd.w, gam.w, bet.w, e + 3), wv.w, acc);
+    }
+    acc = group_sum16(acc);
+    if (sub == 0) {
+      float zz = acc + b0;
+      if (a.e0) zz += a.e0[row];
+      if (a.e1) zz += a.e1[row];
+      const float yv = 1.f / (1.f + __expf(-zz));
+      a.y[row] = yv;
+      if (a.t) {
+        const float tv = a.t[row];
+        lacc -= tv * fmaxf(logf(yv), -100.f) + (1.f - tv) * fmaxf(log1pf(-yv), -100.f);
+      }
+    }
+  }
+  if (a.loss_partial) {
+    if (sub == 0) lred[grp] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < kHeadRows; ++r) v += lred[r];
+      a.loss_partial[blockIdx.x] = v;
+    }
+  }
+}
+
 struct HeadBwdArgs {
   const float* h;
   int64_t ldh;
@@ -423,29 +561,39 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
     for (int i = 0; i < MAXV; ++i) {
       const int v = sub + i * kHeadLanes;
       if (v < nv) {
-        const float4 hv = gload<float4>(a.h + row * a.ldh + 4 * v);
-        wacc[i].x = fmaf(gz, hv.x, wacc[i].x);
-        wacc[i].y = fmaf(gz, hv.y, wacc[i].y);
-        wacc[i].z = fmaf(gz, hv.z, wacc[i].z);
-        wacc[i].w = fmaf(gz, hv.w, wacc[i].w);
+        // BN with h == null (fused MLP chain, round 4): the head's input was never written -- the forward applied
+        // BatchNorm + ReLU + Dropout on the way into its dot product -- and is recomputed here from bn_z the same way
+        const bool recompute = BN && a.h == nullptr;
+        float4 hv = recompute ? f4_zero() : gload<float4>(a.h + row * a.ldh + 4 * v);
         const float4 gh = make_float4(gz * wv[i].x, gz * wv[i].y, gz * wv[i].z, gz * wv[i].w);
         gstore<float4>(a.g_h + row * K + 4 * v, gh);
         if (BN) {
           const float4 zv = gload<float4>(a.bn_z + row * K + 4 * v);
           const uint64_t e0 = (uint64_t)row * K + 4 * v;
-          auto one = [&](float z, float mean, float rstd, float gam, float bet, float g, uint64_t e, float& s1, float& s2) {
+          auto one = [&](float z, float mean, float rstd, float gam, float bet, float g, uint64_t e, float& s1, float& s2,
+                         float& act) {
             const float xhat = (z - mean) * rstd;
             const float bn = fmaf(xhat, gam, bet);
             float g1 = (!a.bn_relu || bn > 0.f) ? g : 0.f;
-            if (a.bn_p > 0.f) g1 = rh_drop_hash(seed, ctr, e) >= thr ? g1 * keep_scale : 0.f;
+            float y_ = a.bn_relu ? fmaxf(bn, 0.f) : bn;
+            if (a.bn_p > 0.f) {
+              const bool keep = rh_drop_hash(seed, ctr, e) >= thr;
+              g1 = keep ? g1 * keep_scale : 0.f;
+              y_ = keep ? y_ * keep_scale : 0.f;
+            }
+            if (recompute) act = y_;
             s1 += g1;
             s2 = fmaf(g1, xhat, s2);
           };
-          one(zv.x, bmean[i].x, brstd[i].x, bgam[i].x, bbet[i].x, gh.x, e0 + 0, bs1[i].x, bs2[i].x);
-          one(zv.y, bmean[i].y, brstd[i].y, bgam[i].y, bbet[i].y, gh.y, e0 + 1, bs1[i].y, bs2[i].y);
-          one(zv.z, bmean[i].z, brstd[i].z, bgam[i].z, bbet[i].z, gh.z, e0 + 2, bs1[i].z, bs2[i].z);
-          one(zv.w, bmean[i].w, brstd[i].w, bgam[i].w, bbet[i].w, gh.w, e0 + 3, bs1[i].w, bs2[i].w);
+          one(zv.x, bmean[i].x, brstd[i].x, bgam[i].x, bbet[i].x, gh.x, e0 + 0, bs1[i].x, bs2[i].x, hv.x);
+          one(zv.y, bmean[i].y, brstd[i].y, bgam[i].y, bbet[i].y, gh.y, e0 + 1, bs1[i].y, bs2[i].y, hv.y);
+          one(zv.z, bmean[i].z, brstd[i].z, bgam[i].z, bbet[i].z, gh.z, e0 + 2, bs1[i].z, bs2[i].z, hv.z);
+          one(zv.w, bmean[i].w, brstd[i].w, bgam[i].w, bbet[i].w, gh.w, e0 + 3, bs1[i].w, bs2[i].w, hv.w);
         }
+        wacc[i].x = fmaf(gz, hv.x, wacc[i].x);
+        wacc[i].y = fmaf(gz, hv.y, wacc[i].y);
+        wacc[i].z = fmaf(gz, hv.z, wacc[i].z);
+        wacc[i].w = fmaf(gz, hv.w, wacc[i].w);
       }
     }
   }
@@ -766,6 +914,30 @@ extern "C" int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, con
   return 0;
 }
 
+// Output head of the fused MLP chain: see head_bnact_fwd_kernel.  z (B, K) = PRE-BatchNorm activations of the last hidden
+// layer, stats (ceil(B / stats_rows), 2, K) the per-slab (sum, M2) of the GEMM that produced it, ctr the dropout counter
+// that GEMM drew for this layer.  t / loss_partial as rh_head_loss_fwd (both NULL: no loss terms); loss_partial has
+// rh_head_loss_nblocks(B) entries.  K % 4 == 0, K <= 256.
+extern "C" int rh_head_bnact_fwd(const float* z, int64_t ldz, const float* stats, int stats_rows, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                 float p_drop, const int64_t* rng, const int64_t* ctr, float* stat_out, const float* w,
+                                 const float* bias, const float* e0, const float* e1, int B, int K, float* y, const float* t,
+                                 float* loss_partial, void* stream) {
+  RH_REQUIRE(z && stats && gamma && beta && rng && ctr && stat_out && w && y, RH_E_BADARG, "rh_head_bnact_fwd: null pointer");
+  RH_REQUIRE(B >= 2 && K >= 4 && K % 4 == 0 && K <= kHeadBnMaxK && ldz >= K && stats_rows >= 1, RH_E_UNSUPPORTED,
+             "rh_head_bnact_fwd: bad shape B=%d K=%d (K %% 4 == 0, K <= %d)", B, K, kHeadBnMaxK);
+  RH_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (t == nullptr) == (loss_partial == nullptr), RH_E_BADARG,
+             "rh_head_bnact_fwd: bad arguments");
+  RH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), RH_E_BADARG,
+             "rh_head_bnact_fwd: running_mean and running_var go together");
+  HeadBnFwdArgs a{z, ldz, stats, stats_rows, gamma, beta, running_mean, running_var, momentum, eps, p_drop, rng, ctr,
+                  stat_out, w, bias, e0, e1, B, K, y, t, loss_partial};
+  hipLaunchKernelGGL(head_bnact_fwd_kernel, dim3(head_fwd_grid(B)), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                     a);
+  RH_LAUNCH_CHECK("rh_head_bnact_fwd");
+  return 0;
+}
+
 struct HeadBnArgs {
   const float *z, *stat, *gamma, *beta;
   const int64_t *rng, *ctr;
@@ -780,6 +952,7 @@ static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const floa
 // rh_head_bwd_ex + the BatchNorm-backward column sums of the hidden layer below the head (h = dropout(relu(bn(bn_z)))
 // and the head is its only consumer): bn_partial (rh_head_nblocks(B), 2, K) = per-block (sum g1, sum g1 * xhat), what
 // rh_bn_relu_dropout_bwd_pre takes instead of launching its own statistics pass.  K % 4 == 0.
+// h may be NULL: the head's input is then recomputed from bn_z (forward = rh_head_bnact_fwd, which never wrote it).
 extern "C" int rh_head_bwd_bn(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                               const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
                               float* partial, int reduce, const float* bn_z, const float* bn_stat, const float* bn_gamma,
@@ -823,7 +996,7 @@ extern "C" int rh_head_loss_bwd(const float* h, int64_t ldh, const float* w, con
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
                          float* partial, void* stream, int reduce, const HeadBnArgs* bn) {
-  RH_REQUIRE(h && w && y && g_h && g_z && (g_w || !reduce) && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
+  RH_REQUIRE((h || bn) && w && y && g_h && g_z && (g_w || !reduce) && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
   RH_REQUIRE(B >= 1 && K >= 1 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
              "rh_head_bwd: K=%d unsupported (1 .. %d)", K, 4 * kHeadLanes * kHeadMaxV4);
   HeadBwdArgs a{h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, partial, g_w, g_b};

@@ -1147,6 +1147,185 @@ class _HeadFn(torch.autograd.Function):
         return (g_h, g_w, g_b, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1))
 
 
+# Fused MLP chain (round 4): [Linear -> BatchNorm1d -> ReLU -> Dropout] x L -> Linear(., 1) (+ wide / FM terms)
+# -> sigmoid of torch_rechub/basic/layers.py:276-292 + models/ranking/deepfm.py:39-43 as ONE autograd node over L + 1 forward
+# launches and 3 L + 1 backward launches.  A/B switch for benchmarks: RECHUB_MLP_CHAIN=0 (tests flip the attribute).
+FUSE_MLP_CHAIN = os.environ.get("RECHUB_MLP_CHAIN", "1") == "1"
+_CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
+
+
+class _MlpChainFn(torch.autograd.Function):
+    """y (B,) = sigmoid(head(hidden_L(... hidden_1(x))) + e0 + e1), hidden_l = Dropout(ReLU(BatchNorm1d(Linear_l(.)))) in
+    training mode.  No hidden layer's BatchNorm / ReLU / Dropout runs as a pass of its own: the statistics are a by-product
+    of the GEMM that produced the pre-activations (csrc/gemm.hip, STATS), the normalisation + activation + mask are applied
+    where the NEXT layer (rh_linear_bnact_fwd) or the head (rh_head_bnact_fwd) reads them; in the backward the BatchNorm sums
+    come from the head's backward (rh_head_bwd_bn, h = NULL) / the input-gradient GEMM's epilogue (rh_linear_dgrad_bnbwd).
+    Saved for the backward: x, the pre-activations h_l, the activations a_l of all but the last hidden layer (written by the
+    consuming GEMM for the weight gradient), per-layer (mean, rstd) and dropout counters, y.
+    params = [W_l, b_l, gamma_l, beta_l] * L + [head_w, head_b]."""
+
+    @staticmethod
+    def forward(ctx, x, e0, e1, cfg, *params):
+        bns, ps = cfg["bns"], cfg["p"]
+        L = len(bns)
+        require_hip(x, *[t for t in params if t is not None])
+        B = x.shape[0]
+        dev = x.device
+        rng = _dropout_rng(dev)
+        hs, stats, rows, ctrs, stat, acts = [], [], [], [], [], []
+        inp = x
+        for l in range(L):
+            W, b, gamma, beta = params[4 * l:4 * l + 4]
+            N, K = W.shape
+            h = torch.empty((B, N), dtype=torch.float32, device=dev)
+            r = _lib.call("rh_gemm_stats_rows", B, N)
+            st = torch.empty((-(-B // r), 2, N), dtype=torch.float32, device=dev)
+            ctr = torch.empty(1, dtype=torch.int64, device=dev)
+            if l == 0:
+                _lib.call("rh_linear_fwd", _p(inp), inp.stride(0), _p(W), K, _p(b), B, N, K, _p(h), N, _p(st), _p(rng),
+                          _p(ctr), _p(bns[0].num_batches_tracked), _stream())
+            else:
+                pb, pg, pbt = bns[l - 1], params[4 * (l - 1) + 2], params[4 * (l - 1) + 3]
+                so = torch.empty((4, K), dtype=torch.float32, device=dev)
+                act = torch.empty((B, K), dtype=torch.float32, device=dev)
+                _lib.call("rh_linear_bnact_fwd", _p(hs[-1]), K, B, K, _p(stats[-1]), rows[-1], _p(pg), _p(pbt),
+                          _p(pb.running_mean), _p(pb.running_var), float(pb.momentum), float(pb.eps), float(ps[l - 1]),
+                          _p(rng), _p(ctrs[-1]), _p(so), _p(act), _p(W), K, _p(b), N, _p(h), N, _p(st), _p(rng), _p(ctr),
+                          _p(bns[l].num_batches_tracked), _stream())
+                stat.append(so)
+                acts.append(act)
+            hs.append(h)
+            stats.append(st)
+            rows.append(r)
+            ctrs.append(ctr)
+        hw, hb = params[4 * L], params[4 * L + 1]
+        K = hs[-1].shape[1]
+        lb, lg, lbt = bns[-1], params[4 * (L - 1) + 2], params[4 * (L - 1) + 3]
+        so = torch.empty((4, K), dtype=torch.float32, device=dev)
+        c0, c1 = _col(e0, B), _col(e1, B)
+        y = torch.empty((B,), dtype=torch.float32, device=dev)
+        t = fusion.target
+        partial = None
+        ctx.fused_t = None
+        if t is not None and t.numel() == B and t.device == dev and any(ctx.needs_input_grad):
+            partial = torch.empty((_lib.call("rh_head_loss_nblocks", B),), dtype=torch.float32, device=dev)
+            ctx.fused_t = t
+        _lib.call("rh_head_bnact_fwd", _p(hs[-1]), K, _p(stats[-1]), rows[-1], _p(lg), _p(lbt), _p(lb.running_mean),
+                  _p(lb.running_var), float(lb.momentum), float(lb.eps), float(ps[-1]), _p(rng), _p(ctrs[-1]), _p(so), _p(hw),
+                  _p(hb), _p(c0), _p(c1), B, K, _p(y), _p(ctx.fused_t), _p(partial), _stream())
+        if ctx.fused_t is not None:
+            fusion.head = dict(y_ptr=y.data_ptr(), partial=partial, t=t)
+        stat.append(so)
+        ctx.L, ctx.ps = L, [float(v) for v in ps]
+        ctx.params = params  # the parameter objects themselves (ops.deferred keys gradients by identity)
+        ctx.shapes = (None if e0 is None else e0.shape, None if e1 is None else e1.shape)
+        ctx.save_for_backward(x, y, *hs, *acts, *stat, *ctrs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        L, ps, params = ctx.L, ctx.ps, ctx.params
+        saved = ctx.saved_tensors
+        x, y = saved[0], saved[1]
+        hs = saved[2:2 + L]
+        acts = saved[2 + L:2 + L + (L - 1)]
+        stat = saved[2 + L + (L - 1):2 + L + (L - 1) + L]
+        ctrs = saved[2 + L + (L - 1) + L:]
+        B = x.shape[0]
+        dev = x.device
+        rng = _dropout_rng(dev)
+        hw, hb = params[4 * L], params[4 * L + 1]
+        K = hs[-1].shape[1]
+        # ---- head: d loss / d y -> g of the last hidden layer's OUTPUT + that layer's BatchNorm-backward sums
+        g_a = torch.empty((B, K), dtype=torch.float32, device=dev)
+        g_z = torch.empty((B,), dtype=torch.float32, device=dev)
+        nblk = _lib.call("rh_head_nblocks", B)
+        partial = torch.empty((nblk, K + 1), dtype=torch.float32, device=dev)
+        armed = deferred.armed
+        has_bias = hb is not None
+        defer = armed is not None and id(hw) in armed and (not has_bias or id(hb) in armed)
+        g_w = None if defer else torch.empty_like(hw)
+        g_b = torch.empty((1,), dtype=torch.float32, device=dev) if (has_bias and not defer) else None
+        g_loss = fusion.g_loss
+        t = gl = None
+        if ctx.fused_t is not None and g_loss is not None and g_loss[1] == y.data_ptr():
+            fusion.g_loss = None  # (see _HeadFn.backward: the fused BCE's gradient is formed per row inside the launch)
+            t, gl = ctx.fused_t, g_loss[0]
+            zero = g_loss[2]
+            if g_y.data_ptr() == zero.data_ptr() and g_y._version == g_loss[3]:
+                g_y = None
+            else:
+                g_y = g_y.contiguous()
+        else:
+            g_y = g_y.contiguous()
+        bn_partial = torch.empty((nblk, 2, K), dtype=torch.float32, device=dev)
+        _lib.call("rh_head_bwd_bn", _p(None), K, _p(hw), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_a), _p(g_z), _p(g_w),
+                  _p(g_b), _p(partial), 0 if defer else 1, _p(hs[-1]), _p(stat[-1]), _p(params[4 * (L - 1) + 2]),
+                  _p(params[4 * (L - 1) + 3]), ps[-1], _p(rng), _p(ctrs[-1]), 1, _p(bn_partial), _stream())
+        if defer:
+            g_w = deferred.offer(hw, partial.data_ptr(), nblk, K + 1, K, lambda: partial[:, :K].sum(0).view_as(hw), partial)
+            if has_bias:
+                g_b = deferred.offer(hb, partial.data_ptr() + 4 * K, nblk, K + 1, 1, lambda: partial[:, K].sum().view(1),
+                                     partial)
+        grads = [None] * (4 * L + 2)
+        grads[4 * L], grads[4 * L + 1] = g_w, g_b
+        nchunks = nblk
+        g_x = None
+        for l in range(L - 1, -1, -1):
+            W, b, gamma, beta = params[4 * l:4 * l + 4]
+            N, Kin = W.shape
+            # BatchNorm + ReLU + Dropout backward of layer l from the sums its consumer formed: finalize + apply
+            g_h = torch.empty((B, N), dtype=torch.float32, device=dev)
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            _lib.call("rh_bn_relu_dropout_bwd_pre", _p(hs[l]), _p(g_a), B, N, _p(gamma), _p(beta), ps[l], _p(rng),
+                      _p(ctrs[l]), _p(bn_partial), nchunks, _p(stat[l]), _p(g_h), _p(dgamma), _p(dbeta), 1, _stream())
+            grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
+            inp = acts[l - 1] if l > 0 else x
+            if l > 0:
+                r = _lib.call("rh_gemm_stats_rows", B, Kin)
+                nchunks = -(-B // r)
+                bn_partial = torch.empty((nchunks, 2, Kin), dtype=torch.float32, device=dev)
+                g_a = torch.empty((B, Kin), dtype=torch.float32, device=dev)
+                _lib.call("rh_linear_dgrad_bnbwd", _p(g_h), N, _p(W), Kin, B, N, Kin, _p(g_a), Kin, _p(hs[l - 1]), Kin,
+                          _p(stat[l - 1]), _p(params[4 * (l - 1) + 2]), _p(params[4 * (l - 1) + 3]), ps[l - 1], _p(rng),
+                          _p(ctrs[l - 1]), _p(bn_partial), _stream())
+            elif ctx.needs_input_grad[0]:
+                g_x = torch.empty((B, Kin), dtype=torch.float32, device=dev)
+                _lib.call("rh_linear_dgrad", _p(g_h), N, _p(W), Kin, B, N, Kin, _p(g_x), Kin, _stream())
+            grads[4 * l], grads[4 * l + 1] = linear_wgrad(g_h, inp, want_bias=b is not None, weight=W, bias=b)
+        s0, s1 = ctx.shapes
+        return (g_x, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1), None) + tuple(grads)
+
+
+def mlp_chain_ok(x, blocks, head, extras):
+    """blocks = [(nn.Linear, nn.BatchNorm1d, p_drop)] of consecutive Linear -> BatchNorm1d -> ReLU -> Dropout layers in
+    training mode, head = the closing nn.Linear(., 1): can _MlpChainFn run them?"""
+    if not (FUSE_MLP_CHAIN and blocks and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and
+            x.dtype == torch.float32 and x.stride(1) == 1 and 2 <= x.shape[0] <= _CHAIN_MAX_B and len(extras) <= 2 and
+            type(head) is torch.nn.Linear and head.out_features == 1 and head.weight.dtype == torch.float32 and
+            all(e.numel() == x.shape[0] for e in extras)):
+        return False
+    width = x.shape[1]
+    for lin, bn, p in blocks:
+        if not (type(lin) is torch.nn.Linear and type(bn) is torch.nn.BatchNorm1d and bn.training and bn.affine and
+                bn.track_running_stats and bn.momentum is not None and lin.in_features == width and
+                lin.weight.is_contiguous() and lin.weight.dtype == torch.float32 and lin.out_features % 4 == 0 and
+                lin.out_features <= _GEMM_MAX_NK and width <= _GEMM_MAX_NK and 0.0 <= p < 1.0 and linear_ok(x, lin.weight)):
+            return False
+        width = lin.out_features
+    return width <= 256 and head.in_features == width and _lib.call("rh_head_nblocks", x.shape[0]) <= 128
+
+
+def mlp_chain_sigmoid(x, blocks, head, *extras):
+    """sigmoid((head(hidden(x)) + sum(extras)).squeeze(1)) through _MlpChainFn; see mlp_chain_ok."""
+    e = list(extras) + [None, None]
+    cfg = {"bns": [bn for _, bn, _ in blocks], "p": [p for _, _, p in blocks]}
+    params = []
+    for lin, bn, _ in blocks:
+        params += [lin.weight, lin.bias, bn.weight, bn.bias]
+    return _MlpChainFn.apply(x, e[0], e[1], cfg, *params, head.weight, head.bias)
+
+
 def head_ok(h, lin, extras):
     K = lin.in_features
     return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and lin.out_features == 1 and 1 <= K <= 1024 and
