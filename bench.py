@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--brief", action="store_true",
                     help="headline only: skip batch_sweep / zipf / secondary_configs / step_accounting (SURVEY 8d extras)")
     ap.add_argument("--no-step-accounting", action="store_true", help="skip the nested rocprofv3 pass (step_accounting)")
+    ap.add_argument("--acct-only", action="store_true",
+                    help="of the extra lines (batch sweep, Zipf, secondary configs, step accounting) only the step accounting")
     ap.add_argument("--cpu-protocol", default="auto", choices=["auto", "full", "bounded"],
                     help="cpu_baseline: full = SURVEY 8(d)'s 3 warm-up + 10 timed steps per leg (~90 s at the Criteo shape); "
                          "bounded = about --cpu-budget seconds of steps; auto = full unless a step is too slow on this host")
@@ -977,35 +979,36 @@ def main():
 
             keep_args = wl.args
             sweep = {}
-            for b in (2048, 8192, 32768, 65536):
+            for b in (() if args.acct_only else (2048, 8192, 32768, 65536)):
                 sweep[str(b)] = guarded(f"batch_sweep B={b}", lambda b=b: _short_run(args, device, rank, use_graph, batch=b,
                                                                                     wl=wl)[0])
             wl.args = keep_args
             sweep["4096"] = {"batch": 4096, "ms_per_step": round(head["ms_per_step"], 4), "value": round(head["value"], 1),
                              "unit": "samples/s", "steps": args.steps, "note": "the headline run"}
-            extras["batch_sweep"] = {"what": "whole hipGraph-replayed training step (batch assembly, forward, backward, "
-                                             "dense-exact Adam) at other per-GPU batch sizes, same tables and dataset; 30 "
-                                             "timed steps each after the warm-up into the steady state", "runs": sweep}
-            extras["zipf"] = guarded("zipf", lambda: dict(_short_run(args, device, rank, use_graph, dist_kind="zipf",
-                                                                     rows=8_000_000, steps=50)[0],
-                                                          index_dist="Zipf(1.05) per field (bounded power law)",
-                                                          rows_per_gpu=8_000_000))
-            wl2 = copy.copy(wl)
-            wl2.name = "dcnv2"
-            sec = {"dcnv2": guarded("dcnv2", lambda: dict(_short_run(args, device, rank, use_graph, model="dcnv2", steps=30,
-                                                                     wl=wl2)[0],
-                                                          workload="BASELINE.json configs[2] shape on one GPU: DCN-v2 "
-                                                                   "(CrossNetMix 3 layers, rank 32, 4 experts; parallel DNN)"))}
-            wl.args = keep_args
-            for name in ("din", "dssm"):
-                def one(name=name):
-                    r, w = _short_run(args, device, rank, use_graph, model=name, steps=20, rows=0)
-                    r["workload"] = w.desc
-                    del w
-                    return r
-                sec[name] = guarded(name, one)
-                torch.cuda.empty_cache()
-            extras["secondary_configs"] = sec
+            if not args.acct_only:
+                extras["batch_sweep"] = {"what": "whole hipGraph-replayed training step (batch assembly, forward, backward, "
+                                                 "dense-exact Adam) at other per-GPU batch sizes, same tables and dataset; 30 "
+                                                 "timed steps each after the warm-up into the steady state", "runs": sweep}
+                extras["zipf"] = guarded("zipf", lambda: dict(_short_run(args, device, rank, use_graph, dist_kind="zipf",
+                                                                         rows=8_000_000, steps=50)[0],
+                                                              index_dist="Zipf(1.05) per field (bounded power law)",
+                                                              rows_per_gpu=8_000_000))
+                wl2 = copy.copy(wl)
+                wl2.name = "dcnv2"
+                sec = {"dcnv2": guarded("dcnv2", lambda: dict(_short_run(args, device, rank, use_graph, model="dcnv2", steps=30,
+                                                                         wl=wl2)[0],
+                                                              workload="BASELINE.json configs[2] shape on one GPU: DCN-v2 "
+                                                                       "(CrossNetMix 3 layers, rank 32, 4 experts; parallel DNN)"))}
+                wl.args = keep_args
+                for name in ("din", "dssm"):
+                    def one(name=name):
+                        r, w = _short_run(args, device, rank, use_graph, model=name, steps=20, rows=0)
+                        r["workload"] = w.desc
+                        del w
+                        return r
+                    sec[name] = guarded(name, one)
+                    torch.cuda.empty_cache()
+                extras["secondary_configs"] = sec
             if not args.no_step_accounting:
                 extras["step_accounting"] = guarded("step_accounting", lambda: step_accounting(args))
         acct = extras.get("step_accounting") or {}

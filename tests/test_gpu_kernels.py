@@ -1777,7 +1777,7 @@ def test_mlp_chain_equals_the_layer_by_layer_kernels(B, K0, dims, p, monkeypatch
     np.testing.assert_allclose(A["y"].cpu().numpy(), R["y"].cpu().numpy(), rtol=1e-5, atol=2e-6)
     for k in ("gx", "g0", "g1"):
         scale = max(1e-6, float(R[k].abs().max()))
-        assert float((A[k] - R[k]).abs().max()) <= 2e-5 * scale, k
+        assert float((A[k] - R[k]).abs().max()) <= 2e-5 * scale + 2e-8, k  # (+ an absolute floor: B = 2 gradients are ~1e-4)
     for n in R["params"]:
         scale = max(1e-3, float(R["params"][n].abs().max()))
         # (a Linear bias in front of BatchNorm has a mathematically zero gradient: rounding noise on both sides)
