@@ -342,6 +342,7 @@ int rh_bn_stats_from_partial(const float* partial, int rows_per_chunk, int B, in
  *   rh_linear_dgrad: g (M, N), w (N, K) -> gx (M, K).  Exact f32 (MFMA f32 == fmaf chain); summation order over k is
  *   permuted inside each 32-wide K tile. */
 int rh_gemm_stats_rows(int M, int N);
+int rh_gemm_chain_stats_rows(int M); /* slab height of the `stats` rh_linear_bnact_fwd writes (64, or 32 when M <= 32) */
 int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
                   float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr, int64_t* bn_batches,
                   void* stream);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "rh_linear_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                       c_ptr],
     "rh_linear_dgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr],
+    "rh_gemm_chain_stats_rows": [c_int],
     "rh_linear_bnact_fwd": [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr,
                             c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_linear_dgrad_bnbwd": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
@@ -151,7 +152,7 @@ _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctyp
 # functions whose int return value is a result, not a status
 _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblocks", "rh_cross_max_layers",
                     "rh_bn_act_nchunks", "rh_dice_nblocks", "rh_linear_wgrad_workspace", "rh_linear_wgrad_tiles", "rh_linear_wgrad_splits",
-                    "rh_head_nblocks", "rh_ce_nblocks", "rh_bn_prelu_nblocks", "rh_head_loss_nblocks", "rh_cross_mix_nblocks", "rh_cross_moe_kp", "rh_cross_moe_supported", "rh_cross_moe_mid_blocks", "rh_din_att_l1_supported", "rh_din_att_l1_chunk_rows", "rh_prelu_nblocks", "rh_gemm_stats_rows", "rh_bn_dice_stats_blocks", "rh_augru_max_dim"}
+                    "rh_head_nblocks", "rh_ce_nblocks", "rh_bn_prelu_nblocks", "rh_head_loss_nblocks", "rh_cross_mix_nblocks", "rh_cross_moe_kp", "rh_cross_moe_supported", "rh_cross_moe_mid_blocks", "rh_din_att_l1_supported", "rh_din_att_l1_chunk_rows", "rh_prelu_nblocks", "rh_gemm_stats_rows", "rh_gemm_chain_stats_rows", "rh_bn_dice_stats_blocks", "rh_augru_max_dim"}
 
 ABI_VERSION = 1
 _lib = None

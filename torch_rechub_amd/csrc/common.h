@@ -139,12 +139,88 @@ static __device__ __forceinline__ void gatomic_add_f4(float* p, float4 v) {
     unsafeAtomicAdd(&(base)[(off) + 3], (v).w); \
   } while (0)
 
-// Counter-based dropout hash of csrc/mlp.hip (seed, call counter, element index) -> 32 random bits; shared with the head
-// backward of csrc/linear.hip, which forms the BatchNorm-backward column sums of the layer below from the same mask.
+// Per-column batch statistics from per-slab (sum, M2) pairs -- what the STATS epilogue of csrc/gemm.hip writes: slab k holds
+// rows [k * rows, (k + 1) * rows) of the M rows, stats[(k * 2 + {0, 1}) * K + c] = (sum, M2 about the slab mean) of column c.
+// Chan et al.'s combination (mean = sum_k sum_k / M, M2 = sum_k [M2_k + n_k (mean_k - mean)^2]) in a FIXED order
+// (deterministic): a workgroup of NT threads walks the K columns min(K, NT) at a time; with K < NT, G = NT / K thread groups
+// split a column's slabs (k = g, g + G, ...) and are summed in group order through `red` (NT floats of LDS).  Every thread
+// keeps up to MAXS slabs of its column in registers -- all loads of the pass in flight at once (unconditional, clamped
+// addresses: no branch per load) -- longer lists continue with a dependent loop (correct, slow; the callers size their slabs
+// so that it never runs at CTR batch sizes).  emit(c, mean, var) is called by ONE thread per column (var = biased).
+// All NT threads must call this (it synchronises the workgroup).
+template <int NT, int MAXS, typename F>
+static __device__ __forceinline__ void rh_combine_slabs(const float* __restrict__ stats, int nslab, int rows, int M, int K,
+                                                        float* red, int tid, F emit) {
+  const int kc = K < NT ? K : NT;       // columns per pass
+  const int G = K < NT ? NT / K : 1;    // slab groups per column
+  const int cl = tid % kc, g = tid / kc;
+  const bool live = g < G;
+  const float full = (float)rows, inv_full = 1.f / full;
+  const float tail = (float)(M - (nslab - 1) * rows), inv_tail = 1.f / tail;
+  for (int c0 = 0; c0 < K; c0 += kc) {  // uniform trip count
+    const int c = c0 + cl;
+    const bool ok = live && c < K;
+    const int cc = c < K ? c : K - 1;
+    float ps[MAXS], pm[MAXS];
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      const int k = g + i * G;
+      const int kk = (ok && k < nslab) ? k : 0;
+      ps[i] = stats[((int64_t)kk * 2 + 0) * K + cc];
+      pm[i] = stats[((int64_t)kk * 2 + 1) * K + cc];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) s += (ok && g + i * G < nslab) ? ps[i] : 0.f;
+    if (ok)
+      for (int k = g + MAXS * G; k < nslab; k += G) s += stats[((int64_t)k * 2 + 0) * K + c];
+    __syncthreads();  // (the previous pass is done with red)
+    if (live) red[g * kc + cl] = s;
+    __syncthreads();
+    float tot = red[cl];
+    for (int q = 1; q < G; ++q) tot += red[q * kc + cl];
+    const float mean = tot / (float)M;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      const int k = g + i * G;
+      if (ok && k < nslab) {
+        const float d = ps[i] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
+        m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, pm[i]);
+      }
+    }
+    if (ok) {
+      for (int k = g + MAXS * G; k < nslab; k += G) {
+        const float d = stats[((int64_t)k * 2 + 0) * K + c] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
+        m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, stats[((int64_t)k * 2 + 1) * K + c]);
+      }
+    }
+    __syncthreads();
+    if (live) red[g * kc + cl] = m2;
+    __syncthreads();
+    if (ok && g == 0) {
+      float m2t = red[cl];
+      for (int q = 1; q < G; ++q) m2t += red[q * kc + cl];
+      emit(c, mean, fmaxf(m2t / (float)M, 0.f));
+    }
+  }
+  __syncthreads();
+}
+
+// Counter-based dropout hash (seed, call counter, element index) -> 32 random bits; shared by every kernel that applies or
+// re-derives a dropout mask (csrc/mlp.hip, the head / GEMM prologues and epilogues of the fused MLP chain), so forward and
+// backward -- fused or not -- see the same mask.  Round 4: the 64-bit splitmix form (three 64-bit multiplies = twelve
+// quarter-rate v_mul_*_u32, ~250 cycles per element and wavefront) made the mask the most expensive part of the kernels
+// that recompute it on an operand load; this one is the `lowbias32` integer finaliser (two 32-bit multiplies, full
+// avalanche on sequential inputs) over index ^ key, the key (seed, counter) folded per call: ~80 cycles.
 static __device__ __forceinline__ uint32_t rh_drop_hash(uint64_t seed, uint64_t ctr, uint64_t idx) {
-  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed + ctr * 0xD1B54A32D192ED03ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t k0 = (uint32_t)seed ^ ((uint32_t)ctr * 0x9E3779B1u) ^ ((uint32_t)(ctr >> 32) * 0xC2B2AE3Du);  // per call
+  const uint32_t k1 = (uint32_t)(seed >> 32);
+  uint32_t h = (uint32_t)idx ^ k0 ^ (((uint32_t)(idx >> 32) + k1) * 0x85EBCA77u);
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
 }

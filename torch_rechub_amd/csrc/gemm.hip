@@ -149,61 +149,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
       ctr = (uint64_t)a.pro_ctr[0];
     }
   }
-  if (PRO) {
-    // statistics of the K columns of A: Chan's combination of the per-slab (sum, M2) pairs in slab order (the arithmetic
-    // of csrc/mlp.hip::chan_combine with one thread per column), every load of a column in flight at once
-    const int nslab = (a.M + a.pro_rows - 1) / a.pro_rows;
-    const float full = (float)a.pro_rows, inv_full = 1.f / full;
-    const float tail = (float)(a.M - (nslab - 1) * a.pro_rows), inv_tail = 1.f / tail;
-    for (int c = tid; c < ((a.K + kBK - 1) / kBK) * kBK; c += NT) {
-      float mean = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
-      if (c < a.K) {
-        float ps[kProMaxSlabs], pm[kProMaxSlabs];
-#pragma unroll
-        for (int k = 0; k < kProMaxSlabs; ++k) {
-          const bool ok = k < nslab;
-          ps[k] = ok ? a.pro_stats[((int64_t)k * 2 + 0) * a.K + c] : 0.f;
-          pm[k] = ok ? a.pro_stats[((int64_t)k * 2 + 1) * a.K + c] : 0.f;
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < kProMaxSlabs; ++k) sum += ps[k];
-        for (int k = kProMaxSlabs; k < nslab; ++k) sum += a.pro_stats[((int64_t)k * 2 + 0) * a.K + c];
-        mean = sum / (float)a.M;
-        float m2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < kProMaxSlabs; ++k) {
-          if (k < nslab) {
-            const float d = ps[k] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
-            m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, pm[k]);
-          }
-        }
-        for (int k = kProMaxSlabs; k < nslab; ++k) {
-          const float d = a.pro_stats[((int64_t)k * 2 + 0) * a.K + c] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
-          m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, a.pro_stats[((int64_t)k * 2 + 1) * a.K + c]);
-        }
-        const float var = fmaxf(m2 / (float)a.M, 0.f);
-        rstd = rsqrtf(var + a.pro_eps);
-        gam = a.pro_gamma[c];
-        bet = a.pro_beta[c];
-        if (blockIdx.x == 0 && blockIdx.y == 0) {
-          a.pro_stat_out[c] = mean;
-          a.pro_stat_out[a.K + c] = rstd;
-          if (a.pro_running_mean != nullptr) {
-            const float n = (float)a.M;
-            const float unbiased = a.M > 1 ? var * (n / (n - 1.f)) : var;
-            a.pro_running_mean[c] = fmaf(a.pro_momentum, mean - a.pro_running_mean[c], a.pro_running_mean[c]);
-            a.pro_running_var[c] = fmaf(a.pro_momentum, unbiased - a.pro_running_var[c], a.pro_running_var[c]);
-          }
-        }
-      }
-      pro_c[c] = mean;
-      pro_c[kProMaxK + c] = rstd;
-      pro_c[2 * kProMaxK + c] = gam;
-      pro_c[3 * kProMaxK + c] = bet;
-    }
-    __syncthreads();
-  }
   // PRO: one float4 of A (row `row`, columns k .. k + 3) -> the hidden layer's output; columns past K come out as 0
   auto pro_apply = [&](float4 v, int row, int k) -> float4 {
     const float4 mean = *reinterpret_cast<const float4*>(pro_c + k);
@@ -322,6 +267,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   float fa0[16], fb0[16], fa1[16], fb1[16];
   gfetch(0, ra0, rb0);
   if (ntiles > 1) gfetch(kBK, ra1, rb1);
+  // (PRO: the first two tiles are in flight while the statistics of A's columns are combined)
+  if (PRO) {
+    // statistics of the K columns of A: Chan's combination of the per-slab (sum, M2) pairs in slab order (common.h,
+    // the arithmetic of csrc/mlp.hip::chan_combine), all loads of a column pass in flight at once
+    const int nslab = (a.M + a.pro_rows - 1) / a.pro_rows;
+    for (int c = a.K + tid; c < ((a.K + kBK - 1) / kBK) * kBK; c += NT)  // zero tail: columns past K transform to 0
+      pro_c[c] = pro_c[kProMaxK + c] = pro_c[2 * kProMaxK + c] = pro_c[3 * kProMaxK + c] = 0.f;
+    rh_combine_slabs<NT, kProMaxSlabs>(a.pro_stats, nslab, a.pro_rows, a.M, a.K, lds, tid, [&](int c, float mean, float var) {
+      const float rstd = rsqrtf(var + a.pro_eps);
+      pro_c[c] = mean;
+      pro_c[kProMaxK + c] = rstd;
+      pro_c[2 * kProMaxK + c] = a.pro_gamma[c];
+      pro_c[3 * kProMaxK + c] = a.pro_beta[c];
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        a.pro_stat_out[c] = mean;
+        a.pro_stat_out[a.K + c] = rstd;
+        if (a.pro_running_mean != nullptr) {
+          const float n = (float)a.M;
+          const float unbiased = a.M > 1 ? var * (n / (n - 1.f)) : var;
+          a.pro_running_mean[c] = fmaf(a.pro_momentum, mean - a.pro_running_mean[c], a.pro_running_mean[c]);
+          a.pro_running_var[c] = fmaf(a.pro_momentum, unbiased - a.pro_running_var[c], a.pro_running_var[c]);
+        }
+      }
+    });
+  }
   lstore(0, ra0, rb0, 0);
   if (ntiles > 1) lstore(1, ra1, rb1, kBK);
   if (RH_PROBE != 1 && ntiles > 2) gfetch(2 * kBK, ra0, rb0);
@@ -494,9 +464,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
 // one tile per workgroup; 64x64 tiles unless that leaves most of the 256 CUs idle
 bool big_tiles(int M, int N) { return (int64_t)((M + 63) / 64) * ((N + 63) / 64) >= 192; }
 
+// (PRO always takes the 64-row tile: half as many workgroups repeat the statistics prologue, and y's own slabs come out
+// 64 rows high -- at most 64 of them for the next consumer's prologue at CTR batch sizes)
+bool chain_tiles(int M) { return M > 32; }
+
 template <bool B_KMAJOR, bool STATS, bool PRO = false, bool BNBWD = false>
 void launch(const GemmArgs& a, hipStream_t s) {
-  if (big_tiles(a.M, a.N)) {
+  if (PRO ? chain_tiles(a.M) : big_tiles(a.M, a.N)) {
     hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), 0,
                        s, a);
   } else {
@@ -508,6 +482,7 @@ void launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int rh_gemm_stats_rows(int M, int N) { return big_tiles(M, N) ? 64 : 32; }
+extern "C" int rh_gemm_chain_stats_rows(int M) { return chain_tiles(M) ? 64 : 32; }  // slab height of rh_linear_bnact_fwd
 
 extern "C" int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N,
                              int K, float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr,

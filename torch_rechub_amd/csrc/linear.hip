@@ -357,7 +357,7 @@ struct HeadBnFwdArgs {
   float* loss_partial;
 };
 constexpr int kHeadBnMaxK = 256;
-constexpr int kHeadBnMaxSlabs = 64;
+constexpr int kHeadBnMaxSlabs = 64;  // slabs per thread in registers (x 256 / K thread groups per column)
 
 __global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFwdArgs a) {
   RH_CHAIN_PRIO();
@@ -365,36 +365,10 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFw
   __shared__ float cst[4 * kHeadBnMaxK];  // mean, rstd, gamma, beta
   const int K = a.K, B = a.B;
   {
-    const int c = threadIdx.x;
+    __shared__ float red[RH_BLOCK];
     const int nslab = (B + a.rows - 1) / a.rows;
-    const float full = (float)a.rows, inv_full = 1.f / full;
-    const float tail = (float)(B - (nslab - 1) * a.rows), inv_tail = 1.f / tail;
-    if (c < K) {
-      float ps[kHeadBnMaxSlabs], pm[kHeadBnMaxSlabs];
-#pragma unroll
-      for (int k = 0; k < kHeadBnMaxSlabs; ++k) {
-        const bool ok = k < nslab;
-        ps[k] = ok ? a.stats[((int64_t)k * 2 + 0) * K + c] : 0.f;
-        pm[k] = ok ? a.stats[((int64_t)k * 2 + 1) * K + c] : 0.f;
-      }
-      float sum = 0.f;
-#pragma unroll
-      for (int k = 0; k < kHeadBnMaxSlabs; ++k) sum += ps[k];
-      for (int k = kHeadBnMaxSlabs; k < nslab; ++k) sum += a.stats[((int64_t)k * 2 + 0) * K + c];
-      const float mean = sum / (float)B;
-      float m2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < kHeadBnMaxSlabs; ++k) {
-        if (k < nslab) {
-          const float d = ps[k] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
-          m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, pm[k]);
-        }
-      }
-      for (int k = kHeadBnMaxSlabs; k < nslab; ++k) {
-        const float d = a.stats[((int64_t)k * 2 + 0) * K + c] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
-        m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, a.stats[((int64_t)k * 2 + 1) * K + c]);
-      }
-      const float var = fmaxf(m2 / (float)B, 0.f);
+    rh_combine_slabs<RH_BLOCK, kHeadBnMaxSlabs>(a.stats, nslab, a.rows, B, K, red, (int)threadIdx.x,
+                                                [&](int c, float mean, float var) {
       const float rstd = rsqrtf(var + a.eps);
       cst[c] = mean;
       cst[kHeadBnMaxK + c] = rstd;
@@ -410,8 +384,7 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFw
           a.running_var[c] = fmaf(a.momentum, unbiased - a.running_var[c], a.running_var[c]);
         }
       }
-    }
-    __syncthreads();
+    });
   }
   float keep_scale = 1.f;
   uint32_t thr = 0;

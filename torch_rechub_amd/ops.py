@@ -1178,7 +1178,7 @@ class _MlpChainFn(torch.autograd.Function):
             W, b, gamma, beta = params[4 * l:4 * l + 4]
             N, K = W.shape
             h = torch.empty((B, N), dtype=torch.float32, device=dev)
-            r = _lib.call("rh_gemm_stats_rows", B, N)
+            r = _lib.call("rh_gemm_stats_rows", B, N) if l == 0 else _lib.call("rh_gemm_chain_stats_rows", B)
             st = torch.empty((-(-B // r), 2, N), dtype=torch.float32, device=dev)
             ctr = torch.empty(1, dtype=torch.int64, device=dev)
             if l == 0:
@@ -1420,7 +1420,7 @@ def bce_mean(y, t):
     of a head that already scored against ``t`` (StepFusion), the mean is finished by the step's scalar launch."""
     head = fusion.head
     if head is not None and head["y_ptr"] == y.data_ptr() and head["t"].data_ptr() == t.data_ptr() and \
-            y.grad_fn is not None and y.grad_fn.__class__.__name__ == "_HeadFnBackward":
+            y.grad_fn is not None and y.grad_fn.__class__.__name__ in ("_HeadFnBackward", "_MlpChainFnBackward"):
         fusion.head = None
         return _FusedBceFn.apply(y, t, head["partial"])
     return _BceFn.apply(y, t)
