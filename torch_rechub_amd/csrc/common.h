@@ -141,13 +141,16 @@ static __device__ __forceinline__ void gatomic_add_f4(float* p, float4 v) {
 
 // Per-column batch statistics from per-slab (sum, M2) pairs -- what the STATS epilogue of csrc/gemm.hip writes: slab k holds
 // rows [k * rows, (k + 1) * rows) of the M rows, stats[(k * 2 + {0, 1}) * K + c] = (sum, M2 about the slab mean) of column c.
-// Chan et al.'s combination (mean = sum_k sum_k / M, M2 = sum_k [M2_k + n_k (mean_k - mean)^2]) in a FIXED order
-// (deterministic): a workgroup of NT threads walks the K columns min(K, NT) at a time; with K < NT, G = NT / K thread groups
-// split a column's slabs (k = g, g + G, ...) and are summed in group order through `red` (NT floats of LDS).  Every thread
-// keeps up to MAXS slabs of its column in registers -- all loads of the pass in flight at once (unconditional, clamped
-// addresses: no branch per load) -- longer lists continue with a dependent loop (correct, slow; the callers size their slabs
-// so that it never runs at CTR batch sizes).  emit(c, mean, var) is called by ONE thread per column (var = biased).
-// All NT threads must call this (it synchronises the workgroup).
+// ONE pass over the slabs, about a shift = the mean of slab 0 (so nothing large cancels: the slab means differ from it by
+// ~ std / sqrt(rows)):   d_k = mean_k - shift,  S1 = sum_k n_k d_k,  S2 = sum_k (M2_k + n_k d_k^2)
+//                        mean = shift + S1 / M,  M2 = S2 - S1^2 / M           (the parallel-variance identity of Chan et al.)
+// in a FIXED order (deterministic).  A workgroup of NT threads walks the K columns min(K, NT) at a time; with K < NT,
+// G = NT / K thread groups split a column's slabs (k = g, g + G, ...) and are summed in group order through `red` (2 NT
+// floats of LDS).  Loads go out in rounds of MAXS slabs per thread (2 MAXS registers; unconditional, clamped addresses: no
+// branch per load).  Consumers of the statistics that run BESIDE the optimizer's resident sweep must stay small in
+// registers -- a 256-register variant of this prologue (all 64 slabs of a column in flight at once) could not be placed on
+// a SIMD until the sweep had finished (194 us for a 26 us kernel).  emit(c, mean, var) is called by ONE thread per column
+// (var = biased).  All NT threads must call this (it synchronises the workgroup).
 template <int NT, int MAXS, typename F>
 static __device__ __forceinline__ void rh_combine_slabs(const float* __restrict__ stats, int nslab, int rows, int M, int K,
                                                         float* red, int tid, F emit) {
@@ -161,47 +164,43 @@ static __device__ __forceinline__ void rh_combine_slabs(const float* __restrict_
     const int c = c0 + cl;
     const bool ok = live && c < K;
     const int cc = c < K ? c : K - 1;
-    float ps[MAXS], pm[MAXS];
+    const float shift = stats[cc] * (nslab == 1 ? inv_tail : inv_full);  // mean of slab 0
+    float s1 = 0.f, s2 = 0.f;
+    for (int base = 0; base < nslab; base += MAXS * G) {  // uniform trip count
+      float ps[MAXS], pm[MAXS];
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) {
-      const int k = g + i * G;
-      const int kk = (ok && k < nslab) ? k : 0;
-      ps[i] = stats[((int64_t)kk * 2 + 0) * K + cc];
-      pm[i] = stats[((int64_t)kk * 2 + 1) * K + cc];
+      for (int i = 0; i < MAXS; ++i) {
+        const int k = base + g + i * G;
+        const int kk = (ok && k < nslab) ? k : 0;
+        ps[i] = stats[((int64_t)kk * 2 + 0) * K + cc];
+        pm[i] = stats[((int64_t)kk * 2 + 1) * K + cc];
+      }
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        const int k = base + g + i * G;
+        if (ok && k < nslab) {
+          const bool last = k == nslab - 1;
+          const float n = last ? tail : full;
+          const float d = ps[i] * (last ? inv_tail : inv_full) - shift;
+          s1 = fmaf(n, d, s1);
+          s2 += fmaf(n * d, d, pm[i]);
+        }
+      }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXS; ++i) s += (ok && g + i * G < nslab) ? ps[i] : 0.f;
-    if (ok)
-      for (int k = g + MAXS * G; k < nslab; k += G) s += stats[((int64_t)k * 2 + 0) * K + c];
     __syncthreads();  // (the previous pass is done with red)
-    if (live) red[g * kc + cl] = s;
-    __syncthreads();
-    float tot = red[cl];
-    for (int q = 1; q < G; ++q) tot += red[q * kc + cl];
-    const float mean = tot / (float)M;
-    float m2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXS; ++i) {
-      const int k = g + i * G;
-      if (ok && k < nslab) {
-        const float d = ps[i] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
-        m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, pm[i]);
-      }
+    if (live) {
+      red[g * kc + cl] = s1;
+      red[NT + g * kc + cl] = s2;
     }
-    if (ok) {
-      for (int k = g + MAXS * G; k < nslab; k += G) {
-        const float d = stats[((int64_t)k * 2 + 0) * K + c] * (k == nslab - 1 ? inv_tail : inv_full) - mean;
-        m2 += fmaf((k == nslab - 1 ? tail : full) * d, d, stats[((int64_t)k * 2 + 1) * K + c]);
-      }
-    }
-    __syncthreads();
-    if (live) red[g * kc + cl] = m2;
     __syncthreads();
     if (ok && g == 0) {
-      float m2t = red[cl];
-      for (int q = 1; q < G; ++q) m2t += red[q * kc + cl];
-      emit(c, mean, fmaxf(m2t / (float)M, 0.f));
+      float t1 = red[cl], t2 = red[NT + cl];
+      for (int q = 1; q < G; ++q) {
+        t1 += red[q * kc + cl];
+        t2 += red[NT + q * kc + cl];
+      }
+      const float dm = t1 / (float)M;
+      emit(c, shift + dm, fmaxf((t2 - t1 * dm) / (float)M, 0.f));
     }
   }
   __syncthreads();

@@ -77,7 +77,7 @@ struct GemmArgs {
   float* bwd_partial;       // BNBWD: (ceil(M / BM), 2, N)
 };
 
-constexpr int kProMaxSlabs = 64;  // PRO: slabs combined from registers in one round of loads (more: a second, looped round)
+constexpr int kProMaxSlabs = 32;  // PRO: slabs per thread and round of loads of the statistics prologue (common.h)
 constexpr int kProMaxK = 1024;
 
 static __device__ __forceinline__ float4 load4_guard(const float* row, int k, int K, bool row_ok) {
@@ -90,6 +90,10 @@ static __device__ __forceinline__ float4 load4_guard(const float* row, int k, in
   return v;
 }
 
+// (PRO / BNBWD run BESIDE the optimizer's resident sweep -- 2 wavefronts of 112 registers per SIMD at its default grid -- and
+// must fit into what those leave free (288 registers per SIMD), or their workgroups are not placed until the sweep ends:
+// measured 194 us for a 26 us kernel with a 256 + 31 register prologue.  Forcing 3 wavefronts per SIMD (168 registers) spills
+// ~210 bytes per lane to scratch, so the budget is met by the prologue's shape instead: 219 + 16.)
 template <int WM, int WN, bool B_KMAJOR, bool STATS, bool PRO = false, bool BNBWD = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a) {
   RH_CHAIN_PRIO();

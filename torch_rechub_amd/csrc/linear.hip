@@ -357,7 +357,7 @@ struct HeadBnFwdArgs {
   float* loss_partial;
 };
 constexpr int kHeadBnMaxK = 256;
-constexpr int kHeadBnMaxSlabs = 64;  // slabs per thread in registers (x 256 / K thread groups per column)
+constexpr int kHeadBnMaxSlabs = 32;  // slabs per thread and round of loads (common.h, rh_combine_slabs)
 
 __global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFwdArgs a) {
   RH_CHAIN_PRIO();
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFw
   __shared__ float cst[4 * kHeadBnMaxK];  // mean, rstd, gamma, beta
   const int K = a.K, B = a.B;
   {
-    __shared__ float red[RH_BLOCK];
+    __shared__ float red[2 * RH_BLOCK];
     const int nslab = (B + a.rows - 1) / a.rows;
     rh_combine_slabs<RH_BLOCK, kHeadBnMaxSlabs>(a.stats, nslab, a.rows, B, K, red, (int)threadIdx.x,
                                                 [&](int c, float mean, float var) {
