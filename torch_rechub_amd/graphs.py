@@ -27,6 +27,7 @@ class SegmentedGraph(object):
         self.segments = []   # [CUDAGraph, eager fn | None]: fn runs after the graph
         self.before = []     # eager fns that run before the first segment of every replay
         self.after_fns = []  # eager fns that run after the last segment of every replay
+        self.seg_stream = {}  # segment index -> callable returning the stream that segment is REPLAYED on (default: current)
         self._stream = None
         self._pool = None
 
@@ -71,6 +72,11 @@ class SegmentedGraph(object):
         self.segments[-1][1] = fn
         self._begin()
 
+    def replay_segment_on(self, index, stream_fn):
+        """Segment ``index`` is replayed on ``stream_fn()`` instead of the replaying stream (the eager functions around it
+        order the streams).  A captured graph is not bound to the stream it was captured on."""
+        self.seg_stream[int(index)] = stream_fn
+
     def at_start(self, fn):
         """``fn`` runs eagerly before the first segment of every replay."""
         self.before.append(fn)
@@ -84,8 +90,13 @@ class SegmentedGraph(object):
     def replay(self):
         for fn in self.before:
             fn()
-        for g, fn in self.segments:
-            g.replay()
+        for i, (g, fn) in enumerate(self.segments):
+            sfn = self.seg_stream.get(i)
+            if sfn is not None:
+                with torch.cuda.stream(sfn()):
+                    g.replay()
+            else:
+                g.replay()
             if fn is not None:
                 fn()
         for fn in self.after_fns:

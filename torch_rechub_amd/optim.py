@@ -118,6 +118,8 @@ class TableAdam(torch.optim.Adam):
                 # branch of the step's graph: 0.312 ms), external-event nodes (1.66 ms), CU-masked streams (0.350 ms), the
                 # row-list table gradient (backward 159 vs 103 us at B = 65536).
                 self.overlap_sweep = os.environ.get("RECHUB_STEP_FORM", "deferred") != "inline"
+                self.head_on_side = os.environ.get("RECHUB_HEAD_SIDE", "1") == "1"
+                self._head_event = None
                 self._step_recs, self._last_recs = [], []
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
@@ -259,7 +261,7 @@ class TableAdam(torch.optim.Adam):
             # segmented replay: EVERY replay joins the sweep forked by the previous one before its first segment (the
             # refresh below must not meet a row the sweep is still writing), whatever the state at capture time was
             if self._join_seg is not seg:
-                seg.at_start(self._join_sweep)
+                seg.at_start(self._head_begin if self.head_on_side else self._join_sweep)
                 self._join_seg = seg
             self._sweep_inflight = False
             if training and self._refresh_ahead(rec, seg):
@@ -288,11 +290,11 @@ class TableAdam(torch.optim.Adam):
                 if not capturing:
                     self._fork_sweep()
                 elif seg is not None:
-                    seg.cut(self._fork_sweep)  # every replay: eager side-stream launch after the refresh above
+                    self._cut_fork(seg)  # every replay: eager side-stream launch after the refresh above
                     self._sweep_pending, self._sweep_inflight = False, True
             elif capturing and seg is not None and self.overlap_sweep and self._gathers >= (self._gathers_per_step or 1):
                 # captured from a settled state (nothing pending at capture time): the replays still fork one sweep each
-                seg.cut(self._fork_sweep)
+                self._cut_fork(seg)
                 self._sweep_inflight = True
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
 
@@ -319,7 +321,7 @@ class TableAdam(torch.optim.Adam):
                 self._touch(dict(r, training=True), groups, ops._stream(), refresh=True)
             self._ahead = len(recs)
             self._gathers = 1
-            seg.cut(self._fork_sweep)  # every replay: the side-stream launch, after the refreshes above
+            self._cut_fork(seg, head_only=True)  # every replay: the side-stream launch, after the refreshes above
             self._sweep_pending, self._sweep_inflight = False, True
             return True
         if k < getattr(self, "_ahead", 0) and same(rec, recs[k]):
@@ -344,6 +346,50 @@ class TableAdam(torch.optim.Adam):
             _lib.call("rh_adam_lazy_sweep", ops._p(grp["ldesc"]), len(grp["members"]),
                       ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
                       ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, mode, t_value, stream)
+
+    # -- the head of the step on the sweep's queue (round 4) --------------------------------------------------------------
+    # Two-segment replay:  [batch assembly, refresh] | fork sweep | [forward ... touched rows].  Forked from the MAIN stream,
+    # the sweep waited ~20 us for the cross-queue event behind the refresh before it started -- and the sweep's path
+    # (head + that wait + ~240 us) is the longer of the step's two.  With head_on_side the FIRST segment is replayed on the
+    # sweep's own stream: batch assembly -> refresh -> sweep are consecutive kernels of one queue (no event in between; the
+    # previous sweep is in front of them on that queue, which IS the join), and it is the chain on the main stream that waits
+    # for the event recorded behind the refresh.  The cross-queue latency moves from the longer path to the shorter one.
+    def _head_begin(self):
+        """at_start of a segmented replay: the head segment (on the side stream) follows the previous step's chain."""
+        if self._side is None:
+            self._side = self._make_side_stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._sweep_inflight = False  # (whatever was in flight is in front of the head on the same queue)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = self._make_side_stream()
+        return self._side
+
+    def _cut_fork(self, seg, head_only=False):
+        """Close the head segment: the sweep is forked here on every replay.  The head may run on the sweep's stream when
+        everything captured so far IS the head (batch assembly + the refreshes): a step with one gather, or refresh-ahead."""
+        head = self.head_on_side and len(seg.segments) == 1 and (head_only or (self._gathers_per_step or 1) == 1)
+        if head:
+            seg.replay_segment_on(0, self._side_stream)
+            seg.cut(self._fork_sweep_behind_head)
+        else:
+            if self.head_on_side and self._join_seg is seg and self._head_begin in seg.before:
+                seg.before[seg.before.index(self._head_begin)] = self._join_sweep  # the head stays on the main stream
+            seg.cut(self._fork_sweep)
+
+    def _fork_sweep_behind_head(self):
+        """After the head segment was enqueued on the side stream: mark the end of the refresh there (the chain waits for
+        it), then the sweep of the last completed step right behind it on the same queue."""
+        side = self._side_stream()
+        if self._head_event is None:
+            self._head_event = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            self._head_event.record()
+            if self._host_step > 0:
+                self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+        torch.cuda.current_stream().wait_event(self._head_event)
+        self._sweep_pending, self._sweep_inflight = False, True
 
     def _fork_sweep(self):
         """Launch the sweep of the last completed step on the side stream, ordered after everything queued so far."""
