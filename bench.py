@@ -709,11 +709,16 @@ def parse_step_trace(trace_csv, steps_wanted):
     n = len(marks) - 1
     wall = (rows[marks[-1]][0] - rows[marks[0]][0]) / n / 1e3
     per_kernel, order = {}, []
-    main_q = rows[marks[0]][3]
+    # the step's chain runs on the queue of its scalar launch / gather; the optimizer's queue (the deferred sweep -- and,
+    # since round 4, the head segment in front of it: batch assembly + refresh) is the other one
+    main_q = next((r[3] for r in rows[marks[0]:marks[-1]] if "step_scalars" in r[2] or "embed_fwd" in r[2]), rows[marks[0]][3])
     for i in range(marks[0], marks[-1]):
         st, en, name, q = rows[i]
         short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("rechub::", "").split("(")[0][:60]
-        if q != main_q:
+        head_seg = q != main_q and ("batch_gather" in name or "adam_lazy_touched" in name)
+        if head_seg:
+            short += " [head segment, optimizer queue]"
+        elif q != main_q:
             short += " [side stream]"
         if short not in per_kernel:
             per_kernel[short] = [0, 0.0, name]
@@ -727,7 +732,7 @@ def parse_step_trace(trace_csv, steps_wanted):
         cnt, tot, full = per_kernel[k]
         us = tot / n
         side = k.endswith("[side stream]")
-        if not side:
+        if not side:  # (the head segment gates the chain: the chain waits for the event behind the refresh)
             busy += us
         grp = _account_group(full) + ("_deferred_on_side_stream_overlapped" if side else "")
         groups[grp] = round(groups.get(grp, 0.0) + us, 2)
