@@ -1410,6 +1410,117 @@ def test_torch_library_ops_opcheck_and_values():
             assert torch.allclose(u, v, rtol=1e-6, atol=1e-7)
 
 
+def test_torch_library_round4_ops_opcheck_and_values():
+    """torch.ops.rechub_hip.{cross_net_v2, cross_net_mix, din_attention_input, din_attention_pool, embedding_bag_masked,
+    inbatch_negative_sample} (SURVEY 8(b)): opcheck (schema, fake impl, autograd registration, AOT dispatch) on the device;
+    values and gradients against the modules / autograd.Function paths the models run, which the reference fixtures pin."""
+    import torch_rechub_amd.library  # noqa: F401
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import CrossNetMix, CrossNetV2
+    g = torch.Generator().manual_seed(4)
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_dynamic")
+    B, d, L = 70, 44, 3
+
+    def leaf(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev()).requires_grad_()
+
+    def same_grads(ya, la, yb, lb, rtol=2e-5):
+        G = torch.randn(ya.shape, generator=g).to(dev())
+        ga = torch.autograd.grad((ya * G).sum(), la)
+        gb = torch.autograd.grad((yb * G).sum(), lb)
+        for u, v in zip(ga, gb):
+            close(u, v.detach().cpu().numpy(), rtol=rtol, atol_scale=2e-6, what="gradient")
+
+    # CrossNetV2 against the module
+    x, W, b = leaf(B, d), leaf(L, d, d, scale=0.1), leaf(L, d, scale=0.1)
+    torch.library.opcheck(torch.ops.rechub_hip.cross_net_v2.default, (x, W, b), test_utils=tests)
+    mod = CrossNetV2(d, L).to(dev())
+    with torch.no_grad():
+        for l in range(L):
+            mod.w[l].weight.copy_(W[l])
+            mod.b[l].copy_(b[l])
+    xa, xb = x.detach().clone().requires_grad_(), x.detach().clone().requires_grad_()
+    ya, yb = torch.ops.rechub_hip.cross_net_v2(xa, W, b), mod(xb)
+    close(ya, yb.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="cross_net_v2")
+    G = torch.randn(ya.shape, generator=g).to(dev())
+    ga = torch.autograd.grad((ya * G).sum(), [xa, W, b])
+    (yb * G).sum().backward()
+    close(ga[0], xb.grad.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="cross_net_v2 g_x")
+    for l in range(L):
+        close(ga[1][l], mod.w[l].weight.grad.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what=f"cross_net_v2 g_W[{l}]")
+        close(ga[2][l], mod.b[l].grad.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what=f"cross_net_v2 g_b[{l}]")
+
+    # CrossNetMix against the module (csrc/moe.hip path: rank 8, 4 experts)
+    E, r = 4, 8
+    mix = CrossNetMix(d, num_layers=L, low_rank=r, num_experts=E).to(dev())
+    with torch.no_grad():
+        for p_ in mix.parameters():
+            p_.normal_(0, 0.2, generator=None)
+    U = torch.stack([u.detach() for u in mix.u_list]).requires_grad_()
+    V = torch.stack([v.detach() for v in mix.v_list]).requires_grad_()
+    C = torch.stack([c.detach() for c in mix.c_list]).requires_grad_()
+    bias = torch.stack([bb.detach().reshape(-1) for bb in mix.bias]).requires_grad_()
+    gating = torch.stack([gg.weight.detach().reshape(-1) for gg in mix.gating]).requires_grad_()
+    xm = leaf(B, d)
+    torch.library.opcheck(torch.ops.rechub_hip.cross_net_mix.default, (xm, U, V, C, bias, gating), test_utils=tests)
+    xa, xb = xm.detach().clone().requires_grad_(), xm.detach().clone().requires_grad_()
+    ya, yb = torch.ops.rechub_hip.cross_net_mix(xa, U, V, C, bias, gating), mix(xb)
+    close(ya, yb.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="cross_net_mix")
+    G = torch.randn(ya.shape, generator=g).to(dev())
+    ga = torch.autograd.grad((ya * G).sum(), [xa, U, V, C, bias, gating])
+    (yb * G).sum().backward()
+    close(ga[0], xb.grad.cpu().numpy(), rtol=5e-5, atol_scale=5e-6, what="cross_net_mix g_x")
+    for l in range(L):
+        close(ga[1][l], mix.u_list[l].grad.cpu().numpy(), rtol=5e-5, atol_scale=5e-6, what="cross_net_mix g_U")
+        close(ga[2][l], mix.v_list[l].grad.cpu().numpy(), rtol=5e-5, atol_scale=5e-6, what="cross_net_mix g_V")
+        close(ga[3][l], mix.c_list[l].grad.cpu().numpy(), rtol=5e-5, atol_scale=5e-6, what="cross_net_mix g_C")
+        close(ga[4][l], mix.bias[l].grad.reshape(-1).cpu().numpy(), rtol=5e-5, atol_scale=5e-6, what="cross_net_mix g_bias")
+    for e in range(E):
+        close(ga[5][e], mix.gating[e].weight.grad.reshape(-1).cpu().numpy(), rtol=5e-5, atol_scale=5e-6, what="g_gating")
+
+    # DIN attention kernels against eager torch (din.py:79-81, :89-92)
+    hist, tgt, aw = leaf(9, 13, 16), leaf(9, 16), leaf(9, 13)
+    torch.library.opcheck(torch.ops.rechub_hip.din_attention_input.default, (hist, tgt), test_utils=tests)
+    torch.library.opcheck(torch.ops.rechub_hip.din_attention_pool.default, (aw, hist), test_utils=tests)
+    t3 = tgt.unsqueeze(1).expand(-1, 13, -1)
+    ref_in = torch.cat([t3, hist, t3 - hist, t3 * hist], dim=-1).view(-1, 64)
+    ya = torch.ops.rechub_hip.din_attention_input(hist, tgt)
+    assert torch.equal(ya, ref_in)
+    same_grads(ya, [hist, tgt], ref_in, [hist, tgt])
+    ref_pool = (aw.unsqueeze(-1) * hist).sum(dim=1)
+    yp = torch.ops.rechub_hip.din_attention_pool(aw, hist)
+    close(yp, ref_pool.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="din_attention_pool")
+    same_grads(yp, [aw, hist], ref_pool, [aw, hist])
+
+    # masked embedding bag against eager torch (layers.py:223-229, :247-251, :204-205)
+    tab = leaf(60, 16)
+    seq = torch.randint(0, 60, (11, 7), generator=g)
+    seq[:, 4:] = 0  # post-padded
+    seq = seq.to(dev())
+    for mode, sentinel in (("sum", 0), ("mean", 0), ("concat", -1), ("mean", -1)):
+        torch.library.opcheck(torch.ops.rechub_hip.embedding_bag_masked.default, (tab, seq, sentinel, mode), test_utils=tests)
+        rows = tab[seq]
+        mask = (seq != sentinel).float().unsqueeze(-1)
+        ref = rows if mode == "concat" else ((rows * mask).sum(1) if mode == "sum" else (rows * mask).sum(1) / (mask.sum(1) + 1e-16))
+        got = torch.ops.rechub_hip.embedding_bag_masked(tab, seq, sentinel, mode)
+        close(got, ref.detach().cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what=f"embedding_bag_masked {mode}")
+        same_grads(got, [tab], ref, [tab])
+
+    # in-batch negatives: hard = the reference's known answer (tests/test_inbatch_sampling.py:26-30), random = invariants
+    scores = torch.tensor([[0.0, 0.1, 0.9], [0.2, 0.0, 0.8], [0.3, 0.7, 0.0]], device=dev())
+    torch.library.opcheck(torch.ops.rechub_hip.inbatch_negative_sample.default, (scores, 1, True, 0, 0), test_utils=tests[:2])
+    assert torch.ops.rechub_hip.inbatch_negative_sample(scores, 1, True, 0, 0).view(-1).tolist() == [2, 2, 1]
+    big = torch.randn(256, 256, generator=g).to(dev())
+    n1 = torch.ops.rechub_hip.inbatch_negative_sample(big, 20, False, 2022, 0)
+    n2 = torch.ops.rechub_hip.inbatch_negative_sample(big, 20, False, 2022, 0)
+    n3 = torch.ops.rechub_hip.inbatch_negative_sample(big, 20, False, 2022, 1)
+    assert torch.equal(n1, n2) and not torch.equal(n1, n3)
+    rows_ = torch.arange(256, device=dev()).unsqueeze(1)
+    assert bool((n1 != rows_).all()) and int(n1.min()) >= 0 and int(n1.max()) < 256
+    assert all(len(set(r_)) == 20 for r_ in n1.cpu().tolist())
+    ops.check_errors()
+
+
 def test_torch_library_functional_gather_and_adam_ops():
     """torch.ops.rechub_hip.embedding_fm_lr (the fused gather + FM + LR as a FUNCTIONAL op: per-lookup gradient rows ->
     one dense gradient per table in the autograd formula) and adam_step_ (mutated arguments declared in the schema):

@@ -396,8 +396,41 @@ def test_torch_library_ops_trace_under_fake_tensors():
         assert tabs[1].grad.shape == (300, 16) and lw.grad.shape == (1, 64) and lb.grad.shape == (1,)
         assert torch.ops.rechub_hip.adam_step_(torch.empty(8, 4), torch.empty(8, 4), torch.empty(8, 4), torch.empty(8, 4), 1,
                                                1e-3, 0.9, 0.999, 1e-8, 0.0) is None
+        # round 4: the rest of SURVEY 8(b)'s list -- CrossNetV2, CrossNetMix, the DIN attention kernels, the masked
+        # embedding bag (sum / mean / concat) and the in-batch sampler -- with their autograd formulas
+        x2 = torch.empty(64, 429, requires_grad=True)
+        W2, b2 = torch.empty(3, 429, 429, requires_grad=True), torch.empty(3, 429, requires_grad=True)
+        o2 = torch.ops.rechub_hip.cross_net_v2(x2, W2, b2)
+        o2.sum().backward()
+        assert o2.shape == (64, 429) and W2.grad.shape == (3, 429, 429) and b2.grad.shape == (3, 429) and x2.grad.shape == (64, 429)
+        U = torch.empty(3, 4, 429, 32, requires_grad=True)
+        V = torch.empty(3, 4, 429, 32, requires_grad=True)
+        C = torch.empty(3, 4, 32, 32, requires_grad=True)
+        bm, gt = torch.empty(3, 429, requires_grad=True), torch.empty(4, 429, requires_grad=True)
+        xm = torch.empty(64, 429, requires_grad=True)
+        om = torch.ops.rechub_hip.cross_net_mix(xm, U, V, C, bm, gt)
+        om.sum().backward()
+        assert om.shape == (64, 429) and U.grad.shape == U.shape and C.grad.shape == C.shape and gt.grad.shape == (4, 429)
+        hist, tgt = torch.empty(8, 100, 16, requires_grad=True), torch.empty(8, 16, requires_grad=True)
+        ai = torch.ops.rechub_hip.din_attention_input(hist, tgt)
+        aw = torch.empty(8, 100, requires_grad=True)
+        ap = torch.ops.rechub_hip.din_attention_pool(aw, hist)
+        assert ai.shape == (800, 64) and ap.shape == (8, 16)
+        (ai.sum() + ap.sum()).backward()
+        assert hist.grad.shape == (8, 100, 16) and tgt.grad.shape == (8, 16) and aw.grad.shape == (8, 100)
+        tab = torch.empty(500, 16, requires_grad=True)
+        seq = torch.empty(8, 50, dtype=torch.int64)
+        assert torch.ops.rechub_hip.embedding_bag_masked(tab, seq, 0, "mean").shape == (8, 16)
+        bag = torch.ops.rechub_hip.embedding_bag_masked(tab, seq, -1, "concat")
+        assert bag.shape == (8, 50, 16)
+        bag.sum().backward()
+        assert tab.grad.shape == (500, 16)
+        neg = torch.ops.rechub_hip.inbatch_negative_sample(torch.empty(64, 64), 20, False, 2022, 0)
+        assert neg.shape == (64, 20) and neg.dtype == torch.int64
     with pytest.raises(RuntimeError, match="HIP device"):
         torch.ops.rechub_hip.fm(torch.zeros(2, 3, 4), True)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        torch.ops.rechub_hip.cross_net_v2(torch.zeros(2, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4))
     schema = str(torch.ops.rechub_hip.cross_network.default._schema)
     assert schema.startswith("rechub_hip::cross_network(Tensor x, Tensor W, Tensor b) -> Tensor")
 

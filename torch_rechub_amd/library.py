@@ -6,8 +6,16 @@ boundary.  With these, ``FakeTensorMode`` / ``torch.export`` / ``torch.compile``
     torch.ops.rechub_hip.cross_network(x, W, b)                CrossNetwork.forward  basic/layers.py:412-420
     torch.ops.rechub_hip.dice(x, alpha, eps)                   Dice.forward          basic/activation.py:15-25
 
-    torch.ops.rechub_hip.embedding_fm_lr(tables, idx, dense, lr_w, lr_b, want_fm)
+    torch.ops.rechub_hip.embedding_fm_lr(tables, idx, dense, lr_w, lr_b)
                                                                EmbeddingLayer.forward + FM + LR  layers.py:77-127, :313-319, :185-189
+    torch.ops.rechub_hip.cross_net_v2(x, W, b)                 CrossNetV2.forward    basic/layers.py:440-444
+    torch.ops.rechub_hip.cross_net_mix(x, U, V, C, bias, gating)  CrossNetMix.forward  basic/layers.py:470-506
+    torch.ops.rechub_hip.din_attention_input(history, target) / din_attention_pool(att_weight, history)
+                                                               ActivationUnit.forward  models/ranking/din.py:77-92
+    torch.ops.rechub_hip.embedding_bag_masked(weight, idx, pad_sentinel, mode)
+                                                               sequence gather + InputMask + pooling  layers.py:86-99, :148-161, :204-251
+    torch.ops.rechub_hip.inbatch_negative_sample(scores, k, hard, seed, call)
+                                                               inbatch_negative_sampling  utils/match.py:104-161
     torch.ops.rechub_hip.adam_step_(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay)
                                                                torch.optim.Adam on one tensor    trainers/ctr_trainer.py:59-61, :99
 
@@ -305,3 +313,308 @@ def adam_step_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
 @adam_step_.register_fake
 def _(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
     return None
+
+
+# =====================================================================================================================
+# Round 4: the rest of SURVEY 8(b)'s op list.  The kernels behind these ops are the ones the layers of
+# ``torch_rechub_amd.basic`` / the models call through ``autograd.Function``; here the SAME forward / backward bodies run
+# under a stand-in for the autograd context (``_Ctx``), so that each direction is a dispatcher op of its own with a
+# schema, a fake implementation and an autograd formula made of ops (AOT autograd can trace the backward too).  A
+# backward op recomputes what the forward would have saved (these are the functional restatements: nothing is cached
+# between two op calls).
+class _Ctx(object):
+    """What an ``autograd.Function`` body touches on its ``ctx``, outside autograd."""
+
+    def __init__(self, needs_input_grad=()):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+# ---- CrossNetV2: x_{l+1} = x0 * (W_l x_l) + b_l + x_l  (basic/layers.py:440-444) ----------------------------------------
+def _cross_v2_layers(x, W, b):
+    """[(x_l, y_l)] for every layer and the output; y_l = x_l W_l^T on the library GEMM, the rest ONE pass per layer."""
+    ops.require_hip(x, W, b)
+    if x.dim() != 2 or W.dim() != 3 or W.shape[1] != x.shape[1] or W.shape[2] != x.shape[1] or b.shape != W.shape[:2]:
+        raise ValueError("rechub_hip::cross_net_v2: x (B, d), W (L, d, d), b (L, d)")
+    x0 = x.contiguous()
+    B, d = x0.shape
+    xl, layers = x0, []
+    for l in range(W.shape[0]):
+        y = torch.mm(xl, W[l].t()).contiguous()
+        out = torch.empty_like(x0)
+        _lib.call("rh_cross_v2_epilogue_fwd", _p(x0), _p(y), _p(b[l].contiguous()), _p(xl), B, d, _p(out), _stream())
+        layers.append((xl, y))
+        xl = out
+    return x0, layers, xl
+
+
+@torch.library.custom_op("rechub_hip::cross_net_v2", mutates_args=())
+def cross_net_v2(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _cross_v2_layers(x, W, b)[2]
+
+
+@cross_net_v2.register_fake
+def _(x, W, b):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("rechub_hip::cross_net_v2_backward", mutates_args=())
+def cross_net_v2_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor,
+                          g: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    x0, layers, _ = _cross_v2_layers(x, W, b)
+    B, d = x0.shape
+    g = g.contiguous()
+    g_x0_total = torch.zeros_like(x0)
+    g_W, g_b = torch.empty_like(W), torch.empty_like(b)
+    for l in reversed(range(W.shape[0])):
+        xl, y = layers[l]
+        g_x0, g_y = torch.empty_like(x0), torch.empty_like(y)
+        _lib.call("rh_cross_v2_epilogue_bwd", _p(x0), _p(y), _p(g), B, d, _p(g_x0), _p(g_y), _stream())
+        g_x0_total += g_x0
+        g_b[l] = g.sum(0)
+        g_W[l] = torch.mm(g_y.t(), xl)
+        g = (g + torch.mm(g_y, W[l])).contiguous()  # residual + through W_l
+    return g + g_x0_total, g_W, g_b
+
+
+@cross_net_v2_backward.register_fake
+def _(x, W, b, g):
+    return torch.empty_like(x), torch.empty_like(W), torch.empty_like(b)
+
+
+def _cross_v2_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _cross_v2_bwd(ctx, g):
+    x, W, b = ctx.saved_tensors
+    return torch.ops.rechub_hip.cross_net_v2_backward(x, W, b, g)
+
+
+cross_net_v2.register_autograd(_cross_v2_bwd, setup_context=_cross_v2_setup)
+
+
+# ---- CrossNetMix: mixture of low-rank experts (basic/layers.py:470-506), all layers, csrc/moe.hip --------------------------
+def _mix_params(U, V, C, bias, gating):
+    L, E = U.shape[0], U.shape[1]
+    if V.shape != U.shape or C.shape[:2] != (L, E) or gating.shape[0] != E or bias.shape[0] != L:
+        raise ValueError("rechub_hip::cross_net_mix: U, V (L, E, d, r), C (L, E, r, r), bias (L, d), gating (E, d)")
+    d = U.shape[2]
+    return L, E, ([U[l] for l in range(L)] + [V[l] for l in range(L)] + [C[l] for l in range(L)] +
+                  [bias[l].reshape(d, 1) for l in range(L)] + [gating[e].reshape(1, d) for e in range(E)])
+
+
+@torch.library.custom_op("rechub_hip::cross_net_mix", mutates_args=())
+def cross_net_mix(x: torch.Tensor, U: torch.Tensor, V: torch.Tensor, C: torch.Tensor, bias: torch.Tensor,
+                  gating: torch.Tensor) -> torch.Tensor:
+    L, E, params = _mix_params(U, V, C, bias, gating)
+    if not ops.cross_moe_ok(x, L, E, U.shape[2], U.shape[3]):
+        raise ValueError("rechub_hip::cross_net_mix: unsupported shape (rh_cross_moe_supported)")
+    return ops._CrossMoeFn.forward(_Ctx(), x.contiguous(), L, E, *params)
+
+
+@cross_net_mix.register_fake
+def _(x, U, V, C, bias, gating):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("rechub_hip::cross_net_mix_backward", mutates_args=())
+def cross_net_mix_backward(x: torch.Tensor, U: torch.Tensor, V: torch.Tensor, C: torch.Tensor, bias: torch.Tensor,
+                           gating: torch.Tensor, g: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor,
+                                                                             torch.Tensor, torch.Tensor, torch.Tensor]:
+    L, E, params = _mix_params(U, V, C, bias, gating)
+    ctx = _Ctx()
+    ops._CrossMoeFn.forward(ctx, x.contiguous(), L, E, *params)
+    grads = ops._CrossMoeFn.backward(ctx, g.contiguous())
+    g_x, rest = grads[0], grads[3:]
+    return (g_x, torch.stack(rest[0:L]), torch.stack(rest[L:2 * L]), torch.stack(rest[2 * L:3 * L]),
+            torch.stack([t.reshape(-1) for t in rest[3 * L:4 * L]]), torch.stack([t.reshape(-1) for t in rest[4 * L:4 * L + E]]))
+
+
+@cross_net_mix_backward.register_fake
+def _(x, U, V, C, bias, gating, g):
+    return (torch.empty_like(x), torch.empty_like(U), torch.empty_like(V), torch.empty_like(C), torch.empty_like(bias),
+            torch.empty_like(gating))
+
+
+def _mix_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _mix_bwd(ctx, g):
+    return torch.ops.rechub_hip.cross_net_mix_backward(*ctx.saved_tensors, g)
+
+
+cross_net_mix.register_autograd(_mix_bwd, setup_context=_mix_setup)
+
+
+# ---- DIN target attention (models/ranking/din.py:77-92): the two kernels around the attention MLP ---------------------
+#   din_attention_input(history (B, L, D), target (B, D)) -> (B * L, 4 D) = cat[t, h, t - h, t * h]     din.py:79-81
+#   din_attention_pool(att_weight (B, L), history (B, L, D)) -> (B, D) = sum_L att_weight * history        din.py:89-92
+# (the MLP between them is nn.Linear + BatchNorm1d + rechub_hip::dice; no padding mask, SURVEY Q6)
+@torch.library.custom_op("rechub_hip::din_attention_input", mutates_args=())
+def din_attention_input(history: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    return ops._AttInputFn.forward(_Ctx(), history, target)
+
+
+@din_attention_input.register_fake
+def _(history, target):
+    B, L, D = history.shape
+    return history.new_empty((B * L, 4 * D))
+
+
+@torch.library.custom_op("rechub_hip::din_attention_input_backward", mutates_args=())
+def din_attention_input_backward(history: torch.Tensor, target: torch.Tensor,
+                                 g: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    ctx = _Ctx()
+    ops._AttInputFn.forward(ctx, history, target)
+    return ops._AttInputFn.backward(ctx, g)
+
+
+@din_attention_input_backward.register_fake
+def _(history, target, g):
+    return torch.empty_like(history), torch.empty_like(target)
+
+
+def _att_in_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _att_in_bwd(ctx, g):
+    return torch.ops.rechub_hip.din_attention_input_backward(*ctx.saved_tensors, g)
+
+
+din_attention_input.register_autograd(_att_in_bwd, setup_context=_att_in_setup)
+
+
+@torch.library.custom_op("rechub_hip::din_attention_pool", mutates_args=())
+def din_attention_pool(att_weight: torch.Tensor, history: torch.Tensor) -> torch.Tensor:
+    return ops._AttPoolFn.forward(_Ctx(), att_weight, history)
+
+
+@din_attention_pool.register_fake
+def _(att_weight, history):
+    B, L, D = history.shape
+    return history.new_empty((B, D))
+
+
+@torch.library.custom_op("rechub_hip::din_attention_pool_backward", mutates_args=())
+def din_attention_pool_backward(att_weight: torch.Tensor, history: torch.Tensor,
+                                g: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    ctx = _Ctx()
+    ops._AttPoolFn.forward(ctx, att_weight, history)
+    return ops._AttPoolFn.backward(ctx, g)
+
+
+@din_attention_pool_backward.register_fake
+def _(att_weight, history, g):
+    return torch.empty_like(att_weight), torch.empty_like(history)
+
+
+def _att_pool_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _att_pool_bwd(ctx, g):
+    return torch.ops.rechub_hip.din_attention_pool_backward(*ctx.saved_tensors, g)
+
+
+din_attention_pool.register_autograd(_att_pool_bwd, setup_context=_att_pool_setup)
+
+
+# ---- masked embedding bag: gather + InputMask + Sum / Average / ConcatPooling (basic/layers.py:86-99,148-161,204-251) -----
+_BAG_MODES = {"sum": 0, "mean": 1, "concat": 2}
+
+
+@torch.library.custom_op("rechub_hip::embedding_bag_masked", mutates_args=())
+def embedding_bag_masked(weight: torch.Tensor, idx: torch.Tensor, pad_sentinel: int, mode: str) -> torch.Tensor:
+    """(B, D) for mode 'sum' / 'mean' (mean divides by the count of idx != pad_sentinel, + 1e-16: layers.py:229),
+    (B, L, D) for 'concat' (no mask).  pad_sentinel = padding_idx, or -1 when the feature has none (layers.py:154-157)."""
+    ops.require_hip(weight, idx)
+    if mode not in _BAG_MODES or idx.dim() != 2 or idx.dtype not in (torch.int64, torch.int32):
+        raise ValueError("rechub_hip::embedding_bag_masked: idx (B, L) integer, mode in sum | mean | concat")
+    B, L = idx.shape
+    V, D = weight.shape
+    m = _BAG_MODES[mode]
+    w = weight.contiguous()
+    out = torch.empty((B, L, D) if m == 2 else (B, D), dtype=torch.float32, device=weight.device)
+    _lib.call("rh_seq_pool_fwd", _p(w), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0), idx.stride(1), B, L, D,
+              m, int(pad_sentinel), _p(out), out.stride(0), _p(ops.err_flag(weight.device)), _stream())
+    return out
+
+
+@embedding_bag_masked.register_fake
+def _(weight, idx, pad_sentinel, mode):
+    B, L = idx.shape
+    D = weight.shape[1]
+    return weight.new_empty((B, L, D) if mode == "concat" else (B, D))
+
+
+@torch.library.custom_op("rechub_hip::embedding_bag_masked_backward", mutates_args=())
+def embedding_bag_masked_backward(weight: torch.Tensor, idx: torch.Tensor, g: torch.Tensor, pad_sentinel: int,
+                                  mode: str) -> torch.Tensor:
+    """Dense gradient of the table (functional form: a fresh zero buffer receives the scatter; the trainers scatter into
+    their persistent gradient buffers instead)."""
+    ops.require_hip(weight, idx, g)
+    B, L = idx.shape
+    V, D = weight.shape
+    g = g.contiguous()
+    buf = torch.zeros((V, D), dtype=torch.float32, device=weight.device)
+    _lib.call("rh_seq_pool_bwd", _p(buf), V, _p(idx), 1 if idx.dtype == torch.int64 else 0, idx.stride(0), idx.stride(1), B, L,
+              D, _BAG_MODES[mode], int(pad_sentinel), int(pad_sentinel), _p(g), g.stride(0), 1.0, _p(ops.err_flag(weight.device)),
+              _stream())  # (pad_sentinel >= 0 is the feature's padding_idx: nn.Embedding gives that row no gradient)
+    return buf
+
+
+@embedding_bag_masked_backward.register_fake
+def _(weight, idx, g, pad_sentinel, mode):
+    return torch.empty_like(weight)
+
+
+def _bag_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+    ctx.sentinel, ctx.mode = inputs[2], inputs[3]
+
+
+def _bag_bwd(ctx, g):
+    weight, idx = ctx.saved_tensors
+    return torch.ops.rechub_hip.embedding_bag_masked_backward(weight, idx, g, ctx.sentinel, ctx.mode), None, None, None
+
+
+embedding_bag_masked.register_autograd(_bag_bwd, setup_context=_bag_setup)
+
+
+# ---- in-batch negatives (utils/match.py:104-161) ------------------------------------------------------------------------
+@torch.library.custom_op("rechub_hip::inbatch_negative_sample", mutates_args=())
+def inbatch_negative_sample(scores: torch.Tensor, k: int, hard: bool, seed: int, call: int) -> torch.Tensor:
+    """(B, K) int64 negatives per row of the (B, B) score matrix, never the row's own column.  hard: the K largest
+    off-diagonal scores (utils/match.py:124-131, deterministic); else K distinct columns uniformly at random from the
+    counter-based stream (seed, call) -- the FUNCTIONAL form of the sampler's device-side state (the trainers advance
+    ``call`` on the device): same (seed, call) -> same indices (the 'fast' stream of utils/match.py here; its distribution,
+    not the reference's randperm indices -- DESIGN 5)."""
+    ops.require_hip(scores)
+    B = scores.shape[0]
+    if scores.dim() != 2 or scores.shape[1] != B or not 1 <= k <= B - 1:
+        raise ValueError("rechub_hip::inbatch_negative_sample: scores (B, B), 1 <= k <= B - 1")
+    if hard:
+        masked = scores.detach().clone()
+        masked.fill_diagonal_(float("-inf"))
+        return masked.topk(k, dim=1).indices
+    st = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, int(call)], dtype=torch.int64).to(scores.device)
+    out = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    _lib.call("rh_inbatch_sample", _p(st), B, int(k), _p(out), _stream())
+    return out
+
+
+@inbatch_negative_sample.register_fake
+def _(scores, k, hard, seed, call):
+    return scores.new_empty((scores.shape[0], k), dtype=torch.int64)
