@@ -1047,6 +1047,13 @@ def main():
                                      "loader_median_ms_per_step": round(e["loader_median_ms_per_step"], 1),
                                      "warmup_steps": e["warmup_steps"], "timed_steps": e["timed_steps"],
                                      "step_ms": e["step_ms"], "rows": r["rows"]}
+                if r.get("end_to_end_dataframe"):
+                    d_ = r["end_to_end_dataframe"]
+                    cpu["end_to_end_dataframe"] = {
+                        "value": round(d_["samples_per_s"], 1), "median_ms_per_step": round(d_["median_ms_per_step"], 1),
+                        "loader_median_ms_per_step": round(d_["loader_median_ms_per_step"], 1), "loader_ms": d_["loader_ms"],
+                        "sample": "x as a pandas DataFrame (tutorial 00): TorchDataset.__getitem__ indexes 39 Series per sample "
+                                  "(utils/data.py:21-22); " + d_["note"]}
                 cpu["model_step"] = {"value": round(m["samples_per_s"], 1), "median_ms_per_step": round(m["median_ms_per_step"], 1),
                                      "warmup_steps": m["warmup_steps"], "timed_steps": m["timed_steps"], "step_ms": m["step_ms"],
                                      "sample": "model-step-only (fwd+bwd+dense Adam), pre-collated batches, no DataLoader; the "

@@ -300,5 +300,25 @@ def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=2
 
     e2e = leg(e2e_ms, n_warm)
     e2e["loader_median_ms_per_step"] = float(np.median(loader_ms))
-    return dict(end_to_end=e2e, model_step=leg(step_ms, n_warm + len(e2e_ms) + (n_warm if full else 0)),
+    # SURVEY 8(d), "once as DataFrame, as tutorial 00 does": x handed to DataGenerator as a pandas DataFrame (y a Series).
+    # TorchDataset.__getitem__ (utils/data.py:21-22) then indexes 39 Series per SAMPLE; the model step behind it is the one
+    # timed above, so this leg times the LOADER alone (n_df batches, at least 1 warm-up) and adds the model-step median.
+    import pandas as pd
+    df = pd.DataFrame(x)
+    df_dl, _, _ = port_dataloaders(df, pd.Series(y), [0.7, 0.1], batch_size)
+    it_df = iter(df_dl)
+    next(it_df)
+    df_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        xb, yb = next(it_df)
+        {k: v.to(device) for k, v in xb.items()}, yb.to(device)
+        df_ms.append(1e3 * (time.perf_counter() - t0))
+    step_med = float(np.median(step_ms))
+    df_leg = dict(loader_median_ms_per_step=float(np.median(df_ms)), loader_ms=[round(v, 1) for v in df_ms],
+                  median_ms_per_step=float(np.median(df_ms)) + step_med,
+                  samples_per_s=batch_size / ((float(np.median(df_ms)) + step_med) * 1e-3),
+                  note="loader timed alone (1 warm-up + 3 batches), model-step median of this run added")
+    return dict(end_to_end=e2e, end_to_end_dataframe=df_leg,
+                model_step=leg(step_ms, n_warm + len(e2e_ms) + (n_warm if full else 0)),
                 cores=torch.get_num_threads(), rows=rows, build_s=build_s, full_protocol=bool(full))
