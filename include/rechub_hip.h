@@ -386,6 +386,10 @@ int rh_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, in
 int rh_linear_wgrad_splits(int B, int N, int K);
 int rh_linear_wgrad_partial(const float* g, int64_t ldg, const float* x, int64_t ldx, int B, int N, int K, float* partial,
                             void* stream);
+/* n <= 8 independent rh_linear_wgrad_partial problems as ONE launch (the two weight gradients per layer of CrossNetMix's
+ * backward, torch_rechub/basic/layers.py:470-506: nothing else in that backward waits for them).  Host arrays of n entries. */
+int rh_linear_wgrad_partial_group(int n, const float* const* g, const int64_t* ldg, const float* const* x, const int64_t* ldx,
+                                  const int* B, const int* N, const int* K, float* const* partial, void* stream);
 int rh_head_nblocks(int B);
 int rh_head_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
                 int K, float* y, void* stream);

@@ -1671,6 +1671,29 @@ def test_cross_net_mix_two_product_form_vs_reference_formula(B, d, L, E, r, stri
             close(a.grad, b.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what=f"crossmix g_{name}[{i}]")
 
 
+def test_grouped_weight_gradient_launch_is_the_single_launches_bit_for_bit(monkeypatch):
+    """rh_linear_wgrad_partial_group (round 4: the 2 L weight gradients of CrossNetMix's backward as ONE launch) runs the
+    same workgroup body on the same (tile, split) decomposition as 2 L single launches: every parameter gradient of the
+    stack must be bit-equal between the two forms (configs[2] shape: d = 429, 3 layers, 4 experts, rank 32)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import CrossNetMix
+    torch.manual_seed(3)
+    mix = CrossNetMix(429, num_layers=3, low_rank=32, num_experts=4).to(dev())
+    x = torch.randn(4096, 432, device=dev())[:, :429]
+    gy = torch.randn(4096, 429, device=dev())
+    got = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "WGRAD_GROUP", flag)
+        mix.zero_grad()
+        xi = x.detach().clone().requires_grad_()
+        mix(xi).backward(gy)
+        got[flag] = [xi.grad.clone()] + [p_.grad.clone() for p_ in mix.parameters()]
+    torch.cuda.synchronize()
+    assert len(got[True]) == len(got[False]) > 10
+    for a_, b_ in zip(got[True], got[False]):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("B,L,D,dims,softmax", [
     (37, 50, 16, [256, 128], False),   # configs[3] layer widths; 1850 rows: not a multiple of 32
     (5, 7, 8, [64], True),

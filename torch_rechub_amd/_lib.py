@@ -95,6 +95,7 @@ SIGNATURES = {
     "rh_linear_wgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_linear_wgrad_splits": [c_int, c_int, c_int],
     "rh_linear_wgrad_partial": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr],
+    "rh_linear_wgrad_partial_group": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_head_bwd_ex": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                        c_int, c_ptr],
     "rh_head_bwd_bn": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int,

@@ -44,13 +44,12 @@ struct WgradArgs {
 // LONG: the build for long reductions (see the two kernels below): simple prefetch loop and ONE LDS tile; otherwise the
 // round-1 form (ping-pong register sets, one LDS tile per wavefront).  Same sums in the same order either way.
 template <bool LONG>
-__device__ __forceinline__ void linear_wgrad_body(const WgradArgs& a, float* red) {
+__device__ __forceinline__ void linear_wgrad_body(const WgradArgs& a, float* red, const int bx, const int by, const int s) {
   RH_CHAIN_PRIO();
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int half = lane >> 5, c = lane & 31;
   // (Measured and dropped: a 1-D launch that puts the tiles of one split on ONE XCD, so that its L2 serves the rows they
   // share -- 945 us against 884 for DIN's four long launches; with x-fastest tiles each XCD streams its own column range.)
-  const int bx = blockIdx.x, by = blockIdx.y, s = blockIdx.z;
   const int k0 = bx * kTile, n0 = by * kTile;
   const int b_lo = s * a.rows_per_split;
   const int b_hi = min(a.B, b_lo + a.rows_per_split);
@@ -221,13 +220,36 @@ __device__ __forceinline__ void linear_wgrad_body(const WgradArgs& a, float* red
 // reductions, where the latency of the operand loads is hidden by the other wavefronts (DIN, B * L = 409 600 rows).
 __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs a) {
   extern __shared__ float red[];  // kWaves * kPartStride floats
-  linear_wgrad_body<false>(a, red);
+  linear_wgrad_body<false>(a, red, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent weight-gradient problems as ONE launch (round 4): the backward of CrossNetMix leaves two per layer
+// (g_UTb = g_Y^T wp, g_VgT = g_PG^T x_l), none of which anything else in the backward waits for -- eight launches of
+// 16.5 us each were a sixth of the DCN-v2 step.  Workgroup b belongs to problem i with prefix[i] <= b < prefix[i + 1]; inside
+// a problem the workgroups are numbered tile-column fastest, then tile row, then split, as the 3-D grid of the single launch.
+constexpr int kWgradGroup = 8;
+struct WgradGroupArgs {
+  WgradArgs p[kWgradGroup];
+  int prefix[kWgradGroup + 1];
+  int tiles_k[kWgradGroup], tiles_n[kWgradGroup];
+  int n;
+};
+
+__global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_group_kernel(const WgradGroupArgs ga) {
+  extern __shared__ float red[];
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int q = 1; q < kWgradGroup; ++q) i += (q < ga.n && b >= ga.prefix[q]) ? 1 : 0;
+  const int local = b - ga.prefix[i];
+  const int tk = ga.tiles_k[i], tn = ga.tiles_n[i];
+  linear_wgrad_body<false>(ga.p[i], red, local % tk, (local / tk) % tn, local / (tk * tn));
 }
 
 __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void linear_wgrad_long_kernel(
     const WgradArgs a) {
   extern __shared__ float red[];  // kPartStride floats: the block's tile + its db slice
-  linear_wgrad_body<true>(a, red);
+  linear_wgrad_body<true>(a, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
@@ -844,6 +866,43 @@ static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)N * K + N + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK),
                        0, st, a);
   RH_LAUNCH_CHECK("rh_linear_wgrad");
+  return 0;
+}
+
+// n <= 8 problems of rh_linear_wgrad_partial as one launch: arrays of n entries each (host memory); problem i writes its
+// slabs to partial[i] (rh_linear_wgrad_workspace(B[i], N[i], K[i]) floats, S = rh_linear_wgrad_splits(...) as the single call).
+extern "C" int rh_linear_wgrad_partial_group(int n, const float* const* g, const int64_t* ldg, const float* const* x,
+                                             const int64_t* ldx, const int* B, const int* N, const int* K,
+                                             float* const* partial, void* stream) {
+  RH_REQUIRE(n >= 1 && n <= kWgradGroup && g && ldg && x && ldx && B && N && K && partial, RH_E_BADARG,
+             "rh_linear_wgrad_partial_group: 1 <= n <= %d problems", kWgradGroup);
+  WgradGroupArgs ga{};
+  ga.n = n;
+  ga.prefix[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    RH_REQUIRE(g[i] && x[i] && partial[i] && B[i] >= 1 && N[i] >= 1 && K[i] >= 1 && ldg[i] >= N[i] && ldx[i] >= K[i], RH_E_BADARG,
+               "rh_linear_wgrad_partial_group: bad problem %d", i);
+    RH_REQUIRE(B[i] < kLongRows, RH_E_UNSUPPORTED, "rh_linear_wgrad_partial_group: B = %d (long reductions take the single call)",
+               B[i]);
+    WgradArgs a{g[i], ldg[i], x[i], ldx[i], B[i], N[i], K[i], 1, B[i], partial[i], nullptr, nullptr, 0};
+    int tn, tk;
+    wgrad_plan(B[i], N[i], K[i], &tn, &tk, &a.S, &a.rows_per_split);
+    ga.p[i] = a;
+    ga.tiles_k[i] = tk;
+    ga.tiles_n[i] = tn;
+    ga.prefix[i + 1] = ga.prefix[i] + tk * tn * a.S;
+  }
+  for (int i = n; i < kWgradGroup; ++i) ga.prefix[i + 1] = ga.prefix[n];
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_group_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kWaves * kPartStride * sizeof(float)));
+    RH_REQUIRE(e == hipSuccess, (int)e, "rh_linear_wgrad_partial_group: cannot reserve LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linear_wgrad_group_kernel, dim3((unsigned)ga.prefix[n]), dim3(RH_BLOCK),
+                     (size_t)kWaves * kPartStride * sizeof(float), reinterpret_cast<hipStream_t>(stream), ga);
+  RH_LAUNCH_CHECK("rh_linear_wgrad_partial_group");
   return 0;
 }
 

@@ -1989,22 +1989,34 @@ class _CrossMoeFn(torch.autograd.Function):
         ws1 = _lib.call("rh_linear_wgrad_workspace", B, KP, d)
         ws2 = _lib.call("rh_linear_wgrad_workspace", B, d, KP)
         slabV, slabU, gC = [], [], []
+        # The two weight gradients of a layer (g_UTb = g_Y^T wp, g_VgT = g_PG^T x_l) feed nothing but the final unpack: they
+        # are collected and run as grouped launches of <= 8 problems after the loop (round 4: 2 L launches of ~16.5 us -> 1)
+        group = WGRAD_GROUP and B < 32768
+        problems = []
         for l in reversed(range(L)):
             xl, v1, v2, gate, wp, Y = saved[6 * l:6 * l + 6]
             g_Y = torch.empty((B, d), dtype=torch.float32, device=dev)
             _lib.call("rh_cross_moe_res_bwd", _p(G), G.stride(0), _p(x), x.stride(0), _p(Y), B, d, 1 if l == L - 1 else 0,
                       _p(g_Y), _p(acc), _stream())
             pu = torch.empty((ws2,), dtype=torch.float32, device=dev)  # g_UTb (d, KP) = g_Y^T wp
-            _lib.call("rh_linear_wgrad_partial", _p(g_Y), d, _p(wp), KP, B, d, KP, _p(pu), _stream())
+            if group:
+                problems.append((g_Y, d, wp, KP, d, KP, pu))
+            else:
+                _lib.call("rh_linear_wgrad_partial", _p(g_Y), d, _p(wp), KP, B, d, KP, _p(pu), _stream())
             g_wp = torch.mm(g_Y, UTb[l])
             g_PG = torch.empty((B, KP), dtype=torch.float32, device=dev)
             pc = torch.empty((nb, E * r * r), dtype=torch.float32, device=dev)
             _lib.call("rh_cross_moe_mid_bwd", _p(g_wp), _p(v1), _p(v2), _p(gate), _p(Cc[l]), B, E, r, _p(g_PG), _p(pc),
                       _stream())
             pv = torch.empty((ws1,), dtype=torch.float32, device=dev)  # g_VgT (KP, d) = g_PG^T x_l
-            _lib.call("rh_linear_wgrad_partial", _p(g_PG), KP, _p(xl), xl.stride(0), B, KP, d, _p(pv), _stream())
+            if group:
+                problems.append((g_PG, KP, xl, xl.stride(0), KP, d, pv))
+            else:
+                _lib.call("rh_linear_wgrad_partial", _p(g_PG), KP, _p(xl), xl.stride(0), B, KP, d, _p(pv), _stream())
             G = torch.addmm(G, g_PG, VgT[l])  # gradient of x_l: residual + through the first product
             slabV.append(pv), slabU.append(pu), gC.append(pc)
+        for i in range(0, len(problems), 8):
+            linear_wgrad_partial_group(problems[i:i + 8], B)
         slabV.reverse(), slabU.reverse(), gC.reverse()
         g_x = G + acc  # x is both x_0 (Hadamard factor of every layer) and the first x_l
         g_U = [torch.empty(ctx.shapes[l], dtype=torch.float32, device=dev) for l in range(L)]
@@ -2018,6 +2030,26 @@ class _CrossMoeFn(torch.autograd.Function):
                   cast(_ptr_array(g_U)), cast(_ptr_array(g_V)), cast(_ptr_array(g_b)), cast(_ptr_array(g_C)),
                   cast(_ptr_array(g_W)), _stream())
         return (g_x, None, None) + tuple(g_U) + tuple(g_V) + tuple(g_C) + tuple(g_b) + tuple(g_W)
+
+
+WGRAD_GROUP = True  # A/B twin for tests: False = one rh_linear_wgrad_partial launch per problem
+
+
+def linear_wgrad_partial_group(problems, B):
+    """ONE launch for <= 8 independent weight-gradient problems (g (B, N) ld, x (B, K) ld, N, K, partial workspace)."""
+    import ctypes
+    n = len(problems)
+    g = (ctypes.c_void_p * n)(*[p_[0].data_ptr() for p_ in problems])
+    ldg = (ctypes.c_int64 * n)(*[int(p_[1]) for p_ in problems])
+    x = (ctypes.c_void_p * n)(*[p_[2].data_ptr() for p_ in problems])
+    ldx = (ctypes.c_int64 * n)(*[int(p_[3]) for p_ in problems])
+    Bs = (ctypes.c_int * n)(*[int(B)] * n)
+    Ns = (ctypes.c_int * n)(*[int(p_[4]) for p_ in problems])
+    Ks = (ctypes.c_int * n)(*[int(p_[5]) for p_ in problems])
+    part = (ctypes.c_void_p * n)(*[p_[6].data_ptr() for p_ in problems])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _lib.call("rh_linear_wgrad_partial_group", n, cast(g), cast(ldg), cast(x), cast(ldx), cast(Bs), cast(Ns), cast(Ks),
+              cast(part), _stream())
 
 
 def cross_moe(x, u_list, v_list, c_list, bias_list, gating_weights):
