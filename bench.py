@@ -673,6 +673,7 @@ def _short_run(args, device, rank, use_graph, model=None, batch=None, dist_kind=
 
 ACCOUNT_GROUPS = (  # first match wins; kernel-name substring -> row of SURVEY 8(d)'s whole-step accounting
     ("batch_gather_kernel", "batch_assembly"), ("batch_advance", "batch_assembly"),
+    ("refresh_assemble", "batch_assembly_and_table_refresh"),
     ("adam_lazy_touched", "table_refresh_before_gather"), ("embed_fwd", "gather_fwd"), ("embed_bwd", "gather_bwd"),
     ("embed_scatter", "gather_bwd"), ("Cijk_", "mlp_gemm_library"), ("gemm_f32", "mlp_gemm_own"),
     ("linear_fwd", "mlp_gemm_own"), ("linear_dgrad", "mlp_gemm_own"),
@@ -702,7 +703,7 @@ def parse_step_trace(trace_csv, steps_wanted):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2]]
+    marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
     if len(marks) < 3:
         return None
     marks = marks[-(min(steps_wanted, len(marks) - 1) + 1):]
@@ -715,7 +716,7 @@ def parse_step_trace(trace_csv, steps_wanted):
     for i in range(marks[0], marks[-1]):
         st, en, name, q = rows[i]
         short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("rechub::", "").split("(")[0][:60]
-        head_seg = q != main_q and ("batch_gather" in name or "adam_lazy_touched" in name)
+        head_seg = q != main_q and ("batch_gather" in name or "adam_lazy_touched" in name or "refresh_assemble" in name)
         if head_seg:
             short += " [head segment, optimizer queue]"
         elif q != main_q:

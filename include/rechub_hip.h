@@ -549,6 +549,15 @@ int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
 /* rh_adam_lazy_touched, refresh argument: 0 = the touched-rows step (rows take their gradient); 1 = pre-gather refresh of
  * every row of the batch (no gradient traffic). */
+/* rh_batch_gather + rh_adam_lazy_touched (refresh = 1, int64 indices) as ONE launch (round 4): the batch is assembled into the
+ * static buffers (sparse_out (B, Fd), dense_out (B, ND), label_out (B)) from dataset rows perm[(pos + b) mod N] -- exactly
+ * rh_batch_gather's arguments -- while the refresh part reads the same indices straight from the dataset.  idesc must
+ * describe index columns INSIDE sparse_out (pointer = sparse_out + column, stride = Fd): the gather that follows reads them. */
+int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc, int B, int F,
+                                  int D, const double* hyper, const float* ring, int ring_size, int samples_per_block,
+                                  int32_t* err_flag, const int64_t* perm, const int64_t* pos, int64_t N, const int64_t* sparse,
+                                  int Fd, const float* dense, int ND, const float* label, int64_t* sparse_out, float* dense_out,
+                                  float* label_out, void* stream);
 /* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
  * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,

@@ -133,6 +133,8 @@ SIGNATURES = {
                                c_ptr, c_int, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
+    "rh_adam_lazy_refresh_assemble": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,
+                                      c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr],
     "rh_l2norm_fwd": [c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr, c_ptr],
     "rh_l2norm_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr],
@@ -157,6 +159,16 @@ _VALUE_RETURNING = {"rh_abi_version", "rh_embed_bwd_nchunks", "rh_cross_bwd_nblo
 
 ABI_VERSION = 1
 _lib = None
+
+
+def ab(name, default=True):
+    """Same-box A/B switches of benchmarks, ONE environment variable: RECHUB_AB="chain=0,headside=0,assemble=0" turns the named
+    round-4 paths off (each has a bit- or tolerance-pinned twin; the tests flip the module attributes instead)."""
+    for item in filter(None, os.environ.get("RECHUB_AB", "").split(",")):
+        k, _, v = item.partition("=")
+        if k.strip() == name:
+            return v.strip() not in ("0", "false", "off")
+    return default
 
 
 class PackItem(ctypes.Structure):

@@ -211,6 +211,19 @@ struct LazyTouchedArgs {
   int ring_mask;
   int T, B, F, spb;
   int* err;
+  // ASSEMBLE (round 4): the batch does not exist yet -- this launch also assembles it (rh_batch_gather's work) and reads its
+  // own indices straight from the resident dataset: sample b of the batch = dataset row perm[(pos + b) mod N]
+  const int64_t* perm;
+  const int64_t* pos;
+  int64_t N;
+  const int64_t* src_sparse;  // (N, Fd)
+  int Fd;
+  const float* src_dense;     // (N, ND) or null
+  int ND;
+  const float* src_label;     // (N,) or null
+  int64_t* sparse_out;        // (B, Fd): the batch buffer the fields' index columns point into
+  float* dense_out;
+  float* label_out;
 };
 
 struct LazySweepArgs {
@@ -230,7 +243,7 @@ struct LazySweepArgs {
   LazyTouchedArgs touch;
 };
 
-template <int LPR, typename IdxT, bool REFRESH>
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f);
 
 template <int LPR, bool MERGED = false>
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
 
 // REFRESH: the pre-gather pass -- the rows carry no gradient yet (their gradient rows are zero), so they are neither
 // read nor re-zeroed and the closing step is the zero-gradient form too (a quarter less traffic per row)
-template <int LPR, typename IdxT, bool REFRESH>
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f) {
   constexpr int LPP = RH_BLOCK / LPR;
   constexpr int D = 4 * LPR;
@@ -379,6 +392,9 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   const int64_t rows = a.ldesc[5 * T + ti];
   const IdxT* ip = reinterpret_cast<const IdxT*>(a.idesc[f]);
   const int64_t st = a.idesc[F + f];
+  // ASSEMBLE: the field's index column is column `acol` of the batch buffer, i.e. of the dataset rows
+  const int64_t acol = ASSEMBLE ? (reinterpret_cast<const int64_t*>(ip) - a.sparse_out) : 0;
+  const int64_t apos = ASSEMBLE ? a.pos[0] : 0;
   const AdamScalars h = load_scalars(a.hyper);
   const int t = (int)a.hyper[12];
   const int q = threadIdx.x % LPR;
@@ -406,7 +422,14 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     const bool extra = base >= b1;
     const int64_t b = base + slot;
     const bool ok = !extra && b < b1;
-    int64_t r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
+    int64_t r;
+    if (ASSEMBLE) {
+      int64_t p = apos + (ok ? b : b1 - 1);
+      if (p >= a.N) p %= a.N;
+      r = gload<int64_t>(a.src_sparse + gload<int64_t>(a.perm + p) * a.Fd + acol);
+    } else {
+      r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
+    }
     bool valid = ok && (uint64_t)r < (uint64_t)rows && r != pad;
     if (extra) {
       r = pad;
@@ -489,6 +512,34 @@ template <int LPR, typename IdxT, bool REFRESH>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
   RH_CHAIN_PRIO();
   lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Batch assembly + pre-gather refresh as ONE launch (round 4; reference: TorchDataset.__getitem__ + default_collate,
+// torch_rechub/utils/data.py:14-25,61-83, then the rows optimizer.step() would have left in the tables, trainers/ctr_trainer.py:99).
+// Row blockIdx.y < F of the grid: the refresh of field f for its 64-sample chunk, the indices read from the dataset through
+// perm (what rh_batch_gather would have written).  Row blockIdx.y == F: the assembly of that chunk into the static batch
+// buffers (all sparse columns, dense columns, labels; 16 lanes per sample as batch_gather_kernel) -- nothing in THIS launch
+// reads them, so the two parts need no ordering; the short copy runs under the refresh's latency chain.
+template <int LPR>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_refresh_assemble_kernel(const LazyTouchedArgs a) {
+  RH_CHAIN_PRIO();
+  if ((int)blockIdx.y < a.F) {
+    lazy_touched_body<LPR, int64_t, true, true>(a, (int)blockIdx.x, (int)blockIdx.y);
+    return;
+  }
+  constexpr int G = 16;
+  const int lig = threadIdx.x % G;
+  const int64_t pos = a.pos[0];
+  const int64_t b0 = (int64_t)blockIdx.x * a.spb;
+  const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
+  for (int64_t b = b0 + threadIdx.x / G; b < b1; b += RH_BLOCK / G) {
+    int64_t p = pos + b;
+    if (p >= a.N) p %= a.N;
+    const int64_t src = a.perm[p];
+    for (int j = lig; j < a.Fd; j += G) a.sparse_out[b * a.Fd + j] = a.src_sparse[src * a.Fd + j];
+    for (int j = lig; j < a.ND; j += G) a.dense_out[b * a.ND + j] = a.src_dense[src * a.ND + j];
+    if (lig == 0 && a.src_label != nullptr) a.label_out[b] = a.src_label[src];
+  }
 }
 
 template <int LPR>
@@ -856,6 +907,38 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
   }
 #undef RH_LT
   RH_LAUNCH_CHECK("rh_adam_lazy_touched");
+  return 0;
+}
+
+extern "C" int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc, int B,
+                                             int F, int D, const double* hyper, const float* ring, int ring_size,
+                                             int samples_per_block, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
+                                             int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND,
+                                             const float* label, int64_t* sparse_out, float* dense_out, float* label_out,
+                                             void* stream) {
+  RH_REQUIRE(ldesc && field_table && idesc && hyper && ring && perm && pos && sparse && sparse_out, RH_E_BADARG,
+             "rh_adam_lazy_refresh_assemble: null pointer");
+  RH_REQUIRE(T >= 1 && F >= 1 && F <= 65534 && B >= 1 && N >= 1 && Fd >= 1 && ND >= 0, RH_E_BADARG,
+             "rh_adam_lazy_refresh_assemble: bad shape");
+  RH_REQUIRE(ND == 0 || (dense && dense_out), RH_E_BADARG, "rh_adam_lazy_refresh_assemble: dense pointers null");
+  RH_REQUIRE(label == nullptr || label_out != nullptr, RH_E_BADARG, "rh_adam_lazy_refresh_assemble: label_out null");
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
+             "rh_adam_lazy_refresh_assemble: ring_size must be a power of two <= %d", kMaxRing);
+  const int spb = samples_per_block <= 0 ? 64 : ((samples_per_block + 63) / 64) * 64;
+  LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag,
+                    perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out};
+  const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)(F + 1));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (D / 4) {
+    case 1: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<1>), grid, dim3(RH_BLOCK), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<2>), grid, dim3(RH_BLOCK), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<4>), grid, dim3(RH_BLOCK), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<8>), grid, dim3(RH_BLOCK), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<16>), grid, dim3(RH_BLOCK), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<32>), grid, dim3(RH_BLOCK), 0, s, a); break;
+    default: rh_set_error("rh_adam_lazy_refresh_assemble: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
+  }
+  RH_LAUNCH_CHECK("rh_adam_lazy_refresh_assemble");
   return 0;
 }
 

@@ -1149,8 +1149,8 @@ class _HeadFn(torch.autograd.Function):
 
 # Fused MLP chain (round 4): [Linear -> BatchNorm1d -> ReLU -> Dropout] x L -> Linear(., 1) (+ wide / FM terms)
 # -> sigmoid of torch_rechub/basic/layers.py:276-292 + models/ranking/deepfm.py:39-43 as ONE autograd node over L + 1 forward
-# launches and 3 L + 1 backward launches.  A/B switch for benchmarks: RECHUB_MLP_CHAIN=0 (tests flip the attribute).
-FUSE_MLP_CHAIN = os.environ.get("RECHUB_MLP_CHAIN", "1") == "1"
+# launches and 3 L + 1 backward launches.  A/B switch for benchmarks: RECHUB_AB=chain=0 (tests flip the attribute).
+FUSE_MLP_CHAIN = _lib.ab("chain")
 _CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
 
 

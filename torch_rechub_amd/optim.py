@@ -21,6 +21,7 @@ from . import _lib, graphs, ops
 
 
 SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  # rh_adam_lazy_sweep modes
+ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 
 
 class TableAdam(torch.optim.Adam):
@@ -118,8 +119,9 @@ class TableAdam(torch.optim.Adam):
                 # branch of the step's graph: 0.312 ms), external-event nodes (1.66 ms), CU-masked streams (0.350 ms), the
                 # row-list table gradient (backward 159 vs 103 us at B = 65536).
                 self.overlap_sweep = os.environ.get("RECHUB_STEP_FORM", "deferred") != "inline"
-                self.head_on_side = os.environ.get("RECHUB_HEAD_SIDE", "1") == "1"
+                self.head_on_side = _lib.ab("headside")
                 self._head_event = None
+                self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._step_recs, self._last_recs = [], []
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
@@ -281,7 +283,10 @@ class TableAdam(torch.optim.Adam):
                                    "(or capture with torch_rechub_amd.graphs.SegmentedGraph)")
             else:
                 self._join_sweep()
-        self._touch(rec, self._lazy_setup(), ops._stream(), refresh=True)
+        pre, self._pre_refreshed = self._pre_refreshed, None
+        if not (pre is not None and training and self._same_gather(rec, pre)):
+            # (pre: rh_adam_lazy_refresh_assemble already refreshed exactly these lookups when the batch was assembled)
+            self._touch(rec, self._lazy_setup(), ops._stream(), refresh=True)
         if rec.get("training", torch.is_grad_enabled()):
             self._gathers += 1
             if getattr(self, "_ahead_broken", False) and capturing:
@@ -297,6 +302,56 @@ class TableAdam(torch.optim.Adam):
                 self._cut_fork(seg)
                 self._sweep_inflight = True
                 # plain capture: leave it pending, step_tables() sweeps in line (device-side step number)
+
+    @staticmethod
+    def _same_gather(a, b):
+        return a["idesc"] is b["idesc"] and (a["B"], a["F"], a["D"], a["idx_is_i64"]) == (b["B"], b["F"], b["D"], b["idx_is_i64"]) \
+            and len(a["weights"]) == len(b["weights"]) and all(x is y for x, y in zip(a["weights"], b["weights"])) \
+            and list(a["pads"]) == list(b["pads"])
+
+    def assemble_with_refresh(self, loader, B=None):
+        """Called by the trainers INSTEAD of the loader's batch assembly when the coming step is known to gather ONE index
+        batch that lives in the loader's static buffer (the previous step's record): the assembly and the pre-gather refresh
+        of that batch run as ONE launch (rh_adam_lazy_refresh_assemble), the refresh reading its indices from the dataset.
+        Returns False (nothing launched: the caller assembles the ordinary way) whenever that is not the situation."""
+        if self.lazy_k <= 1 or not self._tables or not ASSEMBLE_WITH_REFRESH or not self._k_decided:
+            return False
+        recs = self._last_recs
+        if len(recs) != 1 or (self._gathers_per_step or 0) != 1 or self._gathers != 0:
+            return False
+        args = loader.assembly_args(B)
+        rec = recs[0]
+        if args is None or not rec["idx_is_i64"] or rec["B"] != args["B"]:
+            return False
+        sp = args["sparse_out"]
+        lo, hi = sp.data_ptr(), sp.data_ptr() + 8 * sp.shape[1]
+        cols = rec.get("keep")
+        if not cols or any((not torch.is_tensor(c)) or c.dim() != 1 or c.stride(0) != sp.shape[1] or
+                           not lo <= c.data_ptr() < hi for c in cols):
+            return False  # the gather's index columns are not columns of this loader's batch buffer
+        groups = [g for g in self._lazy_setup() if g["D"] == rec["D"] and any(id(w) in g["local"] for w in rec["weights"])]
+        if len(groups) != 1:
+            return False
+        grp = groups[0]
+        capturing = torch.cuda.is_current_stream_capturing()
+        seg = graphs.active()
+        if capturing and seg is None and self.overlap_sweep:
+            return False  # (a plain capture with a pending deferred sweep: on_gather raises with the explanation)
+        if capturing and seg is not None and self.overlap_sweep:
+            if self._join_seg is not seg:  # what on_gather does in front of the first refresh of a segmented capture
+                seg.at_start(self._head_begin if self.head_on_side else self._join_sweep)
+                self._join_seg = seg
+            self._sweep_inflight = False
+        elif self._sweep_inflight:
+            self._join_sweep()
+        a = args
+        _lib.call("rh_adam_lazy_refresh_assemble", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
+                  ops._p(rec["idesc"]), rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64,
+                  ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"], ops._p(a["sparse"]),
+                  a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]), ops._p(a["dense_out"]),
+                  ops._p(a["label_out"]), ops._stream())
+        self._pre_refreshed = rec
+        return True
 
     def _refresh_ahead(self, rec, seg):
         """Deferred form, a step with SEVERAL gathers (two-tower / sequence models): the sweep may only start once the rows
@@ -354,6 +409,7 @@ class TableAdam(torch.optim.Adam):
     # sweep's own stream: batch assembly -> refresh -> sweep are consecutive kernels of one queue (no event in between; the
     # previous sweep is in front of them on that queue, which IS the join), and it is the chain on the main stream that waits
     # for the event recorded behind the refresh.  The cross-queue latency moves from the longer path to the shorter one.
+    # (A/B: RECHUB_AB=headside=0.)
     def _head_begin(self):
         """at_start of a segmented replay: the head segment (on the side stream) follows the previous step's chain."""
         if self._side is None:
@@ -557,6 +613,7 @@ class TableAdam(torch.optim.Adam):
             self._small_done = False
             if self.lazy_k > 1 and self._tables:
                 self._gathers = 0  # the abandoned forward's gathers do not count towards the step's gather count
+                self._pre_refreshed = None
                 if self._touch_log:
                     # the abandoned backward scattered gradient rows that no optimizer step will consume (and re-zero)
                     for p in self._tables:

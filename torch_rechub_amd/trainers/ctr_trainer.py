@@ -124,7 +124,9 @@ class CTRTrainer(object):
 
     def _load(self, loader, B=None):
         """Next batch of a DeviceDataLoader; its position counter is advanced by this step's scalar launch."""
-        x, y = loader.load_next(B, advance=False)
+        opt = self.optimizer
+        fused = isinstance(opt, TableAdam) and self.dp is None and opt.assemble_with_refresh(loader, B)
+        x, y = loader.load_next(B, advance=False, assemble=not fused)
         self._counters.append(loader.counter(loader.batch_size if B is None else B))
         return x, y
 

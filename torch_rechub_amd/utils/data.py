@@ -284,17 +284,32 @@ class DeviceDataLoader(object):
                                            generator=self.generator))
         self.pos.zero_()
 
-    def load_next(self, B=None, advance=True):
+    def assembly_args(self, B=None):
+        """The arguments of rh_batch_gather for the batch at the current position -- for a caller that runs the assembly
+        inside a launch of its own (optim.TableAdam: rh_adam_lazy_refresh_assemble) after ``load_next(assemble=False)`` --
+        or None when this loader's batches need more than that one gather (padded-sequence columns)."""
+        B = self.batch_size if B is None else B
+        x, y, sp, de, seqs = self._buffers(B)
+        if seqs:
+            return None
+        return dict(perm=self.perm, pos=self.pos, N=self.N, B=B, sparse=self.sparse, F=self.F, dense=self.dense, ND=self.NDL,
+                    label=self.label, sparse_out=sp, dense_out=de, label_out=y if self.label is not None else None)
+
+    def load_next(self, B=None, advance=True, assemble=True):
         """Assemble the batch at the current position into the static buffers and advance the position.
 
         ``advance=False``: the caller advances the position later in the step (``counter()`` -> ops.StepFusion: the
-        trainers fold it into the step's single scalar launch instead of a launch of its own)."""
+        trainers fold it into the step's single scalar launch instead of a launch of its own).
+        ``assemble=False``: only the views are returned; the caller launches the assembly itself (``assembly_args``)."""
         B = self.batch_size if B is None else B
         x, y, sp, de, seqs = self._buffers(B)
         s = ops._stream()
-        _lib.call("rh_batch_gather", ops._p(self.perm), ops._p(self.pos), self.N, B, ops._p(self.sparse), self.F,
-                  ops._p(self.dense), self.NDL, ops._p(self.label), ops._p(sp), ops._p(de),
-                  ops._p(y if self.label is not None else None), s)
+        if assemble:
+            _lib.call("rh_batch_gather", ops._p(self.perm), ops._p(self.pos), self.N, B, ops._p(self.sparse), self.F,
+                      ops._p(self.dense), self.NDL, ops._p(self.label), ops._p(sp), ops._p(de),
+                      ops._p(y if self.label is not None else None), s)
+        elif seqs:
+            raise ValueError("load_next(assemble=False) on a loader with sequence columns")
         if advance:
             _lib.call("rh_batch_advance", ops._p(self.pos), B, self.N, s)
         for dst, src in seqs:
