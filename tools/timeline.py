@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?"),
                  r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Workgroup_Size_X", "?")))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2]]
+marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
 lo = marks[-(n + 1)]
 t0 = rows[lo][0]
 for st, en, name, q, s, gx, gy, wx in rows[lo:marks[-1] + 1]:
