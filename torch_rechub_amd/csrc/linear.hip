@@ -280,6 +280,11 @@ __global__ __launch_bounds__(RH_BLOCK) void wgrad_reduce_kernel(const WgradArgs 
 // wavefronts to cover the latency of the operand loads (tuning knob RH_TUNE_WGRAD_BLOCKS).
 int g_long_blocks = 1024;   // negative: -value workgroups with the default build of the kernel (A/B)
 constexpr int kLongRows = 32768;
+// RH_TUNE_WGRAD_SHORT_FORM: build used for batch-sized reductions (B < 32768).  0: the round-1 form (78 VGPRs + 128 AGPRs,
+// four LDS tiles); 1: the 128-register, one-LDS-tile build of the long reductions.  Beside the optimizer's resident sweep
+// (2 wavefronts of 112 registers per SIMD) only ONE wavefront of the 206-register build fits on a SIMD where the launch's
+// ~500 workgroups want two: measured 28.5 us alone, 39.5 us beside the sweep (round 4).
+int g_short_form = 0;
 
 void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
   *tiles_n = (N + kTile - 1) / kTile;
@@ -848,7 +853,7 @@ static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, 
   int tn, tk;
   wgrad_plan(B, N, K, &tn, &tk, &a.S, &a.rows_per_split);
   a.direct = (reduce && a.S == 1) ? 1 : 0;
-  const bool long_form = B >= kLongRows && g_long_blocks > 0;
+  const bool long_form = (B >= kLongRows && g_long_blocks > 0) || (B < kLongRows && g_short_form == 1);
   const size_t lds = (size_t)(long_form ? 1 : kWaves) * kPartStride * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -909,6 +914,10 @@ extern "C" int rh_linear_wgrad_partial_group(int n, const float* const* g, const
 extern "C" int rh_linear_set_tuning(int key, int value) {
   if (key == RH_TUNE_WGRAD_BLOCKS) {
     g_long_blocks = value;
+    return 0;
+  }
+  if (key == RH_TUNE_WGRAD_SHORT_FORM) {
+    g_short_form = value;
     return 0;
   }
   return RH_E_BADARG;
