@@ -420,6 +420,15 @@ int rh_head_bwd_bn(const float* h, int64_t ldh, const float* w, const float* y, 
                    const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b, float* partial,
                    int reduce, const float* bn_z, const float* bn_stat, const float* bn_gamma, const float* bn_beta,
                    float bn_p, const int64_t* bn_rng, const int64_t* bn_ctr, int bn_relu, float* bn_partial, void* stream);
+/* rh_head_bwd_bn + rh_step_scalars as ONE launch (one extra workgroup does the scalar work; arguments as rh_step_scalars):
+ * nothing between the head's forward and its backward reads the loss mean / Adam corrections / device counters. */
+int rh_head_bwd_bn_scalars(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
+                           const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b, float* partial,
+                           int reduce, const float* bn_z, const float* bn_stat, const float* bn_gamma, const float* bn_beta,
+                           float bn_p, const int64_t* bn_rng, const int64_t* bn_ctr, int bn_relu, float* bn_partial,
+                           const float* loss_partial, int n_partial, float* loss, double* hyper, int64_t* step, float* ring,
+                           int ring_size, int64_t* c0, int64_t inc0, int64_t mod0, int64_t* c1, int64_t inc1, int64_t mod1,
+                           void* stream);
 int rh_head_loss_nblocks(int B);
 int rh_head_loss_fwd(const float* h, int64_t ldh, const float* w, const float* bias, const float* e0, const float* e1, int B,
                      int K, float* y, const float* t, float* loss_partial, void* stream);
@@ -515,6 +524,14 @@ int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream);
 /* the same + the Adam step of every packed parameter on the element just summed (= rh_pack_grads then rh_adam_small over the
  * same n parameters, sdesc in rh_adam_small's layout, hyper already holding this step's scalars): one launch */
 int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper, void* stream);
+/* rh_adam_lazy_step_mode + rh_pack_grads / rh_pack_grads_adam as ONE launch (round 4): the end of a step -- touched rows +
+ * dense tables of the table optimizer, and the packing of the dense gradients with the dense parameters' Adam step -- touch
+ * disjoint memory and need only this step's Adam scalars.  n_items <= 32; sdesc / pack_hyper NULL: packing without Adam. */
+int rh_adam_lazy_step_pack(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
+                           const RhPackItem* items, int n_items, float* flat, const int64_t* sdesc, const double* pack_hyper,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)

@@ -100,6 +100,9 @@ SIGNATURES = {
                        c_int, c_ptr],
     "rh_head_bwd_bn": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
                        c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
+    "rh_head_bwd_bn_scalars": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                               c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr,
+                               c_ptr, c_ptr, c_int, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr],
     "rh_bn_relu_dropout_bwd_pre": [c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr,
                                    c_ptr, c_ptr, c_int, c_ptr],
     "rh_pack_grads": [c_ptr, c_int, c_ptr, c_ptr],
@@ -131,6 +134,8 @@ SIGNATURES = {
                           c_ptr],
     "rh_adam_lazy_step_mode": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                                c_ptr, c_int, c_ptr],
+    "rh_adam_lazy_step_pack": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
+                               c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
     "rh_adam_lazy_refresh_assemble": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,

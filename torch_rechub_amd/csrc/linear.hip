@@ -471,6 +471,63 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bnact_fwd_kernel(const HeadBnFw
   }
 }
 
+// The scalar work of one training step (see step_scalars_kernel below); shared with head_bwd_kernel, whose launch can carry it
+// as one extra workgroup (round 4): nothing between the head's forward and its backward needs these scalars.
+struct StepScalarArgs {
+  const float* loss_partial;
+  int n;
+  float inv_b;
+  float* loss;
+  double* hyper;
+  int64_t* step;
+  float* ring;
+  int64_t ring_mask;
+  int64_t *c0, inc0, mod0, *c1, inc1, mod1;
+  int on;  // head_bwd_kernel: 1 = the last workgroup of the grid runs step_scalars_body
+};
+
+static __device__ __forceinline__ void step_scalars_body(const StepScalarArgs& q, float* red /* RH_BLOCK / RH_WAVE floats */) {
+  if (q.loss_partial != nullptr) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < q.n; i += RH_BLOCK) acc += q.loss_partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) q.loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * q.inv_b;
+  }
+  if (threadIdx.x == 0) {
+    if (q.hyper != nullptr) {
+      const int64_t t = *q.step + 1;
+      *q.step = t;
+      const double lr = q.hyper[0], b1 = q.hyper[1], b2 = q.hyper[2];
+      const double bc1 = 1.0 - pow(b1, (double)t);
+      const double bc2 = 1.0 - pow(b2, (double)t);
+      q.hyper[8] = lr / bc1;
+      q.hyper[9] = sqrt(bc2);
+      q.hyper[10] = 1.0 - b1;
+      q.hyper[11] = 1.0 - b2;
+      q.hyper[12] = (double)t;
+      const double A = q.hyper[8] * q.hyper[9], E = q.hyper[3] * q.hyper[9];
+      q.hyper[13] = A;
+      q.hyper[14] = E;
+      if (q.ring != nullptr) {
+        q.ring[2 * (t & q.ring_mask) + 0] = (float)A;
+        q.ring[2 * (t & q.ring_mask) + 1] = (float)E;
+      }
+    }
+    if (q.c0 != nullptr) {
+      int64_t p = *q.c0 + q.inc0;
+      if (q.mod0 > 0 && p >= q.mod0) p %= q.mod0;
+      *q.c0 = p;
+    }
+    if (q.c1 != nullptr) {
+      int64_t p = *q.c1 + q.inc1;
+      if (q.mod1 > 0 && p >= q.mod1) p %= q.mod1;
+      *q.c1 = p;
+    }
+  }
+}
+
 struct HeadBwdArgs {
   const float* h;
   int64_t ldh;
@@ -497,6 +554,7 @@ struct HeadBwdArgs {
   float* bn_partial;
   float bn_p;
   int bn_relu;
+  StepScalarArgs sc;  // sc.on: the grid has one workgroup more, which runs the step's scalar work instead of rows
 };
 
 template <int MAXV, bool BN = false>
@@ -504,6 +562,11 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
   RH_CHAIN_PRIO();
   __shared__ float red[kHeadRows][kHeadLanes * 4 + 1];
   __shared__ float gb_red[kHeadRows];
+  const int nrow_blocks = (int)gridDim.x - (a.sc.on ? 1 : 0);
+  if (a.sc.on && (int)blockIdx.x == nrow_blocks) {
+    step_scalars_body(a.sc, gb_red);
+    return;
+  }
   const int sub = threadIdx.x % kHeadLanes, grp = threadIdx.x / kHeadLanes;
   const int K = a.K, nv = K / 4;
   float4 wacc[MAXV];
@@ -543,7 +606,7 @@ __global__ __launch_bounds__(RH_BLOCK) void head_bwd_kernel(const HeadBwdArgs a)
   const float tw = has_tail ? a.w[tcol] : 0.f;
   float tacc = 0.f;
   const float lscale = a.t ? a.g_loss[0] / (float)a.B : 0.f;
-  for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < a.B; row += (int64_t)gridDim.x * kHeadRows) {
+  for (int64_t row = (int64_t)blockIdx.x * kHeadRows + grp; row < a.B; row += (int64_t)nrow_blocks * kHeadRows) {
     const float yv = a.y[row];
     // the BCE gradient formed inline (t given) and / or an upstream gradient of y (another consumer of the prediction)
     float gy = a.t ? lscale * (yv - a.t[row]) / fmaxf((1.f - yv) * yv, 1e-12f) : a.g_y[row];
@@ -747,51 +810,10 @@ __global__ __launch_bounds__(RH_BLOCK) void bce_bwd_kernel(const float* __restri
 //   Adam bias corrections of step t + 1 (== rh_adam_prepare: step counter, hyper[8..14], the (A, E) ring)
 //   up to two device counters advanced: *c = (*c + inc) % mod (mod == 0: no wrap) -- the loader's batch position, ...
 // Each part is skipped when its pointer is null.
-__global__ __launch_bounds__(RH_BLOCK) void step_scalars_kernel(const float* __restrict__ loss_partial, int n, float inv_b,
-                                                                float* __restrict__ loss, double* hyper, int64_t* step,
-                                                                float* ring, int64_t ring_mask, int64_t* c0, int64_t inc0,
-                                                                int64_t mod0, int64_t* c1, int64_t inc1, int64_t mod1) {
+__global__ __launch_bounds__(RH_BLOCK) void step_scalars_kernel(const StepScalarArgs q) {
   RH_CHAIN_PRIO();
   __shared__ float red[RH_BLOCK / RH_WAVE];
-  if (loss_partial != nullptr) {
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += RH_BLOCK) acc += loss_partial[i];
-    acc = wave_sum(acc);
-    if (threadIdx.x % RH_WAVE == 0) red[threadIdx.x / RH_WAVE] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_b;
-  }
-  if (threadIdx.x == 0) {
-    if (hyper != nullptr) {
-      const int64_t t = *step + 1;
-      *step = t;
-      const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2];
-      const double bc1 = 1.0 - pow(b1, (double)t);
-      const double bc2 = 1.0 - pow(b2, (double)t);
-      hyper[8] = lr / bc1;
-      hyper[9] = sqrt(bc2);
-      hyper[10] = 1.0 - b1;
-      hyper[11] = 1.0 - b2;
-      hyper[12] = (double)t;
-      const double A = hyper[8] * hyper[9], E = hyper[3] * hyper[9];
-      hyper[13] = A;
-      hyper[14] = E;
-      if (ring != nullptr) {
-        ring[2 * (t & ring_mask) + 0] = (float)A;
-        ring[2 * (t & ring_mask) + 1] = (float)E;
-      }
-    }
-    if (c0 != nullptr) {
-      int64_t p = *c0 + inc0;
-      if (mod0 > 0 && p >= mod0) p %= mod0;
-      *c0 = p;
-    }
-    if (c1 != nullptr) {
-      int64_t p = *c1 + inc1;
-      if (mod1 > 0 && p >= mod1) p %= mod1;
-      *c1 = p;
-    }
-  }
+  step_scalars_body(q, red);
 }
 
 }  // namespace
@@ -804,9 +826,9 @@ extern "C" int rh_step_scalars(const float* loss_partial, int n_partial, int64_t
   RH_REQUIRE(hyper == nullptr || step != nullptr, RH_E_BADARG, "rh_step_scalars: hyper without step");
   RH_REQUIRE(ring == nullptr || (ring_size > 0 && (ring_size & (ring_size - 1)) == 0), RH_E_BADARG,
              "rh_step_scalars: ring_size must be a power of two");
-  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), loss_partial,
-                     n_partial, loss_partial ? 1.f / (float)B : 0.f, loss, hyper, step, ring, (int64_t)(ring_size - 1), c0,
-                     inc0, mod0, c1, inc1, mod1);
+  const StepScalarArgs q{loss_partial, n_partial, loss_partial ? 1.f / (float)B : 0.f, loss, hyper, step, ring,
+                         (int64_t)(ring_size - 1), c0, inc0, mod0, c1, inc1, mod1, 0};
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), q);
   RH_LAUNCH_CHECK("rh_step_scalars");
   return 0;
 }
@@ -988,7 +1010,37 @@ struct HeadBnArgs {
 };
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
-                         float* partial, void* stream, int reduce = 1, const HeadBnArgs* bn = nullptr);
+                         float* partial, void* stream, int reduce = 1, const HeadBnArgs* bn = nullptr,
+                         const StepScalarArgs* sc = nullptr);
+
+// rh_head_bwd_bn whose launch also carries the step's scalar work (rh_step_scalars' arguments) as ONE extra workgroup: the
+// mean of the BCE terms the head's forward left behind, the Adam bias corrections of the coming optimizer step and the
+// device counters.  Nothing between the head's forward and this launch reads those scalars (the loss value is consumed
+// after the backward; trainers/ctr_trainer.py:88-99), so the scalar launch of the step disappears (round 4).
+extern "C" int rh_head_bwd_bn_scalars(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y,
+                                      const float* t, const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w,
+                                      float* g_b, float* partial, int reduce, const float* bn_z, const float* bn_stat,
+                                      const float* bn_gamma, const float* bn_beta, float bn_p, const int64_t* bn_rng,
+                                      const int64_t* bn_ctr, int bn_relu, float* bn_partial, const float* loss_partial,
+                                      int n_partial, float* loss, double* hyper, int64_t* step, float* ring, int ring_size,
+                                      int64_t* c0, int64_t inc0, int64_t mod0, int64_t* c1, int64_t inc1, int64_t mod1,
+                                      void* stream) {
+  RH_REQUIRE(g_y != nullptr || (t != nullptr && g_loss != nullptr), RH_E_BADARG,
+             "rh_head_bwd_bn_scalars: give g_y and / or (t, g_loss)");
+  RH_REQUIRE((t != nullptr) == (g_loss != nullptr), RH_E_BADARG, "rh_head_bwd_bn_scalars: t and g_loss go together");
+  RH_REQUIRE(bn_z && bn_stat && bn_gamma && bn_beta && bn_partial && (bn_p <= 0.f || (bn_rng && bn_ctr)), RH_E_BADARG,
+             "rh_head_bwd_bn_scalars: null pointer");
+  RH_REQUIRE(K % 4 == 0 && bn_p >= 0.f && bn_p < 1.f, RH_E_UNSUPPORTED, "rh_head_bwd_bn_scalars: K=%d p=%g unsupported", K, bn_p);
+  RH_REQUIRE(loss_partial == nullptr || (loss != nullptr && n_partial >= 1), RH_E_BADARG,
+             "rh_head_bwd_bn_scalars: loss_partial needs loss and n_partial >= 1");
+  RH_REQUIRE(hyper == nullptr || step != nullptr, RH_E_BADARG, "rh_head_bwd_bn_scalars: hyper without step");
+  RH_REQUIRE(ring == nullptr || (ring_size > 0 && (ring_size & (ring_size - 1)) == 0), RH_E_BADARG,
+             "rh_head_bwd_bn_scalars: ring_size must be a power of two");
+  const HeadBnArgs bn{bn_z, bn_stat, bn_gamma, bn_beta, bn_rng, bn_ctr, bn_partial, bn_p, bn_relu};
+  const StepScalarArgs sc{loss_partial, n_partial, loss_partial ? 1.f / (float)B : 0.f, loss, hyper, step, ring,
+                          (int64_t)(ring_size - 1), c0, inc0, mod0, c1, inc1, mod1, 1};
+  return head_bwd_impl(h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, g_w, g_b, partial, stream, reduce, &bn, &sc);
+}
 
 // rh_head_bwd_ex + the BatchNorm-backward column sums of the hidden layer below the head (h = dropout(relu(bn(bn_z)))
 // and the head is its only consumer): bn_partial (rh_head_nblocks(B), 2, K) = per-block (sum g1, sum g1 * xhat), what
@@ -1036,13 +1088,15 @@ extern "C" int rh_head_loss_bwd(const float* h, int64_t ldh, const float* w, con
 
 static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const float* y, const float* g_y, const float* t,
                          const float* g_loss, int B, int K, float* g_h, float* g_z, float* g_w, float* g_b,
-                         float* partial, void* stream, int reduce, const HeadBnArgs* bn) {
+                         float* partial, void* stream, int reduce, const HeadBnArgs* bn, const StepScalarArgs* sc) {
   RH_REQUIRE((h || bn) && w && y && g_h && g_z && (g_w || !reduce) && partial, RH_E_BADARG, "rh_head_bwd: null pointer");
   RH_REQUIRE(B >= 1 && K >= 1 && K <= 4 * kHeadLanes * kHeadMaxV4 && ldh >= K, RH_E_UNSUPPORTED,
              "rh_head_bwd: K=%d unsupported (1 .. %d)", K, 4 * kHeadLanes * kHeadMaxV4);
   HeadBwdArgs a{h, ldh, w, y, g_y, t, g_loss, B, K, g_h, g_z, partial, g_w, g_b};
+  if (sc != nullptr) a.sc = *sc;
   const int need = K < 4 ? 1 : (K / 4 + kHeadLanes - 1) / kHeadLanes;
-  const dim3 grid(head_grid(B)), block(RH_BLOCK);
+  const int row_blocks = head_grid(B);
+  const dim3 grid(row_blocks + (sc != nullptr ? 1 : 0)), block(RH_BLOCK);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (bn != nullptr) {
     a.bn_z = bn->z, a.bn_stat = bn->stat, a.bn_gamma = bn->gamma, a.bn_beta = bn->beta, a.bn_rng = bn->rng;
@@ -1057,7 +1111,7 @@ static int head_bwd_impl(const float* h, int64_t ldh, const float* w, const floa
   else if (need <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, grid, block, 0, st, a);
   else if (need <= 8) hipLaunchKernelGGL(head_bwd_kernel<8>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(head_bwd_kernel<16>, grid, block, 0, st, a);
-  if (reduce) launch_colsum(partial, (int)grid.x, K + 1, g_w, K, g_b, nullptr, 0, nullptr, st);
+  if (reduce) launch_colsum(partial, row_blocks, K + 1, g_w, K, g_b, nullptr, 0, nullptr, st);
   RH_LAUNCH_CHECK("rh_head_bwd");
   return 0;
 }

@@ -1036,13 +1036,26 @@ class StepFusion(object):
         self.counters = []     # [(int64 device tensor of one element, increment, modulus)]
         self.head = None       # dict(y_ptr, partial, t) of the head launch that computed BCE terms
         self.g_loss = None     # (1,) gradient of the loss, handed from the fused BCE backward to the head backward
+        self.defer_scalars = False  # armed by a trainer whose backward follows the forward at once (train_step)
+        self.pending = None    # scalar work a fused-BCE forward left to the chain's head backward (see _FusedBceFn)
 
 
 fusion = StepFusion()
 
 
-def fusion_begin(target=None, optimizer=None, counters=()):
+def _flush_pending_scalars():
+    """A fused-BCE forward left its scalar work to a head backward that never ran (an abandoned step): run it now, so that
+    the loader's position and the loss buffer are what they would have been."""
+    pend, fusion.pending = fusion.pending, None
+    if pend is not None:
+        _lib.call("rh_step_scalars", _p(pend["partial"]), pend["partial"].numel(), pend["B"], _p(pend["loss"]), _p(None),
+                  _p(None), _p(None), 0, *pend["flat"], _stream())
+
+
+def fusion_begin(target=None, optimizer=None, counters=(), defer_scalars=False):
+    _flush_pending_scalars()
     fusion.clear()
+    fusion.defer_scalars = bool(defer_scalars)
     if target is not None and target.is_cuda and target.dtype == torch.float32 and target.dim() == 1 and \
             target.is_contiguous():
         fusion.target = target
@@ -1053,9 +1066,10 @@ def fusion_begin(target=None, optimizer=None, counters=()):
 def fusion_end():
     """Disarm; returns the device counters nobody advanced (the caller launches rh_batch_advance for them)."""
     left = fusion.counters
-    g = fusion.g_loss
+    g, pend = fusion.g_loss, fusion.pending
     fusion.clear()
     fusion.g_loss = g  # the backward of this step has not run yet
+    fusion.pending = pend  # ... and may carry the step's scalar work (_FusedBceFn, defer_scalars)
     return left
 
 
@@ -1259,9 +1273,23 @@ class _MlpChainFn(torch.autograd.Function):
         else:
             g_y = g_y.contiguous()
         bn_partial = torch.empty((nblk, 2, K), dtype=torch.float32, device=dev)
-        _lib.call("rh_head_bwd_bn", _p(None), K, _p(hw), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_a), _p(g_z), _p(g_w),
-                  _p(g_b), _p(partial), 0 if defer else 1, _p(hs[-1]), _p(stat[-1]), _p(params[4 * (L - 1) + 2]),
-                  _p(params[4 * (L - 1) + 3]), ps[-1], _p(rng), _p(ctrs[-1]), 1, _p(bn_partial), _stream())
+        pend = fusion.pending
+        if pend is not None and pend["y_ptr"] == y.data_ptr():
+            fusion.pending = None
+            opt = pend["opt"]
+            hyper = step = ring = None
+            ring_size = 0
+            if opt is not None and opt.can_fuse_prepare():
+                hyper, step, ring, ring_size = opt.fuse_prepare()
+            _lib.call("rh_head_bwd_bn_scalars", _p(None), K, _p(hw), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_a), _p(g_z),
+                      _p(g_w), _p(g_b), _p(partial), 0 if defer else 1, _p(hs[-1]), _p(stat[-1]), _p(params[4 * (L - 1) + 2]),
+                      _p(params[4 * (L - 1) + 3]), ps[-1], _p(rng), _p(ctrs[-1]), 1, _p(bn_partial), _p(pend["partial"]),
+                      pend["partial"].numel(), _p(pend["loss"]), _p(hyper), _p(step), _p(ring), ring_size, *pend["flat"],
+                      _stream())
+        else:
+            _lib.call("rh_head_bwd_bn", _p(None), K, _p(hw), _p(y), _p(g_y), _p(t), _p(gl), B, K, _p(g_a), _p(g_z), _p(g_w),
+                      _p(g_b), _p(partial), 0 if defer else 1, _p(hs[-1]), _p(stat[-1]), _p(params[4 * (L - 1) + 2]),
+                      _p(params[4 * (L - 1) + 3]), ps[-1], _p(rng), _p(ctrs[-1]), 1, _p(bn_partial), _stream())
         if defer:
             g_w = deferred.offer(hw, partial.data_ptr(), nblk, K + 1, K, lambda: partial[:, :K].sum(0).view_as(hw), partial)
             if has_bias:
@@ -1388,10 +1416,6 @@ class _FusedBceFn(torch.autograd.Function):
     def forward(ctx, y, t, partial):
         loss = torch.empty((1,), dtype=torch.float32, device=y.device)
         opt = fusion.optimizer
-        hyper = step = ring = None
-        ring_size = 0
-        if opt is not None and opt.can_fuse_prepare():
-            hyper, step, ring, ring_size = opt.fuse_prepare()
         cs = fusion.counters[:2]
         fusion.counters = fusion.counters[2:]
         flat = []
@@ -1399,8 +1423,18 @@ class _FusedBceFn(torch.autograd.Function):
             flat += [_p(c), int(inc), int(mod)]
         while len(flat) < 6:
             flat += [_NULL, 0, 0]
-        _lib.call("rh_step_scalars", _p(partial), partial.numel(), y.numel(), _p(loss), _p(hyper), _p(step), _p(ring),
-                  ring_size, *flat, _stream())
+        if fusion.defer_scalars and y.grad_fn is not None and y.grad_fn.__class__.__name__ == "_MlpChainFnBackward":
+            # the chain's head backward carries this scalar work as one extra workgroup of its own launch (the loss value
+            # is then written during the backward; the trainer that armed defer_scalars reads it only afterwards)
+            fusion.pending = dict(partial=partial, B=y.numel(), loss=loss, flat=flat, y_ptr=y.data_ptr(), opt=opt,
+                                  keep=[c for c, _, _ in cs])
+        else:
+            hyper = step = ring = None
+            ring_size = 0
+            if opt is not None and opt.can_fuse_prepare():
+                hyper, step, ring, ring_size = opt.fuse_prepare()
+            _lib.call("rh_step_scalars", _p(partial), partial.numel(), y.numel(), _p(loss), _p(hyper), _p(step), _p(ring),
+                      ring_size, *flat, _stream())
         ctx.y_ptr = y.data_ptr()
         ctx.shape = y.shape
         ctx.dev = y.device

@@ -130,7 +130,7 @@ class CTRTrainer(object):
         self._counters.append(loader.counter(loader.batch_size if B is None else B))
         return x, y
 
-    def _forward_loss(self, x_dict, y):
+    def _forward_loss(self, x_dict, y, defer_scalars=False):
         """_compute_loss under an armed ops.StepFusion: head + BCE terms in one launch, the loss mean / Adam bias
         corrections / device counters in ONE scalar launch (ops.StepFusion).  Anything the fusion did not absorb is
         launched here."""
@@ -140,7 +140,8 @@ class CTRTrainer(object):
         counters, self._counters = self._counters, []
         if isinstance(self.optimizer, TableAdam):
             self.optimizer.rollback_abandoned_prepare()
-        ops.fusion_begin(target=y if fuse else None, optimizer=self.optimizer if fuse else None, counters=counters)
+        ops.fusion_begin(target=y if fuse else None, optimizer=self.optimizer if fuse else None, counters=counters,
+                         defer_scalars=defer_scalars and fuse)
         try:
             loss = self._compute_loss(x_dict, y)
         finally:
@@ -180,7 +181,9 @@ class CTRTrainer(object):
 
     def train_step(self, x_dict, y):
         """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
-        loss = self._forward_loss(x_dict, y)
+        # (defer_scalars: the backward below follows at once and the loss value is read after it -- the fused MLP chain's
+        # head backward may then carry the step's scalar launch)
+        loss = self._forward_loss(x_dict, y, defer_scalars=self.dp is None)
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
@@ -207,7 +210,7 @@ class CTRTrainer(object):
         if defer:
             # with this step's Adam scalars already on the device (the step's scalar launch computed them in the forward),
             # the packing launch also steps the dense parameters: rh_pack_grads + rh_adam_small as ONE launch
-            self.bucket.pack(items, adam=self.optimizer.small_adam_args())
+            self.bucket.pack(items, adam=self.optimizer.small_adam_args(), defer_to=self.optimizer)
         elif packed or self.dp is not None:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
