@@ -487,8 +487,8 @@ class TableAdam(torch.optim.Adam):
     def take_pack(self, items, n, flat, adam):
         """Offered by the trainer's packing step (distributed.DenseGradBucket.pack): True when the end-of-step launch of this
         optimizer will carry the packing (rh_adam_lazy_step_pack) -- i.e. the coming step() takes the merged launch."""
-        if not PACK_IN_STEP or self.lazy_k <= 1 or not self._tables or n > 32 or not self._k_decided:
-            return False
+        if not PACK_IN_STEP or self.lazy_k <= 1 or not self._tables or n > 32 or not self._k_decided or adam is None:
+            return False  # (adam None: step_tables runs rh_adam_small on the flat bucket BEFORE the table launch)
         if not self._merge_ok(self._lazy_setup()):
             return False
         self._pending_pack = (items, n, flat, adam)
