@@ -21,6 +21,7 @@ from . import _lib, graphs, ops
 
 
 SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  # rh_adam_lazy_sweep modes
+EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 PACK_IN_STEP = _lib.ab("packstep")  # False (RECHUB_AB=packstep=0): rh_pack_grads(_adam) as a launch of its own
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 
@@ -124,6 +125,7 @@ class TableAdam(torch.optim.Adam):
                 self._head_event = None
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._pending_pack = None   # (items, n, flat, adam) of a packing step this optimizer's launch will carry
+                self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
@@ -288,11 +290,18 @@ class TableAdam(torch.optim.Adam):
         pre, self._pre_refreshed = self._pre_refreshed, None
         if not (pre is not None and training and self._same_gather(rec, pre)):
             # (pre: rh_adam_lazy_refresh_assemble already refreshed exactly these lookups when the batch was assembled)
+            if self._head_forks and capturing and seg is not None:
+                # ... but this is not the gather it announced, and the eager head forks the sweep in front of the graph:
+                # every replay joins that sweep before this refresh runs (as a refresh-ahead mismatch does)
+                seg.cut(self._join_forked_sweep)
             self._touch(rec, self._lazy_setup(), ops._stream(), refresh=True)
         if rec.get("training", torch.is_grad_enabled()):
             self._gathers += 1
             if getattr(self, "_ahead_broken", False) and capturing:
                 return  # the sweep of this step ran (and was joined) already
+            if self._head_forks and capturing:
+                self._head_forks = False
+                return  # the eager head of every replay launches this step's sweep (assemble_with_refresh)
             if self._sweep_pending and self._gathers >= (self._gathers_per_step or 1):
                 if not capturing:
                     self._fork_sweep()
@@ -339,6 +348,37 @@ class TableAdam(torch.optim.Adam):
         seg = graphs.active()
         if capturing and seg is None and self.overlap_sweep:
             return False  # (a plain capture with a pending deferred sweep: on_gather raises with the explanation)
+        a = args
+        ft = self._field_table(rec, grp)
+        keep = (grp["ldesc"], ft, rec["idesc"], a)  # (the tensors behind the pointers below)
+        cargs = (ops._p(grp["ldesc"]), len(grp["members"]), ops._p(ft), ops._p(rec["idesc"]), rec["B"], rec["F"], rec["D"],
+                 ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64, ops._p(ops.err_flag(self._tables[0].device)),
+                 ops._p(a["perm"]), ops._p(a["pos"]), a["N"], ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"],
+                 ops._p(a["label"]), ops._p(a["sparse_out"]), ops._p(a["dense_out"]), ops._p(a["label_out"]))
+        if capturing and seg is not None and self.overlap_sweep and self.head_on_side and EAGER_HEAD and \
+                len(seg.segments) == 1 and self._join_seg is not seg:
+            # The head of the step is now ONE kernel: it is not captured at all.  Every replay launches it eagerly on the
+            # sweep's queue -- [wait for the previous chain] head -> event -> sweep -- in front of the ONE graph that holds
+            # the chain (which waits for the event).  One graph launch per step less than the two-segment form.
+            def head(cargs=cargs, keep=keep):
+                side = self._side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+                if self._head_event is None:
+                    self._head_event = torch.cuda.Event()
+                with torch.cuda.stream(side):
+                    _lib.call("rh_adam_lazy_refresh_assemble", *cargs, ops._stream())
+                    self._head_event.record()
+                    if self._host_step > 0:
+                        self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+                torch.cuda.current_stream().wait_event(self._head_event)
+                self._sweep_pending, self._sweep_inflight = False, True
+
+            seg.at_start(head)
+            self._join_seg = seg
+            self._head_forks = True  # on_gather: the sweep of this step is forked by head(), no cut
+            self._sweep_pending, self._sweep_inflight = False, True
+            self._pre_refreshed = rec
+            return True
         if capturing and seg is not None and self.overlap_sweep:
             if self._join_seg is not seg:  # what on_gather does in front of the first refresh of a segmented capture
                 seg.at_start(self._head_begin if self.head_on_side else self._join_sweep)
@@ -346,12 +386,7 @@ class TableAdam(torch.optim.Adam):
             self._sweep_inflight = False
         elif self._sweep_inflight:
             self._join_sweep()
-        a = args
-        _lib.call("rh_adam_lazy_refresh_assemble", ops._p(grp["ldesc"]), len(grp["members"]), ops._p(self._field_table(rec, grp)),
-                  ops._p(rec["idesc"]), rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64,
-                  ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"], ops._p(a["sparse"]),
-                  a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]), ops._p(a["dense_out"]),
-                  ops._p(a["label_out"]), ops._stream())
+        _lib.call("rh_adam_lazy_refresh_assemble", *cargs, ops._stream())
         self._pre_refreshed = rec
         return True
 
