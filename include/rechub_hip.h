@@ -524,14 +524,6 @@ int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream);
 /* the same + the Adam step of every packed parameter on the element just summed (= rh_pack_grads then rh_adam_small over the
  * same n parameters, sdesc in rh_adam_small's layout, hyper already holding this step's scalars): one launch */
 int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper, void* stream);
-/* rh_adam_lazy_step_mode + rh_pack_grads / rh_pack_grads_adam as ONE launch (round 4): the end of a step -- touched rows +
- * dense tables of the table optimizer, and the packing of the dense gradients with the dense parameters' Adam step -- touch
- * disjoint memory and need only this step's Adam scalars.  n_items <= 32; sdesc / pack_hyper NULL: packing without Adam. */
-int rh_adam_lazy_step_pack(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                           const RhPackItem* items, int n_items, float* flat, const int64_t* sdesc, const double* pack_hyper,
-                           void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)

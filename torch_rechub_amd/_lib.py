@@ -134,8 +134,6 @@ SIGNATURES = {
                           c_ptr],
     "rh_adam_lazy_step_mode": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                                c_ptr, c_int, c_ptr],
-    "rh_adam_lazy_step_pack": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
-                               c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
     "rh_adam_lazy_refresh_assemble": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,

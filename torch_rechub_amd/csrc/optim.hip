@@ -247,7 +247,7 @@ template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f);
 
 // (bx_, gdim_: this workgroup's index and the number of workgroups of the sweep / merged part -- blockIdx.x / gridDim.x unless
-// the launch carries more parts, see adam_lazy_step_pack_kernel)
+// a launch carries more parts: round 4 measured the dense-gradient packing as such a part and dropped it)
 template <int LPR, bool MERGED>
 static __device__ __forceinline__ void lazy_sweep_body(const LazySweepArgs& a, const int bx_, const int gdim_) {
   constexpr int RPB = RH_BLOCK / LPR;  // rows per block
@@ -549,13 +549,9 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_refresh_assemble_kernel(co
   }
 }
 
-struct PackArgs;
-template <int LPR>
-void launch_step_pack(const LazySweepArgs& a, unsigned opt_blocks, hipStream_t s, const PackArgs& pa);  // (defined below)
-
 template <int LPR>
 int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_t* h_window, hipStream_t s,
-                 const LazyTouchedArgs* touch = nullptr, const PackArgs* pack = nullptr) {
+                 const LazyTouchedArgs* touch = nullptr) {
   constexpr int RPB = RH_BLOCK / LPR;
   a.vb_prefix[0] = 0;
   for (int t = 0; t < a.T; ++t) {
@@ -586,8 +582,6 @@ int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_
     int64_t period = (grid + a.touch_blocks) / a.touch_blocks;
     if (period > 1 && period % 8 == 0) period -= 1;  // block id mod 8 = XCD: keep the touched workgroups on all of them
     a.touch_period = (int)period;
-    if (pack != nullptr) launch_step_pack<LPR>(a, (unsigned)(grid + a.touch_blocks), s, *pack);
-    else
     hipLaunchKernelGGL((adam_lazy_sweep_kernel<LPR, true>), dim3((unsigned)(grid + a.touch_blocks)), dim3(RH_BLOCK), 0, s,
                        a);
   } else {
@@ -761,36 +755,6 @@ template <bool ADAM>
 __global__ __launch_bounds__(RH_BLOCK) void pack_grads_kernel(const PackArgs a) {
   RH_CHAIN_PRIO();
   pack_body<ADAM>(a, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// The end of the step as ONE launch (round 4): the merged touched-rows + sweep launch (rh_adam_lazy_step_mode) AND the packing
-// of the dense gradients + the dense parameters' Adam step (rh_pack_grads_adam).  The two touch disjoint memory -- tables,
-// their gradient buffers and moments on one side; the flat gradient bucket, the partial slabs and the dense parameters on the
-// other -- and both only need this step's Adam scalars, so nothing orders them: the last `pack_blocks` workgroups of the grid
-// run the packing, the others the optimizer part (10 us of launch + latency off the step's chain).
-template <int LPR, bool ADAM>
-__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_pack_kernel(const LazySweepArgs a, const PackArgs pa,
-                                                                      const int pack_blocks) {
-  RH_CHAIN_PRIO();
-  const int opt_blocks = (int)gridDim.x - pack_blocks;
-  if ((int)blockIdx.x >= opt_blocks) {
-    pack_body<ADAM>(pa, (int)blockIdx.x - opt_blocks, pack_blocks);
-    return;
-  }
-  lazy_sweep_body<LPR, true>(a, (int)blockIdx.x, opt_blocks);
-}
-
-template <int LPR>
-void launch_step_pack(const LazySweepArgs& a, unsigned opt_blocks, hipStream_t s, const PackArgs& pa) {
-  int64_t pb = pa.vb_prefix[pa.n];
-  if (pb > 1024) pb = 1024;
-  if (pb < 1) pb = 1;
-  if (pa.sdesc != nullptr)
-    hipLaunchKernelGGL((adam_lazy_step_pack_kernel<LPR, true>), dim3(opt_blocks + (unsigned)pb), dim3(RH_BLOCK), 0, s, a, pa,
-                       (int)pb);
-  else
-    hipLaunchKernelGGL((adam_lazy_step_pack_kernel<LPR, false>), dim3(opt_blocks + (unsigned)pb), dim3(RH_BLOCK), 0, s, a, pa,
-                       (int)pb);
 }
 
 // fills a.it / a.vb_prefix from the caller's items [base, base + a.n); returns false on a bad item
@@ -1001,7 +965,7 @@ extern "C" int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const 
 static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                          void* stream, const PackArgs* pack = nullptr) {
+                          void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc, RH_E_BADARG,
              "rh_adam_lazy_step: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1, RH_E_BADARG, "rh_adam_lazy_step: bad shape");
@@ -1020,12 +984,12 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
-    case 1: rc = launch_sweep<1>(a, sweep_mode, h_rows, h_window, s, &ta, pack); break;
-    case 2: rc = launch_sweep<2>(a, sweep_mode, h_rows, h_window, s, &ta, pack); break;
-    case 4: rc = launch_sweep<4>(a, sweep_mode, h_rows, h_window, s, &ta, pack); break;
-    case 8: rc = launch_sweep<8>(a, sweep_mode, h_rows, h_window, s, &ta, pack); break;
-    case 16: rc = launch_sweep<16>(a, sweep_mode, h_rows, h_window, s, &ta, pack); break;
-    case 32: rc = launch_sweep<32>(a, sweep_mode, h_rows, h_window, s, &ta, pack); break;
+    case 1: rc = launch_sweep<1>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 2: rc = launch_sweep<2>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 4: rc = launch_sweep<4>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 8: rc = launch_sweep<8>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 16: rc = launch_sweep<16>(a, sweep_mode, h_rows, h_window, s, &ta); break;
+    case 32: rc = launch_sweep<32>(a, sweep_mode, h_rows, h_window, s, &ta); break;
     default: break;
   }
   RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_step: embed_dim %d unsupported", D);
@@ -1078,27 +1042,4 @@ extern "C" int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t
              "rh_adam_lazy_step_mode: sweep_mode %d", sweep_mode);
   return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
                         err_flag, sweep_mode, stream);
-}
-
-// rh_adam_lazy_step_mode + rh_pack_grads(_adam) as ONE launch (n_items <= 32; sdesc / pack_hyper NULL: plain packing).
-extern "C" int rh_adam_lazy_step_pack(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
-                                      const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
-                                      const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
-                                      int sweep_mode, const RhPackItem* items, int n_items, float* flat, const int64_t* sdesc,
-                                      const double* pack_hyper, void* stream) {
-  RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
-             "rh_adam_lazy_step_pack: sweep_mode %d", sweep_mode);
-  RH_REQUIRE(items != nullptr && flat != nullptr && n_items >= 1 && n_items <= kPackItems, RH_E_UNSUPPORTED,
-             "rh_adam_lazy_step_pack: 1 <= n_items <= %d", kPackItems);
-  RH_REQUIRE((sdesc == nullptr) == (pack_hyper == nullptr), RH_E_BADARG, "rh_adam_lazy_step_pack: sdesc and pack_hyper go together");
-  PackArgs pa;
-  pa.n = n_items;
-  pa.flat = flat;
-  pa.sdesc = sdesc;
-  pa.hyper = pack_hyper;
-  pa.T = n_items;
-  pa.base = 0;
-  RH_REQUIRE(pack_fill(pa, items, 0), RH_E_BADARG, "rh_adam_lazy_step_pack: bad item");
-  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, sweep_mode, stream, &pa);
 }

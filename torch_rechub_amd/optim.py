@@ -22,7 +22,6 @@ from . import _lib, graphs, ops
 
 SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  # rh_adam_lazy_sweep modes
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
-PACK_IN_STEP = _lib.ab("packstep")  # False (RECHUB_AB=packstep=0): rh_pack_grads(_adam) as a launch of its own
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 
 
@@ -124,7 +123,6 @@ class TableAdam(torch.optim.Adam):
                 self.head_on_side = _lib.ab("headside")
                 self._head_event = None
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
-                self._pending_pack = None   # (items, n, flat, adam) of a packing step this optimizer's launch will carry
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
@@ -519,27 +517,6 @@ class TableAdam(torch.optim.Adam):
         return not (grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or
                     not any(id(w) in grp["local"] for w in rec["weights"]))
 
-    def take_pack(self, items, n, flat, adam):
-        """Offered by the trainer's packing step (distributed.DenseGradBucket.pack): True when the end-of-step launch of this
-        optimizer will carry the packing (rh_adam_lazy_step_pack) -- i.e. the coming step() takes the merged launch."""
-        if not PACK_IN_STEP or self.lazy_k <= 1 or not self._tables or n > 32 or not self._k_decided or adam is None:
-            return False  # (adam None: step_tables runs rh_adam_small on the flat bucket BEFORE the table launch)
-        if not self._merge_ok(self._lazy_setup()):
-            return False
-        self._pending_pack = (items, n, flat, adam)
-        return True
-
-    def _launch_pending_pack(self):
-        """The packing was promised to a merged launch that did not happen: run it on its own."""
-        pend, self._pending_pack = self._pending_pack, None
-        if pend is not None:
-            items, n, flat, adam = pend
-            if adam is not None:
-                _lib.call("rh_pack_grads_adam", ctypes.cast(items, ctypes.c_void_p), n, ops._p(flat), ops._p(adam[0]),
-                          ops._p(adam[1]), ops._stream())
-            else:
-                _lib.call("rh_pack_grads", ctypes.cast(items, ctypes.c_void_p), n, ops._p(flat), ops._stream())
-
     def _merged_step(self, groups, stream):
         """The touched-rows step of the batch and the window sweep as ONE launch (rh_adam_lazy_step) when the step has a
         single index batch over a single table group with int64 indices -- the DeepFM / DCN / WideDeep step.  The short,
@@ -549,21 +526,11 @@ class TableAdam(torch.optim.Adam):
         rec, grp = self._touch_log[0], groups[0]
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
         mode = SWEEP_DENSE_TABLES if self.overlap_sweep else SWEEP_WINDOW
-        pend, self._pending_pack = self._pending_pack, None
-        if pend is not None:  # the packing of the dense gradients (+ the dense parameters' Adam step) in the same launch
-            items, n, flat, adam = pend
-            _lib.call("rh_adam_lazy_step_pack", ops._p(grp["ldesc"]), len(grp["members"]),
-                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
-                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
-                      ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), mode,
-                      ctypes.cast(items, ctypes.c_void_p), n, ops._p(flat), ops._p(adam[0] if adam is not None else None),
-                      ops._p(adam[1] if adam is not None else None), stream)
-        else:
-            _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
-                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
-                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
-                      ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), mode,
-                      stream)
+        _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
+                  ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                  ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
+                  ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), mode,
+                  stream)
         if self.overlap_sweep:
             self._sweep_pending = True
         return True
@@ -603,7 +570,6 @@ class TableAdam(torch.optim.Adam):
         if self._merged_step(groups, stream):
             del self._touch_log[:]
             return
-        self._launch_pending_pack()  # (promised to the merged launch, which was not taken after all)
         for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
             self._touch(rec, groups, stream)
         del self._touch_log[:]

@@ -210,7 +210,7 @@ class CTRTrainer(object):
         if defer:
             # with this step's Adam scalars already on the device (the step's scalar launch computed them in the forward),
             # the packing launch also steps the dense parameters: rh_pack_grads + rh_adam_small as ONE launch
-            self.bucket.pack(items, adam=self.optimizer.small_adam_args(), defer_to=self.optimizer)
+            self.bucket.pack(items, adam=self.optimizer.small_adam_args())
         elif packed or self.dp is not None:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
