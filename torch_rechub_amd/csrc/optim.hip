@@ -344,9 +344,21 @@ static __device__ __forceinline__ void lazy_sweep_body(const LazySweepArgs& a, c
     while (j < t) {  // wavefront-uniform
       const int nxt = wave_min_uniform(first > j ? first : t);  // the next joining step, > j
       if (first <= j) {
-        for (int jj = j; jj < nxt; ++jj) {
-          const float A = ring_s[2 * (jj & a.ring_mask)], E = ring_s[2 * (jj & a.ring_mask) + 1];
-          adam_f4_zero_g(u.P, u.M, u.V, h, A, E);
+        // two steps per iteration, both ring entries read (LDS) before the first step's arithmetic: at the 2 wavefronts per
+        // SIMD of the deferred form the read's latency is otherwise exposed once per replayed step (same operations in the
+        // same order).  Round 3 measured it on the sweep alone (188 -> 172 us at 512 workgroups) with no gain for the step --
+        // chain and sweep were co-critical then; with the round-4 chain the sweep's path is the longer one: 0.275 -> 0.269 ms.
+        int jj = j;
+        for (; jj + 2 <= nxt; jj += 2) {
+          const float2 ae0 = *reinterpret_cast<const float2*>(ring_s + 2 * (jj & a.ring_mask));
+          const float2 ae1 = *reinterpret_cast<const float2*>(ring_s + 2 * ((jj + 1) & a.ring_mask));
+          __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the second read to its use)
+          adam_f4_zero_g(u.P, u.M, u.V, h, ae0.x, ae0.y);
+          adam_f4_zero_g(u.P, u.M, u.V, h, ae1.x, ae1.y);
+        }
+        if (jj < nxt) {
+          const float2 ae = *reinterpret_cast<const float2*>(ring_s + 2 * (jj & a.ring_mask));
+          adam_f4_zero_g(u.P, u.M, u.V, h, ae.x, ae.y);
         }
       }
       j = nxt;
