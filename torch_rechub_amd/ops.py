@@ -1166,9 +1166,6 @@ class _HeadFn(torch.autograd.Function):
 # launches and 3 L + 1 backward launches.  A/B switch for benchmarks: RECHUB_AB=chain=0 (tests flip the attribute).
 FUSE_MLP_CHAIN = _lib.ab("chain")
 _CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
-# The chain's weight-gradient launches on a second stream (RECHUB_AB=wgradbranch=0: in line): nothing on the backward's
-# critical path reads them -- 2 x ~20 us off the DeepFM step's chain.
-WGRAD_BRANCH = _lib.ab("wgradbranch")
 
 
 class _MlpChainFn(torch.autograd.Function):
@@ -1302,12 +1299,6 @@ class _MlpChainFn(torch.autograd.Function):
         grads[4 * L], grads[4 * L + 1] = g_w, g_b
         nchunks = nblk
         g_x = None
-        cur = torch.cuda.current_stream()
-        branch = None
-        if WGRAD_BRANCH:
-            branch = _BRANCH_STREAMS.get(cur.device.index)
-            if branch is None:
-                branch = _BRANCH_STREAMS[cur.device.index] = torch.cuda.Stream(device=cur.device)
         for l in range(L - 1, -1, -1):
             W, b, gamma, beta = params[4 * l:4 * l + 4]
             N, Kin = W.shape
@@ -1329,25 +1320,7 @@ class _MlpChainFn(torch.autograd.Function):
             elif ctx.needs_input_grad[0]:
                 g_x = torch.empty((B, Kin), dtype=torch.float32, device=dev)
                 _lib.call("rh_linear_dgrad", _p(g_h), N, _p(W), Kin, B, N, Kin, _p(g_x), Kin, _stream())
-            if branch is not None:
-                # the weight gradient of layer l feeds nothing but the step's packing launch: it runs on a second stream (a
-                # parallel branch of the captured graph) beside the input-gradient GEMM / the next layer's BatchNorm backward
-                branch.wait_stream(cur)
-                g_h.record_stream(branch)
-                inp.record_stream(branch)
-                with torch.cuda.stream(branch):
-                    grads[4 * l], grads[4 * l + 1] = linear_wgrad(g_h, inp, want_bias=b is not None, weight=W, bias=b)
-            else:
-                grads[4 * l], grads[4 * l + 1] = linear_wgrad(g_h, inp, want_bias=b is not None, weight=W, bias=b)
-        if branch is not None:
-            cur.wait_stream(branch)  # join: the packing launch (and autograd's consumers of dW / db) follow on this stream
-            for it in deferred.items.values():
-                k = it.get("keep")
-                if torch.is_tensor(k) and k.device == dev:
-                    k.record_stream(cur)
-            for g_ in grads:
-                if torch.is_tensor(g_):
-                    g_.record_stream(cur)
+            grads[4 * l], grads[4 * l + 1] = linear_wgrad(g_h, inp, want_bias=b is not None, weight=W, bias=b)
         s0, s1 = ctx.shapes
         return (g_x, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1), None) + tuple(grads)
 
