@@ -39,7 +39,7 @@ CRITEO_VOCABS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 56
                  10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 N_DENSE = 13
 EMBED_DIM = 16
-DEFERRED_SWEEP_PMC_TRAFFIC = 208.8e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 508.6 + 100 852.2) KiB, profiles/r03_pmc_sweep_{FETCH,WRITE}_SIZE.txt (re-collected in round 4: profiles/r04_pmc_sweep_*, same kernel, same window)
+DEFERRED_SWEEP_PMC_TRAFFIC = 208.9e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 561.3 + 100 850.6) KiB, profiles/r04_pmc_sweep_{FETCH,WRITE}_SIZE.txt (round 3's passes gave 208.8e6: profiles/r03_pmc_sweep_*)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a float4 copy
 
 # algorithmic bytes: F=26, D=16, fp32, int64 indices as the loader holds them
@@ -917,7 +917,7 @@ def main():
                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --trace-inner`, mean over the
                     # steady-state dispatches of adam_lazy_sweep_kernel<4, false>; 2 * FETCH + WRITE (KiB), gfx950 correction
                     roofline["traffic"] = DEFERRED_SWEEP_PMC_TRAFFIC
-                    roofline["traffic_source"] = ("profiles/r03_pmc_sweep_{FETCH,WRITE}_SIZE.txt (rocprofv3 --pmc, separate "
+                    roofline["traffic_source"] = ("profiles/r04_pmc_sweep_{FETCH,WRITE}_SIZE.txt (rocprofv3 --pmc, separate "
                                                   "passes; not re-collected by bench.py)")
             pmc_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
             if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0 and best is None and \
