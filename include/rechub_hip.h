@@ -56,6 +56,7 @@ const char* rh_last_error(void);
 /* key 3 (an LDS-padding residency cap of the deferred sweep) was measured in round 3 and removed: rh_set_tuning(3, .) fails */
 #define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
                                   the residency cap that lets the step's chain keep its wave slots and issue cycles */
+#define RH_TUNE_SWEEP_STAGGER_NS 12 /* rh_adam_sweep_stagger: hold-back in nanoseconds (default 6000; 0 = no launch) */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
 #define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build */
 #define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront
@@ -554,6 +555,9 @@ int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_
 #define RH_SWEEP_FLUSH 1
 #define RH_SWEEP_LAZY_TABLES 2
 #define RH_SWEEP_DENSE_TABLES 3
+/* A one-lane launch that occupies `stream` for RH_TUNE_SWEEP_STAGGER_NS: placed in front of a deferred sweep whose release
+ * coincides with a kernel launch of the step's chain, so that the two are not dispatched together (csrc/optim.hip). */
+int rh_adam_sweep_stagger(void* stream);
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
@@ -562,12 +566,15 @@ int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table
 /* rh_batch_gather + rh_adam_lazy_touched (refresh = 1, int64 indices) as ONE launch (round 4): the batch is assembled into the
  * static buffers (sparse_out (B, Fd), dense_out (B, ND), label_out (B)) from dataset rows perm[(pos + b) mod N] -- exactly
  * rh_batch_gather's arguments -- while the refresh part reads the same indices straight from the dataset.  idesc must
- * describe index columns INSIDE sparse_out (pointer = sparse_out + column, stride = Fd): the gather that follows reads them. */
+ * describe index columns INSIDE sparse_out (pointer = sparse_out + column, stride = Fd): the gather that follows reads them.
+ * lookahead != 0: further workgroups also refresh those lookups of the NEXT batch (dataset rows perm[(pos + B + b) mod N],
+ * b < B) whose table rows lie in the window ((t - 1) mod K) * w .. + w of the coming deferred sweep (t = hyper[12]): that sweep
+ * then skips every row the next batch reads, so the next call of this function may run while it is still in flight. */
 int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc, int B, int F,
                                   int D, const double* hyper, const float* ring, int ring_size, int samples_per_block,
                                   int32_t* err_flag, const int64_t* perm, const int64_t* pos, int64_t N, const int64_t* sparse,
                                   int Fd, const float* dense, int ND, const float* label, int64_t* sparse_out, float* dense_out,
-                                  float* label_out, void* stream);
+                                  float* label_out, int lookahead, void* stream);
 /* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
  * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,

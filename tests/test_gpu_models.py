@@ -343,6 +343,64 @@ def test_abandoned_step_leaves_the_optimizer_where_it_was():
         assert torch.equal(ta.optimizer.state[pa]["exp_avg_sq"], tb.optimizer.state[pb]["exp_avg_sq"])
 
 
+@pytest.mark.parametrize("relaxed", [True, False])
+def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(relaxed, monkeypatch):
+    """The headline form of the step at table sizes where the deferred window sweep (K = 64, 33 M rows) is as long as the
+    step itself, so that sweeps really are in flight under the following steps: 110 steps (3 eager, the rest hipGraph replays
+    with the eager one-kernel head) against a table_update="dense" twin, bit for bit, after the flush.
+    relaxed = True (default form, round 4): the head pre-refreshes the next batch's lookups inside the coming sweep's window
+    (rh_adam_lazy_refresh_assemble, lookahead = 1) and waits only for the sweep BEFORE the last one; ~64 rows per field and step
+    are in that situation here.  relaxed = False: the strict join (head on the sweep's queue).  Reference semantics:
+    torch.optim.Adam steps every row every step (trainers/ctr_trainer.py:59-61,99)."""
+    from torch_rechub_amd import optim
+    from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
+    from torch_rechub_amd.models.ranking import DeepFM
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    monkeypatch.setenv("RECHUB_STEP_FORM", "deferred")
+    monkeypatch.setattr(optim, "RELAXED_JOIN", relaxed)
+    vocabs = [10131227, 2202608, 12517, 93145, 5683, 8351593, 14992, 5461306, 5652, 7046547, 286181, 142572]
+    B, nb = 4096, 110
+    g = torch.Generator().manual_seed(5)
+    cols = []
+    for v in vocabs:  # no row twice inside a batch (the scatter-add then has no order-dependent sums): an arithmetic progression
+        stride = torch.randint(max(1, (v - 1) // B // 2), (v - 1) // B + 1, (nb, 1), generator=g)
+        start = (torch.rand(nb, 1, generator=g) * ((v - 1) - stride * (B - 1))).long()
+        cols.append((start + stride * torch.arange(B).view(1, B)).view(-1) + 1)
+    sparse = torch.stack(cols, 1).contiguous()
+    assert all(int(sparse[:, i].max()) < v for i, v in enumerate(vocabs))
+    dense = torch.rand(nb * B, 13, generator=g)
+    label = (torch.rand(nb * B, generator=g) < 0.3).float()
+
+    def build():
+        torch.manual_seed(7)
+        dfe = [DenseFeature(f"I{i}") for i in range(13)]
+        sfe = [SparseFeature(f"C{i}", v, 16) for i, v in enumerate(vocabs)]
+        m = DeepFM(dfe + sfe, sfe, {"dims": [256, 128], "dropout": 0.0, "activation": "relu"})
+        return m, [f.name for f in sfe], [f.name for f in dfe]
+
+    kw = dict(optimizer_params={"lr": 1e-3, "weight_decay": 1e-5}, device="cuda:0", show_progress=False, use_graph=True)
+    ma, names, dnames = build()
+    mb, _, _ = build()
+    mb.load_state_dict(ma.state_dict())
+    ta = CTRTrainer(ma, table_update="lazy", **kw)
+    tb = CTRTrainer(mb, table_update="dense", **kw)
+    losses = []
+    for t in (ta, tb):
+        dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        losses.append(t.train_one_epoch(dl))
+    assert ta.optimizer.lazy_k == 64 and ta._form == "deferred"
+    assert (ta.optimizer._look_token is not None) == relaxed  # the form under test did run
+    assert losses[0] == losses[1]
+    assert _assert_no_row_behind(ta) == nb
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for pa, pb in zip(ta.optimizer._tables, tb.optimizer._tables):
+        assert torch.equal(ta.optimizer.state[pa]["exp_avg"], tb.optimizer.state[pb]["exp_avg"])
+        assert torch.equal(ta.optimizer.state[pa]["exp_avg_sq"], tb.optimizer.state[pb]["exp_avg_sq"])
+
+
 def test_graph_mode_flush_leaves_no_row_behind_match_trainer(monkeypatch):
     """Same property through MatchTrainer (in-batch negatives, history feature mean-pooled from the item table).
 

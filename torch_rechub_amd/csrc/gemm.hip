@@ -105,7 +105,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   constexpr int A_TILE = BM * kLd;
   constexpr int B_TILE = B_KMAJOR ? BN * kLd : kBK * kLdN;
   __shared__ float lds[2 * (A_TILE + B_TILE)];
-  __shared__ float pro_c[PRO ? 4 * kProMaxK : 1];  // PRO: mean, rstd, gamma, beta of the K columns of A (zero past K)
+  // PRO: mean, rstd, gamma, beta of the K columns of A (zero past K), 4 x kp floats of DYNAMIC LDS (kp = K rounded up to the
+  // K tile): the kernel runs beside the optimizer's sweep, whose workgroups are sized so that two of them leave a CU just
+  // enough LDS for one workgroup of this kernel at CTR widths (csrc/optim.hip, kDeferredSweepLds)
+  extern __shared__ float pro_c[];
+  const int kp = ((a.K + kBK - 1) / kBK) * kBK;
   const int tid = threadIdx.x, lane = tid % RH_WAVE, wave = tid / RH_WAVE;
   const int wm = wave / WN, wn = wave % WN;
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber them so that the tiles_n
@@ -156,9 +160,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   // PRO: one float4 of A (row `row`, columns k .. k + 3) -> the hidden layer's output; columns past K come out as 0
   auto pro_apply = [&](float4 v, int row, int k) -> float4 {
     const float4 mean = *reinterpret_cast<const float4*>(pro_c + k);
-    const float4 rstd = *reinterpret_cast<const float4*>(pro_c + kProMaxK + k);
-    const float4 gam = *reinterpret_cast<const float4*>(pro_c + 2 * kProMaxK + k);
-    const float4 bet = *reinterpret_cast<const float4*>(pro_c + 3 * kProMaxK + k);
+    const float4 rstd = *reinterpret_cast<const float4*>(pro_c + kp + k);
+    const float4 gam = *reinterpret_cast<const float4*>(pro_c + 2 * kp + k);
+    const float4 bet = *reinterpret_cast<const float4*>(pro_c + 3 * kp + k);
     const uint64_t e = (uint64_t)row * (uint64_t)a.K + (uint64_t)k;
     auto one = [&](float x, float m, float r, float g, float b, uint64_t idx) -> float {
       const float xhat = (x - m) * r;
@@ -277,13 +281,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
     // the arithmetic of csrc/mlp.hip::chan_combine), all loads of a column pass in flight at once
     const int nslab = (a.M + a.pro_rows - 1) / a.pro_rows;
     for (int c = a.K + tid; c < ((a.K + kBK - 1) / kBK) * kBK; c += NT)  // zero tail: columns past K transform to 0
-      pro_c[c] = pro_c[kProMaxK + c] = pro_c[2 * kProMaxK + c] = pro_c[3 * kProMaxK + c] = 0.f;
+      pro_c[c] = pro_c[kp + c] = pro_c[2 * kp + c] = pro_c[3 * kp + c] = 0.f;
     rh_combine_slabs<NT, kProMaxSlabs>(a.pro_stats, nslab, a.pro_rows, a.M, a.K, lds, tid, [&](int c, float mean, float var) {
       const float rstd = rsqrtf(var + a.pro_eps);
       pro_c[c] = mean;
-      pro_c[kProMaxK + c] = rstd;
-      pro_c[2 * kProMaxK + c] = a.pro_gamma[c];
-      pro_c[3 * kProMaxK + c] = a.pro_beta[c];
+      pro_c[kp + c] = rstd;
+      pro_c[2 * kp + c] = a.pro_gamma[c];
+      pro_c[3 * kp + c] = a.pro_beta[c];
       if (blockIdx.x == 0 && blockIdx.y == 0) {
         a.pro_stat_out[c] = mean;
         a.pro_stat_out[a.K + c] = rstd;
@@ -474,11 +478,12 @@ bool chain_tiles(int M) { return M > 32; }
 
 template <bool B_KMAJOR, bool STATS, bool PRO = false, bool BNBWD = false>
 void launch(const GemmArgs& a, hipStream_t s) {
+  const unsigned dyn = PRO ? 4u * (unsigned)(((a.K + kBK - 1) / kBK) * kBK) * sizeof(float) : 0u;  // pro_c
   if (PRO ? chain_tiles(a.M) : big_tiles(a.M, a.N)) {
-    hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), 0,
+    hipLaunchKernelGGL((gemm_f32_kernel<2, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 63) / 64), dim3(256), dyn,
                        s, a);
   } else {
-    hipLaunchKernelGGL((gemm_f32_kernel<1, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 31) / 32), dim3(128), 0,
+    hipLaunchKernelGGL((gemm_f32_kernel<1, 2, B_KMAJOR, STATS, PRO, BNBWD>), dim3((a.N + 63) / 64, (a.M + 31) / 32), dim3(128), dyn,
                        s, a);
   }
 }

@@ -24,6 +24,8 @@ int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workg
 // 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.  (An LDS-padding cap reached 0.311 ms and was removed: it also
 // kept LDS-hungry kernels of the chain off the CU.)
 int g_deferred_grid = 512;
+int g_stagger_ns = 6000;  // RH_TUNE_SWEEP_STAGGER_NS
+
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
 
@@ -224,6 +226,9 @@ struct LazyTouchedArgs {
   int64_t* sparse_out;        // (B, Fd): the batch buffer the fields' index columns point into
   float* dense_out;
   float* label_out;
+  // LOOK (round 4): rows of grid.y behind the assembly row pre-refresh the lookups of the NEXT batch (samples pos + B + b)
+  // that fall into the window the coming deferred sweep walks; look = samples per lookahead workgroup (0: none)
+  int look;
 };
 
 struct LazySweepArgs {
@@ -243,7 +248,7 @@ struct LazySweepArgs {
   LazyTouchedArgs touch;
 };
 
-template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false>
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false, bool LOOK = false>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f);
 
 // (bx_, gdim_: this workgroup's index and the number of workgroups of the sweep / merged part -- blockIdx.x / gridDim.x unless
@@ -391,9 +396,20 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
   lazy_sweep_body<LPR, MERGED>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// One lane waits `ticks` of the constant wall clock (rh_adam_sweep_stagger).
+__global__ void stream_delay_kernel(const long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 // REFRESH: the pre-gather pass -- the rows carry no gradient yet (their gradient rows are zero), so they are neither
 // read nor re-zeroed and the closing step is the zero-gradient form too (a quarter less traffic per row)
-template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE>
+// LOOK (with REFRESH, ASSEMBLE): the workgroup walks `look` samples of the NEXT batch instead (dataset rows
+// perm[(pos + B + b) mod N]) and refreshes only those of their rows that lie in the window the deferred sweep launched behind
+// this pass is going to walk.  That sweep then finds every row the next batch reads already stamped and leaves it alone, so
+// the next step's refresh (and gather) may run WHILE that sweep is still running: the sweep has to be done only before the
+// refresh after that (optim.TableAdam, "relaxed join").  ~ B * F / K rows per step.
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE, bool LOOK>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f) {
   constexpr int LPP = RH_BLOCK / LPR;
   constexpr int D = 4 * LPR;
@@ -419,8 +435,8 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
   const int lane = threadIdx.x % RH_WAVE;
-  const int64_t b0 = (int64_t)bx * a.spb;
-  const int64_t b1 = (b0 + a.spb < (int64_t)a.B) ? b0 + a.spb : (int64_t)a.B;
+  int64_t b0 = (int64_t)bx * (LOOK ? a.look : a.spb);
+  int64_t b1 = (b0 + (LOOK ? a.look : a.spb) < (int64_t)a.B) ? b0 + (LOOK ? a.look : a.spb) : (int64_t)a.B;
   // REFRESH replays up to K steps per row: the per-step (A, E) ring entries come from LDS, as in the sweep.  Read from
   // global memory inside the replay loop they were one dependent L2 round trip per replayed step (the compiler emits a
   // vector load + s_waitcnt vmcnt per iteration): the pass was bound by that latency, 26.8 us in the DeepFM step.
@@ -435,14 +451,36 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   // is still kept exact -- zero or not, dense Adam moves it like every other row -- by ONE more pass of the first workgroup
   // of the field whose only live lookup is that row.  (As a separate block of code with its own replay loop in front of
   // this loop it cost the pass 26 -> 48 us in the DeepFM step, where no field has a padding row at all.)
-  const bool pad_pass = REFRESH && pad >= 0 && pad < rows && bx == 0;  // block-uniform
+  const bool pad_pass = !LOOK && REFRESH && pad >= 0 && pad < rows && bx == 0;  // block-uniform
+  __shared__ int64_t s_look[LOOK ? RH_BLOCK : 1];
+  __shared__ int s_nlook;
+  const int64_t look_b1 = b1;
+  for (int64_t sub = LOOK ? b0 : 0; sub < (LOOK ? look_b1 : 1); sub += RH_BLOCK) {
+  if (LOOK) {
+    // the samples sub .. sub + 255 of the next batch, one per thread: keep the rows inside the coming sweep's window
+    const int64_t w = a.ldesc[7 * T + ti];
+    const int64_t ws = ((int64_t)(t - 1) % K) * w;
+    if (threadIdx.x == 0) s_nlook = 0;
+    __syncthreads();  // (also: the previous round is done with s_look)
+    const int64_t b = sub + threadIdx.x;
+    if (b < look_b1) {
+      int64_t p = (apos + (int64_t)a.B + b) % a.N;
+      const int64_t r = gload<int64_t>(a.src_sparse + gload<int64_t>(a.perm + p) * a.Fd + acol);
+      if (r >= ws && r < ws + w && r < rows && r != pad) s_look[atomicAdd(&s_nlook, 1)] = r;
+    }
+    __syncthreads();
+    b0 = 0;
+    b1 = s_nlook;
+  }
   const int64_t b_end = b1 + (pad_pass ? LPP : 0);
   for (int64_t base = b0; base < b_end; base += LPP) {  // uniform trip count: the claim is broadcast by shuffle
     const bool extra = base >= b1;
     const int64_t b = base + slot;
     const bool ok = !extra && b < b1;
     int64_t r;
-    if (ASSEMBLE) {
+    if (LOOK) {
+      r = s_look[ok ? b : 0];
+    } else if (ASSEMBLE) {
       int64_t p = apos + (ok ? b : b1 - 1);
       if (p >= a.N) p %= a.N;
       r = gload<int64_t>(a.src_sparse + gload<int64_t>(a.perm + p) * a.Fd + acol);
@@ -525,6 +563,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     gstore<float4>(v + rr * D + q * 4, V);
     if (!REFRESH) gstore<float4>(g + rr * D + q * 4, f4_zero());
   }
+  }
 }
 
 template <int LPR, typename IdxT, bool REFRESH>
@@ -544,6 +583,13 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_refresh_assemble_kernel(co
   RH_CHAIN_PRIO();
   if ((int)blockIdx.y < a.F) {
     lazy_touched_body<LPR, int64_t, true, true>(a, (int)blockIdx.x, (int)blockIdx.y);
+    return;
+  }
+  if ((int)blockIdx.y > a.F) {
+    // lookahead rows: R = look / spb fields share one grid row (a lookahead workgroup walks R times the samples)
+    const int R = a.look / a.spb;
+    const int f = ((int)blockIdx.y - a.F - 1) * R + (int)blockIdx.x % R;
+    if (f < a.F) lazy_touched_body<LPR, int64_t, true, true, true>(a, (int)blockIdx.x / R, f);
     return;
   }
   constexpr int G = 16;
@@ -829,6 +875,10 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     g_deferred_grid = value;
     return 0;
   }
+  if (key == RH_TUNE_SWEEP_STAGGER_NS) {
+    g_stagger_ns = value;
+    return 0;
+  }
   return RH_E_BADARG;
 }
 
@@ -875,7 +925,8 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
                                   const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value,
                                   void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring, RH_E_BADARG, "rh_adam_lazy_sweep: null pointer");
-  RH_REQUIRE(mode >= RH_SWEEP_WINDOW && mode <= RH_SWEEP_DENSE_TABLES, RH_E_BADARG, "rh_adam_lazy_sweep: mode %d", mode);
+  RH_REQUIRE(mode >= RH_SWEEP_WINDOW && mode <= RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
+             "rh_adam_lazy_sweep: mode %d", mode);
   RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_sweep: ring_size must be a power of two <= %d", kMaxRing);
@@ -900,6 +951,30 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
   }
   RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: embed_dim %d unsupported", D);
   RH_LAUNCH_CHECK("rh_adam_lazy_sweep");
+  return 0;
+}
+
+// Relaxed-join step (optim.py): the deferred sweep is released by the event behind the head's refresh and would start within
+// a microsecond of the chain's first GEMM (the cross-queue latency happens to equal the gather in front of it).  Dispatched
+// TOGETHER, the two launches interleave on the CUs, the sweep's resident wavefronts end up unevenly spread over the SIMDs, and
+// in 15-30 % of the steps the chain's 240-register kernels (PRO GEMM, head) found no SIMD with room until sweep workgroups
+// retired: 125 us instead of 26 (tools/step_stats.py, profiles/r04_relaxed_join.txt).  Released a few microseconds INTO that
+// GEMM -- its workgroups already placed, one per CU -- the sweep spreads evenly: 0 slow steps of 300 at 5 / 7 / 11 us.  This
+// one-lane launch in front of the sweep is that hold-back.  (A 55 KB LDS request per sweep workgroup and a per-CU admission
+// counter were measured and did not fix it.)
+extern "C" int rh_adam_sweep_stagger(void* stream) {
+  if (g_stagger_ns <= 0) return 0;
+  static long long khz = 0;
+  if (khz == 0) {
+    int dev = 0, rate = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, dev) != hipSuccess ||
+        rate <= 0)
+      rate = 100000;
+    khz = rate;
+  }
+  hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
+                     (long long)g_stagger_ns * khz / 1000000);
+  RH_LAUNCH_CHECK("rh_adam_sweep_stagger");
   return 0;
 }
 
@@ -944,7 +1019,7 @@ extern "C" int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const 
                                              int samples_per_block, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
                                              int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND,
                                              const float* label, int64_t* sparse_out, float* dense_out, float* label_out,
-                                             void* stream) {
+                                             int lookahead, void* stream) {
   RH_REQUIRE(ldesc && field_table && idesc && hyper && ring && perm && pos && sparse && sparse_out, RH_E_BADARG,
              "rh_adam_lazy_refresh_assemble: null pointer");
   RH_REQUIRE(T >= 1 && F >= 1 && F <= 65534 && B >= 1 && N >= 1 && Fd >= 1 && ND >= 0, RH_E_BADARG,
@@ -954,9 +1029,13 @@ extern "C" int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const 
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_refresh_assemble: ring_size must be a power of two <= %d", kMaxRing);
   const int spb = samples_per_block <= 0 ? 64 : ((samples_per_block + 63) / 64) * 64;
+  const int chunks = (B + spb - 1) / spb;
+  // lookahead workgroups walk R chunks each (one sample per thread and round), R fields share a grid row
+  int R = RH_BLOCK / spb >= 1 ? RH_BLOCK / spb : 1;
+  if (chunks % R != 0) R = 1;
   LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag,
-                    perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out};
-  const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)(F + 1));
+                    perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, lookahead ? R * spb : 0};
+  const dim3 grid((unsigned)chunks, (unsigned)(F + 1 + (lookahead ? (F + R - 1) / R : 0)));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (D / 4) {
     case 1: hipLaunchKernelGGL((adam_lazy_refresh_assemble_kernel<1>), grid, dim3(RH_BLOCK), 0, s, a); break;

@@ -23,6 +23,7 @@ from . import _lib, graphs, ops
 SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  # rh_adam_lazy_sweep modes
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
+RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
 
 
 class TableAdam(torch.optim.Adam):
@@ -122,6 +123,8 @@ class TableAdam(torch.optim.Adam):
                 self.overlap_sweep = os.environ.get("RECHUB_STEP_FORM", "deferred") != "inline"
                 self.head_on_side = _lib.ab("headside")
                 self._head_event = None
+                self._sweep_events = None   # relaxed join: the ends of the sweeps launched by the last two heads
+                self._look_token = None     # relaxed join: (graph, loader generation, step) the last head looked ahead for
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
@@ -364,14 +367,44 @@ class TableAdam(torch.optim.Adam):
                 if self._head_event is None:
                     self._head_event = torch.cuda.Event()
                 with torch.cuda.stream(side):
-                    _lib.call("rh_adam_lazy_refresh_assemble", *cargs, ops._stream())
+                    _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 0, ops._stream())
                     self._head_event.record()
                     if self._host_step > 0:
                         self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
                 torch.cuda.current_stream().wait_event(self._head_event)
                 self._sweep_pending, self._sweep_inflight = False, True
 
-            seg.at_start(head)
+            def head_relaxed(cargs=cargs, keep=keep, seg=seg, loader=loader):
+                # Relaxed join (round 4).  The strict form above has two cross-queue waits on the step's critical cycle
+                # (chain -> head on the sweep's queue -> chain: 12 + 20 us of the 273 us period in profiles/r04_step_timeline.txt)
+                # because the head must follow the previous sweep AND the previous chain.  Here the head stays on the chain's
+                # queue and also refreshes the lookups of the NEXT batch that fall into the window of the sweep launched behind
+                # it (lookahead = 1): that sweep meets no row the next batch reads, so the next head does not wait for it --
+                # only for the sweep before it, which has had a whole step.  The sweep leaves the critical cycle altogether.
+                # The preview holds when the next head belongs to the same captured step, the loader's perm / pos moved only
+                # by this step's own advance and exactly one step was completed in between; anything else joins everything.
+                main = torch.cuda.current_stream()
+                side = self._side_stream()
+                if self._sweep_events is None:
+                    self._sweep_events = [torch.cuda.Event(), torch.cuda.Event()]
+                    self._head_event = self._head_event or torch.cuda.Event()
+                ev = self._sweep_events[self._host_step & 1]  # last recorded two heads ago
+                if self._look_token == (id(seg), loader.generation, self._host_step):
+                    main.wait_event(ev)
+                else:
+                    main.wait_stream(side)
+                _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 1, ops._stream())
+                self._head_event.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(self._head_event)
+                    if self._host_step > 0:
+                        _lib.call("rh_adam_sweep_stagger", ops._stream())  # not in the same microsecond as the chain's GEMM
+                        self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+                    ev.record()
+                self._look_token = (id(seg), loader.generation, self._host_step + 1)
+                self._sweep_pending, self._sweep_inflight = False, True
+
+            seg.at_start(head_relaxed if RELAXED_JOIN else head)
             self._join_seg = seg
             self._head_forks = True  # on_gather: the sweep of this step is forked by head(), no cut
             self._sweep_pending, self._sweep_inflight = False, True
@@ -384,7 +417,7 @@ class TableAdam(torch.optim.Adam):
             self._sweep_inflight = False
         elif self._sweep_inflight:
             self._join_sweep()
-        _lib.call("rh_adam_lazy_refresh_assemble", *cargs, ops._stream())
+        _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 0, ops._stream())
         self._pre_refreshed = rec
         return True
 

@@ -162,6 +162,9 @@ class DeviceDataLoader(object):
         self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
         self.perm = torch.arange(self.N, dtype=torch.int64, device=dev)
         self._bufs = {}
+        # bumped whenever perm / pos change other than by the training step's own fused advance (pos += B): a consumer that
+        # looked one batch ahead (optim.TableAdam's relaxed join) then knows its preview is void
+        self.generation = 0
 
     @classmethod
     def from_parquet(cls, file_paths, sparse_names, dense_names, label_name, batch_size, device="cuda:0", shuffle=True,
@@ -283,6 +286,7 @@ class DeviceDataLoader(object):
             self.perm.copy_(torch.randperm(self.N, dtype=torch.int64, device=self.sparse.device,
                                            generator=self.generator))
         self.pos.zero_()
+        self.generation += 1
 
     def assembly_args(self, B=None):
         """The arguments of rh_batch_gather for the batch at the current position -- for a caller that runs the assembly
@@ -312,6 +316,7 @@ class DeviceDataLoader(object):
             raise ValueError("load_next(assemble=False) on a loader with sequence columns")
         if advance:
             _lib.call("rh_batch_advance", ops._p(self.pos), B, self.N, s)
+            self.generation += 1
         for dst, src in seqs:
             dst.copy_(src)
         return x, y
