@@ -674,6 +674,7 @@ def _short_run(args, device, rank, use_graph, model=None, batch=None, dist_kind=
 ACCOUNT_GROUPS = (  # first match wins; kernel-name substring -> row of SURVEY 8(d)'s whole-step accounting
     ("batch_gather_kernel", "batch_assembly"), ("batch_advance", "batch_assembly"),
     ("refresh_assemble", "batch_assembly_and_table_refresh"),
+    ("adam_lazy_step_ahead", "touched_rows_step_and_next_batch_assembly_refresh"),
     ("adam_lazy_touched", "table_refresh_before_gather"), ("embed_fwd", "gather_fwd"), ("embed_bwd", "gather_bwd"),
     ("embed_scatter", "gather_bwd"), ("Cijk_", "mlp_gemm_library"), ("gemm_f32", "mlp_gemm_own"),
     ("linear_fwd", "mlp_gemm_own"), ("linear_dgrad", "mlp_gemm_own"),
@@ -703,7 +704,11 @@ def parse_step_trace(trace_csv, steps_wanted):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
     rows.sort()
+    rows = [r for r in rows if "stream_delay" not in r[2]]  # (the one-lane hold-back in front of the deferred sweep)
     marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
+    ahead = sum(1 for r in rows if "step_ahead" in r[2])
+    if ahead > len(marks):  # step-ahead form: the head of a step is the LAST launch of the one before; a step starts at its gather
+        marks = [i for i, r in enumerate(rows) if "embed_fwd_kernel" in r[2]]
     if len(marks) < 3:
         return None
     marks = marks[-(min(steps_wanted, len(marks) - 1) + 1):]

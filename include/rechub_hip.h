@@ -56,9 +56,9 @@ const char* rh_last_error(void);
 /* key 3 (an LDS-padding residency cap of the deferred sweep) was measured in round 3 and removed: rh_set_tuning(3, .) fails */
 #define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
                                   the residency cap that lets the step's chain keep its wave slots and issue cycles */
-#define RH_TUNE_SWEEP_STAGGER_NS 12 /* rh_adam_sweep_stagger: hold-back in nanoseconds (default 6000; 0 = no launch) */
+#define RH_TUNE_SWEEP_STAGGER_NS 12 /* rh_adam_sweep_stagger: hold-back in nanoseconds (default 15000; 0 = no launch) */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
-#define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build */
+#define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build (default) */
 #define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront
                                   kernel (C = 64 / 128 / 256); default 16 | 32 */
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
@@ -575,6 +575,18 @@ int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const int64_t* fi
                                   int32_t* err_flag, const int64_t* perm, const int64_t* pos, int64_t N, const int64_t* sparse,
                                   int Fd, const float* dense, int ND, const float* label, int64_t* sparse_out, float* dense_out,
                                   float* label_out, int lookahead, void* stream);
+/* The end of step t and the head of step t + 1 as ONE launch (round 4): rh_adam_lazy_step_mode(RH_SWEEP_DENSE_TABLES) of the
+ * batch just trained on + rh_adam_lazy_refresh_assemble of the NEXT batch (arguments as there; B is the size of both; *pos
+ * must already point at the next batch, i.e. the step's scalar launch has advanced it -- the finished batch is read back
+ * from dataset positions pos - B ..; look_depth = batches after the next one whose lookups inside the coming deferred sweep's
+ * window are refreshed too, 0..4).  Every part claims a row with atomicMax on its last-step word and the claimant applies the
+ * row's gradient, so a row both batches look up is stepped exactly once.  The caller's hipGraph of a step then starts with
+ * the gather; optim.TableAdam ("step ahead") keeps the bookkeeping. */
+int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                            const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                            const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
+                            int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
+                            int64_t* sparse_out, float* dense_out, float* label_out, int look_depth, void* stream);
 /* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
  * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,

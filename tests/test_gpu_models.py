@@ -343,14 +343,17 @@ def test_abandoned_step_leaves_the_optimizer_where_it_was():
         assert torch.equal(ta.optimizer.state[pa]["exp_avg_sq"], tb.optimizer.state[pb]["exp_avg_sq"])
 
 
-@pytest.mark.parametrize("relaxed", [True, False])
-def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(relaxed, monkeypatch):
+@pytest.mark.parametrize("form", ["ahead", "relaxed", "strict"])
+def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(form, monkeypatch):
     """The headline form of the step at table sizes where the deferred window sweep (K = 64, 33 M rows) is as long as the
     step itself, so that sweeps really are in flight under the following steps: 110 steps (3 eager, the rest hipGraph replays
     with the eager one-kernel head) against a table_update="dense" twin, bit for bit, after the flush.
-    relaxed = True (default form, round 4): the head pre-refreshes the next batch's lookups inside the coming sweep's window
-    (rh_adam_lazy_refresh_assemble, lookahead = 1) and waits only for the sweep BEFORE the last one; ~64 rows per field and step
-    are in that situation here.  relaxed = False: the strict join (head on the sweep's queue).  Reference semantics:
+    "ahead" (default form, round 4): the LAST launch of every replay (rh_adam_lazy_step_ahead) steps the touched rows AND
+    assembles / refreshes the next batch (a row both batches look up is claimed by one of the two passes) AND refreshes the
+    lookups of the two batches after it that fall into the coming sweep's window; a sweep is joined three replays later.
+    "relaxed": the head an eager launch in front of the graph, one batch of lookahead (rh_adam_lazy_refresh_assemble,
+    lookahead = 1), a sweep joined two replays later; ~64 rows per field and step are in the window here.  "strict": the
+    head on the sweep's queue, every sweep joined before the next head.  Reference semantics:
     torch.optim.Adam steps every row every step (trainers/ctr_trainer.py:59-61,99)."""
     from torch_rechub_amd import optim
     from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
@@ -358,7 +361,8 @@ def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(relaxed
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
     monkeypatch.setenv("RECHUB_STEP_FORM", "deferred")
-    monkeypatch.setattr(optim, "RELAXED_JOIN", relaxed)
+    monkeypatch.setattr(optim, "RELAXED_JOIN", form != "strict")
+    monkeypatch.setattr(optim, "STEP_AHEAD", form == "ahead")
     vocabs = [10131227, 2202608, 12517, 93145, 5683, 8351593, 14992, 5461306, 5652, 7046547, 286181, 142572]
     B, nb = 4096, 110
     g = torch.Generator().manual_seed(5)
@@ -390,7 +394,8 @@ def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(relaxed
         dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
         losses.append(t.train_one_epoch(dl))
     assert ta.optimizer.lazy_k == 64 and ta._form == "deferred"
-    assert (ta.optimizer._look_token is not None) == relaxed  # the form under test did run
+    assert (ta.optimizer._look_token is not None) == (form != "strict")  # the form under test did run
+    assert (len(ta.optimizer._sweep_events or ()) == optim.LOOK_DEPTH + 1) == (form == "ahead")
     assert losses[0] == losses[1]
     assert _assert_no_row_behind(ta) == nb
     sa, sb = ma.state_dict(), mb.state_dict()

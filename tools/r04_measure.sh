@@ -20,6 +20,7 @@ f=max(glob.glob(f'/tmp/{m}_prof/**/*kernel_trace.csv',recursive=True),key=os.pat
 rows=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
 marks=[i for i,r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
+if sum(1 for r in rows if "step_ahead" in r[2])>len(marks): marks=[i for i,r in enumerate(rows) if "embed_fwd_kernel" in r[2]]
 lo,hi=marks[-3],marks[-2]
 agg={}
 for st,en,n in rows[lo:hi]:

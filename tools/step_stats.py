@@ -20,6 +20,8 @@ def short(name):
 
 
 marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
+if sum(1 for r in rows if "step_ahead" in r[2]) > len(marks):  # step-ahead form: a step starts at its gather
+    marks = [i for i, r in enumerate(rows) if "embed_fwd_kernel" in r[2]]
 marks = marks[-(last + 1):]
 per, dur, start = [], {}, {}
 for a, b in zip(marks[:-1], marks[1:]):

@@ -15,6 +15,8 @@ for r in csv.DictReader(open(f)):
                  r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Workgroup_Size_X", "?")))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
+if sum(1 for r in rows if "step_ahead" in r[2]) > len(marks):  # step-ahead form: a step starts at its gather
+    marks = [i for i, r in enumerate(rows) if "embed_fwd_kernel" in r[2]]
 lo = marks[-(n + 1)]
 t0 = rows[lo][0]
 for st, en, name, q, s, gx, gy, wx in rows[lo:marks[-1] + 1]:

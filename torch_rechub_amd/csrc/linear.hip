@@ -283,8 +283,10 @@ constexpr int kLongRows = 32768;
 // RH_TUNE_WGRAD_SHORT_FORM: build used for batch-sized reductions (B < 32768).  0: the round-1 form (78 VGPRs + 128 AGPRs,
 // four LDS tiles); 1: the 128-register, one-LDS-tile build of the long reductions.  Beside the optimizer's resident sweep
 // (2 wavefronts of 112 registers per SIMD) only ONE wavefront of the 206-register build fits on a SIMD where the launch's
-// ~500 workgroups want two: measured 28.5 us alone, 39.5 us beside the sweep (round 4).
-int g_short_form = 0;
+// ~500 workgroups want two: measured 28.5 us alone, 39.5 us beside the sweep (round 4).  Default 1 since the relaxed join
+// (optim.py) took the sweep off the step's critical cycle: 0.2622 -> 0.2580 ms per step (same box, two rounds); while the
+// sweep's path was the longer one the two builds tied.
+int g_short_form = 1;
 
 void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
   *tiles_n = (N + kTile - 1) / kTile;

@@ -24,7 +24,7 @@ int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workg
 // 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.  (An LDS-padding cap reached 0.311 ms and was removed: it also
 // kept LDS-hungry kernels of the chain off the CU.)
 int g_deferred_grid = 512;
-int g_stagger_ns = 6000;  // RH_TUNE_SWEEP_STAGGER_NS
+int g_stagger_ns = 15000;  // RH_TUNE_SWEEP_STAGGER_NS (untraced landscape, tools/period_hist.py: 12-18 us clean, 9 us 21 % slow steps)
 
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
 constexpr int kChunk4 = RH_BLOCK * kVecPerThread;               // float4 per virtual block
@@ -226,9 +226,11 @@ struct LazyTouchedArgs {
   int64_t* sparse_out;        // (B, Fd): the batch buffer the fields' index columns point into
   float* dense_out;
   float* label_out;
-  // LOOK (round 4): rows of grid.y behind the assembly row pre-refresh the lookups of the NEXT batch (samples pos + B + b)
-  // that fall into the window the coming deferred sweep walks; look = samples per lookahead workgroup (0: none)
+  // LOOK (round 4): further workgroups pre-refresh those lookups of the batches AFTER this one (samples pos + off + B + b,
+  // b < look_n) that fall into the window the coming deferred sweep walks; look = samples per lookahead workgroup (0: none)
   int look;
+  int look_n;   // samples the lookahead covers (B x depth)
+  int64_t off;  // ASSEMBLE: sample b of this pass is dataset position pos + off + b (0: the batch at pos; -B: the one before)
 };
 
 struct LazySweepArgs {
@@ -248,7 +250,7 @@ struct LazySweepArgs {
   LazyTouchedArgs touch;
 };
 
-template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false, bool LOOK = false>
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false, bool LOOK = false, bool GRAD = !REFRESH>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f);
 
 // (bx_, gdim_: this workgroup's index and the number of workgroups of the sweep / merged part -- blockIdx.x / gridDim.x unless
@@ -409,7 +411,10 @@ __global__ void stream_delay_kernel(const long long ticks) {
 // this pass is going to walk.  That sweep then finds every row the next batch reads already stamped and leaves it alone, so
 // the next step's refresh (and gather) may run WHILE that sweep is still running: the sweep has to be done only before the
 // refresh after that (optim.TableAdam, "relaxed join").  ~ B * F / K rows per step.
-template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE, bool LOOK>
+// GRAD (default: !REFRESH): the rows may carry a gradient -- it is read, applied in the closing step and re-zeroed.  REFRESH
+// with GRAD is the refresh of the NEXT batch inside the end-of-step launch of THIS step (adam_lazy_step_ahead_kernel): a row
+// both batches look up is claimed by one of the two passes, and whichever it is applies the gradient.
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE, bool LOOK, bool GRAD>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f) {
   constexpr int LPP = RH_BLOCK / LPR;
   constexpr int D = 4 * LPR;
@@ -435,8 +440,9 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
   const int q = threadIdx.x % LPR;
   const int slot = threadIdx.x / LPR;
   const int lane = threadIdx.x % RH_WAVE;
+  const int64_t nsamp = LOOK ? a.look_n : a.B;
   int64_t b0 = (int64_t)bx * (LOOK ? a.look : a.spb);
-  int64_t b1 = (b0 + (LOOK ? a.look : a.spb) < (int64_t)a.B) ? b0 + (LOOK ? a.look : a.spb) : (int64_t)a.B;
+  int64_t b1 = (b0 + (LOOK ? a.look : a.spb) < nsamp) ? b0 + (LOOK ? a.look : a.spb) : nsamp;
   // REFRESH replays up to K steps per row: the per-step (A, E) ring entries come from LDS, as in the sweep.  Read from
   // global memory inside the replay loop they were one dependent L2 round trip per replayed step (the compiler emits a
   // vector load + s_waitcnt vmcnt per iteration): the pass was bound by that latency, 26.8 us in the DeepFM step.
@@ -464,7 +470,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     __syncthreads();  // (also: the previous round is done with s_look)
     const int64_t b = sub + threadIdx.x;
     if (b < look_b1) {
-      int64_t p = (apos + (int64_t)a.B + b) % a.N;
+      const int64_t p = (apos + a.off + (int64_t)a.B + b) % a.N;
       const int64_t r = gload<int64_t>(a.src_sparse + gload<int64_t>(a.perm + p) * a.Fd + acol);
       if (r >= ws && r < ws + w && r < rows && r != pad) s_look[atomicAdd(&s_nlook, 1)] = r;
     }
@@ -481,8 +487,9 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
     if (LOOK) {
       r = s_look[ok ? b : 0];
     } else if (ASSEMBLE) {
-      int64_t p = apos + (ok ? b : b1 - 1);
+      int64_t p = apos + a.off + (ok ? b : b1 - 1);
       if (p >= a.N) p %= a.N;
+      if (p < 0) p += a.N;
       r = gload<int64_t>(a.src_sparse + gload<int64_t>(a.perm + p) * a.Fd + acol);
     } else {
       r = (int64_t)gload<IdxT>(ip + (ok ? b : b1 - 1) * st);
@@ -539,7 +546,7 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       P = gload<float4>(p + rr * D + q * 4);
       M = gload<float4>(m + rr * D + q * 4);
       V = gload<float4>(v + rr * D + q * 4);
-      if (!REFRESH) G = gload<float4>(g + rr * D + q * 4);
+      if (GRAD) G = gload<float4>(g + rr * D + q * 4);
     }
     // replay in segments between the steps at which rows of the wavefront join (see adam_lazy_sweep_kernel): fixed exec
     // mask and a scalar step counter inside a segment (the ring entry becomes a scalar load)
@@ -556,12 +563,13 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       j = nxt;
     }
     if (!act) continue;
-    if (REFRESH) adam_f4_zero_g(P, M, V, h, h.A, h.E);
-    else adam_f4(P, G, M, V, h, h.A, h.E);
+    if (GRAD) adam_f4(P, G, M, V, h, h.A, h.E);  // (an all-zero G gives the bits of the zero-gradient form)
+    else adam_f4_zero_g(P, M, V, h, h.A, h.E);
     gstore<float4>(p + rr * D + q * 4, P);
     gstore<float4>(m + rr * D + q * 4, M);
     gstore<float4>(v + rr * D + q * 4, V);
-    if (!REFRESH) gstore<float4>(g + rr * D + q * 4, f4_zero());
+    // (REFRESH with GRAD: most rows of the NEXT batch carry no gradient -- their gradient rows are zero already)
+    if (GRAD && (!REFRESH || G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)) gstore<float4>(g + rr * D + q * 4, f4_zero());
   }
   }
 }
@@ -605,6 +613,77 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_refresh_assemble_kernel(co
     for (int j = lig; j < a.ND; j += G) a.dense_out[b * a.ND + j] = a.src_dense[src * a.ND + j];
     if (lig == 0 && a.src_label != nullptr) a.label_out[b] = a.src_label[src];
   }
+}
+
+// The END of step t and the HEAD of step t + 1 as ONE launch (round 4, relaxed join with the head folded into the previous
+// step's graph; reference: optimizer.step() of step t, trainers/ctr_trainer.py:99, then TorchDataset.__getitem__ +
+// default_collate of batch t + 1, utils/data.py:14-25,61-83).  Parts, in workgroup order:
+//   B  refresh of the lookups of batch t + 1 (dataset positions pos .. pos + B: the step's scalar launch has advanced pos),
+//      replay form WITH gradient: a row that batch t also looked up is claimed by one of the two passes (atomicMax on its
+//      last-step word, as in the merged touched + sweep launch) and the claimant applies the gradient;
+//   A  the touched-rows step of batch t, its indices read from the dataset too (positions pos - B ..): the static batch buffer
+//      they were gathered from is being overwritten by part D of this very launch;
+//   C  lookahead: the lookups of batches t + 2 .. t + 1 + depth that fall into the window of the sweep launched behind this
+//      step (LOOK above);
+//   D  assembly of batch t + 1 into the static batch buffers;
+//   E  the dense (K = 1) tables' step, as rh_adam_lazy_step_mode(RH_SWEEP_DENSE_TABLES).
+// What the strict form ran as three dependent launches with two idle gaps between them (touched rows 22 us, gap, assembly +
+// refresh 30 us, gap) overlaps inside one launch; the step's graph then begins with the gather.
+struct StepAheadParts {
+  int nB, chunksB;  // part B: chunksB x F workgroups of spbB samples
+  int spbB;
+  int nA, chunksA;  // part A
+  int spbA;
+  int nC, chunksC;  // part C: chunksC x F workgroups of `look` samples
+  int nD;           // part D
+};
+
+template <int LPR>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const LazySweepArgs a, const StepAheadParts parts) {
+  RH_CHAIN_PRIO();
+  int bx = (int)blockIdx.x;
+  if (bx < parts.nB) {
+    LazyTouchedArgs ta = a.touch;
+    ta.spb = parts.spbB;
+    ta.off = 0;
+    lazy_touched_body<LPR, int64_t, true, true, false, true>(ta, bx % parts.chunksB, bx / parts.chunksB);
+    return;
+  }
+  bx -= parts.nB;
+  if (bx < parts.nA) {
+    LazyTouchedArgs ta = a.touch;
+    ta.spb = parts.spbA;
+    ta.off = -(int64_t)ta.B;
+    lazy_touched_body<LPR, int64_t, false, true, false, true>(ta, bx % parts.chunksA, bx / parts.chunksA);
+    return;
+  }
+  bx -= parts.nA;
+  if (bx < parts.nC) {
+    LazyTouchedArgs ta = a.touch;
+    ta.off = 0;
+    lazy_touched_body<LPR, int64_t, true, true, true, true>(ta, bx % parts.chunksC, bx / parts.chunksC);
+    return;
+  }
+  bx -= parts.nC;
+  if (bx < parts.nD) {
+    const LazyTouchedArgs& ta = a.touch;
+    constexpr int G = 16;
+    const int lig = threadIdx.x % G;
+    const int64_t pos = ta.pos[0];
+    const int64_t b0 = (int64_t)bx * parts.spbB;
+    const int64_t b1 = (b0 + parts.spbB < (int64_t)ta.B) ? b0 + parts.spbB : (int64_t)ta.B;
+    for (int64_t b = b0 + threadIdx.x / G; b < b1; b += RH_BLOCK / G) {
+      int64_t p = pos + b;
+      if (p >= ta.N) p %= ta.N;
+      const int64_t src = ta.perm[p];
+      for (int j = lig; j < ta.Fd; j += G) ta.sparse_out[b * ta.Fd + j] = ta.src_sparse[src * ta.Fd + j];
+      for (int j = lig; j < ta.ND; j += G) ta.dense_out[b * ta.ND + j] = ta.src_dense[src * ta.ND + j];
+      if (lig == 0 && ta.src_label != nullptr) ta.label_out[b] = ta.src_label[src];
+    }
+    return;
+  }
+  bx -= parts.nD;
+  lazy_sweep_body<LPR, true>(a, bx, (int)gridDim.x - parts.nB - parts.nA - parts.nC - parts.nD);
 }
 
 template <int LPR>
@@ -1034,7 +1113,8 @@ extern "C" int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const 
   int R = RH_BLOCK / spb >= 1 ? RH_BLOCK / spb : 1;
   if (chunks % R != 0) R = 1;
   LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag,
-                    perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, lookahead ? R * spb : 0};
+                    perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, lookahead ? R * spb : 0,
+                    lookahead ? B : 0, 0};
   const dim3 grid((unsigned)chunks, (unsigned)(F + 1 + (lookahead ? (F + R - 1) / R : 0)));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (D / 4) {
@@ -1085,6 +1165,76 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
   }
   RH_REQUIRE(rc == 0 && D % 4 == 0, RH_E_UNSUPPORTED, "rh_adam_lazy_step: embed_dim %d unsupported", D);
   RH_LAUNCH_CHECK("rh_adam_lazy_step");
+  return 0;
+}
+
+// rh_adam_lazy_step_mode(RH_SWEEP_DENSE_TABLES) of step t + rh_adam_lazy_refresh_assemble of batch t + 1 as ONE launch (see
+// adam_lazy_step_ahead_kernel).  B is the size of BOTH batches; pos must already be advanced to batch t + 1; idesc describes
+// index columns inside sparse_out (as rh_adam_lazy_refresh_assemble).  look_depth >= 0: batches looked ahead for the coming
+// deferred sweep's window.
+extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                       const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                       const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm,
+                                       const int64_t* pos, int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND,
+                                       const float* label, int64_t* sparse_out, float* dense_out, float* label_out,
+                                       int look_depth, void* stream) {
+  RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc && perm && pos && sparse && sparse_out,
+             RH_E_BADARG, "rh_adam_lazy_step_ahead: null pointer");
+  RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1 && N >= B && Fd >= 1 && ND >= 0 && look_depth >= 0 &&
+                 look_depth <= 4, RH_E_BADARG, "rh_adam_lazy_step_ahead: bad shape");
+  RH_REQUIRE(ND == 0 || (dense && dense_out), RH_E_BADARG, "rh_adam_lazy_step_ahead: dense pointers null");
+  RH_REQUIRE(label == nullptr || label_out != nullptr, RH_E_BADARG, "rh_adam_lazy_step_ahead: label_out null");
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
+             "rh_adam_lazy_step_ahead: ring_size must be a power of two <= %d", kMaxRing);
+  LazySweepArgs a;
+  a.ldesc = ldesc;
+  a.hyper = hyper;
+  a.ring = ring;
+  a.ring_mask = ring_size - 1;
+  a.T = T;
+  a.flush = 0;
+  a.t_value = -1;
+  a.vb_prefix[0] = 0;
+  for (int t = 0; t < T; ++t) {  // the dense (K = 1) tables only, as launch_sweep(RH_SWEEP_DENSE_TABLES)
+    const bool dense_table = h_window[t] >= h_rows[t];
+    const int64_t w = dense_table ? h_rows[t] : 0;
+    const int rpb = RH_BLOCK / (D / 4);
+    a.vb_prefix[t + 1] = a.vb_prefix[t] + (w + rpb - 1) / rpb;
+  }
+  for (int t = T + 1; t <= kMaxTensors; ++t) a.vb_prefix[t] = a.vb_prefix[T];
+  a.total_vblocks = a.vb_prefix[T];
+  a.touch_blocks = a.touch_chunks = 0;
+  a.touch_period = 1;
+  const int look = RH_BLOCK;
+  a.touch = LazyTouchedArgs{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, 64, err_flag,
+                            perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out,
+                            look, look_depth * B, 0};
+  StepAheadParts parts;
+  parts.spbB = 64;
+  parts.chunksB = (B + parts.spbB - 1) / parts.spbB;
+  parts.nB = parts.chunksB * F;
+  parts.spbA = 256;
+  parts.chunksA = (B + parts.spbA - 1) / parts.spbA;
+  parts.nA = parts.chunksA * F;
+  parts.chunksC = (look_depth * B + look - 1) / look;
+  parts.nC = parts.chunksC * F;
+  parts.nD = parts.chunksB;
+  int64_t sweep_grid = a.total_vblocks;
+  const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
+  if (sweep_grid > cap) sweep_grid = cap;
+  if (sweep_grid < 1) sweep_grid = 1;
+  const dim3 grid((unsigned)(parts.nB + parts.nA + parts.nC + parts.nD + sweep_grid));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (D / 4) {
+    case 1: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<1>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 2: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<2>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 4: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<4>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 8: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<8>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 16: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<16>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 32: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<32>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    default: rh_set_error("rh_adam_lazy_step_ahead: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
+  }
+  RH_LAUNCH_CHECK("rh_adam_lazy_step_ahead");
   return 0;
 }
 

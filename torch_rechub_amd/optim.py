@@ -24,6 +24,8 @@ SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  #
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
+STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
+LOOK_DEPTH = 2  # step-ahead form: batches beyond the next one whose lookups in the coming sweep's window are refreshed early
 
 
 class TableAdam(torch.optim.Adam):
@@ -125,6 +127,7 @@ class TableAdam(torch.optim.Adam):
                 self._head_event = None
                 self._sweep_events = None   # relaxed join: the ends of the sweeps launched by the last two heads
                 self._look_token = None     # relaxed join: (graph, loader generation, step) the last head looked ahead for
+                self._step_ahead = None          # step-ahead form: what _merged_step launches while the graph `seg` is captured
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
@@ -404,7 +407,47 @@ class TableAdam(torch.optim.Adam):
                 self._look_token = (id(seg), loader.generation, self._host_step + 1)
                 self._sweep_pending, self._sweep_inflight = False, True
 
-            seg.at_start(head_relaxed if RELAXED_JOIN else head)
+            def head_ahead(cargs=cargs, keep=keep, seg=seg, loader=loader):
+                # Step ahead (round 4): the previous replay's LAST launch (rh_adam_lazy_step_ahead) has already assembled this
+                # batch and refreshed its rows, and looked LOOK_DEPTH batches further ahead for the window of the sweep launched
+                # behind it -- that sweep may run under this replay and the next; only the one launched LOOK_DEPTH + 1 tails ago
+                # has to be done.  Nothing is launched here then.  Whenever that is not the situation (first replay, another
+                # graph, the loader reshuffled or moved, a step in between): join everything and prepare the batch the ordinary way.
+                main = torch.cuda.current_stream()
+                if self._sweep_events is None or len(self._sweep_events) != LOOK_DEPTH + 1:
+                    self._sweep_events = [torch.cuda.Event() for _ in range(LOOK_DEPTH + 1)]
+                    self._head_event = self._head_event or torch.cuda.Event()
+                if self._look_token == (id(seg), loader.generation, self._host_step):
+                    ev = self._sweep_events[(self._host_step + 1) % (LOOK_DEPTH + 1)]
+                    if not ev.query():  # (normally long done: every packet between two graphs costs the chain ~7 us of idle queue)
+                        main.wait_event(ev)
+                else:
+                    main.wait_stream(self._side_stream())
+                    _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 0, ops._stream())
+                self._sweep_pending, self._sweep_inflight = False, True
+
+            def tail_ahead(seg=seg, loader=loader):
+                # after the step's graph (its last launch prepared the next batch): the sweep of the step just completed, by
+                # value, on the side stream behind an event; it is not joined before LOOK_DEPTH + 1 further replays
+                self._host_step += 1
+                h = self._host_step
+                side = self._side_stream()
+                self._head_event.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(self._head_event)
+                    _lib.call("rh_adam_sweep_stagger", ops._stream())  # not in the same microsecond as the next chain's GEMM
+                    self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
+                    self._sweep_events[h % (LOOK_DEPTH + 1)].record()
+                self._look_token = (id(seg), loader.generation, h)
+                self._sweep_pending, self._sweep_inflight = False, True
+
+            if RELAXED_JOIN and STEP_AHEAD and self._merge_ahead_ok(rec, grp):
+                seg.at_start(head_ahead)
+                seg.after(tail_ahead)
+                self._advance_seg = seg  # (step_tables: tail_ahead counts the replayed steps)
+                self._step_ahead = dict(seg=seg, rec=rec, grp=grp, ft=ft, a=a)
+            else:
+                seg.at_start(head_relaxed if RELAXED_JOIN else head)
             self._join_seg = seg
             self._head_forks = True  # on_gather: the sweep of this step is forked by head(), no cut
             self._sweep_pending, self._sweep_inflight = False, True
@@ -550,6 +593,11 @@ class TableAdam(torch.optim.Adam):
         return not (grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or
                     not any(id(w) in grp["local"] for w in rec["weights"]))
 
+    def _merge_ahead_ok(self, rec, grp):
+        """Will _merged_step of the step being captured see exactly this gather over exactly this table group?"""
+        groups = self._lazy_setup()
+        return len(groups) == 1 and groups[0] is grp and rec["idx_is_i64"] and self.overlap_sweep
+
     def _merged_step(self, groups, stream):
         """The touched-rows step of the batch and the window sweep as ONE launch (rh_adam_lazy_step) when the step has a
         single index batch over a single table group with int64 indices -- the DeepFM / DCN / WideDeep step.  The short,
@@ -557,6 +605,21 @@ class TableAdam(torch.optim.Adam):
         if not self._merge_ok(groups):
             return False
         rec, grp = self._touch_log[0], groups[0]
+        ah = self._step_ahead
+        if ah is not None and graphs.active() is ah["seg"] and torch.cuda.is_current_stream_capturing():
+            self._step_ahead = None
+            if not (self._same_gather(rec, ah["rec"]) and grp is ah["grp"] and self.overlap_sweep):
+                raise RuntimeError("TableAdam: the captured step does not end with the gather its head announced "
+                                   "(step-ahead form; RECHUB_AB=ahead=0 captures the eager-head form)")
+            a = ah["a"]
+            _lib.call("rh_adam_lazy_step_ahead", ops._p(grp["ldesc"]), len(grp["members"]),
+                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(ah["ft"]), ops._p(rec["idesc"]), rec["B"],
+                      rec["F"], ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"],
+                      ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]),
+                      ops._p(a["dense_out"]), ops._p(a["label_out"]), LOOK_DEPTH, stream)
+            self._sweep_pending = True
+            return True
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
         mode = SWEEP_DENSE_TABLES if self.overlap_sweep else SWEEP_WINDOW
         _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
