@@ -24,6 +24,7 @@ int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workg
 // 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.  (An LDS-padding cap reached 0.311 ms and was removed: it also
 // kept LDS-hungry kernels of the chain off the CU.)
 int g_deferred_grid = 512;
+int g_gate_ns = 28000;  // RH_TUNE_SWEEP_GATE_NS: rh_adam_sweep_gate, hold-back behind the opening (the end of the step's graph)
 int g_stagger_ns = 15000;  // RH_TUNE_SWEEP_STAGGER_NS (untraced landscape, tools/period_hist.py: 12-18 us clean, 9 us 21 % slow steps)
 
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
@@ -402,6 +403,30 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
 __global__ void stream_delay_kernel(const long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+// Gate word layout: gate[0] = count of openings (int64), gate[1] = wall clock of the last opening.
+// stream_gate_kernel: one lane waits until the count has reached `expected`, then until `ticks` after THAT opening (a gate that
+// is reached late adds no delay of its own).  Gives up after `timeout` ticks and raises *err: a gate nobody opens must not
+// wedge the queue.  stream_gate_open_kernel: one lane, the opening -- in stream order behind whatever it announces.
+__global__ void stream_gate_kernel(const long long* gate, const long long expected, const long long ticks, const long long timeout,
+                                   int* err) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > timeout) {
+      if (err != nullptr) atomicOr(err, RH_ERR_GATE_TIMEOUT);
+      return;
+    }
+  }
+  const long long opened = __hip_atomic_load(gate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (wall_clock64() - opened < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+__global__ void stream_gate_open_kernel(long long* gate) {
+  __hip_atomic_store(gate + 1, (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (relaxed: what the opening announces was published by the END of the launches in front of this one; the time word is only a hint)
+  __hip_atomic_fetch_add(gate, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // REFRESH: the pre-gather pass -- the rows carry no gradient yet (their gradient rows are zero), so they are neither
@@ -958,6 +983,10 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     g_stagger_ns = value;
     return 0;
   }
+  if (key == RH_TUNE_SWEEP_GATE_NS) {
+    g_gate_ns = value;
+    return 0;
+  }
   return RH_E_BADARG;
 }
 
@@ -1041,8 +1070,7 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
 // GEMM -- its workgroups already placed, one per CU -- the sweep spreads evenly: 0 slow steps of 300 at 5 / 7 / 11 us.  This
 // one-lane launch in front of the sweep is that hold-back.  (A 55 KB LDS request per sweep workgroup and a per-CU admission
 // counter were measured and did not fix it.)
-extern "C" int rh_adam_sweep_stagger(void* stream) {
-  if (g_stagger_ns <= 0) return 0;
+static long long wall_khz() {
   static long long khz = 0;
   if (khz == 0) {
     int dev = 0, rate = 0;
@@ -1051,9 +1079,38 @@ extern "C" int rh_adam_sweep_stagger(void* stream) {
       rate = 100000;
     khz = rate;
   }
+  return khz;
+}
+
+extern "C" int rh_adam_sweep_stagger(void* stream) {
+  if (g_stagger_ns <= 0) return 0;
   hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
-                     (long long)g_stagger_ns * khz / 1000000);
+                     (long long)g_stagger_ns * wall_khz() / 1000000);
   RH_LAUNCH_CHECK("rh_adam_sweep_stagger");
+  return 0;
+}
+
+// The same hold-back released by a DEVICE word instead of an event (step-ahead form).  rh_adam_sweep_gate_open is captured as
+// the LAST launch of the step's graph: one lane counts the opening and notes its time.  rh_adam_sweep_gate occupies `stream`
+// until the count has reached `expected` and RH_TUNE_SWEEP_GATE_NS have passed SINCE THAT OPENING.  An event record between
+// two graph launches cost the chain ~7 us of idle queue (this launch ~2); and a sweep that is released late -- the one before
+// it ran long -- is not held back any further, where a fixed delay behind an event added itself to every sweep and left the
+// side queue (delay + 231 us per step) no slack against a 245 us period.  A gate not opened within 50 ms gives up and raises
+// RH_ERR_GATE_TIMEOUT in *err_flag.
+extern "C" int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int32_t* err_flag, void* stream) {
+  RH_REQUIRE(gate != nullptr, RH_E_BADARG, "rh_adam_sweep_gate: null gate");
+  hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(gate), (long long)expected,
+                     (long long)(g_gate_ns > 0 ? g_gate_ns : 0) * wall_khz() / 1000000, 50 * wall_khz(), err_flag);
+  RH_LAUNCH_CHECK("rh_adam_sweep_gate");
+  return 0;
+}
+
+extern "C" int rh_adam_sweep_gate_open(int64_t* gate, void* stream) {
+  RH_REQUIRE(gate != nullptr, RH_E_BADARG, "rh_adam_sweep_gate_open: null gate");
+  hipLaunchKernelGGL(stream_gate_open_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<long long*>(gate));
+  RH_LAUNCH_CHECK("rh_adam_sweep_gate_open");
   return 0;
 }
 

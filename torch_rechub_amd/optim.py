@@ -127,7 +127,11 @@ class TableAdam(torch.optim.Adam):
                 self._head_event = None
                 self._sweep_events = None   # relaxed join: the ends of the sweeps launched by the last two heads
                 self._look_token = None     # relaxed join: (graph, loader generation, step) the last head looked ahead for
-                self._step_ahead = None          # step-ahead form: what _merged_step launches while the graph `seg` is captured
+                self._step_ahead = None     # step-ahead form: what _merged_step launches while the graph `seg` is captured
+                # step-ahead form: the sweep's release is a device word the LAST launch of the step's graph counts up
+                # (rh_adam_sweep_gate_open): [openings, wall clock of the last one]
+                self._gate = torch.zeros(2, dtype=torch.int64, device=dev)
+                self._gate_seen = 0  # openings issued so far (one per replay of a step-ahead graph)
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
@@ -424,6 +428,7 @@ class TableAdam(torch.optim.Adam):
                 else:
                     main.wait_stream(self._side_stream())
                     _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 0, ops._stream())
+                self._gate_seen += 1  # the last launch of this replay's graph opens the gate of this step's sweep
                 self._sweep_pending, self._sweep_inflight = False, True
 
             def tail_ahead(seg=seg, loader=loader):
@@ -432,10 +437,11 @@ class TableAdam(torch.optim.Adam):
                 self._host_step += 1
                 h = self._host_step
                 side = self._side_stream()
-                self._head_event.record()
                 with torch.cuda.stream(side):
-                    side.wait_event(self._head_event)
-                    _lib.call("rh_adam_sweep_stagger", ops._stream())  # not in the same microsecond as the next chain's GEMM
+                    # released by the graph's own last launch (no event record between two graph launches of the chain) and
+                    # held back RH_TUNE_SWEEP_GATE_NS behind it: into the next step's first GEMM, not beside a launch of the chain
+                    _lib.call("rh_adam_sweep_gate", ops._p(self._gate), self._gate_seen,
+                              ops._p(ops.err_flag(self._tables[0].device)), ops._stream())
                     self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
                     self._sweep_events[h % (LOOK_DEPTH + 1)].record()
                 self._look_token = (id(seg), loader.generation, h)
@@ -618,6 +624,7 @@ class TableAdam(torch.optim.Adam):
                       rec["F"], ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"],
                       ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]),
                       ops._p(a["dense_out"]), ops._p(a["label_out"]), LOOK_DEPTH, stream)
+            _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
             self._sweep_pending = True
             return True
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
