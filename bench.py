@@ -39,7 +39,9 @@ CRITEO_VOCABS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 56
                  10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 N_DENSE = 13
 EMBED_DIM = 16
-DEFERRED_SWEEP_PMC_TRAFFIC = 208.9e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 561.3 + 100 850.6) KiB, profiles/r04_pmc_sweep_{FETCH,WRITE}_SIZE.txt (round 3's passes gave 208.8e6: profiles/r03_pmc_sweep_*)
+DEFERRED_SWEEP_PMC_TRAFFIC_K64 = 208.9e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 561.3 + 100 850.6) KiB, profiles/r04_pmc_sweep_{FETCH,WRITE}_SIZE.txt (round 3's passes gave 208.8e6: profiles/r03_pmc_sweep_*)
+# per lazy_k: (bytes per launch of adam_lazy_sweep_kernel<4, false>, files under profiles/)
+DEFERRED_SWEEP_PMC_TRAFFIC = {64: (DEFERRED_SWEEP_PMC_TRAFFIC_K64, "r04_pmc_sweep")}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a float4 copy
 
 # algorithmic bytes: F=26, D=16, fp32, int64 indices as the loader holds them
@@ -66,7 +68,7 @@ def parse():
     ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink every table")
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
-    ap.add_argument("--lazy-k", type=int, default=64)
+    ap.add_argument("--lazy-k", type=int, default=128)
     ap.add_argument("--tables", default="auto", choices=["auto", "replicate", "shard", "both"],
                     help="N > 1 placement of the embedding tables; both compute the reference's global-batch update. "
                          "replicate: one replica per rank, gradient rows all-gathered (nn.DataParallel's layout, SURVEY "
@@ -626,8 +628,10 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
     res["step_bytes"] = step_bytes
     res["overlap_sweep"] = bool(getattr(opt, "overlap_sweep", False))
     tune = getattr(trainer, "_tune", None) or {}
-    res["step_form"] = {"chosen": {"form": tune["chosen"][0], "deferred_sweep_workgroups": tune["chosen"][1]},
-                        "candidates": [{"form": c[0], "deferred_sweep_workgroups": c[1]} for c in tune["cands"]],
+    res["step_form"] = {"chosen": {"form": tune["chosen"][0], "deferred_sweep_workgroups": tune["chosen"][1],
+                                   "sweep_hold_back_ns": tune["chosen"][2]},
+                        "candidates": [{"form": c[0], "deferred_sweep_workgroups": c[1], "sweep_hold_back_ns": c[2]}
+                                       for c in tune["cands"]],
                         "ms_per_step_during_tuning": tune.get("ms")} if tune.get("chosen") else \
         {"chosen": {"form": getattr(trainer, "_form", None), "pinned": True}}
     # the north-star kernels over batch sizes (same tables, same stream, HIP events): their bandwidth regime starts
@@ -918,11 +922,11 @@ def main():
                                       "captured chain of the step runs beside it, i.e. under contention -- the duration "
                                       "rocprofv3 reports for adam_lazy_sweep_kernel<4, false> in profiles/r03_*")
                 roofline["hidden_under_the_step"] = True
-                if args.lazy_k == 64 and args.vocab_scale == 1.0 and best is None:
+                if args.lazy_k in DEFERRED_SWEEP_PMC_TRAFFIC and args.vocab_scale == 1.0 and best is None:
                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --trace-inner`, mean over the
                     # steady-state dispatches of adam_lazy_sweep_kernel<4, false>; 2 * FETCH + WRITE (KiB), gfx950 correction
-                    roofline["traffic"] = DEFERRED_SWEEP_PMC_TRAFFIC
-                    roofline["traffic_source"] = ("profiles/r04_pmc_sweep_{FETCH,WRITE}_SIZE.txt (rocprofv3 --pmc, separate "
+                    roofline["traffic"], src = DEFERRED_SWEEP_PMC_TRAFFIC[args.lazy_k]
+                    roofline["traffic_source"] = (f"profiles/{src}_{{FETCH,WRITE}}_SIZE.txt (rocprofv3 --pmc, separate "
                                                   "passes; not re-collected by bench.py)")
             pmc_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
             if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0 and best is None and \

@@ -187,8 +187,12 @@ def test_device_loader_training_equals_host_loader_training(use_graph):
             continue
         if k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias") or k.endswith("running_mean"):
             continue  # bias in front of BatchNorm: zero gradient + rounding noise, Adam makes its path arbitrary
-        # same arithmetic; only the order of the fp32 atomic adds differs between two runs
-        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-5, rtol=1e-4)
+        # same arithmetic; only the order of the fp32 atomic adds differs between two runs.  Measured run-to-run spread of ONE
+        # configuration over these 12 steps (round 4, host batches vs host batches): 1.6e-5 on the embedding tables (Adam
+        # turns the rounding noise of near-cancelling gradient elements into lr-sized steps: single elements jump by 8e-3),
+        # 2e-4 .. 7e-4 on the bias in front of BatchNorm -- atol = 1e-5 sat inside that spread and failed one run in three.
+        # A wrong batch, order or optimizer step shows up at 1e-2.
+        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-4, rtol=1e-4)
     if use_graph:
         assert tb._graph is not None
         lb2 = tb.train_one_epoch(dl)  # second epoch replays the captured graph from the first batch on
@@ -254,7 +258,7 @@ def test_graph_mode_flush_leaves_no_row_behind_ctr_trainer(overlap, monkeypatch)
     epochs = 2
     if overlap == "auto":
         monkeypatch.delenv("RECHUB_STEP_FORM", raising=False)
-        epochs = 9  # 3 eager + 105 replayed steps: past lazy_k + 8 + 3 candidates x 22 steps of tuning
+        epochs = 10  # 3 eager + 117 replayed steps: past lazy_k + 8 + 4 candidates x 22 steps of tuning
     else:
         monkeypatch.setenv("RECHUB_STEP_FORM", {"0": "inline", "1": "deferred"}[overlap])
     epochs = int(os.environ.get("RECHUB_SOAK_EPOCHS", epochs))  # soak runs: thousands of replayed steps, same bits demanded
@@ -345,14 +349,14 @@ def test_abandoned_step_leaves_the_optimizer_where_it_was():
 
 @pytest.mark.parametrize("form", ["ahead", "relaxed", "strict"])
 def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(form, monkeypatch):
-    """The headline form of the step at table sizes where the deferred window sweep (K = 64, 33 M rows) is as long as the
+    """The headline form of the step at table sizes where the deferred window sweep (K = 128, 33 M rows) is as long as the
     step itself, so that sweeps really are in flight under the following steps: 110 steps (3 eager, the rest hipGraph replays
     with the eager one-kernel head) against a table_update="dense" twin, bit for bit, after the flush.
     "ahead" (default form, round 4): the LAST launch of every replay (rh_adam_lazy_step_ahead) steps the touched rows AND
     assembles / refreshes the next batch (a row both batches look up is claimed by one of the two passes) AND refreshes the
     lookups of the two batches after it that fall into the coming sweep's window; a sweep is joined three replays later.
     "relaxed": the head an eager launch in front of the graph, one batch of lookahead (rh_adam_lazy_refresh_assemble,
-    lookahead = 1), a sweep joined two replays later; ~64 rows per field and step are in the window here.  "strict": the
+    lookahead = 1), a sweep joined two replays later; ~32 rows per field and step are in the window here.  "strict": the
     head on the sweep's queue, every sweep joined before the next head.  Reference semantics:
     torch.optim.Adam steps every row every step (trainers/ctr_trainer.py:59-61,99)."""
     from torch_rechub_amd import optim
@@ -393,7 +397,7 @@ def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(form, m
     for t in (ta, tb):
         dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
         losses.append(t.train_one_epoch(dl))
-    assert ta.optimizer.lazy_k == 64 and ta._form == "deferred"
+    assert ta.optimizer.lazy_k == 128 and ta._form == "deferred"
     assert (ta.optimizer._look_token is not None) == (form != "strict")  # the form under test did run
     assert (len(ta.optimizer._sweep_events or ()) == optim.LOOK_DEPTH + 1) == (form == "ahead")
     assert losses[0] == losses[1]

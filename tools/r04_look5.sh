@@ -10,5 +10,5 @@ for tag in ${TAGS:-ahead}; do
   echo "== $tag"; python tools/step_stats.py /tmp/tl_$tag 150 2>&1 | tee "$OUT/step_stats_$tag.txt"
   python tools/timeline.py /tmp/tl_$tag 1 | head -24
 done
-bash tools/r04_look4.sh g24=RECHUB_TUNE=13=24000 g26=RECHUB_TUNE=13=26000 g28= g30=RECHUB_TUNE=13=30000 g32=RECHUB_TUNE=13=32000 g22=RECHUB_TUNE=13=22000 g28b=
+bash tools/r04_look4.sh g16=RECHUB_TUNE=13=16000 g22=RECHUB_TUNE=13=22000 g28= g34=RECHUB_TUNE=13=34000 g40=RECHUB_TUNE=13=40000
 for r in 1 2; do bash tools/r04_ab.sh $OUT/ab4 ahead_$r= relaxed_$r=RECHUB_AB=ahead=0,RECHUB_TUNE=12=6000; done

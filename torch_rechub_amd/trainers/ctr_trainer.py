@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=64, tables=None, shard_min_rows=0, lazy_small_rows=None):
+                 table_update=None, lazy_k=128, tables=None, shard_min_rows=0, lazy_small_rows=None):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
@@ -64,6 +64,11 @@ class CTRTrainer(object):
             regularization_params = {"embedding_l1": 0.0, "embedding_l2": 0.0, "dense_l1": 0.0, "dense_l2": 0.0}
         # table_update: "lazy" = blocked-lazy exact Adam (bit-identical to "dense", ~1/lazy_k of its HBM traffic),
         # "dense" = every row every step.  An embedding regulariser adds a dense gradient term -> dense mode.
+        # lazy_k = 128 (round 4; 64 before): the window sweep replays the same number of element-steps per training step
+        # whatever lazy_k is, but touches half as many rows twice as long -- half its HBM traffic beside the step's chain --
+        # while the pre-gather refresh of the batch's rows replays twice as far.  Measured on the headline step (same box,
+        # step-ahead form): lazy_k 32 / 64 / 96 / 128 / 160 / 192 / 256 / 384 = 0.282 / 0.255 / 0.247 / 0.244 / 0.250 / 0.251 /
+        # 0.256 / 0.276 ms.
         if table_update is None:
             table_update = os.environ.get("RECHUB_TABLE_ADAM", "lazy")
         if table_update not in ("lazy", "dense"):
@@ -275,7 +280,10 @@ class CTRTrainer(object):
     # kernels are heavy themselves (DIN, B = 65536: the sweep slows them by what it hides).  Round 3 also built a
     # "pipelined" form (0.37-0.39 ms where "deferred" reaches 0.305) and a "branch" form (0.312 ms); both were removed
     # in round 4, DESIGN 4.3 keeps their numbers and timelines.
-    TUNE_CANDIDATES = (("deferred", 512), ("deferred", 256), ("inline", 0))
+    # (form, residency cap of the deferred sweep in workgroups, hold-back of the sweep behind the end of the step's graph in ns
+    # -- step-ahead form, rh_adam_sweep_gate: WHERE in the next step's chain the sweep's workgroups are dispatched decides
+    # whether they spread evenly over the SIMDs; 22 us was a 305 us step where 28 us was a 245 us one, tools/period_hist.py)
+    TUNE_CANDIDATES = (("deferred", 512, 28000), ("deferred", 512, 36000), ("deferred", 256, 28000), ("inline", 0, 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
     def _tune_step_form(self, loader):
@@ -301,9 +309,16 @@ class CTRTrainer(object):
             cands = [c for c in self.TUNE_CANDIDATES if (not form or c[0] == form) and
                      (not grid or c[0] == "inline" or c[1] == int(grid))]
             if form and (grid or not cands):  # fully pinned (also forms / grids that are not tuning candidates)
-                cands = [(form, int(grid or 512) if form != "inline" else 0)]
-            # a user who pinned the deferred sweep's grid through RECHUB_TUNE (key 8, exact match) keeps it
+                cands = [(form, int(grid or 512) if form != "inline" else 0, 0)]
+            # a user who pinned the deferred sweep's grid / hold-back through RECHUB_TUNE (keys 8 / 13, exact match) keeps them
             pinned = {kv.split("=")[0].strip() for kv in os.environ.get("RECHUB_TUNE", "").split(",") if "=" in kv}
+            if "13" in pinned or form and (grid or len(cands) == 1):
+                seen, kept = set(), []
+                for c in cands:  # one candidate per (form, grid): the hold-back stays what the user / the library set
+                    if c[:2] not in seen:
+                        seen.add(c[:2])
+                        kept.append((c[0], c[1], 0))
+                cands = kept
             active = lazy and self.dp is None and len(cands) > 1 and "8" not in pinned
             st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
                                "cands": cands}
@@ -340,9 +355,11 @@ class CTRTrainer(object):
 
     def _apply_candidate(self, cand, loader):
         from .. import _lib
-        form, grid = cand
+        form, grid, hold = cand
         if form != "inline":
             _lib.call("rh_set_tuning", 8, int(grid))
+            if hold:
+                _lib.call("rh_set_tuning", 13, int(hold))
         if self._form != form:
             self._switch_form(form, loader)
 
