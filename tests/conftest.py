@@ -165,7 +165,8 @@ def assert_trajectory_close(got, want, travel, what, atol=3e-4, rtol=1e-3, outli
     and every element to within a quarter of the distance Adam can travel in these steps."""
     diff = np.abs(got - want)
     bad = diff > atol + rtol * np.abs(want)
-    assert bad.mean() <= outlier_frac, f"{what}: {bad.sum()} / {bad.size} elements off (max {diff.max():.3e})"
+    # (at least two elements: in a 3 x 16 table 0.5 % is less than one, and single near-cancelling elements do jump)
+    assert bad.sum() <= max(2, outlier_frac * bad.size), f"{what}: {bad.sum()} / {bad.size} elements off (max {diff.max():.3e})"
     assert diff.max() <= 0.25 * travel + atol, f"{what}: max diff {diff.max():.3e}"
 
 

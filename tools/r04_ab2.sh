@@ -1,9 +1,9 @@
 #!/bin/bash
-# Same-box A/B with extra bench arguments: tools/r04_ab2.sh <outdir> "<tag>|<ENV=V,...>|<bench args>" ...
+# Same-box A/B with extra bench arguments: tools/r04_ab2.sh <outdir> "<tag>|<ENV=V;ENV=V...>|<bench args>" ...
 out=$1; shift; mkdir -p $out
 for spec in "$@"; do
   IFS='|' read -r tag envs args <<< "$spec"
-  envs=$(echo "$envs" | tr ',' ' ')
+  envs=$(echo "$envs" | tr ';' ' ')
   env $envs timeout 300 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --brief --no-kernel-sweep --no-step-accounting $args > $out/$tag.json 2> $out/$tag.err
   python - <<PY
 import json

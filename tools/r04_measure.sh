@@ -9,7 +9,7 @@ OUT=gpurun_out/r04
 mkdir -p "$OUT"
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 [ -d _refmount/torch_rechub ] && export RECHUB_REFERENCE=$PWD/_refmount
-STAGES=${STAGES:-"tests bench bench300 prof pmc models ab"}
+STAGES=${STAGES:-"tests bench bench300 prof pmc models ab hist"}
 model_table() {  # kernel table of ONE traced step of a secondary config
   m=$1
   (cd /tmp && rm -rf /tmp/${m}_prof && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/${m}_prof -o $m -- python $OLDPWD/bench.py --model $m --trace-inner --steps 10 --warmup 5 > /dev/null 2> $OLDPWD/$OUT/${m}_prof.err)
@@ -49,6 +49,8 @@ pmc) for c in FETCH_SIZE WRITE_SIZE; do
  done;;
 models) for m in dcnv2 din dssm; do model_table $m > "$OUT/${m}_step_kernels.txt" 2>&1; head -3 "$OUT/${m}_step_kernels.txt"; done;;
 ab) echo "== same-box A/B (200 steps each, two rounds)"
-  for r in 1 2; do bash tools/r04_ab.sh $OUT/ab all_on_$r= assemble_off_$r=RECHUB_AB=assemble=0 headside_off_$r=RECHUB_AB=headside=0 chain_off_$r=RECHUB_AB=chain=0 round3_$r=RECHUB_AB=assemble=0,chain=0,headside=0; done 2>&1 | tee "$OUT/ab.txt";;
+  for r in 1 2; do bash tools/r04_ab2.sh $OUT/ab "all_on_$r||" "eager_head_$r|RECHUB_AB=ahead=0;RECHUB_TUNE=12=6000|" "strict_join_$r|RECHUB_AB=lookahead=0|" "chain_off_$r|RECHUB_AB=chain=0|" "wgrad_206reg_$r|RECHUB_TUNE=11=0|" "lazy_k64_$r||--lazy-k 64" "round3_$r|RECHUB_AB=lookahead=0,assemble=0,chain=0,headside=0;RECHUB_TUNE=11=0|--lazy-k 64"; done 2>&1 | tee "$OUT/ab.txt";;
+hist) echo "== step period distribution without a profiler (tools/period_hist.py, 400 steps)"
+  bash tools/r04_period.sh ahead= 'eager_head=RECHUB_AB=ahead=0;RECHUB_TUNE=12=6000' strict_join=RECHUB_AB=lookahead=0 2>&1 | tee "$OUT/period_hist.txt";;
 esac; done
 echo "== done"

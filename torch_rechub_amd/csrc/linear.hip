@@ -252,6 +252,19 @@ __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
   linear_wgrad_body<true>(a, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// (the grouped launch in the 128-register build: RH_TUNE_WGRAD_SHORT_FORM = 1, the default)
+__global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void linear_wgrad_group_long_kernel(
+    const WgradGroupArgs ga) {
+  extern __shared__ float red[];
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int q = 1; q < kWgradGroup; ++q) i += (q < ga.n && b >= ga.prefix[q]) ? 1 : 0;
+  const int local = b - ga.prefix[i];
+  const int tk = ga.tiles_k[i], tn = ga.tiles_n[i];
+  linear_wgrad_body<true>(ga.p[i], red, local % tk, (local / tk) % tn, local / (tk * tn));
+}
+
 // Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
 // "last block reduces" election needs a device-scope fence per block, which on this 8-XCD part writes back and
 // invalidates the XCD's whole L2 (measured: ~140 us for 500 blocks) -- a 3 us launch is the cheaper barrier.
@@ -929,8 +942,12 @@ extern "C" int rh_linear_wgrad_partial_group(int n, const float* const* g, const
     RH_REQUIRE(e == hipSuccess, (int)e, "rh_linear_wgrad_partial_group: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(linear_wgrad_group_kernel, dim3((unsigned)ga.prefix[n]), dim3(RH_BLOCK),
-                     (size_t)kWaves * kPartStride * sizeof(float), reinterpret_cast<hipStream_t>(stream), ga);
+  if (g_short_form == 1)
+    hipLaunchKernelGGL(linear_wgrad_group_long_kernel, dim3((unsigned)ga.prefix[n]), dim3(RH_BLOCK),
+                       (size_t)kPartStride * sizeof(float), reinterpret_cast<hipStream_t>(stream), ga);
+  else
+    hipLaunchKernelGGL(linear_wgrad_group_kernel, dim3((unsigned)ga.prefix[n]), dim3(RH_BLOCK),
+                       (size_t)kWaves * kPartStride * sizeof(float), reinterpret_cast<hipStream_t>(stream), ga);
   RH_LAUNCH_CHECK("rh_linear_wgrad_partial_group");
   return 0;
 }

@@ -2069,7 +2069,7 @@ class _CrossMoeFn(torch.autograd.Function):
         return (g_x, None, None) + tuple(g_U) + tuple(g_V) + tuple(g_C) + tuple(g_b) + tuple(g_W)
 
 
-WGRAD_GROUP = True  # A/B twin for tests: False = one rh_linear_wgrad_partial launch per problem
+WGRAD_GROUP = _lib.ab("wgroup")  # False (RECHUB_AB=wgroup=0, tests): one rh_linear_wgrad_partial launch per problem
 
 
 def linear_wgrad_partial_group(problems, B):
