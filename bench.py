@@ -39,9 +39,11 @@ CRITEO_VOCABS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 56
                  10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 N_DENSE = 13
 EMBED_DIM = 16
-DEFERRED_SWEEP_PMC_TRAFFIC_K64 = 208.9e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 561.3 + 100 850.6) KiB, profiles/r04_pmc_sweep_{FETCH,WRITE}_SIZE.txt (round 3's passes gave 208.8e6: profiles/r03_pmc_sweep_*)
+DEFERRED_SWEEP_PMC_TRAFFIC_K64 = 208.9e6  # bytes per launch of adam_lazy_sweep_kernel<4, false>: (2 * 51 561.3 + 100 850.6) KiB, profiles/r04_k64_pmc_sweep_{FETCH,WRITE}_SIZE.txt (round 3's passes gave 208.8e6: profiles/r03_pmc_sweep_*)
 # per lazy_k: (bytes per launch of adam_lazy_sweep_kernel<4, false>, files under profiles/)
-DEFERRED_SWEEP_PMC_TRAFFIC = {64: (DEFERRED_SWEEP_PMC_TRAFFIC_K64, "r04_pmc_sweep")}
+DEFERRED_SWEEP_PMC_TRAFFIC = {64: (DEFERRED_SWEEP_PMC_TRAFFIC_K64, "r04_k64_pmc_sweep"),
+                              # lazy_k = 128: (2 * 25 830.0 + 50 508.5) KiB = 1.013 x the 103.25 MB of the window's rows
+                              128: (104.6e6, "r04_pmc_sweep")}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a float4 copy
 
 # algorithmic bytes: F=26, D=16, fp32, int64 indices as the loader holds them
@@ -68,7 +70,8 @@ def parse():
     ap.add_argument("--vocab-scale", type=float, default=1.0, help="debug: shrink every table")
     ap.add_argument("--table-adam", default="lazy", choices=["lazy", "dense"],
                     help="how the dense-exact Adam over the tables is executed (results are bit-identical)")
-    ap.add_argument("--lazy-k", type=int, default=128)
+    ap.add_argument("--lazy-k", type=int, default=None,
+                    help="window divisor of the blocked-lazy exact Adam; default: 128 for steps of <= 8192 samples, 64 beyond (the trainer's own rule)")
     ap.add_argument("--tables", default="auto", choices=["auto", "replicate", "shard", "both"],
                     help="N > 1 placement of the embedding tables; both compute the reference's global-batch update. "
                          "replicate: one replica per rank, gradient rows all-gathered (nn.DataParallel's layout, SURVEY "
@@ -90,7 +93,11 @@ def parse():
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="exercise ONLY the rank launcher + rendezvous on CPU (gloo): every rank joins the group, one "
                          "all-reduce, rank 0 prints a JSON line with n_gpus = N and dry_run = true (tests/test_host_logic.py)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.lazy_k_explicit = args.lazy_k is not None
+    if args.lazy_k is None:
+        args.lazy_k = 128 if args.batch <= 8192 else 64
+    return args
 
 
 def self_launch(args):
@@ -245,8 +252,10 @@ class Workload(object):
                 from torch_rechub_amd.models.matching import DSSM
                 tower = {"dims": [256, 128, 64], "activation": "prelu"}
                 m = DSSM(self.user, self.item, user_params=dict(tower), item_params=dict(tower), temperature=0.02)
+        # (a.lazy_k is the headline's value; other batch sizes of the sweep follow the trainer's own rule unless --lazy-k was given)
+        k = a.lazy_k if (a.lazy_k_explicit or (batch or a.batch) <= 8192) else min(a.lazy_k, 64)
         kw = dict(device=str(device), show_progress=False, use_graph=use_graph, table_update=a.table_adam,
-                  lazy_k=a.lazy_k, tables=placement)
+                  lazy_k=k, tables=placement)
         if self.match:
             t = MatchTrainer(m, mode=0, in_batch_neg=True, in_batch_neg_ratio=20, **kw)
         else:
@@ -920,7 +929,7 @@ def main():
                 roofline["regime"] = ("hipGraph-replayed steady-state steps: the deferred window sweep is launched on its "
                                       "side stream after every replay and timed there with HIP events (30 launches) WHILE the "
                                       "captured chain of the step runs beside it, i.e. under contention -- the duration "
-                                      "rocprofv3 reports for adam_lazy_sweep_kernel<4, false> in profiles/r03_*")
+                                      "rocprofv3 reports for adam_lazy_sweep_kernel<4, false> in profiles/r04_bench_kernel_stats.txt (steady-state launches)")
                 roofline["hidden_under_the_step"] = True
                 if args.lazy_k in DEFERRED_SWEEP_PMC_TRAFFIC and args.vocab_scale == 1.0 and best is None:
                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --trace-inner`, mean over the

@@ -75,6 +75,14 @@ def main():
         med = sorted(v)[len(v) // 2]
         print(f"{k:100s} {len(v):7d} {sum(v) / len(v) / 1e3:10.2f} {med / 1e3:10.2f} {min(v) / 1e3:10.2f} {sum(v) / 1e6:10.3f} "
               f"{100.0 * sum(v) / total:6.2f}")
+    for k, v in acc.items():
+        if "adam_lazy_sweep_kernel<4, false>" in k and len(v) >= 40:
+            # after a flush the first lazy_k sweeps replay 1, 2, ... steps (a ramp of lazy_k launches), the eager passes at the end
+            # of bench.py run theirs without a chain beside them: the steady-state launch is the plateau in between
+            p75 = sorted(v)[int(0.75 * len(v))]
+            pl = [x for x in v if abs(x - p75) <= 0.1 * p75]
+            print(f"# {k}: steady-state launches (within 10 % of the 75th percentile, {p75 / 1e3:.1f} us): {len(pl)} of {len(v)}, "
+                  f"mean {sum(pl) / len(pl) / 1e3:.2f} us  <- compare with roofline.avg_launch_ms of the same run")
     if tail:
         print("# gather kernels per launch shape (forward: lane-split kernel 16 samples / workgroup, field-uniform kernel 16 samples /")
         print("# workgroup of 4 wavefronts; backward: ceil8(B / 256) x 26 workgroups):")

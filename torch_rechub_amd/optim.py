@@ -33,7 +33,7 @@ class TableAdam(torch.optim.Adam):
     RING = 1024  # per-step (A, E) history for the lazy replay; lazy_k must be < RING
 
     def __init__(self, params, table_params=(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_k=0,
-                 lazy_small_rows=None, lazy_dense_ratio=None, **kw):
+                 lazy_small_rows=None, lazy_dense_ratio=None, lazy_k_auto=False, **kw):
         """lazy_k <= 1: dense pass over every table row each step (rh_adam_dense).
         lazy_k  > 1: blocked-lazy EXACT mode — rows are refreshed when the batch touches them and at least every
         lazy_k steps (rh_adam_lazy_*); bit-identical to the dense pass after ``flush()``.  Valid only while the table
@@ -72,6 +72,9 @@ class TableAdam(torch.optim.Adam):
         self._small_done = False  # this step's rh_adam_small was folded into the packing launch (small_adam_args)
         self._t_hyper_host = None
         self.lazy_k = int(lazy_k) if tables else 0
+        # lazy_k_auto: at the first lazy step (every row still current) a step of more than 8192 samples takes min(lazy_k, 64):
+        # the pre-gather refresh replays ~ lazy_k / 2 steps per looked-up row, the window sweep's work does not depend on it
+        self._lazy_k_auto = bool(lazy_k_auto)
         if self.lazy_k >= self.RING:
             raise ValueError(f"lazy_k must be < {self.RING}")
         # tables of <= lazy_small_rows rows are stepped densely (K = 1).  Left at its default (4096) the optimizer also
@@ -658,6 +661,9 @@ class TableAdam(torch.optim.Adam):
             for w in rec["weights"]:
                 lookups[id(w)] = lookups.get(id(w), 0) + int(rec["B"])
         changed = False
+        if self._lazy_k_auto and self.lazy_k > 64 and self._touch_log and max(int(r["B"]) for r in self._touch_log) > 8192:
+            self.lazy_k = 64
+            changed = True
         for p in self._tables:
             n = lookups.get(id(p), 0)
             if n and self.table_k(p) != 1 and int(p.shape[0]) <= self.lazy_dense_ratio * n:

@@ -30,7 +30,7 @@ class CTRTrainer(object):
     def __init__(self, model, optimizer_fn=torch.optim.Adam, optimizer_params=None, regularization_params=None,
                  scheduler_fn=None, scheduler_params=None, n_epoch=10, earlystop_patience=10, device="cpu", gpus=None,
                  loss_mode=True, model_path="./", model_logger=None, use_graph=None, show_progress=True,
-                 table_update=None, lazy_k=128, tables=None, shard_min_rows=0, lazy_small_rows=None):
+                 table_update=None, lazy_k=None, tables=None, shard_min_rows=0, lazy_small_rows=None):
         self.model = model
         self.gpus = [] if gpus is None else gpus
         self.device = torch.device(device)
@@ -68,7 +68,9 @@ class CTRTrainer(object):
         # whatever lazy_k is, but touches half as many rows twice as long -- half its HBM traffic beside the step's chain --
         # while the pre-gather refresh of the batch's rows replays twice as far.  Measured on the headline step (same box,
         # step-ahead form): lazy_k 32 / 64 / 96 / 128 / 160 / 192 / 256 / 384 = 0.282 / 0.255 / 0.247 / 0.244 / 0.250 / 0.251 /
-        # 0.256 / 0.276 ms.
+        # 0.256 / 0.276 ms.  The refresh's share grows with the batch (B = 32768: 0.850 ms at 64, 0.901 at 128), so lazy_k = None
+        # (the default) lets the optimizer take 128 for steps of up to 8192 samples and 64 beyond (decided at its first step,
+        # while every row is still current); an explicit lazy_k is kept.
         if table_update is None:
             table_update = os.environ.get("RECHUB_TABLE_ADAM", "lazy")
         if table_update not in ("lazy", "dense"):
@@ -81,7 +83,8 @@ class CTRTrainer(object):
             if lazy_small_rows is not None:  # tables up to this many rows take the dense pass (K = 1) in lazy mode
                 optimizer_params["lazy_small_rows"] = lazy_small_rows
             self.optimizer = TableAdam(self.model.parameters(), table_params=tables,
-                                       lazy_k=(lazy_k if table_update == "lazy" else 0), **optimizer_params)
+                                       lazy_k=((128 if lazy_k is None else lazy_k) if table_update == "lazy" else 0),
+                                       lazy_k_auto=lazy_k is None, **optimizer_params)
         else:
             self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         table_ids = {id(p) for p in tables}
