@@ -526,6 +526,10 @@ int rh_pack_grads(const RhPackItem* items, int n, float* flat, void* stream);
 /* the same + the Adam step of every packed parameter on the element just summed (= rh_pack_grads then rh_adam_small over the
  * same n parameters, sdesc in rh_adam_small's layout, hyper already holding this step's scalars): one launch */
 int rh_pack_grads_adam(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper, void* stream);
+/* rh_pack_grads_adam whose launch also counts an opening of `gate` (as rh_adam_sweep_gate_open) when it STARTS: captured
+ * behind the end-of-step table launch it announces that launch's end without a launch of its own.  gate may be NULL. */
+int rh_pack_grads_adam_gate(const RhPackItem* items, int n, float* flat, const int64_t* sdesc, const double* hyper,
+                            int64_t* gate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blocked-lazy EXACT Adam (same arithmetic as rh_adam_dense, bit-identical results, ~1/K of its HBM traffic)

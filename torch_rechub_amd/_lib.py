@@ -107,6 +107,7 @@ SIGNATURES = {
                                    c_ptr, c_ptr, c_int, c_ptr],
     "rh_pack_grads": [c_ptr, c_int, c_ptr, c_ptr],
     "rh_pack_grads_adam": [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_pack_grads_adam_gate": [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_head_nblocks": [c_int],
     "rh_head_fwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_head_bwd": [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],

@@ -187,7 +187,7 @@ class DenseGradBucket(object):
             for i, p in enumerate(self.params):
                 p.grad = self.view(i)
 
-    def pack(self, deferred_items, adam=None):
+    def pack(self, deferred_items, adam=None, gate=None):
         """Single-GPU fast path: ONE launch (rh_pack_grads) fills the flat bucket from whatever each parameter has -- a
         slab of partial rows registered in ``ops.deferred`` (summed in fixed order), a plain ``.grad`` tensor (copied; added
         on top of a slab when both exist), or nothing (zeros) -- instead of torch.cat + one reduction launch per slab."""
@@ -214,7 +214,10 @@ class DenseGradBucket(object):
                 it.src, it.nparts, it.stride, it.add = 0, 0, 0, 0
             self.packed[i] = True
         self._pack_keep = keep  # alive until the launch is enqueued (and, under capture, pooled by the graph)
-        if adam is not None:  # (sdesc, hyper) of optim.TableAdam.small_adam_args(): the dense parameters' Adam step rides along
+        if adam is not None and gate is not None:  # ... and the launch opens the deferred sweep's gate when it starts (optim.py)
+            _lib.call("rh_pack_grads_adam_gate", ctypes.cast(items, ctypes.c_void_p), n, ops._p(self.flat), ops._p(adam[0]),
+                      ops._p(adam[1]), ops._p(gate), ops._stream())
+        elif adam is not None:  # (sdesc, hyper) of optim.TableAdam.small_adam_args(): the dense parameters' Adam step rides along
             _lib.call("rh_pack_grads_adam", ctypes.cast(items, ctypes.c_void_p), n, ops._p(self.flat), ops._p(adam[0]),
                       ops._p(adam[1]), ops._stream())
         else:

@@ -25,6 +25,7 @@ EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kern
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
+LATE_PACK = _lib.ab("latepack")  # False (RECHUB_AB=latepack=0): the gate is opened by a one-lane launch of its own
 LOOK_DEPTH = 2  # step-ahead form: batches beyond the next one whose lookups in the coming sweep's window are refreshed early
 
 
@@ -135,6 +136,7 @@ class TableAdam(torch.optim.Adam):
                 # (rh_adam_sweep_gate_open): [openings, wall clock of the last one]
                 self._gate = torch.zeros(2, dtype=torch.int64, device=dev)
                 self._gate_seen = 0  # openings issued so far (one per replay of a step-ahead graph)
+                self._gate_by_pack = False
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
@@ -602,6 +604,15 @@ class TableAdam(torch.optim.Adam):
         return not (grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or
                     not any(id(w) in grp["local"] for w in rec["weights"]))
 
+    def gate_for_late_pack(self):
+        """Called by the trainer where it would launch the dense gradients' packing + Adam: while the step-ahead graph is
+        being captured, returns the gate the packing launch shall open -- the trainer then launches it BEHIND step() -- else None."""
+        ah = getattr(self, "_step_ahead", None)
+        if ah is None or graphs.active() is not ah["seg"] or not torch.cuda.is_current_stream_capturing() or not LATE_PACK:
+            return None
+        self._gate_by_pack = True
+        return self._gate
+
     def _merge_ahead_ok(self, rec, grp):
         """Will _merged_step of the step being captured see exactly this gather over exactly this table group?"""
         groups = self._lazy_setup()
@@ -627,7 +638,9 @@ class TableAdam(torch.optim.Adam):
                       rec["F"], ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"],
                       ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]),
                       ops._p(a["dense_out"]), ops._p(a["label_out"]), LOOK_DEPTH, stream)
-            _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
+            if not self._gate_by_pack:  # (else the packing launch behind this one opens it: gate_for_late_pack)
+                _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
+            self._gate_by_pack = False
             self._sweep_pending = True
             return True
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream

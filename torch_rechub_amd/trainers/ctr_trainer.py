@@ -215,13 +215,21 @@ class CTRTrainer(object):
             packed = self.optimizer._bucket is not None  # attached in THIS step: pack it the plain way below
         if packed and not all(p.grad is not None or id(p) in items for p in self.bucket.params):
             raise RuntimeError("a dense parameter stopped receiving gradients; rebuild the trainer")
+        late_gate = None
         if defer:
             # with this step's Adam scalars already on the device (the step's scalar launch computed them in the forward),
             # the packing launch also steps the dense parameters: rh_pack_grads + rh_adam_small as ONE launch
-            self.bucket.pack(items, adam=self.optimizer.small_adam_args())
+            adam = self.optimizer.small_adam_args()
+            # step-ahead form being captured: the packing launch goes BEHIND the end-of-step table launch (the two are
+            # independent) and opens the deferred sweep's gate when it starts, instead of a launch of its own doing that
+            late_gate = self.optimizer.gate_for_late_pack() if adam is not None else None
+            if late_gate is None:
+                self.bucket.pack(items, adam=adam)
         elif packed or self.dp is not None:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
+        if late_gate is not None:
+            self.bucket.pack(items, adam=adam, gate=late_gate)
         return report
 
     def _grad_root(self, loss):
