@@ -57,7 +57,7 @@ const char* rh_last_error(void);
 #define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
                                   the residency cap that lets the step's chain keep its wave slots and issue cycles */
 #define RH_TUNE_SWEEP_STAGGER_NS 12 /* rh_adam_sweep_stagger: hold-back in nanoseconds (default 15000; 0 = no launch) */
-#define RH_TUNE_SWEEP_GATE_NS 13 /* rh_adam_sweep_gate: hold-back behind the opening, ns (default 28000) */
+#define RH_TUNE_SWEEP_GATE_NS 13 /* rh_adam_sweep_gate: hold-back behind the opening, ns (default 32000) */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
 #define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build (default) */
 #define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront
@@ -567,7 +567,7 @@ int rh_adam_sweep_stagger(void* stream);
  * one), zero-initialised by the caller.  rh_adam_sweep_gate_open: a one-lane launch that counts an opening -- captured as the
  * last launch of a step's hipGraph it announces on every replay that the step has finished.  rh_adam_sweep_gate occupies
  * `stream` until the count has reached `expected` and RH_TUNE_SWEEP_GATE_NS have passed since that opening.  A gate not opened
- * within 50 ms gives up and sets bit RH_ERR_GATE_TIMEOUT of *err_flag (the error word of rh_embed_fwd). */
+ * within 2 s gives up and sets bit RH_ERR_GATE_TIMEOUT of *err_flag (the error word of rh_embed_fwd). */
 #define RH_ERR_GATE_TIMEOUT 64
 int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int32_t* err_flag, void* stream);
 int rh_adam_sweep_gate_open(int64_t* gate, void* stream);

@@ -24,7 +24,7 @@ int g_sweep_grid = 0;  // tuning knob RH_TUNE_SWEEP_GRID (0 = default 8192 workg
 // 0.360 / 0.355 / 0.318 / 0.302 / 0.334 / 0.326 / 0.345 ms.  (An LDS-padding cap reached 0.311 ms and was removed: it also
 // kept LDS-hungry kernels of the chain off the CU.)
 int g_deferred_grid = 512;
-int g_gate_ns = 28000;  // RH_TUNE_SWEEP_GATE_NS: rh_adam_sweep_gate, hold-back behind the opening (the end of the step's graph)
+int g_gate_ns = 32000;  // RH_TUNE_SWEEP_GATE_NS: rh_adam_sweep_gate, hold-back behind the opening (the end of the step's graph)
 int g_stagger_ns = 15000;  // RH_TUNE_SWEEP_STAGGER_NS (untraced landscape, tools/period_hist.py: 12-18 us clean, 9 us 21 % slow steps)
 
 constexpr int kVecPerThread = 4;                                // float4 per thread per stream
@@ -1112,13 +1112,13 @@ extern "C" int rh_adam_sweep_stagger(void* stream) {
 // until the count has reached `expected` and RH_TUNE_SWEEP_GATE_NS have passed SINCE THAT OPENING.  An event record between
 // two graph launches cost the chain ~7 us of idle queue (this launch ~2); and a sweep that is released late -- the one before
 // it ran long -- is not held back any further, where a fixed delay behind an event added itself to every sweep and left the
-// side queue (delay + 231 us per step) no slack against a 245 us period.  A gate not opened within 50 ms gives up and raises
+// side queue (delay + 231 us per step) no slack against a 245 us period.  A gate not opened within 2 s gives up and raises
 // RH_ERR_GATE_TIMEOUT in *err_flag.
 extern "C" int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int32_t* err_flag, void* stream) {
   RH_REQUIRE(gate != nullptr, RH_E_BADARG, "rh_adam_sweep_gate: null gate");
   hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const long long*>(gate), (long long)expected,
-                     (long long)(g_gate_ns > 0 ? g_gate_ns : 0) * wall_khz() / 1000000, 50 * wall_khz(), err_flag);
+                     (long long)(g_gate_ns > 0 ? g_gate_ns : 0) * wall_khz() / 1000000, 2000 * wall_khz(), err_flag);
   RH_LAUNCH_CHECK("rh_adam_sweep_gate");
   return 0;
 }

@@ -138,7 +138,7 @@ def check_errors(device=None):
             if v & 1:
                 raise IndexError("torch_rechub_amd: an embedding index was out of range (index < 0 or >= vocab_size)")
             if v & 64:  # RH_ERR_GATE_TIMEOUT
-                raise RuntimeError("torch_rechub_amd: a deferred table sweep waited 50 ms for a training step that never started "
+                raise RuntimeError("torch_rechub_amd: a deferred table sweep waited 2 s for a training step that never started "
                                    "(rh_adam_sweep_gate); the tables may be inconsistent")
             raise RuntimeError(f"torch_rechub_amd: kernel error flag {v}")
 

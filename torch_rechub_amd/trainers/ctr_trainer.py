@@ -294,7 +294,9 @@ class CTRTrainer(object):
     # (form, residency cap of the deferred sweep in workgroups, hold-back of the sweep behind the end of the step's graph in ns
     # -- step-ahead form, rh_adam_sweep_gate: WHERE in the next step's chain the sweep's workgroups are dispatched decides
     # whether they spread evenly over the SIMDs; 22 us was a 305 us step where 28 us was a 245 us one, tools/period_hist.py)
-    TUNE_CANDIDATES = (("deferred", 512, 28000), ("deferred", 512, 36000), ("deferred", 256, 28000), ("inline", 0, 0))
+    # (the opening is counted by the packing launch, ~5 us before the graph ends: 32 / 40 us here = 28 / 36 us behind a separate
+    # opening launch, where the landscape was measured)
+    TUNE_CANDIDATES = (("deferred", 512, 32000), ("deferred", 512, 40000), ("deferred", 256, 32000), ("inline", 0, 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
     def _tune_step_form(self, loader):
