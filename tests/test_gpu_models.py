@@ -200,6 +200,21 @@ def test_device_loader_training_equals_host_loader_training(use_graph):
         assert abs(la2 - lb2) < 1e-5
 
 
+def test_device_loader_generation_counts_out_of_band_moves():
+    """DeviceDataLoader.generation tells a consumer that looked a batch ahead (optim.TableAdam, relaxed join / step ahead)
+    that its preview is void: bumped by reshuffle(), not by constructing views."""
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    N, B = 64, 8
+    sparse = torch.arange(N * 2, dtype=torch.int64, device=dev()).view(N, 2)
+    dl = DeviceDataLoader(sparse, ["a", "b"], None, [], torch.zeros(N, device=dev()), B, shuffle=True)
+    g0 = dl.generation
+    args = dl.assembly_args(B)
+    assert args is not None and args["B"] == B and args["N"] == N and dl.generation == g0
+    dl.reshuffle()
+    assert dl.generation == g0 + 1 and int(dl.pos) == 0
+    assert sorted(dl.perm.tolist()) == list(range(N))
+
+
 def _collision_free_columns(vocabs, widths, n_batches, B, seed):
     """(n_batches * B, sum(widths)) indices in which no table row occurs twice inside one batch (fields listed in
     ``vocabs`` with ``widths`` columns each; columns of one field share its table): the scatter-add then has no

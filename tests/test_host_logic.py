@@ -459,3 +459,42 @@ def test_mlp_head_after_finds_only_a_lone_output_layer_behind_inactive_dropouts(
     from torch_rechub_amd import ops as _ops
     monkeypatch.setattr(_ops, "FUSE_DICE_HEAD", False)
     assert MLP.head_after(mods, 7, 16, mods[5], mods[6]) is None
+
+
+def test_ab_switch_parsing(monkeypatch):
+    """RECHUB_AB="name=0,other=1": ONE variable for the same-box A/B twins of benchmarks (torch_rechub_amd/_lib.py)."""
+    from torch_rechub_amd import _lib
+    monkeypatch.delenv("RECHUB_AB", raising=False)
+    assert _lib.ab("chain") is True and _lib.ab("chain", default=False) is False
+    monkeypatch.setenv("RECHUB_AB", "chain=0, ahead=off,lookahead=1,,junk")
+    assert _lib.ab("chain") is False and _lib.ab("ahead") is False and _lib.ab("lookahead") is True
+    assert _lib.ab("latepack") is True  # not named: the default
+    assert _lib.ab("hain") is True      # exact names only
+
+
+def test_bench_lazy_k_default_follows_the_trainers_rule(monkeypatch):
+    """bench.py --lazy-k: default = what CTRTrainer(lazy_k=None) takes (128 up to 8192 samples per step, 64 beyond); an explicit
+    value is kept for every batch size of the sweep."""
+    import sys
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.lazy_k == 128 and a.lazy_k_explicit is False
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "32768"])
+    a = bench.parse()
+    assert a.lazy_k == 64 and a.lazy_k_explicit is False
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "32768", "--lazy-k", "96"])
+    a = bench.parse()
+    assert a.lazy_k == 96 and a.lazy_k_explicit is True
+
+
+def test_step_form_candidates_carry_form_grid_and_hold_back():
+    """CTRTrainer.TUNE_CANDIDATES: (form, residency cap, hold-back ns) triples; bench.py reports all three."""
+    from torch_rechub_amd.trainers import CTRTrainer
+    cands = CTRTrainer.TUNE_CANDIDATES
+    assert all(len(c) == 3 for c in cands)
+    assert {c[0] for c in cands} == {"deferred", "inline"}
+    assert [c for c in cands if c[0] == "inline"] == [("inline", 0, 0)]
+    assert all(c[1] in (256, 512) and 20000 <= c[2] <= 60000 for c in cands if c[0] == "deferred")
+    assert len({c[:2] for c in cands}) < len(cands)  # at least one (form, grid) comes with two hold-backs
+
