@@ -309,6 +309,7 @@ class DeviceDataLoader(object):
         x, y, sp, de, seqs = self._buffers(B)
         s = ops._stream()
         if assemble:
+            self.generation += 1  # the static batch buffers are overwritten: a batch somebody prepared ahead is gone
             _lib.call("rh_batch_gather", ops._p(self.perm), ops._p(self.pos), self.N, B, ops._p(self.sparse), self.F,
                       ops._p(self.dense), self.NDL, ops._p(self.label), ops._p(sp), ops._p(de),
                       ops._p(y if self.label is not None else None), s)
