@@ -1,0 +1,119 @@
+"""Executable model of the blocked-lazy optimizer's ROW PROTOCOL in the step-ahead form: which launch touches
+which table rows, and which launches may be in flight at the same time.  No kernel runs here -- the model restates what
+csrc/optim.hip's parts do to a row's last-step word (`last`) and checks the two claims the design rests on:
+
+  safety     a deferred window sweep S_t (launched behind the end-of-step launch TR(t), allowed to run under the next `depth`
+             replays) never works on a row that an end-of-step launch running meanwhile also works on;
+  exactness  every row receives every step exactly once, in order, the gradient of step t at step t, and a row is at state
+             t - 1 when the gather of step t reads it -- i.e. what torch.optim.Adam's dense step does (reference:
+             trainers/ctr_trainer.py:59-61,99), executed lazily.
+
+The negative controls run the same model with one batch of lookahead less than the sweep's lifetime needs, and with the
+lookahead switched off under the relaxed join: the safety check must then FAIL (the rows in question are the ~B*F/K per step the
+lookahead exists for)."""
+import numpy as np
+import pytest
+
+
+def simulate(rows, K, B, steps, depth, look, seed):
+    """One table of `rows` rows, window divisor K, `steps` training steps of B lookups.  depth = replays a sweep may overlap,
+    look = batches beyond the next one whose lookups in the coming sweep's window are refreshed early.
+    Returns (conflicts, violations): rows worked on by a sweep and by an overlapping end-of-step launch; exactness failures."""
+    rng = np.random.default_rng(seed)
+    w = -(-rows // K)
+    batches = [rng.integers(0, rows, B) for _ in range(steps + look + 3)]
+    last = np.zeros(rows, dtype=np.int64)          # step every row is at
+    applied = [[] for _ in range(rows)]            # (step, with_gradient) per row, in order
+    grad_pending = np.zeros(rows, dtype=bool)      # gradient row not yet consumed
+    violations = []
+
+    def bring(r, t, who):
+        # replay the zero-gradient steps last[r] + 1 .. t - 1, then step t with the gradient row if it is non-zero
+        for s in range(last[r] + 1, t):
+            applied[r].append((s, False))
+        applied[r].append((t, bool(grad_pending[r])))
+        grad_pending[r] = False
+        last[r] = t
+
+    def window(t):
+        lo = ((t - 1) % K) * w
+        return lo, min(rows, lo + w)
+
+    # the ordinary head of the first step: refresh batch(1) to state 0 = nothing to do
+    live = []          # sweeps in flight: (t, row set it may still work on, replays it may still overlap)
+    conflicts = 0
+    for t in range(1, steps + 1):
+        # gather of step t reads batch(t): rows must be at state t - 1
+        bt = np.unique(batches[t])
+        if not (last[bt] == t - 1).all():
+            violations.append(("stale row read by the gather", t))
+        grad_pending[bt] = True                    # backward of step t leaves gradient rows
+        # TR(t): touched rows of batch t + refresh of batch t + 1 + lookahead, every part claims by last < t
+        lo, hi = window(t)
+        tr_rows = set(bt.tolist()) | set(np.unique(batches[t + 1]).tolist())
+        for j in range(2, 2 + look):
+            nb = np.unique(batches[t + j])
+            tr_rows |= set(nb[(nb >= lo) & (nb < hi)].tolist())
+        # sweeps still in flight must not share a row with this launch
+        for st, srows, left in live:
+            conflicts += len(srows & tr_rows)
+        for r in tr_rows:
+            if last[r] < t:
+                bring(r, t, "tr")
+        if grad_pending.any():
+            violations.append(("gradient row left behind", t))
+        # sweeps age: the one that has overlapped `depth` replays is joined before the NEXT end-of-step launch
+        live = [(st, srows, left - 1) for st, srows, left in live if left - 1 > 0]
+        # S_t: launched behind TR(t); the rows it will work on = window rows behind step t NOW (it reads `last` when it gets there,
+        # any time during its life -- rows stamped later by an overlapping launch are exactly the conflicts counted above)
+        srows = {r for r in range(lo, hi) if last[r] < t}
+        for r in srows:
+            bring(r, t, "sweep")
+        if depth > 0:  # (depth 0 = strict join: the sweep is joined before the next end-of-step launch)
+            live.append((t, srows, depth))
+    # flush: everything to the last step
+    for r in range(rows):
+        if last[r] < steps:
+            for s in range(last[r] + 1, steps + 1):
+                applied[r].append((s, False))
+            last[r] = steps
+    for r in range(rows):
+        if [s for s, _ in applied[r]] != list(range(1, steps + 1)):
+            violations.append(("row did not receive every step once, in order", r))
+            break
+    want = np.zeros((steps + 1, rows), dtype=bool)
+    for t in range(1, steps + 1):
+        want[t, np.unique(batches[t])] = True
+    for r in range(rows):
+        got = {s for s, g in applied[r] if g}
+        if got != set(np.nonzero(want[:, r])[0].tolist()):
+            violations.append(("gradient applied at the wrong step", r))
+            break
+    return conflicts, violations
+
+
+@pytest.mark.parametrize("rows,K,B", [(4096, 64, 256), (1000, 8, 300), (50000, 128, 2048)])
+def test_step_ahead_protocol_is_safe_and_exact(rows, K, B):
+    """Default form: a sweep may run under the next TWO replays (joined before the third), lookahead over two batches."""
+    conflicts, violations = simulate(rows, K, B, steps=3 * K + 5, depth=2, look=2, seed=1)
+    assert conflicts == 0 and violations == []
+
+
+def test_relaxed_join_protocol_is_safe_and_exact():
+    """Eager-head form: a sweep may run under ONE further head (joined before the one after), lookahead over one batch."""
+    conflicts, violations = simulate(4096, 64, 256, steps=200, depth=1, look=1, seed=2)
+    assert conflicts == 0 and violations == []
+
+
+@pytest.mark.parametrize("depth,look", [(2, 1), (1, 0)])
+def test_one_batch_of_lookahead_less_is_a_race(depth, look):
+    """Negative control: with less lookahead than the sweep's lifetime needs, sweeps and end-of-step launches DO meet on rows --
+    the B * F / K rows per step the lookahead exists for.  (Exactness of the bookkeeping itself is unaffected in this
+    sequential model; on the device the two launches would be writing the same row concurrently.)"""
+    conflicts, violations = simulate(4096, 64, 256, steps=200, depth=depth, look=look, seed=3)
+    assert conflicts > 50 and violations == []
+
+
+def test_strict_join_needs_no_lookahead():
+    conflicts, violations = simulate(4096, 64, 256, steps=200, depth=0, look=0, seed=4)
+    assert conflicts == 0 and violations == []
