@@ -498,3 +498,20 @@ def test_step_form_candidates_carry_form_grid_and_hold_back():
     assert all(c[1] in (256, 512) and 20000 <= c[2] <= 60000 for c in cands if c[0] == "deferred")
     assert len({c[:2] for c in cands}) < len(cands)  # at least one (form, grid) comes with two hold-backs
 
+
+
+def test_environment_switches_stay_few_and_documented():
+    """at most twelve RECHUB_* switches in the product, each named in INTEGRATION.md; every A/B twin of
+    RECHUB_AB that the code reads is listed there too."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "torch_rechub_amd", "**", "*.py"), recursive=True) + [os.path.join(root, "bench.py")]
+    text = "\n".join(open(f).read() for f in files)
+    names = set(re.findall(r"RECHUB_[A-Z_]+", text))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert len(names) <= 12, sorted(names)
+    assert all(n in doc for n in names), sorted(n for n in names if n not in doc)
+    twins = set(re.findall(r"_lib\.ab\(\"([a-z]+)\"", text)) | set(re.findall(r"[^_]ab\(\"([a-z]+)\"", text))
+    assert twins and all(t + "=0" in doc for t in twins), sorted(t for t in twins if t + "=0" not in doc)
