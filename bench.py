@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives) even on one GPU")
     ap.add_argument("--no-kernel-sweep", action="store_true", help="skip the gather-kernel batch sweep")
+    ap.add_argument("--no-twin-check", action="store_true",
+                    help="skip the dense-Adam twin that re-trains the same steps after the flush (dense_twin_check)")
     ap.add_argument("--brief", action="store_true",
                     help="headline only: skip batch_sweep / zipf / secondary_configs / step_accounting (SURVEY 8d extras)")
     ap.add_argument("--no-step-accounting", action="store_true", help="skip the nested rocprofv3 pass (step_accounting)")
@@ -486,6 +488,97 @@ def cpu_model_string():
     return platform.processor() or "unknown"
 
 
+def dense_twin_check(args, wl, trainer, loader, device, rng0, n_sample=65536):
+    """After the flush (outside every timed region): a table_update="dense" twin -- same initial weights, same batches in
+    the same order, same dropout masks, every table row stepped by rh_adam_dense every step, which IS what the reference's
+    torch.optim.Adam does (trainers/ctr_trainer.py:59-61, 99) -- is advanced exactly as many steps as the timed
+    trainer has taken, and n_sample table rows (drawn over all tables in proportion to their size) are compared, weights and
+    both Adam moments:
+    * rows no batch looked up (the bulk of a 10 M-row table): their whole history is `g = wd * p` steps, which the lazy
+      optimizer replayed in registers up to K steps late, in the window sweeps beside the chain, in the step-ahead launch's
+      refresh / lookahead parts and in the final flush.  They must equal the twin's BIT FOR BIT (raises otherwise);
+    * rows some batch looked up: their gradient is a sum of float atomics in hardware order on both sides and the two
+      trainings drift apart by that noise (amplified by Adam's division by sqrt(v)), so these are compared to a tolerance
+      and the share inside it is reported (raises below 90 %: a wrong row, batch or step count moves everything).
+    Returns the dict that goes into the JSON line."""
+    import copy
+
+    from torch_rechub_amd import ops
+    opt = trainer.optimizer
+    T = int(opt._t_step.item())
+    B = loader.batch_size
+    if int(loader.pos.item()) != (T * B) % loader.N or T * B > loader.N:
+        return {"skipped": f"loader position {int(loader.pos.item())} is not steps x batch = {T} x {B} (wrapped or moved)"}
+    a2 = copy.copy(args)
+    a2.table_adam = "dense"
+    keep = wl.args
+    wl.args = a2
+    try:
+        ops._dropout_rng(device).copy_(rng0)  # the twin draws the masks the timed run drew (device-resident seed + counter)
+        m2, t2, ld2 = wl.build(None, True, batch=B)
+    finally:
+        wl.args = keep
+    ld2.perm.copy_(loader.perm)
+    ld2.pos.zero_()
+    done = 0
+    t0 = time.perf_counter()
+    while done < T:
+        if T - done < 3 and t2._graph is None:  # (fewer steps than the capture's eager warm-up)
+            x, y = ld2.load_next()
+            t2.train_step(x, y)
+            done += 1
+        else:
+            done += t2._graphed_step(ld2)[1]
+    t2.flush()
+    torch.cuda.synchronize()
+    if int(t2.optimizer._t_step.item()) != T:
+        raise RuntimeError(f"dense twin ran {int(t2.optimizer._t_step.item())} steps, wanted {T}")
+    g = torch.Generator(device=device).manual_seed(77)
+    looked = loader.perm[:T * B]
+    o1, o2 = opt, t2.optimizer
+    total = sum(int(p.shape[0]) for p in o1._tables)
+    out = {"steps": T, "rows_sampled": 0, "untouched_rows": 0, "touched_rows": 0, "untouched_bitwise_equal": True,
+           "touched_elements": 0, "touched_elements_within_tol": 0, "touched_max_abs_diff": 0.0}
+    names = {id(m_.weight): n for n, m_ in trainer.model.embedding.embed_dict.items()}
+    col_of = {n: i for i, n in enumerate(wl.sparse_names)}
+    for p1, p2 in zip(o1._tables, o2._tables):
+        rows = int(p1.shape[0])
+        n = min(rows, max(16, int(round(n_sample * rows / total))))
+        idx = torch.randperm(rows, device=device, generator=g)[:n] if rows <= 4 * n else \
+            torch.randint(0, rows, (n,), device=device, generator=g).unique()
+        col = col_of[names[id(p1)]]
+        touched = torch.isin(idx, wl.sparse[looked, col])
+        un = idx[~touched]
+        to = idx[touched]
+        out["rows_sampled"] += int(idx.numel())
+        out["untouched_rows"] += int(un.numel())
+        out["touched_rows"] += int(to.numel())
+        for what, x1, x2 in (("weight", p1.detach(), p2.detach()), ("exp_avg", o1.state[p1]["exp_avg"], o2.state[p2]["exp_avg"]),
+                             ("exp_avg_sq", o1.state[p1]["exp_avg_sq"], o2.state[p2]["exp_avg_sq"])):
+            if un.numel() and not torch.equal(x1[un], x2[un]):
+                out["untouched_bitwise_equal"] = False
+                d = (x1[un] - x2[un]).abs()
+                raise RuntimeError(f"dense twin: {what} of table {names[id(p1)]} ({rows} rows): {int((d > 0).sum())} elements of "
+                                   f"{int(un.numel())} never-looked-up rows differ from dense Adam after {T} steps (max {float(d.max()):.3e})")
+            if to.numel() and what == "weight":
+                d = (x1[to] - x2[to]).abs()
+                ok = d <= 2e-5 + 1e-3 * x2[to].abs()
+                out["touched_elements"] += int(d.numel())
+                out["touched_elements_within_tol"] += int(ok.sum())
+                out["touched_max_abs_diff"] = max(out["touched_max_abs_diff"], float(d.max()))
+    out["touched_within_tol_frac"] = round(out["touched_elements_within_tol"] / max(1, out["touched_elements"]), 5)
+    out["twin_seconds"] = round(time.perf_counter() - t0, 2)
+    out["what"] = ("table_update='dense' twin (rh_adam_dense over every row every step = torch.optim.Adam semantics) advanced the "
+                   "same steps on the same batches after the timed trainer's flush; sampled rows no batch looked up: weight, "
+                   "exp_avg, exp_avg_sq bit-equal; looked-up rows (float-atomic gradient sums on both sides): weights within "
+                   "2e-5 + 1e-3 |x|")
+    if out["touched_within_tol_frac"] < 0.9:
+        raise RuntimeError(f"dense twin: only {out['touched_within_tol_frac']:.3f} of the looked-up rows' elements agree: {out}")
+    del m2, t2, ld2
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_mode(args, wl, placement, use_graph, world, rank, device, profile):
     """Build, warm up into the steady state, time exactly --steps steps; optionally the per-kernel eager pass; then the
     flush (timed separately) and the no-row-behind check.  Returns a dict."""
@@ -501,6 +594,7 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
     lazy = getattr(opt, "lazy_k", 0) > 1
     res = {"tables": placement}
     graph_ok = False
+    rng0 = ops._dropout_rng(device).clone()  # (seed, call counter) of the fused dropout before the first step: dense_twin_check
 
     def eager_step():
         x, y = loader.load_next()
@@ -617,6 +711,10 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
         if behind != t_now:
             raise RuntimeError(f"flush left rows behind: step counter {t_now}, min(last) {behind}")
     ops.check_errors(device)
+    if profile and lazy and graph_ok and trainer.dp is None and world == 1 and wl.name in ("deepfm", "dcnv2") and \
+            not args.no_twin_check and not args.acct_only:
+        res["dense_twin_check"] = dense_twin_check(args, wl, trainer, loader, device, rng0)
+        print(f"[bench] dense twin check: {res['dense_twin_check']}", file=sys.stderr)
     res["total_elems"] = sum(p.numel() for p in opt._tables) if hasattr(opt, "_tables") else 0
     # lazy sweep: bytes one launch must move = its 1/K window of every table (read + write p, m, v; 4 B/row of `last`
     # both ways) + the K=1 (small) tables in full incl. their gradient.  The other 1 - 1/K of the dense pass's traffic
@@ -1138,6 +1236,7 @@ def main():
             },
             "flush_ms": head["flush_ms"],
             "rows_behind_after_flush": head.get("rows_behind_after_flush"),
+            "dense_twin_check": head.get("dense_twin_check"),
             "host_enqueue_ms_per_step": round(head.get("host_enqueue_ms_per_step", 0.0), 4),
             "epoch_amortised": {"steps_per_epoch": steps_per_epoch,
                                 "value": round(world * B * steps_per_epoch /

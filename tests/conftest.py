@@ -13,6 +13,30 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "noise_tolerant: a HIP-vs-HIP comparison of two runs whose fp32 atomic order differs "
+                                       "(tolerance with an outlier budget); ordered behind every oracle / bit-exact test")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Order of the GPU suite under ``-x``: (0) everything that compares with the oracle, the reference's golden vectors or
+    demands bit-equality -- kernels, full-size properties, the bit-equality tests of the captured step forms bench.py times --
+    then (1) the tolerance comparisons with the reference trainer's trajectory, and LAST (2) the tests marked
+    ``noise_tolerant``: two HIP runs compared under nondeterministic float atomics, where Adam turns summation-order noise
+    of near-cancelling gradient elements into lr-sized steps.  Round 4's driver run stopped at such a test (#318 of 384) and
+    never executed the 66 tests behind it, among them every bit-equality test of the timed step form.  The sort is stable:
+    inside a class the file order is kept."""
+    def rank(item):
+        if item.get_closest_marker("gpu") is None:
+            return 0
+        if item.get_closest_marker("noise_tolerant") is not None:
+            return 3
+        name = item.nodeid
+        if "test_gpu_kernels.py" in name or "test_gpu_properties.py" in name:
+            return 0
+        if "bitwise" in name or "bit_identical" in name or "leaves_no_row_behind" in name or "abandoned_step" in name:
+            return 1
+        return 2
+    items.sort(key=rank)
 
 
 @pytest.fixture(autouse=True)

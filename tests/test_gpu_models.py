@@ -156,9 +156,114 @@ def _deepfm(vocabs, seed):
     return DeepFM(dense + sparse, sparse, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}), dense, sparse
 
 
+def _duplicate_samples(block, B):
+    """Every batch of ``block`` (n_batches * B/2 rows) followed by a copy of itself: B rows per batch in which sample
+    j + B/2 IS sample j.  With ``_collision_free_columns`` underneath, every looked-up table row then receives exactly two
+    IDENTICAL gradient rows per batch -- float atomics whose result does not depend on their order (0 + g, g + g) -- so
+    in-batch duplicates (two lookups racing for one row's claim and one row's gradient) stay comparable bit for bit."""
+    h = B // 2
+    parts = []
+    for b in range(block.shape[0] // h):
+        parts += [block[b * h:(b + 1) * h]] * 2
+    return torch.cat(parts, 0).contiguous()
+
+
+def _loader_twin_data(layout, nb, B, seed):
+    """(vocabs, sparse, dense, label) for the loader-equivalence tests: 'collision_free' = no table row twice inside a
+    batch; 'duplicated_samples' = every sample twice inside its batch (see _duplicate_samples)."""
+    vocabs = [65, 100, 300, 1000, 5000, 20000]
+    g = torch.Generator().manual_seed(seed + 1)
+    if layout == "collision_free":
+        sparse = _collision_free_columns(vocabs, [1] * len(vocabs), nb, B, seed=seed)
+        dense = torch.rand(nb * B, 4, generator=g)
+        label = (torch.rand(nb * B, generator=g) < 0.3).float()
+    else:
+        h = B // 2
+        sparse = _duplicate_samples(_collision_free_columns(vocabs, [1] * len(vocabs), nb, h, seed=seed), B)
+        dense = _duplicate_samples(torch.rand(nb * h, 4, generator=g), B)
+        label = _duplicate_samples((torch.rand(nb * h, generator=g) < 0.3).float(), B)
+    return vocabs, sparse, dense, label
+
+
+def _host_column_batches(sparse, names, dense, dnames, label, B):
+    out = []
+    for i in range(sparse.shape[0] // B):
+        sl = slice(i * B, (i + 1) * B)
+        xb = {n: sparse[sl, j] for j, n in enumerate(names)}
+        xb.update({n: dense[sl, j] for j, n in enumerate(dnames)})
+        out.append((xb, label[sl]))
+    return out
+
+
+def _assert_bitwise_twins(ta, tb, ma, mb):
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    oa, ob = ta.optimizer, tb.optimizer
+    for pa, pb in zip(oa._tables, ob._tables):
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+
+
+@pytest.mark.parametrize("layout", ["collision_free", "duplicated_samples"])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_device_loader_training_equals_host_loader_training(use_graph):
-    """Same batches through (a) host dict batches and (b) the HBM-resident loader (+ hipGraph replay): same weights."""
+def test_device_loader_training_equals_host_loader_training_bitwise(use_graph, layout):
+    """Same batches through (a) host dict batches, eager steps and (b) the HBM-resident loader (+ hipGraph replay in the
+    step-ahead form): the SAME weights, Adam moments and epoch loss, bit for bit.  Round 4 compared the two under random
+    duplicate lookups, i.e. under float atomics in an unspecified order, with a tolerance -- and the driver's run failed on
+    noise.  Here no fp32 sum depends on an order: the batches are collision-free, or hold every sample twice
+    (identical addends), so any difference is a wrong batch, a wrong row or a wrong optimizer step.  Lazy tables (K = 4,
+    lazy_small_rows = 8) so that claims, replay, window sweep and the final flush are all on the path."""
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 12, 64
+    vocabs, sparse, dense, label = _loader_twin_data(layout, nb, B, seed=41)
+    if layout == "duplicated_samples":  # the fixture does what it says: sample j + B/2 is sample j, rows repeat inside a batch
+        assert torch.equal(sparse[:B // 2], sparse[B // 2:B]) and sparse[:B, 0].unique().numel() == B // 2
+    ma, dfe, sfe = _deepfm(vocabs, 1)
+    mb, _, _ = _deepfm(vocabs, 1)
+    mb.load_state_dict(ma.state_dict())
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
+              lazy_small_rows=8)
+    ta = CTRTrainer(ma, **kw)
+    tb = CTRTrainer(mb, use_graph=use_graph, **kw)
+    dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+    host_batches = _host_column_batches(sparse, names, dense, dnames, label, B)
+    la = ta.train_one_epoch(host_batches)
+    lb = tb.train_one_epoch(dl)
+    assert la == lb
+    _assert_bitwise_twins(ta, tb, ma, mb)
+    assert _assert_no_row_behind(tb) == nb
+    if use_graph:
+        assert tb._graph is not None
+        lb2 = tb.train_one_epoch(dl)  # second epoch replays the captured graph from the first batch on
+        la2 = ta.train_one_epoch(host_batches)
+        assert la2 == lb2
+        _assert_bitwise_twins(ta, tb, ma, mb)
+
+
+def noisy_twin_tolerance(a, b, travel, what, atol=1e-4, rtol=1e-4, outlier_frac=0.05):
+    """Two HIP trainings of the same batches under float atomics in an unspecified order: Adam divides by sqrt(v), so an
+    element whose gradient nearly cancels turns summation-order noise into steps of up to lr.  Measured (tools/noise_budget.py,
+    profiles/r05_noise_budget_*.txt: host batches against host batches, the SAME code path twice, 24 trainings per pool box):
+    the share of elements of one tensor beyond atol + rtol |x| never exceeded 1 % (6 of 640 elements in the driver's round-4
+    run, which failed a 0.5 % budget).  The budget here is 5 % (>= 5 x the worst measured share; at least 3 elements), every
+    element within a quarter of the distance Adam can travel.  A wrong batch, batch order or optimizer step moves the BULK of
+    a tensor by ~1e-2 and fails both."""
+    a, b = np.asarray(a), np.asarray(b)
+    diff = np.abs(a - b)
+    bad = diff > atol + rtol * np.abs(b)
+    assert bad.sum() <= max(3, outlier_frac * bad.size), f"{what}: {bad.sum()} / {bad.size} elements off (max {diff.max():.3e})"
+    assert diff.max() <= 0.25 * travel + atol, f"{what}: max diff {diff.max():.3e}"
+    assert np.median(diff) <= atol, f"{what}: median diff {np.median(diff):.3e}"
+
+
+@pytest.mark.noise_tolerant
+def test_device_loader_training_equals_host_loader_training_under_random_duplicates():
+    """The tolerance variant of the test above (ordered LAST in the suite, tests/conftest.py): random lookups into tables of
+    3 .. 1460 rows, so most rows are hit several times per batch by DIFFERENT samples and the table gradient is a sum of
+    float atomics in whatever order the hardware took them.  Bit-equality is not defined here; see noisy_twin_tolerance."""
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
     N, B = 64 * 12, 64
@@ -166,38 +271,20 @@ def test_device_loader_training_equals_host_loader_training(use_graph):
     ma, dfe, sfe = _deepfm(vocabs, 1)
     mb, _, _ = _deepfm(vocabs, 1)
     mb.load_state_dict(ma.state_dict())
-    names = [f.name for f in sfe]
-    dnames = [f.name for f in dfe]
-    ta = CTRTrainer(ma, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False)
-    tb = CTRTrainer(mb, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False,
-                    use_graph=use_graph)
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False)
+    ta, tb = CTRTrainer(ma, **kw), CTRTrainer(mb, use_graph=True, **kw)
     dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
-    host_batches = []
-    for i in range(N // B):
-        sl = slice(i * B, (i + 1) * B)
-        xb = {n: sparse[sl, j] for j, n in enumerate(names)}
-        xb.update({n: dense[sl, j] for j, n in enumerate(dnames)})
-        host_batches.append((xb, label[sl]))
-    la = ta.train_one_epoch(host_batches)
+    la = ta.train_one_epoch(_host_column_batches(sparse, names, dense, dnames, label, B))
     lb = tb.train_one_epoch(dl)
-    assert abs(la - lb) < 1e-5
+    assert tb._graph is not None and abs(la - lb) < 1e-4
     for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
         if k.endswith("num_batches_tracked"):
             assert int(a) == int(b)
             continue
         if k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias") or k.endswith("running_mean"):
             continue  # bias in front of BatchNorm: zero gradient + rounding noise, Adam makes its path arbitrary
-        # same arithmetic; only the order of the fp32 atomic adds differs between two runs.  Measured run-to-run spread of ONE
-        # configuration over these 12 steps (round 4, host batches vs host batches): 1.6e-5 on the embedding tables (Adam
-        # turns the rounding noise of near-cancelling gradient elements into lr-sized steps: single elements jump by 8e-3),
-        # 2e-4 .. 7e-4 on the bias in front of BatchNorm -- atol = 1e-5 sat inside that spread and failed one run in three.
-        # A wrong batch, order or optimizer step shows up at 1e-2.
-        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-4, rtol=1e-4)
-    if use_graph:
-        assert tb._graph is not None
-        lb2 = tb.train_one_epoch(dl)  # second epoch replays the captured graph from the first batch on
-        la2 = ta.train_one_epoch(host_batches)
-        assert abs(la2 - lb2) < 1e-5
+        noisy_twin_tolerance(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k)
 
 
 def test_device_loader_generation_counts_out_of_band_moves():
@@ -362,7 +449,7 @@ def test_abandoned_step_leaves_the_optimizer_where_it_was():
         assert torch.equal(ta.optimizer.state[pa]["exp_avg_sq"], tb.optimizer.state[pb]["exp_avg_sq"])
 
 
-@pytest.mark.parametrize("form", ["ahead", "relaxed", "strict"])
+@pytest.mark.parametrize("form", ["ahead", "relaxed", "strict", "ahead+dup"])
 def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(form, monkeypatch):
     """The headline form of the step at table sizes where the deferred window sweep (K = 128, 33 M rows) is as long as the
     step itself, so that sweeps really are in flight under the following steps: 110 steps (3 eager, the rest hipGraph replays
@@ -372,13 +459,19 @@ def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(form, m
     lookups of the two batches after it that fall into the coming sweep's window; a sweep is joined three replays later.
     "relaxed": the head an eager launch in front of the graph, one batch of lookahead (rh_adam_lazy_refresh_assemble,
     lookahead = 1), a sweep joined two replays later; ~32 rows per field and step are in the window here.  "strict": the
-    head on the sweep's queue, every sweep joined before the next head.  Reference semantics:
+    head on the sweep's queue, every sweep joined before the next head.  "ahead+dup" (round 5): the default form on batches
+    WITH duplicate rows -- every sample occurs twice inside its batch (two lookups race for one row's claim and add to one
+    gradient row; identical addends, so the float atomics have no order-dependent result: _duplicate_samples) and every
+    looked-up row is looked up again by the NEXT batch (the row both passes of the end-of-step launch want: the touched-rows
+    step of batch t and the refresh of batch t + 1).  Reference semantics:
     torch.optim.Adam steps every row every step (trainers/ctr_trainer.py:59-61,99)."""
     from torch_rechub_amd import optim
     from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
     from torch_rechub_amd.models.ranking import DeepFM
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
+    dup = form.endswith("+dup")
+    form = form.split("+")[0]
     monkeypatch.setenv("RECHUB_STEP_FORM", "deferred")
     monkeypatch.setattr(optim, "RELAXED_JOIN", form != "strict")
     monkeypatch.setattr(optim, "STEP_AHEAD", form == "ahead")
@@ -386,14 +479,33 @@ def test_full_size_graph_step_with_long_sweeps_equals_dense_adam_bitwise(form, m
     B, nb = 4096, 110
     g = torch.Generator().manual_seed(5)
     cols = []
-    for v in vocabs:  # no row twice inside a batch (the scatter-add then has no order-dependent sums): an arithmetic progression
-        stride = torch.randint(max(1, (v - 1) // B // 2), (v - 1) // B + 1, (nb, 1), generator=g)
-        start = (torch.rand(nb, 1, generator=g) * ((v - 1) - stride * (B - 1))).long()
-        cols.append((start + stride * torch.arange(B).view(1, B)).view(-1) + 1)
-    sparse = torch.stack(cols, 1).contiguous()
-    assert all(int(sparse[:, i].max()) < v for i, v in enumerate(vocabs))
-    dense = torch.rand(nb * B, 13, generator=g)
-    label = (torch.rand(nb * B, generator=g) < 0.3).float()
+    if not dup:
+        for v in vocabs:  # no row twice inside a batch (the scatter-add then has no order-dependent sums): an arithmetic progression
+            stride = torch.randint(max(1, (v - 1) // B // 2), (v - 1) // B + 1, (nb, 1), generator=g)
+            start = (torch.rand(nb, 1, generator=g) * ((v - 1) - stride * (B - 1))).long()
+            cols.append((start + stride * torch.arange(B).view(1, B)).view(-1) + 1)
+        sparse = torch.stack(cols, 1).contiguous()
+        dense = torch.rand(nb * B, 13, generator=g)
+        label = (torch.rand(nb * B, generator=g) < 0.3).float()
+    else:
+        # batch b looks up, per field, the rows U_b and U_(b-1) (B/4 fresh rows each: arithmetic progressions inside the rows
+        # whose parity is that of the batch, so U_b and U_(b-1) are disjoint), every sample twice: B/2 distinct rows per
+        # field and batch, each hit by two identical samples now and by two more in the next batch
+        q = B // 4
+        for v in vocabs:
+            n_class = (v - 2) // 2  # rows 1 + parity + 2 j, j < n_class
+            stride = torch.randint(max(1, n_class // q // 2), n_class // q + 1, (nb + 1, 1), generator=g)
+            start = (torch.rand(nb + 1, 1, generator=g) * (n_class - stride * (q - 1))).long()
+            fresh = 1 + (torch.arange(nb + 1).view(-1, 1) % 2) + 2 * (start + stride * torch.arange(q).view(1, q))  # (nb + 1, q)
+            half = torch.cat([fresh[1:], fresh[:-1]], 1)  # (nb, B/2): U_b | U_(b-1)
+            cols.append(half.reshape(-1))
+        sparse = _duplicate_samples(torch.stack(cols, 1).contiguous(), B)
+        dense = _duplicate_samples(torch.rand(nb * B // 2, 13, generator=g), B)
+        label = _duplicate_samples((torch.rand(nb * B // 2, generator=g) < 0.3).float(), B)
+        first, second = sparse[:B], sparse[B:2 * B]
+        assert torch.equal(first[:B // 2], first[B // 2:]) and first[:, 0].unique().numel() == B // 2
+        assert len(set(first[:, 0].tolist()) & set(second[:, 0].tolist())) == B // 4  # half of a batch's rows return in the next
+    assert all(int(sparse[:, i].max()) < v and int(sparse[:, i].min()) >= 1 for i, v in enumerate(vocabs))
 
     def build():
         torch.manual_seed(7)
@@ -600,6 +712,49 @@ def test_fit_evaluate_predict_and_checkpoint_roundtrip(tmp_path):
         t.export_onnx("x.onnx")
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_reported_loss_includes_the_dense_regulariser_on_one_gpu(use_graph, monkeypatch):
+    """CTRTrainer(regularization_params={"dense_l2": ...}) on one GPU (trainers/ctr_trainer.py:92-95: loss + reg_loss).  With the
+    fused MLP chain the BCE mean is written by the head's BACKWARD launch when the step's scalars are deferred; a regulariser
+    adds its penalty to that value in the FORWARD, so the deferral must be off then -- round-4 advisor finding: the reported /
+    logged / epoch-summed loss was the add's output over an unwritten buffer (eager) or the previous replay's loss (hipGraph).
+    Twin: the same training with the chain off (layer-by-layer kernels: the loss is formed in the forward)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 6, 64
+    vocabs, sparse, dense, label = _loader_twin_data("collision_free", nb, B, seed=61)
+    reg = {"embedding_l1": 0.0, "embedding_l2": 0.0, "dense_l1": 1e-3, "dense_l2": 1e-2}
+    ma, dfe, sfe = _deepfm(vocabs, 4)
+    mb, _, _ = _deepfm(vocabs, 4)
+    mb.load_state_dict(ma.state_dict())
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 0.0}, regularization_params=reg, device="cuda:0", show_progress=False)
+    batches = _host_column_batches(sparse, names, dense, dnames, label, B)
+    assert ops.FUSE_MLP_CHAIN
+    ta = CTRTrainer(ma, use_graph=use_graph, **kw)
+    got = []
+    if use_graph:
+        dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        done = 0
+        while done < nb:
+            loss, n = ta._graphed_step(dl)
+            got.append((float(loss), n))  # (the first call runs three eager warm-up steps and returns their sum)
+            done += n
+    else:
+        got = [(float(ta.train_step(to_dev(x), y.to(dev()))), 1) for x, y in batches]
+    monkeypatch.setattr(ops, "FUSE_MLP_CHAIN", False)
+    tb = CTRTrainer(mb, **kw)
+    ref = [float(tb.train_step(to_dev(x), y.to(dev()))) for x, y in batches]
+    from torch_rechub_amd.basic.loss_func import RegularizationLoss
+    assert float(RegularizationLoss(**reg)(mb)) > 0.02  # a loss without the penalty, or a stale one, is far outside rtol 1e-4
+    at = 0
+    for value, n in got:
+        np.testing.assert_allclose(value, sum(ref[at:at + n]), rtol=1e-4)
+        at += n
+    assert at == nb
+
+
 def test_stock_optimizer_sees_dense_table_gradients():
     """optimizer_fn other than Adam: tables expose an ordinary dense .grad (persistent buffer) to torch.optim."""
     from torch_rechub_amd import ops
@@ -633,6 +788,7 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
+@pytest.mark.noise_tolerant
 @pytest.mark.parametrize("use_graph,tables", [(False, "replicate"), ("single", "replicate"), ("split", "replicate"),
                                               (False, "shard"), ("single", "shard")])
 def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, monkeypatch, use_graph, tables):
@@ -677,7 +833,7 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
             continue
         if k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias") or k.endswith("running_mean"):
             continue
-        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=1e-5, rtol=1e-4)
+        noisy_twin_tolerance(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=2e-5, rtol=1e-4)
 
 
 def test_dssm_towers_side_by_side_are_the_sequential_towers(monkeypatch):
@@ -891,9 +1047,10 @@ def _same_training(ma, mb, la, lb):
             continue
         if k.endswith("running_mean") or (k.endswith(".bias") and "mlp" in k):
             continue  # biases in front of BatchNorm: rounding-noise gradients, Adam makes their path arbitrary
-        assert_trajectory_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 8, k, atol=2e-5, rtol=2e-4)
+        noisy_twin_tolerance(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 8, k, atol=2e-5, rtol=2e-4)
 
 
+@pytest.mark.noise_tolerant
 @pytest.mark.parametrize("cfg", ["din", "dien"])
 def test_sequence_models_train_from_the_device_loader_under_hipgraph(cfg):
     """(name, L) columns of the HBM-resident dataset become contiguous (B, L) index buffers; the captured step (batch
@@ -924,6 +1081,7 @@ def test_sequence_models_train_from_the_device_loader_under_hipgraph(cfg):
     _same_training(models[0], models[1], la, lb)
 
 
+@pytest.mark.noise_tolerant
 def test_multi_task_training_from_the_device_loader_under_hipgraph():
     """(N, n_task) labels ride behind the dense block through the batch-assembly kernel; MTLTrainer's captured step."""
     from torch_rechub_amd.utils.data import DeviceDataLoader

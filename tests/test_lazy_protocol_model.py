@@ -117,3 +117,20 @@ def test_one_batch_of_lookahead_less_is_a_race(depth, look):
 def test_strict_join_needs_no_lookahead():
     conflicts, violations = simulate(4096, 64, 256, steps=200, depth=0, look=0, seed=4)
     assert conflicts == 0 and violations == []
+
+
+@pytest.mark.parametrize("K,safe", [(2, False), (3, True), (4, True)])
+def test_step_ahead_needs_windows_of_three_consecutive_steps_to_be_disjoint(K, safe):
+    """With LOOK_DEPTH = 2 the sweeps of steps t - 2 and t - 1 may be in flight while the end-of-step launch of step t claims
+    rows of window(t): at K = 2, window(t) IS window(t - 2) and the two meet (round-4 advisor finding).  optim.TableAdam
+    therefore takes the step-ahead form only for lazy_k >= LOOK_DEPTH + 2 (one window of margin) and the relaxed / strict
+    head otherwise (the relaxed join, one sweep in flight, is safe from K = 2 on)."""
+    conflicts, violations = simulate(1200, K, 100, steps=60, depth=2, look=2, seed=5)
+    assert violations == [] and (conflicts == 0) == safe
+    assert simulate(1200, K, 100, steps=60, depth=1, look=1, seed=5) == (0, [])
+
+
+def test_step_ahead_guard_matches_the_model():
+    import torch_rechub_amd.optim as optim
+    src = open(optim.__file__).read()
+    assert "self.lazy_k >= LOOK_DEPTH + 2" in src and optim.LOOK_DEPTH == 2

@@ -406,9 +406,11 @@ cross_net_v2.register_autograd(_cross_v2_bwd, setup_context=_cross_v2_setup)
 # ---- CrossNetMix: mixture of low-rank experts (basic/layers.py:470-506), all layers, csrc/moe.hip --------------------------
 def _mix_params(U, V, C, bias, gating):
     L, E = U.shape[0], U.shape[1]
-    if V.shape != U.shape or C.shape[:2] != (L, E) or gating.shape[0] != E or bias.shape[0] != L:
-        raise ValueError("rechub_hip::cross_net_mix: U, V (L, E, d, r), C (L, E, r, r), bias (L, d), gating (E, d)")
     d = U.shape[2]
+    if V.shape != U.shape or C.shape[:2] != (L, E) or gating.shape[0] != E or bias.shape[0] != L or \
+            bias.numel() != L * d or gating.numel() != E * d:
+        raise ValueError("rechub_hip::cross_net_mix: U, V (L, E, d, r), C (L, E, r, r), bias (L, d) or (L, d, 1), "
+                         "gating (E, d) or (E, 1, d)")
     return L, E, ([U[l] for l in range(L)] + [V[l] for l in range(L)] + [C[l] for l in range(L)] +
                   [bias[l].reshape(d, 1) for l in range(L)] + [gating[e].reshape(1, d) for e in range(E)])
 
@@ -436,8 +438,11 @@ def cross_net_mix_backward(x: torch.Tensor, U: torch.Tensor, V: torch.Tensor, C:
     ops._CrossMoeFn.forward(ctx, x.contiguous(), L, E, *params)
     grads = ops._CrossMoeFn.backward(ctx, g.contiguous())
     g_x, rest = grads[0], grads[3:]
+    # the gradients of bias / gating leave in the callers' shapes: (L, d) or the reference's (L, d, 1) layout
+    # (basic/layers.py:468: nn.Parameter(torch.empty(input_dim, 1)) per layer), as the fake implementation below promises
     return (g_x, torch.stack(rest[0:L]), torch.stack(rest[L:2 * L]), torch.stack(rest[2 * L:3 * L]),
-            torch.stack([t.reshape(-1) for t in rest[3 * L:4 * L]]), torch.stack([t.reshape(-1) for t in rest[4 * L:4 * L + E]]))
+            torch.stack([t.reshape(-1) for t in rest[3 * L:4 * L]]).view_as(bias),
+            torch.stack([t.reshape(-1) for t in rest[4 * L:4 * L + E]]).view_as(gating))
 
 
 @cross_net_mix_backward.register_fake

@@ -616,7 +616,11 @@ class TableAdam(torch.optim.Adam):
     def _merge_ahead_ok(self, rec, grp):
         """Will _merged_step of the step being captured see exactly this gather over exactly this table group?"""
         groups = self._lazy_setup()
-        return len(groups) == 1 and groups[0] is grp and rec["idx_is_i64"] and self.overlap_sweep
+        # lazy_k >= LOOK_DEPTH + 2: the sweeps of the last LOOK_DEPTH steps may be in flight while this step's last launch
+        # claims rows of ITS window -- the windows of LOOK_DEPTH + 1 consecutive steps must be disjoint (at lazy_k = 2,
+        # window(t) is window(t - 2): tests/test_lazy_protocol_model.py); smaller lazy_k takes the relaxed / strict head
+        return len(groups) == 1 and groups[0] is grp and rec["idx_is_i64"] and self.overlap_sweep and \
+            self.lazy_k >= LOOK_DEPTH + 2
 
     def _merged_step(self, groups, stream):
         """The touched-rows step of the batch and the window sweep as ONE launch (rh_adam_lazy_step) when the step has a
@@ -667,16 +671,21 @@ class TableAdam(torch.optim.Adam):
         stepped densely like the small tables.  Measured cost model: ~0.5 ns per lookup for the two touched passes
         against ~0.09 ns per row for the dense pass."""
         self._k_decided = True
-        if self.lazy_dense_ratio <= 0 or torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
+            return  # (a capture must not change the table grouping under itself)
+        changed = False
+        # (before the placement rule's early return: an explicit lazy_small_rows switches the volume rule off, not this one)
+        if self._lazy_k_auto and self.lazy_k > 64 and self._touch_log and max(int(r["B"]) for r in self._touch_log) > 8192:
+            self.lazy_k = 64
+            changed = True
+        if self.lazy_dense_ratio <= 0:
+            if changed:
+                self._lazy_groups = None
             return
         lookups = {}
         for rec in self._touch_log:
             for w in rec["weights"]:
                 lookups[id(w)] = lookups.get(id(w), 0) + int(rec["B"])
-        changed = False
-        if self._lazy_k_auto and self.lazy_k > 64 and self._touch_log and max(int(r["B"]) for r in self._touch_log) > 8192:
-            self.lazy_k = 64
-            changed = True
         for p in self._tables:
             n = lookups.get(id(p), 0)
             if n and self.table_k(p) != 1 and int(p.shape[0]) <= self.lazy_dense_ratio * n:

@@ -190,8 +190,11 @@ class CTRTrainer(object):
     def train_step(self, x_dict, y):
         """forward + loss + backward + optimizer step on device tensors; returns the detached loss tensor."""
         # (defer_scalars: the backward below follows at once and the loss value is read after it -- the fused MLP chain's
-        # head backward may then carry the step's scalar launch)
-        loss = self._forward_loss(x_dict, y, defer_scalars=self.dp is None)
+        # head backward may then carry the step's scalar launch, i.e. the loss buffer is WRITTEN during the backward.  Only
+        # when nothing consumes the loss value in the forward: an active regulariser adds its penalty to it there
+        # (_add_reg) and would read the buffer before it is filled -- round-4 advisor finding: wrong reported loss with
+        # dense_l1 / dense_l2 > 0 on one GPU)
+        loss = self._forward_loss(x_dict, y, defer_scalars=self.dp is None and not self.reg_loss_fn.active())
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
