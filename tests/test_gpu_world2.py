@@ -17,7 +17,7 @@ import torch.multiprocessing as mp
 # Adam turns the rounding noise of near-cancelling elements into lr-sized steps -- compared to a tolerance with an outlier
 # budget (tests/test_gpu_models.py::noisy_twin_tolerance states where the budget comes from) and ordered LAST in the suite
 pytestmark = [pytest.mark.gpu, pytest.mark.noise_tolerant]
-OUTLIERS = 0.05  # share of a tensor's elements allowed beyond atol + rtol |x| (at least 3 elements)
+OUTLIERS = 0.08  # share of a tensor's elements allowed beyond atol + rtol |x| (at least 3 elements)
 
 VOCABS = [3, 4, 10, 27, 105, 305, 583 * 40, 40, 1460 * 40, 24, 18, 15, 633 * 40]
 STEPS, B = 6, 64

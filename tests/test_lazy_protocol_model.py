@@ -134,3 +134,36 @@ def test_step_ahead_guard_matches_the_model():
     import torch_rechub_amd.optim as optim
     src = open(optim.__file__).read()
     assert "self.lazy_k >= LOOK_DEPTH + 2" in src and optim.LOOK_DEPTH == 2
+
+
+def simulate_foreign(rows, K, B, ranks, steps, join_before_touched, seed):
+    """The data-parallel step with REPLICATED tables (strict deferred form): the head of step t refreshes the rows of the LOCAL
+    batch, the sweep of step t - 1 is launched behind it and runs beside the step, and the end-of-step touched pass works on
+    the rows of EVERY rank's batch (gathered index matrix).  Returns the number of rows the sweep and the touched pass both
+    work on while both are in flight."""
+    rng = np.random.default_rng(seed)
+    w = -(-rows // K)
+    last = np.zeros(rows, dtype=np.int64)
+    conflicts = 0
+    for t in range(1, steps + 1):
+        local = np.unique(rng.integers(0, rows, B))
+        foreign = np.unique(rng.integers(0, rows, B * (ranks - 1)))
+        last[local] = np.maximum(last[local], t - 1)          # head: pre-gather refresh of the local batch (stamps the rows)
+        lo = ((t - 2) % K) * w if t > 1 else 0
+        srows = {r for r in range(lo, min(rows, lo + w)) if last[r] < t - 1} if t > 1 else set()
+        touched = set(local.tolist()) | set(foreign.tolist())
+        if not join_before_touched:
+            conflicts += len(srows & touched)                  # the sweep may still be on these rows when they are stepped
+        for r in srows:
+            last[r] = t - 1
+        for r in touched:
+            last[r] = t
+    return conflicts
+
+
+def test_foreign_rows_race_with_the_deferred_sweep_unless_it_is_joined_first():
+    """Round 5: optim.TableAdam._join_before_foreign_rows.  With one rank (or row-sharded tables) every row the touched pass
+    steps was stamped by the head, so the deferred sweep never meets it; with the rows of other ranks' batches it does."""
+    assert simulate_foreign(4096, 16, 128, ranks=1, steps=80, join_before_touched=False, seed=7) == 0
+    assert simulate_foreign(4096, 16, 128, ranks=4, steps=80, join_before_touched=False, seed=7) > 50
+    assert simulate_foreign(4096, 16, 128, ranks=4, steps=80, join_before_touched=True, seed=7) == 0

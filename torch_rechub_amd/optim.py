@@ -140,6 +140,7 @@ class TableAdam(torch.optim.Adam):
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
+                self.foreign_rows = False     # set by the trainers: the touched pass sees rows other ranks looked up
                 self._sweep_pending = False   # sweep of the last completed step not launched yet
                 self._sweep_inflight = False  # ... launched on the side stream, not joined yet
                 self._side = None
@@ -658,6 +659,12 @@ class TableAdam(torch.optim.Adam):
             self._sweep_pending = True
         return True
 
+    SWEEP_BOUND_ROWS = 64_000_000  # lazy rows beyond which a step is bound by the window sweep, not by its chain (lazy_k, tuner)
+
+    def lazy_rows(self):
+        """Rows of the tables that are stepped lazily (window sweep + touched passes)."""
+        return sum(int(p.shape[0]) for p in self._tables if self.table_k(p) != 1)
+
     def table_k(self, p):
         """Window divisor of table ``p``: 1 = stepped densely (with its gradient) by every sweep, lazy_k = blocked-lazy."""
         if self.lazy_k <= 1 or int(p.shape[0]) <= self.lazy_small_rows or id(p) in self._dense_by_volume:
@@ -675,7 +682,12 @@ class TableAdam(torch.optim.Adam):
             return  # (a capture must not change the table grouping under itself)
         changed = False
         # (before the placement rule's early return: an explicit lazy_small_rows switches the volume rule off, not this one)
-        if self._lazy_k_auto and self.lazy_k > 64 and self._touch_log and max(int(r["B"]) for r in self._touch_log) > 8192:
+        if self._lazy_k_auto and self.lazy_k > 64 and self._touch_log and (
+                max(int(r["B"]) for r in self._touch_log) > 8192 or self.lazy_rows() > self.SWEEP_BOUND_ROWS):
+            # (second condition, round 5: with > 64 M lazy rows -- configs[4], 110 M -- the window sweep is far longer than the
+            # step's chain and the pre-gather refresh sits IN FRONT of it on the same path: what counts is refresh + sweep, and the
+            # refresh replays lazy_k / 2 steps per looked-up row.  DSSM: 0.831 ms at 128, 0.788 at 64 -- round 4 had made 128 the
+            # global default for the DeepFM step, where the sweep runs beside a chain of its own length)
             self.lazy_k = 64
             changed = True
         if self.lazy_dense_ratio <= 0:
@@ -694,9 +706,30 @@ class TableAdam(torch.optim.Adam):
         if changed:
             self._lazy_groups = None
 
+    def _join_before_foreign_rows(self):
+        """Replicated tables under data parallelism: the touched-rows step below runs over the GATHERED index matrix, i.e. also
+        over the rows the OTHER ranks' batches looked up -- rows this rank's pre-gather refresh never stamped.  The deferred
+        sweep of the previous step (side stream, no claims) may be replaying exactly such a row of its window at this moment:
+        it read the row's last-step word when it fetched it and would store its state over the step applied here (the step's
+        gradient lost).  Nothing of the kind can happen to the rows of the LOCAL batch (refreshed = stamped before the sweep
+        was launched), nor with row-sharded tables (the shard's gather refreshes the rows of the whole global batch that live
+        on this rank).  So with foreign rows the sweep is joined before the touched pass: eagerly, or -- in a segmented
+        capture -- by one more cut (every replay waits for the side stream there).  Found in round 5 by reading the protocol
+        against the data-parallel step (tests/test_lazy_protocol_model.py::test_foreign_rows_*); the world-2 GPU tests run
+        eager steps on tables small enough for every sweep to be over long before."""
+        if not self.foreign_rows or not self.overlap_sweep:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            seg = graphs.active()
+            if seg is not None and self._sweep_inflight:
+                seg.cut(self._join_forked_sweep)
+        else:
+            self._join_sweep()
+
     def _lazy_step(self, stream):
         if not self._k_decided:
             self._decide_dense_by_volume()
+        self._join_before_foreign_rows()
         groups = self._lazy_setup()
         if self._merged_step(groups, stream):
             del self._touch_log[:]

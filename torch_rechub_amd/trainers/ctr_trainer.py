@@ -88,6 +88,9 @@ class CTRTrainer(object):
         else:
             self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         table_ids = {id(p) for p in tables}
+        if self.dp is not None and (self.tables == "replicate" or shard_min_rows > 0) and getattr(self.optimizer, "lazy_k", 0) > 1:
+            # the gradient-row exchange hands this rank the rows of every rank's batch: TableAdam._join_before_foreign_rows
+            self.optimizer.foreign_rows = True
         if self.dp is not None:
             self.bucket = self.dp.bucket
         else:
@@ -302,6 +305,14 @@ class CTRTrainer(object):
     TUNE_CANDIDATES = (("deferred", 512, 32000), ("deferred", 512, 40000), ("deferred", 256, 32000), ("inline", 0, 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
+    def tune_budget_steps(self):
+        """Upper bound of the replayed steps the self-tuning below takes once the optimizer is in its steady state (bench.py
+        keeps its timed region behind it)."""
+        opt = self.optimizer
+        extra = 2 if (isinstance(opt, TableAdam) and getattr(opt, "lazy_k", 0) > 1 and opt._tables and
+                      opt.lazy_rows() > opt.SWEEP_BOUND_ROWS) else 0
+        return (len(self.TUNE_CANDIDATES) + extra) * (self.TUNE_SETTLE + self.TUNE_STEPS)
+
     def _tune_step_form(self, loader):
         """Self-tuning of HOW the captured step ends, over real training steps (nothing is thrown away): once the lazy
         optimizer is in its steady state (lazy_k + 8 replays after the capture: the window sweeps have their full
@@ -322,7 +333,13 @@ class CTRTrainer(object):
             grid = os.environ.get("RECHUB_SWEEP_GRID", "")
             if grid:
                 _lib.call("rh_set_tuning", 8, int(grid))
-            cands = [c for c in self.TUNE_CANDIDATES if (not form or c[0] == form) and
+            all_cands = list(self.TUNE_CANDIDATES)
+            if lazy and opt.lazy_rows() > opt.SWEEP_BOUND_ROWS:
+                # a step bound by the window sweep (configs[4]: 110 M lazy rows, a 0.65 ms sweep beside a 0.25 ms chain): the
+                # residency cap that protects the chain costs the sweep 20-40 % of its throughput (sweep alone: 188 us at 512
+                # workgroups, 166 at 1024, 158 at 2048) -- let the measurement decide
+                all_cands += [("deferred", 1024, 32000), ("deferred", 2048, 32000)]
+            cands = [c for c in all_cands if (not form or c[0] == form) and
                      (not grid or c[0] == "inline" or c[1] == int(grid))]
             if form and (grid or not cands):  # fully pinned (also forms / grids that are not tuning candidates)
                 cands = [(form, int(grid or 512) if form != "inline" else 0, 0)]
