@@ -81,8 +81,8 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (RCCL collectives) even on one GPU")
     ap.add_argument("--no-kernel-sweep", action="store_true", help="skip the gather-kernel batch sweep")
-    ap.add_argument("--twin-repeat", action="store_true",
-                    help="dense_twin_check: also train a SECOND dense twin and report twin-vs-twin (the comparison's noise floor)")
+    ap.add_argument("--no-twin-repeat", dest="twin_repeat", action="store_false",
+                    help="dense_twin_check: do not train the SECOND dense twin (twin-vs-twin = the comparison's noise floor)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the nested rocprofv3 --pmc passes (roofline.traffic)")
     ap.add_argument("--no-twin-check", action="store_true",
                     help="skip the dense-Adam twin that re-trains the same steps after the flush (dense_twin_check)")
@@ -258,7 +258,8 @@ class Workload(object):
                 tower = {"dims": [256, 128, 64], "activation": "prelu"}
                 m = DSSM(self.user, self.item, user_params=dict(tower), item_params=dict(tower), temperature=0.02)
         # (a.lazy_k is the headline's value; other batch sizes of the sweep follow the trainer's own rule unless --lazy-k was given)
-        k = a.lazy_k if (a.lazy_k_explicit or (batch or a.batch) <= 8192) else min(a.lazy_k, 64)
+        # (None: the trainer's own rule -- 128, or 64 for steps of more than 8192 samples and for sweep-bound table sets)
+        k = a.lazy_k if a.lazy_k_explicit else None
         kw = dict(device=str(device), show_progress=False, use_graph=use_graph, table_update=a.table_adam,
                   lazy_k=k, tables=placement)
         if self.match:
@@ -652,7 +653,9 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
         torch.cuda.synchronize()
 
     # warm-up INTO the steady state: after a flush the first lazy_k window sweeps replay 1, 2, ... steps only
-    warm = max(args.warmup, (args.lazy_k + 8) if lazy else 0)
+    k_eff = int(getattr(opt, "lazy_k", 0))  # (decided by the optimizer at its first step unless --lazy-k was given)
+    res["lazy_k"] = k_eff
+    warm = max(args.warmup, (k_eff + 8) if lazy else 0)
     if lazy and graph_ok and trainer.dp is None:
         # + the trainer's self-tuning of the step's form (deferred / in-line sweep, residency cap): it starts once the
         # optimizer is in its steady state and must be over before the timed region
@@ -1008,7 +1011,7 @@ def trace_inner(args, device, rank):
     model, trainer, loader = wl.build(None, True, batch=args.batch)
     trainer._graphed_step(loader)
     lazy = getattr(trainer.optimizer, "lazy_k", 0) > 1
-    warm = max(args.warmup, (args.lazy_k + 8) if lazy else 0)
+    warm = max(args.warmup, (int(trainer.optimizer.lazy_k) + 8) if lazy else 0)
     if lazy:  # past the trainer's self-tuning of the step's form, as the headline's timed region is
         warm += trainer.tune_budget_steps() + 4
     for _ in range(warm + args.steps):
@@ -1308,7 +1311,7 @@ def main():
                 cpu["error"] = f"{type(e).__name__}: {e}"
         opt_desc = "dense pass per step"
         if args.table_adam == "lazy":
-            opt_desc = (f"blocked-lazy exact replay, K={args.lazy_k}, window sweep "
+            opt_desc = (f"blocked-lazy exact replay, K={head.get('lazy_k', args.lazy_k)}, window sweep "
                         + ("of step t on a side stream under step t+1's forward/backward (joined before step t+2 refreshes "
                            "its rows; residency-capped, chosen by the trainer's self-tuning)" if head["overlap_sweep"]
                            else "in line")

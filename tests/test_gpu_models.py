@@ -1092,6 +1092,87 @@ def _same_training(ma, mb, la, lb):
         noisy_twin_tolerance(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 8, k, atol=2e-5, rtol=2e-4)
 
 
+def _order_free_rows_for(groups, nb, B, L, seed):
+    """Dataset rows for every feature of ``groups`` in which no fp32 sum depends on an order: per TABLE (an owner and every
+    feature sharing it: target item + history item (+ negative history)) one block of collision-free columns per batch, and
+    every sample twice inside its batch (_duplicate_samples).  Histories are post-padded with 0 to 1 .. L positions.
+    Returns (sparse, names, dense, dnames) as _rows_for."""
+    g = torch.Generator().manual_seed(seed)
+    h = B // 2
+    owners, order, dnames = {}, [], []
+    for feas in groups.values():
+        for f in feas:
+            kind = type(f).__name__
+            if kind == "DenseFeature":
+                if f.name not in dnames:
+                    dnames.append(f.name)
+                continue
+            if any(f.name == n for n, _ in order):
+                continue
+            w = 1 if kind == "SparseFeature" else L
+            order.append((f.name, w))
+            owners.setdefault(getattr(f, "shared_with", None) or f.name, []).append((f.name, w, f))
+    cols = {}
+    for i, (owner, members) in enumerate(sorted(owners.items())):
+        width = sum(w for _, w, _ in members)
+        block = _duplicate_samples(_collision_free_columns([members[0][2].vocab_size], [width], nb, h, seed=seed + 10 * i), B)
+        at = 0
+        for name, w, f in members:
+            c = block[:, at:at + w].clone()
+            if w > 1:
+                lens = _duplicate_samples(torch.randint(1, L + 1, (nb * h,), generator=g), B)
+                c[torch.arange(L)[None, :] >= lens[:, None]] = 0
+            cols[name] = c
+            at += w
+    sparse = torch.cat([cols[n] for n, _ in order], 1).contiguous()
+    names = [n if w == 1 else (n, w) for n, w in order]
+    dense = _duplicate_samples(torch.rand(nb * h, len(dnames), generator=g), B) if dnames else None
+    return sparse, names, dense, dnames
+
+
+@pytest.mark.parametrize("cfg", ["din", "dien", "mmoe"])
+def test_sequence_and_multi_task_models_train_from_the_device_loader_bitwise(cfg):
+    """DIN / DIEN (history columns as contiguous (B, L) buffers, attention / recurrences) and MMOE ((N, n_task) labels riding
+    behind the dense block) from the HBM-resident loader under hipGraph replay against eager steps over host batches: the SAME
+    weights and Adam moments, bit for bit, on order-free data (_order_free_rows_for) -- lazy tables (K = 4), so the captured
+    step's refresh, claims, window sweep and flush are on the path.  The tolerance twins of this test (random duplicates) run
+    LAST in the suite (noise_tolerant).  Measured bit-exact in round 5: tools/bitwise_probe.py seq."""
+    import json
+    from torch_rechub_amd.trainers import CTRTrainer, MTLTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    gold = load_golden(f"model_{cfg}.npz")
+    nb, B, L = 8, 16, 7
+    models, trainers = [], []
+    for graph in (False, True):
+        groups = features_from_spec(gold["spec"])
+        for f in {id(f): f for feas in groups.values() for f in feas if hasattr(f, "vocab_size")}.values():
+            f.vocab_size = 1 + 2 * B * (1 + 2 * L) + 100  # room for collision-free batches over shared tables
+        torch.manual_seed(17)
+        params = {"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 8}
+        if cfg == "mmoe":
+            types = json.loads(str(gold["task_types"]))
+            m = build_mtl_model("mmoe", groups, types).to(dev())
+            t = MTLTrainer(m, task_types=types, optimizer_params=params, n_epoch=1, device="cuda:0", show_progress=False,
+                           use_graph=graph, lazy_k=4)
+        else:
+            m = build_amd_model(cfg, groups).to(dev())
+            t = CTRTrainer(m, optimizer_params=params, device="cuda:0", show_progress=False, use_graph=graph, lazy_k=4,
+                           loss_mode=cfg not in AUX_LOSS_CONFIGS)
+        models.append(m)
+        trainers.append(t)
+    models[1].load_state_dict(models[0].state_dict())
+    sparse, names, dense, dnames = _order_free_rows_for(groups, nb, B, L, seed=5)
+    g = torch.Generator().manual_seed(6)
+    label = _duplicate_samples((torch.rand(nb * B // 2, *([2] if cfg == "mmoe" else []), generator=g) < 0.3).float(), B)
+    dl = DeviceDataLoader(sparse.to(dev()), names, None if dense is None else dense.to(dev()), dnames, label.to(dev()), B,
+                          shuffle=False)
+    la = trainers[0].train_one_epoch(_host_batches(sparse, names, dense, dnames, label, B))
+    lb = trainers[1].train_one_epoch(dl)
+    assert trainers[1]._graph is not None
+    assert np.array_equal(np.asarray(la), np.asarray(lb))
+    _assert_bitwise_twins(trainers[0], trainers[1], models[0], models[1])
+
+
 @pytest.mark.noise_tolerant
 @pytest.mark.parametrize("cfg", ["din", "dien"])
 def test_sequence_models_train_from_the_device_loader_under_hipgraph(cfg):

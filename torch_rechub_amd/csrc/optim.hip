@@ -399,6 +399,122 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_kernel(const LazySwe
   lazy_sweep_body<LPR, MERGED>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// The DEFERRED window sweep of the lazy tables with VPL float4 per lane (round 5).  The replay of one element is a dependent
+// chain per step -- v' -> v_sqrt -> + E -> v_rcp -> m' * d -> fma into p, and p feeds the next step's m', v' -- about 80 cycles
+// long against 136 cycles of issue per step for the two packed pairs a lane holds at one float4 per lane.  Beside the step's
+// chain the sweep runs at 2 wavefronts per SIMD (its residency cap): the other wavefront covers only part of that latency and
+// the loop reaches 0.52 of its VALU ceiling.  Here a row of D floats is held by LPR = D / (4 VPL) lanes with VPL
+// float4 EACH (32 contiguous bytes at VPL = 2): 2 VPL independent pair chains per lane at the same wavefront count -- the
+// instruction-level parallelism that more wavefronts would buy, without their wave slots, LDS and registers (more resident
+// sweep wavefronts starve the chain's 240-register kernels: 768 / 1024 workgroups were 0.333-0.354 ms steps in round 3).
+// Same adam_f4_zero_g per float4, same order of steps: the bits of the one-float4 kernel (and of the dense pass).
+// Only the lazy tables' window (RH_SWEEP_LAZY_TABLES by value): no gradient rows, no claims -- which is what keeps the two
+// ping-pong units inside the 128 registers that leave a SIMD room for the chain.
+template <int LPR, int VPL>
+static __device__ __forceinline__ void lazy_sweep_wide_body(const LazySweepArgs& a, const int bx_, const int gdim_) {
+  constexpr int RPB = RH_BLOCK / LPR;
+  constexpr int D = 4 * LPR * VPL;
+  const int64_t bid = bx_, nblk = gdim_;
+  AdamScalars h = load_scalars(a.hyper);
+  const int t = (int)a.t_value;
+  h.A = a.ring[2 * (t & a.ring_mask)];
+  h.E = a.ring[2 * (t & a.ring_mask) + 1];
+  const int T = a.T;
+  const int q = threadIdx.x % LPR;
+  const int slot = threadIdx.x / LPR;
+  __shared__ float ring_s[2 * kMaxRing];
+  for (int i = threadIdx.x; i < 2 * (a.ring_mask + 1); i += RH_BLOCK) ring_s[i] = a.ring[i];
+  __syncthreads();
+  struct Unit {
+    float *p, *m, *v;
+    int* last;
+    int64_t off;  // element offset of this lane's first float4
+    int64_t r;
+    int old;
+    bool live;
+    float4 P[VPL], M[VPL], V[VPL];
+  };
+  auto fetch = [&](int64_t vb, Unit& u) {
+    u.live = false;
+    if (vb >= a.total_vblocks) return;
+    int lo = 0, hi = T;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.vb_prefix[mid] <= vb) lo = mid; else hi = mid;
+    }
+    const int ti = lo;
+    u.p = reinterpret_cast<float*>(a.ldesc[0 * T + ti]);
+    u.m = reinterpret_cast<float*>(a.ldesc[2 * T + ti]);
+    u.v = reinterpret_cast<float*>(a.ldesc[3 * T + ti]);
+    u.last = reinterpret_cast<int*>(a.ldesc[4 * T + ti]);
+    const int64_t rows = a.ldesc[5 * T + ti];
+    const int64_t K = a.ldesc[6 * T + ti];
+    const int64_t w = a.ldesc[7 * T + ti];
+    const int64_t wstart = ((int64_t)(t - 1) % K) * w;
+    const int64_t local = (vb - a.vb_prefix[ti]) * RPB + slot;
+    u.r = wstart + local;
+    if (local >= w || u.r >= rows) return;
+    u.off = u.r * D + (int64_t)q * (4 * VPL);
+    u.old = gload<int>(u.last + u.r);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      u.P[k] = gload<float4>(u.p + u.off + 4 * k);
+      u.M[k] = gload<float4>(u.m + u.off + 4 * k);
+      u.V[k] = gload<float4>(u.v + u.off + 4 * k);
+    }
+    u.live = true;
+  };
+  auto process = [&](Unit& u) {
+    const bool work = u.live && u.old < t;
+    const int first = work ? u.old + 1 : t;
+    int j = wave_min_uniform(first);
+    while (j < t) {  // wavefront-uniform segments between the steps at which rows join (see lazy_sweep_body)
+      const int nxt = wave_min_uniform(first > j ? first : t);
+      if (first <= j) {
+        int jj = j;
+        for (; jj + 2 <= nxt; jj += 2) {
+          const float2 ae0 = *reinterpret_cast<const float2*>(ring_s + 2 * (jj & a.ring_mask));
+          const float2 ae1 = *reinterpret_cast<const float2*>(ring_s + 2 * ((jj + 1) & a.ring_mask));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) adam_f4_zero_g(u.P[k], u.M[k], u.V[k], h, ae0.x, ae0.y);
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) adam_f4_zero_g(u.P[k], u.M[k], u.V[k], h, ae1.x, ae1.y);
+        }
+        if (jj < nxt) {
+          const float2 ae = *reinterpret_cast<const float2*>(ring_s + 2 * (jj & a.ring_mask));
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) adam_f4_zero_g(u.P[k], u.M[k], u.V[k], h, ae.x, ae.y);
+        }
+      }
+      j = nxt;
+    }
+    if (work) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        adam_f4_zero_g(u.P[k], u.M[k], u.V[k], h, h.A, h.E);
+        gstore<float4>(u.p + u.off + 4 * k, u.P[k]);
+        gstore<float4>(u.m + u.off + 4 * k, u.M[k]);
+        gstore<float4>(u.v + u.off + 4 * k, u.V[k]);
+      }
+      if (q == 0) u.last[u.r] = t;
+    }
+  };
+  Unit ua, ub;
+  fetch(bid, ua);
+  for (int64_t vb = bid; vb < a.total_vblocks; vb += 2 * nblk) {
+    fetch(vb + nblk, ub);
+    process(ua);
+    fetch(vb + 2 * nblk, ua);
+    process(ub);
+  }
+}
+
+template <int LPR, int VPL>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_sweep_wide_kernel(const LazySweepArgs a) {
+  lazy_sweep_wide_body<LPR, VPL>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // One lane waits `ticks` of the constant wall clock (rh_adam_sweep_stagger).
 __global__ void stream_delay_kernel(const long long ticks) {
   const long long t0 = wall_clock64();
@@ -711,10 +827,42 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const La
   lazy_sweep_body<LPR, true>(a, bx, (int)gridDim.x - parts.nB - parts.nA - parts.nC - parts.nD);
 }
 
+int g_sweep_wide = 2;  // RH_TUNE_SWEEP_WIDE: float4 per lane of the deferred lazy-table sweep at embed_dim >= 8 (2 = default; 1 = round-4 kernel)
+
+// the deferred window sweep of the lazy tables, VPL float4 per lane (lazy_sweep_wide_body)
+template <int LPR, int VPL>
+int launch_sweep_wide(LazySweepArgs& a, const int64_t* h_rows, const int64_t* h_window, hipStream_t s) {
+  constexpr int RPB = RH_BLOCK / LPR;
+  a.vb_prefix[0] = 0;
+  for (int t = 0; t < a.T; ++t) {
+    int64_t w = h_window[t] < h_rows[t] ? h_window[t] : h_rows[t];
+    if (h_window[t] >= h_rows[t]) w = 0;  // K_t == 1: a dense table, not this launch's
+    a.vb_prefix[t + 1] = a.vb_prefix[t] + (w + RPB - 1) / RPB;
+  }
+  for (int t = a.T + 1; t <= kMaxTensors; ++t) a.vb_prefix[t] = a.vb_prefix[a.T];
+  a.total_vblocks = a.vb_prefix[a.T];
+  a.touch_blocks = a.touch_chunks = 0;
+  a.touch_period = 1;
+  if (a.total_vblocks == 0) return 0;
+  int64_t grid = a.total_vblocks;
+  const int64_t cap = g_deferred_grid > 0 ? g_deferred_grid : (g_sweep_grid > 0 ? g_sweep_grid : 256 * 32);
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((adam_lazy_sweep_wide_kernel<LPR, VPL>), dim3((unsigned)grid), dim3(RH_BLOCK), 0, s, a);
+  return 0;
+}
+
 template <int LPR>
 int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_t* h_window, hipStream_t s,
                  const LazyTouchedArgs* touch = nullptr) {
   constexpr int RPB = RH_BLOCK / LPR;
+  if constexpr (LPR >= 4) {
+    if (mode == RH_SWEEP_LAZY_TABLES && a.t_value >= 0 && touch == nullptr && g_sweep_wide == 4)
+      return launch_sweep_wide<LPR / 4, 4>(a, h_rows, h_window, s);
+  }
+  if constexpr (LPR >= 2) {
+    if (mode == RH_SWEEP_LAZY_TABLES && a.t_value >= 0 && touch == nullptr && g_sweep_wide >= 2)
+      return launch_sweep_wide<LPR / 2, 2>(a, h_rows, h_window, s);
+  }
   a.vb_prefix[0] = 0;
   for (int t = 0; t < a.T; ++t) {
     int64_t w = a.flush ? h_rows[t] : (h_window[t] < h_rows[t] ? h_window[t] : h_rows[t]);
@@ -1002,6 +1150,10 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
   }
   if (key == RH_TUNE_SWEEP_GATE_NS) {
     g_gate_ns = value;
+    return 0;
+  }
+  if (key == RH_TUNE_SWEEP_WIDE) {
+    g_sweep_wide = value;
     return 0;
   }
   return RH_E_BADARG;

@@ -308,10 +308,7 @@ class CTRTrainer(object):
     def tune_budget_steps(self):
         """Upper bound of the replayed steps the self-tuning below takes once the optimizer is in its steady state (bench.py
         keeps its timed region behind it)."""
-        opt = self.optimizer
-        extra = 2 if (isinstance(opt, TableAdam) and getattr(opt, "lazy_k", 0) > 1 and opt._tables and
-                      opt.lazy_rows() > opt.SWEEP_BOUND_ROWS) else 0
-        return (len(self.TUNE_CANDIDATES) + extra) * (self.TUNE_SETTLE + self.TUNE_STEPS)
+        return len(self.TUNE_CANDIDATES) * (self.TUNE_SETTLE + self.TUNE_STEPS)
 
     def _tune_step_form(self, loader):
         """Self-tuning of HOW the captured step ends, over real training steps (nothing is thrown away): once the lazy
@@ -333,13 +330,9 @@ class CTRTrainer(object):
             grid = os.environ.get("RECHUB_SWEEP_GRID", "")
             if grid:
                 _lib.call("rh_set_tuning", 8, int(grid))
-            all_cands = list(self.TUNE_CANDIDATES)
-            if lazy and opt.lazy_rows() > opt.SWEEP_BOUND_ROWS:
-                # a step bound by the window sweep (configs[4]: 110 M lazy rows, a 0.65 ms sweep beside a 0.25 ms chain): the
-                # residency cap that protects the chain costs the sweep 20-40 % of its throughput (sweep alone: 188 us at 512
-                # workgroups, 166 at 1024, 158 at 2048) -- let the measurement decide
-                all_cands += [("deferred", 1024, 32000), ("deferred", 2048, 32000)]
-            cands = [c for c in all_cands if (not form or c[0] == form) and
+            # (round 5 measured larger residency caps for the sweep-bound configs[4] step -- 1024 / 2048 workgroups: 0.98 / 1.04 ms
+            # against 0.834 at 512 and 0.833 at 256 -- the chain loses more than the sweep gains there too; not candidates)
+            cands = [c for c in self.TUNE_CANDIDATES if (not form or c[0] == form) and
                      (not grid or c[0] == "inline" or c[1] == int(grid))]
             if form and (grid or not cands):  # fully pinned (also forms / grids that are not tuning candidates)
                 cands = [(form, int(grid or 512) if form != "inline" else 0, 0)]
