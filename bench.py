@@ -1005,10 +1005,40 @@ def pmc_traffic(args, kernel_key="adam_lazy_sweep_kernel<4, false>", tail=25):
     return out
 
 
+def dp_one_rank(args):
+    """The data-parallel step (RCCL collectives, gradient-row exchange or row-sharded lookup) measured on ONE rank: this file
+    re-executed with --force-dp (a one-rank `nccl` group; every collective is launched, none is skipped) once per table
+    placement, 100 replayed steps each.  NOT a scaling figure -- no scaling curve has been measured (the driver launches
+    N = 2 / 4 / 8 when it has the node) -- but the per-rank cost of the data-parallel machinery next to the N = 1 step:
+    `ratio_to_single` = its ms/step over this run's ms_per_step.  Reference: nn.DataParallel (trainers/ctr_trainer.py:53-55)."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    out = {}
+    for placement in ("replicate", "shard"):
+        cmd = [sys.executable, here, "--force-dp", "--tables", placement, "--steps", "100", "--warmup", str(args.warmup),
+               "--no-cpu-baseline", "--brief", "--no-kernel-sweep", "--model", args.model, "--batch", str(args.batch),
+               "--rows", str(min(args.rows or 8_000_000, 8_000_000)), "--dist", args.dist, "--graph", args.graph]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 200), RANK="0", WORLD_SIZE="1",
+                   LOCAL_RANK="0")
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[placement] = {"error": f"rc {p.returncode}: {p.stderr.decode(errors='replace')[-300:]}"}
+                continue
+            d = json.loads(line[-1])
+            out[placement] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "hipgraph": d["config"]["hipgraph"],
+                              "comm_us_per_step": d.get("comm_us_per_step"), "flush_ms": d.get("flush_ms"),
+                              "rows_behind_after_flush": d.get("rows_behind_after_flush")}
+        except subprocess.TimeoutExpired:
+            out[placement] = {"error": "timed out"}
+    return out
+
+
 def trace_inner(args, device, rank):
     """Child of step_accounting(): steady-state hipGraph steps and nothing else (no flush, no eager passes)."""
     wl = Workload(args, device, rank)
-    model, trainer, loader = wl.build(None, True, batch=args.batch)
+    model, trainer, loader = wl.build(args.tables if args.force_dp else None, True, batch=args.batch)
     trainer._graphed_step(loader)
     lazy = getattr(trainer.optimizer, "lazy_k", 0) > 1
     warm = max(args.warmup, (int(trainer.optimizer.lazy_k) + 8) if lazy else 0)
@@ -1253,6 +1283,17 @@ def main():
                     sec[name] = guarded(name, one)
                     torch.cuda.empty_cache()
                 extras["secondary_configs"] = sec
+            if not args.acct_only:
+                def dp_leg():
+                    r = dp_one_rank(args)
+                    for v in r.values():
+                        if isinstance(v, dict) and v.get("ms_per_step"):
+                            v["ratio_to_single"] = round(v["ms_per_step"] / head["ms_per_step"], 3)
+                    r["what"] = ("`bench.py --force-dp --tables <placement>`: the full data-parallel step on a one-rank RCCL group "
+                                 "(collectives launched, not skipped), 100 replayed steps; per-rank machinery cost, not a scaling "
+                                 "measurement")
+                    return r
+                extras["dp_one_rank"] = guarded("dp_one_rank", dp_leg)
             if not args.no_step_accounting:
                 extras["step_accounting"] = guarded("step_accounting", lambda: step_accounting(args))
         acct = extras.get("step_accounting") or {}

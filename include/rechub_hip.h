@@ -57,7 +57,7 @@ const char* rh_last_error(void);
 #define RH_TUNE_DEFERRED_GRID 8 /* persistent workgroups of a DEFERRED sweep (default 512 = 2 per CU; 0 = as RH_TUNE_SWEEP_GRID):
                                   the residency cap that lets the step's chain keep its wave slots and issue cycles */
 #define RH_TUNE_SWEEP_STAGGER_NS 12 /* rh_adam_sweep_stagger: hold-back in nanoseconds (default 15000; 0 = no launch) */
-#define RH_TUNE_SWEEP_GATE_NS 13 /* rh_adam_sweep_gate: hold-back behind the opening, ns (default 32000) */
+#define RH_TUNE_SWEEP_GATE_NS 13 /* rh_adam_sweep_gate(fallback_ns = 0): hold-back behind the opening, ns (default 32000) */
 #define RH_TUNE_SWEEP_WIDE 14 /* deferred window sweep of the lazy tables: float4 per lane at embed_dim >= 8 (2 = default: two
                                  independent float4 chains per lane, round 5; 1 = one float4 per lane, the round-4 kernel) */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
@@ -351,6 +351,12 @@ int rh_gemm_chain_stats_rows(int M); /* slab height of the `stats` rh_linear_bna
 int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
                   float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr, int64_t* bn_batches,
                   void* stream);
+/* rh_linear_fwd that also counts a CHAIN START in the deferred sweep's gate words (chain_gate[2], RH_GATE_WORDS below) when its
+ * last workgroup starts, i.e. when every workgroup of the launch has been placed: captured as the first own GEMM of a step's
+ * hipGraph it releases the optimizer's sweep of the step before (rh_adam_sweep_gate) beside a chain that is already running. */
+int rh_linear_fwd_gate(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
+                       float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr, int64_t* bn_batches,
+                       int64_t* chain_gate, void* stream);
 int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
                     int64_t ldgx, void* stream);
 /* The fused MLP chain (round 4): the reference's hidden-layer tail  BatchNorm1d -> ReLU -> Dropout
@@ -565,13 +571,17 @@ int rh_pack_grads_adam_gate(const RhPackItem* items, int n, float* flat, const i
 /* A one-lane launch that occupies `stream` for RH_TUNE_SWEEP_STAGGER_NS: placed in front of a deferred sweep whose release
  * coincides with a kernel launch of the step's chain, so that the two are not dispatched together (csrc/optim.hip). */
 int rh_adam_sweep_stagger(void* stream);
-/* The same hold-back released by a device word instead of an event.  gate: two int64 (count of openings, wall clock of the last
- * one), zero-initialised by the caller.  rh_adam_sweep_gate_open: a one-lane launch that counts an opening -- captured as the
- * last launch of a step's hipGraph it announces on every replay that the step has finished.  rh_adam_sweep_gate occupies
- * `stream` until the count has reached `expected` and RH_TUNE_SWEEP_GATE_NS have passed since that opening.  A gate not opened
- * within 2 s gives up and sets bit RH_ERR_GATE_TIMEOUT of *err_flag (the error word of rh_embed_fwd). */
+/* The sweep's release by device words instead of an event.  gate: RH_GATE_WORDS int64, zero-initialised by the caller:
+ * [0] count of openings, [1] wall clock of the last one, [2] count of chain starts (rh_linear_fwd_gate), [4 + 2 (i & 3)],
+ * [5 + 2 (i & 3)] chain-start count and wall clock at opening i.  rh_adam_sweep_gate_open: a one-lane launch that counts an
+ * opening -- captured as the last launch of a step's hipGraph it announces on every replay that the step has finished.
+ * rh_adam_sweep_gate occupies `stream` until the count has reached `expected` AND a chain start has been counted since that
+ * opening (the next step's first own GEMM has placed its workgroups) -- or, failing that, fallback_ns (0: RH_TUNE_SWEEP_GATE_NS)
+ * have passed since the opening (round 4: that hold-back WAS the release; it still is for graphs that count no chain start).  A gate not opened within 2 s gives up and sets bit
+ * RH_ERR_GATE_TIMEOUT of *err_flag (the error word of rh_embed_fwd). */
+#define RH_GATE_WORDS 16
 #define RH_ERR_GATE_TIMEOUT 64
-int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int32_t* err_flag, void* stream);
+int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int64_t fallback_ns, int32_t* err_flag, void* stream);
 int rh_adam_sweep_gate_open(int64_t* gate, void* stream);
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,

@@ -2111,3 +2111,55 @@ def test_inbatch_logits_without_the_score_matrix(B, C, row0, D, K):
     for a, b, what in ((out, ref, "logits"), (u1.grad, u2.grad, "g_user"), (v1.grad, v2.grad, "g_item")):
         scale = max(1.0, float(b.abs().max()))
         assert float((a.double() - b).abs().max()) <= 2e-5 * scale, what
+
+
+def test_sweep_gate_is_released_by_a_chain_start_or_by_its_fallback():
+    """rh_adam_sweep_gate (round 5): behind opening number i a gate waits for a CHAIN START counted after that opening
+    (rh_linear_fwd_gate: the last workgroup of the step's first own GEMM) -- and only without one for `fallback_ns`.  Round 4
+    released the deferred sweep a fixed wall-clock time behind the opening (a 20 % cliff +-6 us).
+    Measured on the side stream with HIP events: (a) opening + chain start -> released at once; (b) opening alone -> released
+    after the fallback; (c) a chain start counted BEFORE the opening does not release it; (d) no opening at all -> the 2 s
+    timeout raises RH_ERR_GATE_TIMEOUT instead of wedging the queue (not exercised here: it would cost the suite 2 s)."""
+    from torch_rechub_amd import _lib, ops
+    gate = torch.zeros(16, dtype=torch.int64, device=dev())
+    err = ops.err_flag(dev())
+    M, N, K = 256, 64, 64
+    x, w, b = torch.randn(M, K, device=dev()), torch.randn(N, K, device=dev()), torch.zeros(N, device=dev())
+    y = torch.empty(M, N, device=dev())
+    side = torch.cuda.Stream()
+    nul = torch.empty(0, device=dev())
+
+    def chain_start():
+        _lib.call("rh_linear_fwd_gate", ops._p(x), K, ops._p(w), K, ops._p(b), M, N, K, ops._p(y), N, 0, 0, 0, 0,
+                  ops._p(gate), ops._stream())
+
+    def gated_ms(expected, fallback_ns, between):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            e0.record()
+            _lib.call("rh_adam_sweep_gate", ops._p(gate), expected, fallback_ns, ops._p(err), ops._stream())
+            e1.record()
+        between()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    def opening_then_chain():
+        _lib.call("rh_adam_sweep_gate_open", ops._p(gate), ops._stream())
+        chain_start()
+
+    # (a) opening 1, then a chain start: released long before the 50 ms fallback
+    assert gated_ms(1, 50_000_000, opening_then_chain) < 10.0
+    assert gate[0].item() == 1 and gate[2].item() == 1
+    np.testing.assert_allclose(y.cpu().numpy(), (x @ w.t()).cpu().numpy(), rtol=1e-4, atol=1e-4)  # (the GEMM is still a GEMM)
+    # (c) + (b) a chain start BEFORE opening 2 does not count for it: the gate falls back after ~30 ms
+    chain_start()
+    torch.cuda.synchronize()
+    t = gated_ms(2, 30_000_000, lambda: _lib.call("rh_adam_sweep_gate_open", ops._p(gate), ops._stream()))
+    assert 25.0 < t < 200.0, t
+    assert gate[0].item() == 2 and gate[2].item() == 2 and gate[4 + 2 * (2 & 3)].item() == 2
+    # a gate reached late (its opening and chain start long past) adds no delay
+    opening_then_chain()
+    torch.cuda.synchronize()
+    assert gated_ms(3, 50_000_000, lambda: None) < 10.0
+    assert not (int(err.item()) & 64)

@@ -82,6 +82,8 @@ SIGNATURES = {
     "rh_gemm_stats_rows": [c_int, c_int],
     "rh_linear_fwd": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                       c_ptr],
+    "rh_linear_fwd_gate": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                           c_ptr, c_ptr],
     "rh_linear_dgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr],
     "rh_gemm_chain_stats_rows": [c_int],
     "rh_linear_bnact_fwd": [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr,
@@ -140,7 +142,7 @@ SIGNATURES = {
     "rh_adam_lazy_refresh_assemble": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                       c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr],
     "rh_adam_sweep_stagger": [c_ptr],
-    "rh_adam_sweep_gate": [c_ptr, c_i64, c_ptr, c_ptr],
+    "rh_adam_sweep_gate": [c_ptr, c_i64, c_i64, c_ptr, c_ptr],
     "rh_adam_sweep_gate_open": [c_ptr, c_ptr],
     "rh_adam_lazy_step_ahead": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                 c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr],

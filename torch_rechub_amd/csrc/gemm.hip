@@ -75,6 +75,7 @@ struct GemmArgs {
   const float* pro_h;       // BNBWD: (M, N) pre-BatchNorm activations of the layer whose gradient the tile holds
   int64_t ldh;
   float* bwd_partial;       // BNBWD: (ceil(M / BM), 2, N)
+  long long* chain_gate;    // rh_linear_fwd_gate: the deferred sweep's gate words (csrc/optim.hip), or null
 };
 
 constexpr int kProMaxSlabs = 32;  // PRO: slabs per thread and round of loads of the statistics prologue (common.h)
@@ -119,6 +120,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   if (nblk % 8 == 0) bid = (bid % 8) * (nblk / 8) + bid / 8;
   const int m0 = (bid / (int)gridDim.x) * BM, n0 = (bid % (int)gridDim.x) * BN;
   const int li = lane & 31, kk = lane >> 5;
+  // rh_linear_fwd_gate: the LAST workgroup in dispatch order counts a chain start when it starts -- every workgroup of this
+  // launch has been placed by then (one per CU at CTR batch sizes), which is the moment the optimizer's deferred sweep may
+  // be dispatched beside the chain (stream_gate_kernel, csrc/optim.hip)
+  if (a.chain_gate != nullptr && tid == 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) == nblk - 1)
+    __hip_atomic_fetch_add(a.chain_gate + 2, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   float4 ra0[A_V4], rb0[B_V4], ra1[A_V4], rb1[B_V4];
   // Per-thread source pointers of its float4 pieces (rows past M / N are clamped: they only feed accumulator rows /
@@ -493,9 +499,29 @@ void launch(const GemmArgs& a, hipStream_t s) {
 extern "C" int rh_gemm_stats_rows(int M, int N) { return big_tiles(M, N) ? 64 : 32; }
 extern "C" int rh_gemm_chain_stats_rows(int M) { return chain_tiles(M) ? 64 : 32; }  // slab height of rh_linear_bnact_fwd
 
+static int linear_fwd_impl(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
+                           float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr, int64_t* bn_batches,
+                           int64_t* chain_gate, void* stream);
+
 extern "C" int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N,
                              int K, float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr,
                              int64_t* bn_batches, void* stream) {
+  return linear_fwd_impl(x, ldx, w, ldw, bias, M, N, K, y, ldy, stats, bn_rng, bn_saved_ctr, bn_batches, nullptr, stream);
+}
+
+// rh_linear_fwd that also counts a CHAIN START in the deferred sweep's gate words (gate[2], see csrc/optim.hip) when its last
+// workgroup starts: captured as the first own GEMM of a step's hipGraph, it releases the sweep of the step before into a
+// chip on which this launch's workgroups are already placed.
+extern "C" int rh_linear_fwd_gate(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N,
+                                  int K, float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr,
+                                  int64_t* bn_batches, int64_t* chain_gate, void* stream) {
+  RH_REQUIRE(chain_gate != nullptr, RH_E_BADARG, "rh_linear_fwd_gate: null gate");
+  return linear_fwd_impl(x, ldx, w, ldw, bias, M, N, K, y, ldy, stats, bn_rng, bn_saved_ctr, bn_batches, chain_gate, stream);
+}
+
+static int linear_fwd_impl(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
+                           float* y, int64_t ldy, float* stats, int64_t* bn_rng, int64_t* bn_saved_ctr, int64_t* bn_batches,
+                           int64_t* chain_gate, void* stream) {
   RH_REQUIRE(x && w && y, RH_E_BADARG, "rh_linear_fwd: null pointer");
   RH_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N, RH_E_BADARG,
              "rh_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
@@ -504,6 +530,7 @@ extern "C" int rh_linear_fwd(const float* x, int64_t ldx, const float* w, int64_
   GemmArgs a{};
   a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.bias = bias; a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
   a.stats = stats; a.bn_rng = bn_rng; a.bn_saved_ctr = bn_saved_ctr; a.bn_batches = bn_batches;
+  a.chain_gate = reinterpret_cast<long long*>(chain_gate);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stats) launch<true, true>(a, s);
   else launch<true, false>(a, s);

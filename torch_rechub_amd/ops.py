@@ -1168,6 +1168,8 @@ class _HeadFn(torch.autograd.Function):
 # -> sigmoid of torch_rechub/basic/layers.py:276-292 + models/ranking/deepfm.py:39-43 as ONE autograd node over L + 1 forward
 # launches and 3 L + 1 backward launches.  A/B switch for benchmarks: RECHUB_AB=chain=0 (tests flip the attribute).
 FUSE_MLP_CHAIN = _lib.ab("chain")
+chain_gate = None      # the gate words of the optimizer whose step-ahead graph is being captured (optim.TableAdam), or None
+chain_gate_used = []   # ... and a mark per rh_linear_fwd_gate launch captured for it
 _CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
 
 
@@ -1198,7 +1200,13 @@ class _MlpChainFn(torch.autograd.Function):
             r = _lib.call("rh_gemm_stats_rows", B, N) if l == 0 else _lib.call("rh_gemm_chain_stats_rows", B)
             st = torch.empty((-(-B // r), 2, N), dtype=torch.float32, device=dev)
             ctr = torch.empty(1, dtype=torch.int64, device=dev)
-            if l == 0:
+            if l == 0 and chain_gate is not None and torch.cuda.is_current_stream_capturing():
+                # the first own GEMM of a step-ahead graph counts the chain start that releases the optimizer's deferred sweep
+                # (optim.TableAdam sets ops.chain_gate while it captures such a step; csrc/optim.hip::stream_gate_kernel)
+                _lib.call("rh_linear_fwd_gate", _p(inp), inp.stride(0), _p(W), K, _p(b), B, N, K, _p(h), N, _p(st), _p(rng),
+                          _p(ctr), _p(bns[0].num_batches_tracked), _p(chain_gate), _stream())
+                chain_gate_used.append(1)
+            elif l == 0:
                 _lib.call("rh_linear_fwd", _p(inp), inp.stride(0), _p(W), K, _p(b), B, N, K, _p(h), N, _p(st), _p(rng),
                           _p(ctr), _p(bns[0].num_batches_tracked), _stream())
             else:

@@ -25,7 +25,9 @@ EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kern
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
+CHAIN_GATE = _lib.ab("chaingate")  # False (RECHUB_AB=chaingate=0): the sweep is released RH_TUNE_SWEEP_GATE_NS behind the opening (round 4)
 LATE_PACK = _lib.ab("latepack")  # False (RECHUB_AB=latepack=0): the gate is opened by a one-lane launch of its own
+GATE_FALLBACK_NS = 80000  # step-ahead form with a chain-start count in the graph: release of a sweep no chain start follows (ns)
 LOOK_DEPTH = 2  # step-ahead form: batches beyond the next one whose lookups in the coming sweep's window are refreshed early
 
 
@@ -134,9 +136,10 @@ class TableAdam(torch.optim.Adam):
                 self._step_ahead = None     # step-ahead form: what _merged_step launches while the graph `seg` is captured
                 # step-ahead form: the sweep's release is a device word the LAST launch of the step's graph counts up
                 # (rh_adam_sweep_gate_open): [openings, wall clock of the last one]
-                self._gate = torch.zeros(2, dtype=torch.int64, device=dev)
+                self._gate = torch.zeros(16, dtype=torch.int64, device=dev)  # RH_GATE_WORDS (include/rechub_hip.h)
                 self._gate_seen = 0  # openings issued so far (one per replay of a step-ahead graph)
                 self._gate_by_pack = False
+                self.gate_by_chain = False  # the captured step-ahead graph holds a chain-start count (rh_linear_fwd_gate)
                 self._pre_refreshed = None  # the record rh_adam_lazy_refresh_assemble refreshed for the coming gather
                 self._head_forks = False    # capture: the eager head function forks the sweep, on_gather must not cut
                 self._step_recs, self._last_recs = [], []
@@ -339,6 +342,8 @@ class TableAdam(torch.optim.Adam):
         batch that lives in the loader's static buffer (the previous step's record): the assembly and the pre-gather refresh
         of that batch run as ONE launch (rh_adam_lazy_refresh_assemble), the refresh reading its indices from the dataset.
         Returns False (nothing launched: the caller assembles the ordinary way) whenever that is not the situation."""
+        if ops.chain_gate is self._gate:
+            ops.chain_gate = None  # (a capture that was abandoned between its head and its last launch)
         if self.lazy_k <= 1 or not self._tables or not ASSEMBLE_WITH_REFRESH or not self._k_decided:
             return False
         recs = self._last_recs
@@ -444,9 +449,12 @@ class TableAdam(torch.optim.Adam):
                 h = self._host_step
                 side = self._side_stream()
                 with torch.cuda.stream(side):
-                    # released by the graph's own last launch (no event record between two graph launches of the chain) and
-                    # held back RH_TUNE_SWEEP_GATE_NS behind it: into the next step's first GEMM, not beside a launch of the chain
+                    # released by the graph's own last launch (no event record between two graph launches of the chain) AND the
+                    # next replay's chain start (its first own GEMM has placed its workgroups: rh_linear_fwd_gate) -- into that
+                    # GEMM, not beside a launch of the chain; without a chain start GATE_FALLBACK_NS behind the opening (round 4:
+                    # a wall-clock hold-back of RH_TUNE_SWEEP_GATE_NS, which remains the release for graphs without an own GEMM)
                     _lib.call("rh_adam_sweep_gate", ops._p(self._gate), self._gate_seen,
+                              GATE_FALLBACK_NS if self.gate_by_chain else 0,
                               ops._p(ops.err_flag(self._tables[0].device)), ops._stream())
                     self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
                     self._sweep_events[h % (LOOK_DEPTH + 1)].record()
@@ -458,6 +466,10 @@ class TableAdam(torch.optim.Adam):
                 seg.after(tail_ahead)
                 self._advance_seg = seg  # (step_tables: tail_ahead counts the replayed steps)
                 self._step_ahead = dict(seg=seg, rec=rec, grp=grp, ft=ft, a=a)
+                # the first own GEMM captured into this graph counts the chain start that releases the sweep (round 5: a
+                # dependency instead of round 4's wall-clock hold-back behind the opening; ops._MlpChainFn, csrc/gemm.hip)
+                ops.chain_gate = self._gate if CHAIN_GATE else None
+                del ops.chain_gate_used[:]
             else:
                 seg.at_start(head_relaxed if RELAXED_JOIN else head)
             self._join_seg = seg
@@ -646,6 +658,10 @@ class TableAdam(torch.optim.Adam):
             if not self._gate_by_pack:  # (else the packing launch behind this one opens it: gate_for_late_pack)
                 _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
             self._gate_by_pack = False
+            # (a graph without an own GEMM in front -- no fused MLP chain -- never counts a chain start: its sweeps are
+            # released by the gate's fallback, RH_TUNE_SWEEP_GATE_NS behind the opening, as in round 4)
+            self.gate_by_chain = bool(ops.chain_gate_used)
+            ops.chain_gate = None
             self._sweep_pending = True
             return True
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream

@@ -345,6 +345,15 @@ class CTRTrainer(object):
                         seen.add(c[:2])
                         kept.append((c[0], c[1], 0))
                 cands = kept
+            if lazy and getattr(opt, "gate_by_chain", False):
+                # the captured step counts its chain starts: the sweep is released by the next step's first GEMM, the hold-back
+                # is no dimension of the step any more (round 4: 22 us = 305 us steps, 28 us = 245 us, box-dependent)
+                seen, kept = set(), []
+                for c in cands:
+                    if c[:2] not in seen:
+                        seen.add(c[:2])
+                        kept.append((c[0], c[1], 0))
+                cands = kept
             active = lazy and self.dp is None and len(cands) > 1 and "8" not in pinned
             st = self._tune = {"active": bool(active), "wait": (opt.lazy_k + 8) if lazy else 0, "i": 0, "n": 0, "ev": [],
                                "cands": cands}
