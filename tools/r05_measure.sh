@@ -72,6 +72,23 @@ pmc) for c in FETCH_SIZE WRITE_SIZE; do
   python tools/prof_summary.py "$OUT/pmc_sweep_$c" --pmc $c --tail 25 > "$OUT/pmc_sweep_${c}.txt" 2>&1
   find "$OUT/pmc_sweep_$c" -name '*.csv' -size +5M -delete
  done;;
+dptrace) for pl in ${DP_PLACEMENTS:-shard replicate}; do
+  (cd /tmp && rm -rf /tmp/dp_prof_$pl && MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/dp_prof_$pl -o dp -- python $OLDPWD/bench.py --force-dp --tables $pl --trace-inner --steps 10 --warmup 5 --rows 4000000 > /dev/null 2> $OLDPWD/$OUT/dp_prof_$pl.err)
+  python - $pl > "$OUT/dp_${pl}_step_kernels.txt" 2>&1 <<'PY'
+import csv,glob,os,sys
+m=sys.argv[1]
+f=max(glob.glob(f'/tmp/dp_prof_{m}/**/*kernel_trace.csv',recursive=True),key=os.path.getsize)
+rows=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"],r.get("Queue_Id","")) for r in csv.DictReader(open(f))]
+rows.sort()
+marks=[i for i,r in enumerate(rows) if "batch_gather_kernel" in r[2] or "refresh_assemble" in r[2]]
+lo,hi=marks[-3],marks[-2]
+print(m, "step wall us", (rows[hi][0]-rows[lo][0])/1e3, "launches", hi-lo)
+t0=rows[lo][0]
+for st,en,n,q in rows[lo:hi]:
+    k=n.replace("void ","").replace("(anonymous namespace)::","").replace("rechub::","").split("(")[0][:64]
+    print("%9.1f %9.1f %7.1f q%s %s"%((st-t0)/1e3,(en-t0)/1e3,(en-st)/1e3,q,k))
+PY
+  head -60 "$OUT/dp_${pl}_step_kernels.txt"; done;;
 twin) timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --brief --twin-repeat --no-kernel-sweep > "$OUT/bench_twin.json" 2> "$OUT/bench_twin.err"; echo "rc=$?"; grep "dense twin check" "$OUT/bench_twin.err" | tail -2; tail -3 "$OUT/bench_twin.err";;
 sec) for m in ${MODELS:-dssm dcnv2 din}; do
     timeout 400 python bench.py --model $m --steps 30 --warmup 5 --no-cpu-baseline --brief > "$OUT/bench_$m.json" 2> "$OUT/bench_$m.err"; echo "$m rc=$?"

@@ -342,10 +342,10 @@ class TableAdam(torch.optim.Adam):
         batch that lives in the loader's static buffer (the previous step's record): the assembly and the pre-gather refresh
         of that batch run as ONE launch (rh_adam_lazy_refresh_assemble), the refresh reading its indices from the dataset.
         Returns False (nothing launched: the caller assembles the ordinary way) whenever that is not the situation."""
-        if ops.chain_gate is self._gate:
-            ops.chain_gate = None  # (a capture that was abandoned between its head and its last launch)
         if self.lazy_k <= 1 or not self._tables or not ASSEMBLE_WITH_REFRESH or not self._k_decided:
             return False
+        if ops.chain_gate is self._gate:
+            ops.chain_gate = None  # (a capture that was abandoned between its head and its last launch)
         recs = self._last_recs
         if len(recs) != 1 or (self._gathers_per_step or 0) != 1 or self._gathers != 0:
             return False
