@@ -954,7 +954,7 @@ def step_accounting(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic(args, kernel_key="adam_lazy_sweep_kernel<4, false>", tail=25):
+def pmc_traffic(args, kernel_key="adam_lazy_sweep_wide_kernel", tail=25):
     """HBM traffic per launch of the dominant kernel, RE-COLLECTED (round 4 reported a constant from profiles/): two nested
     `rocprofv3 --pmc <C> --kernel-trace` passes -- FETCH_SIZE and WRITE_SIZE need 3 + 2 of the 4 TCC slots, so one pass each;
     kernel trace only, no other trace domain -- over this file's --trace-inner mode (the steady-state replayed step), mean over
@@ -1158,7 +1158,7 @@ def main():
                 roofline["regime"] = ("hipGraph-replayed steady-state steps: the deferred window sweep is launched on its "
                                       "side stream after every replay and timed there with HIP events (30 launches) WHILE the "
                                       "captured chain of the step runs beside it, i.e. under contention -- the duration "
-                                      "rocprofv3 reports for adam_lazy_sweep_kernel<4, false> in profiles/r05_bench_kernel_stats.txt (steady-state launches)")
+                                      "rocprofv3 reports for adam_lazy_sweep_wide_kernel<2, 2> in profiles/r05_bench_kernel_stats.txt (steady-state launches)")
                 roofline["hidden_under_the_step"] = True
                 if args.vocab_scale == 1.0 and best is None and not args.brief and not args.no_pmc and not args.acct_only:
                     # re-collected now: two nested rocprofv3 --pmc passes over `bench.py --trace-inner` (pmc_traffic)
@@ -1177,12 +1177,12 @@ def main():
                     roofline["traffic"], src = DEFERRED_SWEEP_PMC_TRAFFIC[args.lazy_k]
                     roofline["traffic_source"] = (f"profiles/{src}_{{FETCH,WRITE}}_SIZE.txt (rocprofv3 --pmc, separate "
                                                   "passes; a stored figure: the live passes were skipped or failed)")
-            pmc_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
-            if dominant == "rh_adam_lazy_sweep" and pmc_traffic and args.vocab_scale == 1.0 and best is None and \
+            stored_traffic = {64: 213.1e6, 32: 421.4e6}.get(args.lazy_k)
+            if dominant == "rh_adam_lazy_sweep" and stored_traffic and args.vocab_scale == 1.0 and best is None and \
                     not head.get("deferred_sweep_ms"):
                 # measured with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel in this
                 # configuration (2*FETCH + WRITE, gfx950 correction, calibrated on rh_adam_dense): profiles/r01_pmc_traffic.md
-                roofline["traffic"] = pmc_traffic
+                roofline["traffic"] = stored_traffic
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, separate passes; not re-collected by bench.py)"
             if dominant == "rh_adam_lazy_step" and args.lazy_k == 64 and args.vocab_scale == 1.0 and best is None and B == 4096:
                 # the merged launch under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py,

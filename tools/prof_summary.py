@@ -76,7 +76,7 @@ def main():
         print(f"{k:100s} {len(v):7d} {sum(v) / len(v) / 1e3:10.2f} {med / 1e3:10.2f} {min(v) / 1e3:10.2f} {sum(v) / 1e6:10.3f} "
               f"{100.0 * sum(v) / total:6.2f}")
     for k, v in acc.items():
-        if "adam_lazy_sweep_kernel<4, false>" in k and len(v) >= 40:
+        if ("adam_lazy_sweep_kernel<4, false>" in k or "adam_lazy_sweep_wide_kernel" in k) and len(v) >= 40:
             # after a flush the first lazy_k sweeps replay 1, 2, ... steps (a ramp of lazy_k launches), the eager passes at the end
             # of bench.py run theirs without a chain beside them: the steady-state launch is the plateau in between
             p75 = sorted(v)[int(0.75 * len(v))]
