@@ -60,8 +60,6 @@ const char* rh_last_error(void);
 #define RH_TUNE_SWEEP_GATE_NS 13 /* rh_adam_sweep_gate(fallback_ns = 0): hold-back behind the opening, ns (default 32000) */
 #define RH_TUNE_SWEEP_WIDE 14 /* deferred window sweep of the lazy tables: float4 per lane at embed_dim >= 8 (2 = default: two
                                  independent float4 chains per lane, round 5; 1 = one float4 per lane, the round-4 kernel) */
-#define RH_TUNE_TOUCHED_WIDE 15 /* rh_adam_lazy_step_ahead: float4 per lane of its touched / refresh / lookahead parts at
-                                   embed_dim >= 8 (2 = default, round 5; 1 = one float4 per lane) */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
 #define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build (default) */
 #define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront

@@ -251,7 +251,7 @@ struct LazySweepArgs {
   LazyTouchedArgs touch;
 };
 
-template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false, bool LOOK = false, bool GRAD = !REFRESH, int VPL = 1>
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE = false, bool LOOK = false, bool GRAD = !REFRESH>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f);
 
 // (bx_, gdim_: this workgroup's index and the number of workgroups of the sweep / merged part -- blockIdx.x / gridDim.x unless
@@ -574,13 +574,10 @@ __global__ void stream_gate_open_kernel(long long* gate) { gate_open(gate); }
 // GRAD (default: !REFRESH): the rows may carry a gradient -- it is read, applied in the closing step and re-zeroed.  REFRESH
 // with GRAD is the refresh of the NEXT batch inside the end-of-step launch of THIS step (adam_lazy_step_ahead_kernel): a row
 // both batches look up is claimed by one of the two passes, and whichever it is applies the gradient.
-// VPL (round 5): float4 per lane -- a row of D floats is held by LPR = D / (4 VPL) lanes with VPL float4 each (2 VPL independent
-// replay chains per lane, RH_BLOCK / LPR rows per pass: the instruction-level parallelism of lazy_sweep_wide_body for the
-// latency-bound replay of the looked-up rows).  Same adam_f4 / adam_f4_zero_g per float4: same bits.
-template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE, bool LOOK, bool GRAD, int VPL>
+template <int LPR, typename IdxT, bool REFRESH, bool ASSEMBLE, bool LOOK, bool GRAD>
 static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& a, int bx, int f) {
   constexpr int LPP = RH_BLOCK / LPR;
-  constexpr int D = 4 * LPR * VPL;
+  constexpr int D = 4 * LPR;
   const int T = a.T, F = a.F;
   const int64_t ti = a.field_table[f];
   if (ti < 0) return;
@@ -704,17 +701,12 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       old = s_old[slot];
       act = old < t;
     }
-    float4 P[VPL], M[VPL], V[VPL], G[VPL];
-    const int64_t eoff = rr * D + (int64_t)q * (4 * VPL);
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      P[k] = M[k] = V[k] = G[k] = f4_zero();
-      if (act) {
-        P[k] = gload<float4>(p + eoff + 4 * k);
-        M[k] = gload<float4>(m + eoff + 4 * k);
-        V[k] = gload<float4>(v + eoff + 4 * k);
-        if (GRAD) G[k] = gload<float4>(g + eoff + 4 * k);
-      }
+    float4 P = f4_zero(), M = f4_zero(), V = f4_zero(), G = f4_zero();
+    if (act) {
+      P = gload<float4>(p + rr * D + q * 4);
+      M = gload<float4>(m + rr * D + q * 4);
+      V = gload<float4>(v + rr * D + q * 4);
+      if (GRAD) G = gload<float4>(g + rr * D + q * 4);
     }
     // replay in segments between the steps at which rows of the wavefront join (see adam_lazy_sweep_kernel): fixed exec
     // mask and a scalar step counter inside a segment (the ring entry becomes a scalar load)
@@ -725,32 +717,27 @@ static __device__ __forceinline__ void lazy_touched_body(const LazyTouchedArgs& 
       if (first <= j) {
         for (int jj = j; jj < nxt; ++jj) {
           const float A = ring[2 * (jj & a.ring_mask)], E = ring[2 * (jj & a.ring_mask) + 1];
-#pragma unroll
-          for (int k = 0; k < VPL; ++k) adam_f4_zero_g(P[k], M[k], V[k], h, A, E);
+          adam_f4_zero_g(P, M, V, h, A, E);
         }
       }
       j = nxt;
     }
     if (!act) continue;
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      if (GRAD) adam_f4(P[k], G[k], M[k], V[k], h, h.A, h.E);  // (an all-zero G gives the bits of the zero-gradient form)
-      else adam_f4_zero_g(P[k], M[k], V[k], h, h.A, h.E);
-      gstore<float4>(p + eoff + 4 * k, P[k]);
-      gstore<float4>(m + eoff + 4 * k, M[k]);
-      gstore<float4>(v + eoff + 4 * k, V[k]);
-      // (REFRESH with GRAD: most rows of the NEXT batch carry no gradient -- their gradient rows are zero already)
-      if (GRAD && (!REFRESH || G[k].x != 0.f || G[k].y != 0.f || G[k].z != 0.f || G[k].w != 0.f))
-        gstore<float4>(g + eoff + 4 * k, f4_zero());
-    }
+    if (GRAD) adam_f4(P, G, M, V, h, h.A, h.E);  // (an all-zero G gives the bits of the zero-gradient form)
+    else adam_f4_zero_g(P, M, V, h, h.A, h.E);
+    gstore<float4>(p + rr * D + q * 4, P);
+    gstore<float4>(m + rr * D + q * 4, M);
+    gstore<float4>(v + rr * D + q * 4, V);
+    // (REFRESH with GRAD: most rows of the NEXT batch carry no gradient -- their gradient rows are zero already)
+    if (GRAD && (!REFRESH || G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)) gstore<float4>(g + rr * D + q * 4, f4_zero());
   }
   }
 }
 
-template <int LPR, typename IdxT, bool REFRESH, int VPL = 1>
+template <int LPR, typename IdxT, bool REFRESH>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyTouchedArgs a) {
   RH_CHAIN_PRIO();
-  lazy_touched_body<LPR, IdxT, REFRESH, false, false, !REFRESH, VPL>(a, (int)blockIdx.x, (int)blockIdx.y);
+  lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Batch assembly + pre-gather refresh as ONE launch (round 4; reference: TorchDataset.__getitem__ + default_collate,
@@ -808,11 +795,10 @@ struct StepAheadParts {
   int nA, chunksA;  // part A
   int spbA;
   int nC, chunksC;  // part C: chunksC x F workgroups of `look` samples
-  int nD, spbD;     // part D: nD workgroups of spbD samples
+  int nD;           // part D
 };
 
-// LPR x VPL: lanes per row x float4 per lane of parts B, A and C (the dense tables' part E keeps one float4 per lane)
-template <int LPR, int VPL>
+template <int LPR>
 __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const LazySweepArgs a, const StepAheadParts parts) {
   RH_CHAIN_PRIO();
   int bx = (int)blockIdx.x;
@@ -820,7 +806,7 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const La
     LazyTouchedArgs ta = a.touch;
     ta.spb = parts.spbB;
     ta.off = 0;
-    lazy_touched_body<LPR, int64_t, true, true, false, true, VPL>(ta, bx % parts.chunksB, bx / parts.chunksB);
+    lazy_touched_body<LPR, int64_t, true, true, false, true>(ta, bx % parts.chunksB, bx / parts.chunksB);
     return;
   }
   bx -= parts.nB;
@@ -828,14 +814,14 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const La
     LazyTouchedArgs ta = a.touch;
     ta.spb = parts.spbA;
     ta.off = -(int64_t)ta.B;
-    lazy_touched_body<LPR, int64_t, false, true, false, true, VPL>(ta, bx % parts.chunksA, bx / parts.chunksA);
+    lazy_touched_body<LPR, int64_t, false, true, false, true>(ta, bx % parts.chunksA, bx / parts.chunksA);
     return;
   }
   bx -= parts.nA;
   if (bx < parts.nC) {
     LazyTouchedArgs ta = a.touch;
     ta.off = 0;
-    lazy_touched_body<LPR, int64_t, true, true, true, true, VPL>(ta, bx % parts.chunksC, bx / parts.chunksC);
+    lazy_touched_body<LPR, int64_t, true, true, true, true>(ta, bx % parts.chunksC, bx / parts.chunksC);
     return;
   }
   bx -= parts.nC;
@@ -844,8 +830,8 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const La
     constexpr int G = 16;
     const int lig = threadIdx.x % G;
     const int64_t pos = ta.pos[0];
-    const int64_t b0 = (int64_t)bx * parts.spbD;
-    const int64_t b1 = (b0 + parts.spbD < (int64_t)ta.B) ? b0 + parts.spbD : (int64_t)ta.B;
+    const int64_t b0 = (int64_t)bx * parts.spbB;
+    const int64_t b1 = (b0 + parts.spbB < (int64_t)ta.B) ? b0 + parts.spbB : (int64_t)ta.B;
     for (int64_t b = b0 + threadIdx.x / G; b < b1; b += RH_BLOCK / G) {
       int64_t p = pos + b;
       if (p >= ta.N) p %= ta.N;
@@ -857,10 +843,9 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const La
     return;
   }
   bx -= parts.nD;
-  lazy_sweep_body<LPR * VPL, true>(a, bx, (int)gridDim.x - parts.nB - parts.nA - parts.nC - parts.nD);
+  lazy_sweep_body<LPR, true>(a, bx, (int)gridDim.x - parts.nB - parts.nA - parts.nC - parts.nD);
 }
 
-int g_touched_wide = 2;  // RH_TUNE_TOUCHED_WIDE: float4 per lane of the touched / refresh / lookahead parts of rh_adam_lazy_step_ahead
 int g_sweep_wide = 2;  // RH_TUNE_SWEEP_WIDE: float4 per lane of the deferred lazy-table sweep at embed_dim >= 8 (2 = default; 1 = round-4 kernel)
 
 // the deferred window sweep of the lazy tables, VPL float4 per lane (lazy_sweep_wide_body)
@@ -1186,10 +1171,6 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     g_sweep_wide = value;
     return 0;
   }
-  if (key == RH_TUNE_TOUCHED_WIDE) {
-    g_touched_wide = value;
-    return 0;
-  }
   return RH_E_BADARG;
 }
 
@@ -1330,27 +1311,20 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
              "rh_adam_lazy_touched: ring_size must be a power of two <= %d", kMaxRing);
   if (B == 0) return 0;
   int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
-  // two float4 per lane at embed_dim >= 8 (RH_TUNE_TOUCHED_WIDE): a pass of a workgroup then covers twice the rows
-  const int vpl = (g_touched_wide == 2 && D >= 8 && D <= 128) ? 2 : 1;
-  const int lpp = RH_BLOCK * 4 * vpl / (D > 0 ? D : 4);
-  if (vpl == 2 && lpp > 0) spb = ((spb + lpp - 1) / lpp) * lpp;
   LazyTouchedArgs a{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
   const dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)F);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define RH_LT2(LPR, VPL)                                                                                            \
-  if (idx_is_i64 && refresh)                                                                                        \
-    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t, true, VPL>), grid, dim3(RH_BLOCK), 0, s, a);        \
-  else if (idx_is_i64)                                                                                              \
-    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t, false, VPL>), grid, dim3(RH_BLOCK), 0, s, a);       \
-  else if (refresh)                                                                                                 \
-    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t, true, VPL>), grid, dim3(RH_BLOCK), 0, s, a);        \
-  else                                                                                                              \
-    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t, false, VPL>), grid, dim3(RH_BLOCK), 0, s, a);
-#define RH_LT(Q)                          \
-  if (vpl == 2) { RH_LT2((Q) / 2, 2) }    \
-  else { RH_LT2((Q), 1) }
+#define RH_LT(LPR)                                                                                             \
+  if (idx_is_i64 && refresh)                                                                                   \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t, true>), grid, dim3(RH_BLOCK), 0, s, a);        \
+  else if (idx_is_i64)                                                                                         \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int64_t, false>), grid, dim3(RH_BLOCK), 0, s, a);       \
+  else if (refresh)                                                                                            \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t, true>), grid, dim3(RH_BLOCK), 0, s, a);        \
+  else                                                                                                         \
+    hipLaunchKernelGGL((adam_lazy_touched_kernel<LPR, int32_t, false>), grid, dim3(RH_BLOCK), 0, s, a);
   switch (D / 4) {
-    case 1: RH_LT2(1, 1) break;
+    case 1: RH_LT(1) break;
     case 2: RH_LT(2) break;
     case 4: RH_LT(4) break;
     case 8: RH_LT(8) break;
@@ -1359,7 +1333,6 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
     default: rh_set_error("rh_adam_lazy_touched: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
   }
 #undef RH_LT
-#undef RH_LT2
   RH_LAUNCH_CHECK("rh_adam_lazy_touched");
   return 0;
 }
@@ -1480,11 +1453,8 @@ extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_
   a.touch = LazyTouchedArgs{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, 64, err_flag,
                             perm, pos, N, sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out,
                             look, look_depth * B, 0};
-  // float4 per lane of the touched parts: 2 at embed_dim >= 8 (RH_TUNE_TOUCHED_WIDE; 1 = the round-4 kernel).  One pass of a
-  // part-B workgroup covers RH_BLOCK / (D / (4 VPL)) rows: spbB follows it, so that a workgroup is one full pass
-  const int vpl = (g_touched_wide == 2 && D >= 8) ? 2 : 1;
   StepAheadParts parts;
-  parts.spbB = 64 * vpl;
+  parts.spbB = 64;
   parts.chunksB = (B + parts.spbB - 1) / parts.spbB;
   parts.nB = parts.chunksB * F;
   parts.spbA = 256;
@@ -1492,27 +1462,22 @@ extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_
   parts.nA = parts.chunksA * F;
   parts.chunksC = (look_depth * B + look - 1) / look;
   parts.nC = parts.chunksC * F;
-  parts.spbD = 64;
-  parts.nD = (B + parts.spbD - 1) / parts.spbD;
+  parts.nD = parts.chunksB;
   int64_t sweep_grid = a.total_vblocks;
   const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
   if (sweep_grid > cap) sweep_grid = cap;
   if (sweep_grid < 1) sweep_grid = 1;
   const dim3 grid((unsigned)(parts.nB + parts.nA + parts.nC + parts.nD + sweep_grid));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define RH_SA(Q)                                                                                                       \
-  if (vpl == 2) hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<(Q) / 2, 2>), grid, dim3(RH_BLOCK), 0, s, a, parts);   \
-  else hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<(Q), 1>), grid, dim3(RH_BLOCK), 0, s, a, parts);
   switch (D / 4) {
-    case 1: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<1, 1>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
-    case 2: RH_SA(2) break;
-    case 4: RH_SA(4) break;
-    case 8: RH_SA(8) break;
-    case 16: RH_SA(16) break;
-    case 32: RH_SA(32) break;
+    case 1: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<1>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 2: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<2>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 4: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<4>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 8: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<8>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 16: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<16>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
+    case 32: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<32>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
     default: rh_set_error("rh_adam_lazy_step_ahead: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
   }
-#undef RH_SA
   RH_LAUNCH_CHECK("rh_adam_lazy_step_ahead");
   return 0;
 }
