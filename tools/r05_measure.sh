@@ -89,6 +89,7 @@ for st,en,n,q in rows[lo:hi]:
     print("%9.1f %9.1f %7.1f q%s %s"%((st-t0)/1e3,(en-t0)/1e3,(en-st)/1e3,q,k))
 PY
   head -60 "$OUT/dp_${pl}_step_kernels.txt"; done;;
+sweepalone) timeout 300 python tools/sweep_alone_probe.py ${SWEEP_K:-128} > "$OUT/sweep_alone.txt" 2> "$OUT/sweep_alone.err"; echo "rc=$?"; cat "$OUT/sweep_alone.txt";;
 twin) timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --brief --twin-repeat --no-kernel-sweep > "$OUT/bench_twin.json" 2> "$OUT/bench_twin.err"; echo "rc=$?"; grep "dense twin check" "$OUT/bench_twin.err" | tail -2; tail -3 "$OUT/bench_twin.err";;
 sec) for m in ${MODELS:-dssm dcnv2 din}; do
     timeout 400 python bench.py --model $m --steps 30 --warmup 5 --no-cpu-baseline --brief > "$OUT/bench_$m.json" 2> "$OUT/bench_$m.err"; echo "$m rc=$?"

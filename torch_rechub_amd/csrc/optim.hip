@@ -874,10 +874,8 @@ template <int LPR>
 int launch_sweep(LazySweepArgs& a, int mode, const int64_t* h_rows, const int64_t* h_window, hipStream_t s,
                  const LazyTouchedArgs* touch = nullptr) {
   constexpr int RPB = RH_BLOCK / LPR;
-  if constexpr (LPR >= 4) {
-    if (mode == RH_SWEEP_LAZY_TABLES && a.t_value >= 0 && touch == nullptr && g_sweep_wide == 4)
-      return launch_sweep_wide<LPR / 4, 4>(a, h_rows, h_window, s);
-  }
+  // (four float4 per lane, measured in round 5: 148 registers -- two such wavefronts leave a SIMD no room for the chain's
+  // 235-register GEMM prologue -- 0.2696 ms per step against 0.2408; not built)
   if constexpr (LPR >= 2) {
     if (mode == RH_SWEEP_LAZY_TABLES && a.t_value >= 0 && touch == nullptr && g_sweep_wide >= 2)
       return launch_sweep_wide<LPR / 2, 2>(a, h_rows, h_window, s);

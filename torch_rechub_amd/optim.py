@@ -27,7 +27,7 @@ RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager 
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
 CHAIN_GATE = _lib.ab("chaingate")  # False (RECHUB_AB=chaingate=0): the sweep is released RH_TUNE_SWEEP_GATE_NS behind the opening (round 4)
 LATE_PACK = _lib.ab("latepack")  # False (RECHUB_AB=latepack=0): the gate is opened by a one-lane launch of its own
-GATE_FALLBACK_NS = 80000  # step-ahead form with a chain-start count in the graph: release of a sweep no chain start follows (ns)
+GATE_FALLBACK_NS = 50000  # step-ahead form with a chain-start count in the graph: release of a sweep no chain start follows (ns)
 LOOK_DEPTH = 2  # step-ahead form: batches beyond the next one whose lookups in the coming sweep's window are refreshed early
 
 
