@@ -107,17 +107,24 @@ class DenseGradBucket(object):
         for p in self.params:
             p.grad = None
         self.packed = [False] * len(self.params)
+        self._pack_keep_dp = []
 
     def all_present(self):
-        return all(p.grad is not None for p in self.params)
+        slabs = ops.deferred.items if ops.deferred.armed is not None else {}
+        return all(p.grad is not None or id(p) in slabs for p in self.params)
 
-    def _runs(self, want_missing):
+    def _runs(self, want_missing, slabs=None):
+        """Maximal runs [i, j) of not-yet-packed parameters that have (want_missing = False) / lack a gradient -- a ``.grad``
+        tensor or, with ``slabs`` (ops.deferred.items), a registered slab of partial rows."""
+        def missing(k):
+            p = self.params[k]
+            return p.grad is None and (slabs is None or id(p) not in slabs)
         runs, i, n = [], 0, len(self.params)
         while i < n:
-            ok = (not self.packed[i]) and ((self.params[i].grad is None) == want_missing)
+            ok = (not self.packed[i]) and (missing(i) == want_missing)
             if ok:
                 j = i
-                while j < n and (not self.packed[j]) and ((self.params[j].grad is None) == want_missing):
+                while j < n and (not self.packed[j]) and (missing(j) == want_missing):
                     j += 1
                 runs.append((i, j))
                 i = j
@@ -163,8 +170,19 @@ class DenseGradBucket(object):
                 self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def flush(self):
-        """Pack (+ start reducing) every gradient that exists and has not been packed yet."""
-        runs = self._runs(want_missing=False)
+        """Pack (+ start reducing) every gradient that exists and has not been packed yet.
+
+        With ``ops.deferred`` armed for these parameters (the trainers' data-parallel step since round 5) a gradient may exist
+        only as the per-split / per-block partial SLAB its backward kernel left behind: the runs are then packed by ONE
+        rh_pack_grads launch that sums the slabs in split order straight into the flat bucket -- instead of one reduction
+        launch per slab (wgrad_reduce x layers, colsum x 2) and a torch.cat per run -- and the all-reduce starts on that."""
+        slabs = ops.deferred.items if (ops.deferred.armed is not None and self.use_cuda) else None
+        runs = self._runs(want_missing=False, slabs=slabs)
+        if slabs is not None:
+            if runs:
+                self._pack_runs(runs, slabs)
+            self._reduce(runs)
+            return
         for i, j in runs:
             torch.cat([self.params[k].grad.reshape(-1) for k in range(i, j)],
                       out=self.flat[self.offsets[i]:self.offsets[j]])
@@ -172,10 +190,37 @@ class DenseGradBucket(object):
                 self.packed[k] = True
         self._reduce(runs)
 
+    def _pack_runs(self, runs, slabs):
+        import ctypes
+
+        from . import _lib
+        idx = [k for i, j in runs for k in range(i, j)]
+        items = (_lib.PackItem * len(idx))()
+        keep = []
+        for n, k in enumerate(idx):
+            p = self.params[k]
+            it, rec, g = items[n], slabs.get(id(p)), p.grad
+            it.numel, it.dst_offset = self.sizes[k], self.offsets[k]
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.float().contiguous()
+            if g is not None:
+                keep.append(g)
+            if rec is not None:
+                it.src, it.nparts, it.stride = rec["src"], rec["nparts"], rec["stride"]
+                it.add = g.data_ptr() if g is not None else 0
+                keep.append(rec["keep"])
+            else:
+                it.src, it.nparts, it.stride, it.add = g.data_ptr(), 1, self.sizes[k], 0
+            self.packed[k] = True
+        self._pack_keep = getattr(self, "_pack_keep_dp", []) + keep  # alive until enqueued (pooled by a capturing graph)
+        self._pack_keep_dp = self._pack_keep
+        _lib.call("rh_pack_grads", ctypes.cast(items, ctypes.c_void_p), len(idx), ops._p(self.flat), ops._stream())
+
     def finish(self, assign_views=False):
         """Pack / reduce what is left (parameters without a gradient contribute zeros, like DDP) and join."""
         self.flush()
-        missing = self._runs(want_missing=True)
+        slabs = ops.deferred.items if (ops.deferred.armed is not None and self.use_cuda) else None
+        missing = self._runs(want_missing=True, slabs=slabs)
         for i, j in missing:
             self.flat[self.offsets[i]:self.offsets[j]].zero_()
             for k in range(i, j):

@@ -206,12 +206,17 @@ class CTRTrainer(object):
         # single GPU, packed optimizer: the weight-gradient / head / LR backward kernels leave their partial slabs to the
         # step's ONE packing launch (ops.DeferredGrads) instead of reducing them one by one
         defer = packed and self.dp is None
-        if defer:
+        # data parallel (round 5): the same slabs, summed by the bucket's own packing launches (DenseGradBucket.flush: one at
+        # the start of the embedding backward -- the all-reduce of the MLP's gradients starts on it -- one for the rest)
+        defer_dp = packed and self.dp is not None and self.bucket.use_cuda
+        if defer or defer_dp:
             ops.deferred.arm(self.bucket.params)
         try:
             loss.backward(self._grad_root(loss))
+            if defer_dp:
+                self.bucket.finish(assign_views=False)
         finally:
-            items = ops.deferred.disarm() if defer else {}
+            items = ops.deferred.disarm() if (defer or defer_dp) else {}
         if fast and not self._bucket_attached:
             # first step: every dense parameter must receive a gradient for the packed one-launch optimizer path
             # (torch.optim.Adam skips parameters without a gradient; the packed path cannot)
@@ -219,7 +224,7 @@ class CTRTrainer(object):
             if self.bucket.all_present() and self.bucket.params:
                 self.optimizer.attach_bucket(self.bucket)
             packed = self.optimizer._bucket is not None  # attached in THIS step: pack it the plain way below
-        if packed and not all(p.grad is not None or id(p) in items for p in self.bucket.params):
+        if packed and not defer_dp and not all(p.grad is not None or id(p) in items for p in self.bucket.params):
             raise RuntimeError("a dense parameter stopped receiving gradients; rebuild the trainer")
         late_gate = None
         if defer:
@@ -231,7 +236,7 @@ class CTRTrainer(object):
             late_gate = self.optimizer.gate_for_late_pack() if adam is not None else None
             if late_gate is None:
                 self.bucket.pack(items, adam=adam)
-        elif packed or self.dp is not None:
+        elif (packed or self.dp is not None) and not defer_dp:
             self.bucket.finish(assign_views=not packed)
         self.optimizer.step()
         if late_gate is not None:
@@ -258,14 +263,21 @@ class CTRTrainer(object):
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
-        loss.backward(self._grad_root(loss))
-        if not self._bucket_attached:
-            self._bucket_attached = True
-            if self.bucket.all_present() and self.bucket.params:
-                self.optimizer.attach_bucket(self.bucket)
-        if self.optimizer._bucket is None or not self.bucket.all_present():
-            raise RuntimeError("split-graph data parallel step needs every dense parameter to receive a gradient")
-        self.bucket.flush()  # pack only (defer = True)
+        defer_dp = self.optimizer._bucket is not None and self.bucket.use_cuda
+        if defer_dp:
+            ops.deferred.arm(self.bucket.params)
+        try:
+            loss.backward(self._grad_root(loss))
+            if not self._bucket_attached:
+                self._bucket_attached = True
+                if self.bucket.all_present() and self.bucket.params:
+                    self.optimizer.attach_bucket(self.bucket)
+            if self.optimizer._bucket is None or not self.bucket.all_present():
+                raise RuntimeError("split-graph data parallel step needs every dense parameter to receive a gradient")
+            self.bucket.flush()  # pack only (defer = True)
+        finally:
+            if defer_dp:
+                ops.deferred.disarm()
         self.dp.deferred_mode = False
         return report, list(self.dp.deferred)
 
