@@ -841,18 +841,25 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
         noisy_twin_tolerance(a.cpu().numpy(), b.cpu().numpy(), 1e-2 * 12, k, atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("use_graph,tables", [(False, "replicate"), ("single", "replicate"), ("split", "replicate"), (False, "shard")])
-def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_world1, monkeypatch, use_graph, tables):
-    """The test above on batches that hold every sample twice over collision-free rows (_duplicate_samples): every float atomic
-    adds identical addends, and the data-parallel step -- loss / world, dense bucket through the all-reduce, (index, gradient
-    row) all-gather + rh_embed_scatter_rows or the row-sharded lookup, lazy Adam's touched pass over the gathered indices --
-    must leave the SAME bits as the single-GPU fused step (measured so in round 5: tools/bitwise_probe.py).  Reference:
-    nn.DataParallel computes the global-batch update (trainers/ctr_trainer.py:53-55)."""
+@pytest.mark.parametrize("use_graph,tables,layout", [(False, "replicate", "duplicated_samples"),
+                                                     ("single", "replicate", "duplicated_samples"),
+                                                     ("split", "replicate", "duplicated_samples"),
+                                                     (False, "shard", "duplicated_samples"),
+                                                     (False, "replicate", "collision_free"),
+                                                     ("single", "replicate", "collision_free")])
+def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_world1, monkeypatch, use_graph, tables, layout):
+    """The test above on order-free batches -- every sample twice over collision-free rows (_duplicate_samples: every float
+    atomic adds identical addends), or collision-free rows outright: the data-parallel step -- loss / world, dense gradients
+    packed from their slabs into the bucket and through the all-reduce, (index, gradient row) all-gather +
+    rh_embed_scatter_rows or the row-sharded lookup, the join of the deferred sweep, lazy Adam's touched pass over the gathered
+    indices -- must leave the SAME bits as the single-GPU fused step (measured so in round 5: tools/bitwise_probe.py,
+    profiles/r05_bitwise_probe_dp.txt; the row-sharded lookup sums its dense gradients in another order and is bit-equal on
+    duplicated samples only).  Reference: nn.DataParallel computes the global-batch update (trainers/ctr_trainer.py:53-55)."""
     from torch_rechub_amd import ops, sharding
     from torch_rechub_amd.trainers import CTRTrainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
     nb, B = 12, 64
-    vocabs, sparse, dense, label = _loader_twin_data("duplicated_samples", nb, B, seed=51)
+    vocabs, sparse, dense, label = _loader_twin_data(layout, nb, B, seed=51)
     ma, dfe, sfe = _deepfm(vocabs, 3)
     mb, _, _ = _deepfm(vocabs, 3)
     mb.load_state_dict(ma.state_dict())

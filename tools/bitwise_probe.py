@@ -36,7 +36,7 @@ def report(name, sa, sb, extra=()):
     sys.stdout.flush()
 
 
-def dp_pairs():
+def dp_pairs(cases=None, layouts=("collision_free", "duplicated_samples")):
     import torch.distributed as dist
     import test_gpu_models as T
     from torch_rechub_amd import sharding
@@ -50,7 +50,7 @@ def dp_pairs():
                             device_id=torch.device("cuda:0"))
     dev = torch.device("cuda:0")
     nb, B = 12, 64
-    for layout in ("collision_free", "duplicated_samples"):
+    for layout in layouts:
         vocabs, sparse, dense, label = T._loader_twin_data(layout, nb, B, seed=51)
         params = {"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64}
 
@@ -65,8 +65,8 @@ def dp_pairs():
         ta = CTRTrainer(ma, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4)
         la = ta.train_one_epoch(loader())
         sa = {k: v.detach().clone() for k, v in ma.state_dict().items()}
-        for use_graph, tables in ((False, "replicate"), ("single", "replicate"), ("split", "replicate"), (False, "shard"),
-                                  ("single", "shard")):
+        for use_graph, tables in (cases or ((False, "replicate"), ("single", "replicate"), ("split", "replicate"), (False, "shard"),
+                                            ("single", "shard"))):
             mb, _, _ = mk()
             mb.load_state_dict(sd0)
             os.environ["RECHUB_FORCE_DP"] = "1"
@@ -168,10 +168,15 @@ def seq_pairs():
 
 
 if __name__ == "__main__":
+    import faulthandler
+    faulthandler.enable()
     which = sys.argv[1:] or ["dp", "seq"]
     for w in which:
         try:
-            {"dp": dp_pairs, "seq": seq_pairs}[w]()
+            {"dp": dp_pairs, "seq": seq_pairs,
+             # the captured row-sharded step twice in one process (round 5: the second capture of the full probe segfaulted)
+             "shard2": lambda: dp_pairs(cases=(("single", "shard"), ("single", "shard")), layouts=("duplicated_samples",)),
+             "shard2x": lambda: dp_pairs(cases=(("single", "shard"),))}[w]()
         except Exception as e:  # noqa: BLE001
             import traceback
             traceback.print_exc()
