@@ -81,6 +81,12 @@ def dp_pairs(cases=None, layouts=("collision_free", "duplicated_samples")):
                 tb.dp.close()
             print(f"[dp {layout} graph={use_graph} tables={tables}] loss plain {la!r} dp {lb!r}")
             report(f"dp one rank, {layout}, graph={use_graph}, tables={tables}", sa, sb)
+            if os.environ.get("PROBE_GC") == "1":  # destroy this trainer's graphs NOW, with an idle device
+                import gc
+                torch.cuda.synchronize()
+                del tb, mb
+                gc.collect()
+                torch.cuda.synchronize()
     os.environ["RECHUB_FORCE_DP"] = "0"
     dist.destroy_process_group()
 
@@ -176,7 +182,20 @@ if __name__ == "__main__":
             {"dp": dp_pairs, "seq": seq_pairs,
              # the captured row-sharded step twice in one process (round 5: the second capture of the full probe segfaulted)
              "shard2": lambda: dp_pairs(cases=(("single", "shard"), ("single", "shard")), layouts=("duplicated_samples",)),
-             "shard2x": lambda: dp_pairs(cases=(("single", "shard"),))}[w]()
+             "shard2x": lambda: dp_pairs(cases=(("single", "shard"),)),
+             "seqA": lambda: dp_pairs(cases=((False, "shard"), ("single", "shard")) * 2, layouts=("duplicated_samples",)),
+             "seqB": lambda: dp_pairs(cases=(("split", "replicate"), (False, "shard"), ("single", "shard")) * 2,
+                                      layouts=("duplicated_samples",)),
+             "seqC": lambda: dp_pairs(cases=((False, "replicate"), ("single", "replicate"), (False, "shard"), ("single", "shard")) * 2,
+                                      layouts=("duplicated_samples",)),
+             "seqD": lambda: dp_pairs(cases=((False, "replicate"), ("single", "replicate"), ("split", "replicate"), (False, "shard"),
+                                             ("single", "shard")) * 2, layouts=("duplicated_samples",)),
+             "cfcf": lambda: dp_pairs(layouts=("collision_free", "collision_free")),
+             "dupdup": lambda: dp_pairs(layouts=("duplicated_samples", "duplicated_samples")),
+             "dupcf": lambda: dp_pairs(layouts=("duplicated_samples", "collision_free")),
+             "single8": lambda: dp_pairs(cases=(("single", "replicate"),) * 8, layouts=("duplicated_samples",)),
+             "mix8": lambda: dp_pairs(cases=(("single", "replicate"), ("split", "replicate"), ("single", "shard")) * 3,
+                                      layouts=("duplicated_samples",))}[w]()
         except Exception as e:  # noqa: BLE001
             import traceback
             traceback.print_exc()
