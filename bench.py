@@ -95,6 +95,7 @@ def parse():
                     help="cpu_baseline: full = SURVEY 8(d)'s 3 warm-up + 10 timed steps per leg (~90 s at the Criteo shape); "
                          "bounded = about --cpu-budget seconds of steps; auto = full unless a step is too slow on this host")
     ap.add_argument("--trace-inner", action="store_true", help=argparse.SUPPRESS)  # child of the step_accounting pass
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)  # child of the pmc_traffic passes
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="exercise ONLY the rank launcher + rendezvous on CPU (gloo): every rank joins the group, one "
                          "all-reduce, rank 0 prints a JSON line with n_gpus = N and dry_run = true (tests/test_host_logic.py)")
@@ -957,8 +958,8 @@ def step_accounting(args):
 def pmc_traffic(args, kernel_key="adam_lazy_sweep_wide_kernel", tail=25):
     """HBM traffic per launch of the dominant kernel, RE-COLLECTED (round 4 reported a constant from profiles/): two nested
     `rocprofv3 --pmc <C> --kernel-trace` passes -- FETCH_SIZE and WRITE_SIZE need 3 + 2 of the 4 TCC slots, so one pass each;
-    kernel trace only, no other trace domain -- over this file's --trace-inner mode (the steady-state replayed step), mean over
-    the last `tail` dispatches of the kernel.  Bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts 64 B per
+    kernel trace only, no other trace domain -- over this file's --pmc-inner mode (the deferred sweep of the workload's tables in
+    its steady state, launched eagerly with nothing beside it: see pmc_inner), mean over the last `tail` dispatches.  Bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts 64 B per
     128-B request of a 16 B / lane streaming read (MI355X_MICROARCH.md, HBM section; calibrated on rh_adam_dense in round 1:
     profiles/r01_pmc_traffic.md).  Returns a dict with `bytes` or `error`."""
     import csv
@@ -978,12 +979,10 @@ def pmc_traffic(args, kernel_key="adam_lazy_sweep_wide_kernel", tail=25):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="rh_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
-               here, "--trace-inner", "--steps", "30", "--warmup", str(args.warmup), "--model", args.model, "--batch",
-               str(args.batch), "--rows", str(min(args.rows or 4_000_000, 4_000_000)), "--lazy-k", str(args.lazy_k),
-               "--table-adam", args.table_adam, "--dist", args.dist, "--vocab-scale", str(args.vocab_scale), "--graph", args.graph]
+               here, "--pmc-inner", "--lazy-k", str(args.lazy_k), "--vocab-scale", str(args.vocab_scale)]
         try:
             p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
-                               stderr=subprocess.PIPE, timeout=200)
+                               stderr=subprocess.PIPE, timeout=75)
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return {"error": f"nested rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-200:]}"}
@@ -1035,6 +1034,26 @@ def dp_one_rank(args):
     return out
 
 
+def pmc_inner(args, device):
+    """Child of pmc_traffic(): the deferred window sweep of the workload's tables and NOTHING else -- the tables of
+    configs[1] under TableAdam(lazy_k), lazy_k + 8 + 40 eager launches of rh_adam_prepare + rh_adam_lazy_sweep(RH_SWEEP_LAZY_TABLES,
+    step by value): the steady state in which every window row is lazy_k steps behind.  No hipGraph, no side stream, no gate:
+    under `rocprofv3 --pmc` dispatches are serialised, and a launch that spin-waits for another queue's progress (the sweep's
+    gate in the replayed step) turns every step into a time-out (round 5: the passes over --trace-inner did not finish)."""
+    from torch_rechub_amd import _lib, ops
+    from torch_rechub_amd.optim import SWEEP_LAZY_TABLES, TableAdam
+    g = torch.Generator(device=device).manual_seed(0)
+    vocabs = [max(3, int(v * args.vocab_scale)) for v in CRITEO_VOCABS]
+    tables = [torch.nn.Parameter(torch.randn(v, EMBED_DIM, device=device, generator=g) * 1e-2) for v in vocabs]
+    opt = TableAdam(tables, table_params=tables, lr=1e-3, weight_decay=1e-5, lazy_k=args.lazy_k)
+    opt.sync_hyper()
+    opt._lazy_setup()
+    for t in range(1, args.lazy_k + 8 + 40 + 1):
+        _lib.call("rh_adam_prepare", ops._p(opt._t_hyper), ops._p(opt._t_step), ops._p(opt._t_ring), opt.RING, ops._stream())
+        opt._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=t)
+    torch.cuda.synchronize()
+
+
 def trace_inner(args, device, rank):
     """Child of step_accounting(): steady-state hipGraph steps and nothing else (no flush, no eager passes)."""
     wl = Workload(args, device, rank)
@@ -1082,6 +1101,9 @@ def main():
 
     parallel = world > 1 or args.force_dp
     use_graph = args.graph in ("1", "auto")  # N > 1: the RCCL collectives are captured with the rest of the step
+    if args.pmc_inner:
+        pmc_inner(args, device)
+        return
     if args.trace_inner:
         trace_inner(args, device, rank)
         return
@@ -1170,7 +1192,10 @@ def main():
                     if pm.get("bytes"):
                         roofline["traffic"] = pm["bytes"]
                         roofline["traffic_source"] = ("re-collected by this run: nested rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                      "passes (kernel trace only) over `bench.py --trace-inner`")
+                                                      "passes (kernel trace only) over `bench.py --pmc-inner` = the same sweep "
+                                                      "launches in their steady state without the step beside them (under "
+                                                      "counter collection dispatches are serialised; the replayed step's gate "
+                                                      "would time out)")
                     roofline["traffic_pmc"] = pm
                 if roofline["traffic"] is None and args.lazy_k in DEFERRED_SWEEP_PMC_TRAFFIC and args.vocab_scale == 1.0 and \
                         best is None:

@@ -68,7 +68,7 @@ prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format c
   (cd /tmp && rm -rf /tmp/tl_r05 && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_r05 -o t -- python "$OLDPWD/bench.py" --trace-inner --steps 30 --warmup 10 --rows 4000000 > /dev/null 2> "$OLDPWD/$OUT/tl.err"); python tools/timeline.py /tmp/tl_r05 2 > "$OUT/step_timeline.txt" 2>&1
   find "$OUT/prof" -name '*kernel_trace.csv' -size +20M -delete;;
 pmc) for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sweep_$c" -o probe -- python "$OLDPWD/bench.py" --trace-inner --steps 30 --warmup 10 --rows 4000000 > /dev/null 2> "$OLDPWD/$OUT/pmc_sweep_$c.err"); echo "pmc $c rc=$?"
+  (cd /tmp && time timeout 90 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_sweep_$c" -o probe -- python "$OLDPWD/bench.py" --pmc-inner > /dev/null 2> "$OLDPWD/$OUT/pmc_sweep_$c.err"); echo "pmc $c rc=$?"
   python tools/prof_summary.py "$OUT/pmc_sweep_$c" --pmc $c --tail 25 > "$OUT/pmc_sweep_${c}.txt" 2>&1
   find "$OUT/pmc_sweep_$c" -name '*.csv' -size +5M -delete
  done;;
