@@ -359,6 +359,14 @@ int rh_linear_fwd_gate(const float* x, int64_t ldx, const float* w, int64_t ldw,
                        int64_t* chain_gate, void* stream);
 int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, int M, int N, int K, float* gx,
                     int64_t ldgx, void* stream);
+/* One CrossNetV2 layer (torch_rechub/basic/layers.py:440-444: x <- x0 * (W_l x) + b_l + x) on the tile GEMM with the Hadamard +
+ * bias + residual as its epilogue (round 5; rounds 1-4: library GEMM + rh_cross_v2_epilogue_fwd as a second pass).
+ * rh_cross_v2_fwd: x0, x (M, d), w (d, d) row-major as nn.Linear.weight, b (d,) -> y (M, d) = x w^T (kept for the backward) and
+ * out (M, d) = x0 * y + b + x.  rh_cross_v2_dgrad: gx (M, d) = g_y w + g with g_y = g * x0 (rh_cross_v2_epilogue_bwd forms g_y
+ * and g_x0 = g * y): the layer's gradient with respect to x, residual path included. */
+int rh_cross_v2_fwd(const float* x0, const float* x, const float* w, const float* b, int M, int d, float* y, float* out,
+                    void* stream);
+int rh_cross_v2_dgrad(const float* g_y, const float* w, const float* g, int M, int d, float* gx, void* stream);
 /* The fused MLP chain (round 4): the reference's hidden-layer tail  BatchNorm1d -> ReLU -> Dropout
  * (torch_rechub/basic/layers.py:283-286) is never run as a pass of its own -- it is applied where its output is consumed.
  * rh_linear_bnact_fwd: layer l + 1 as ONE launch, y = dropout(relu(batch_norm(h))) W^T + b with h (M, K) the PRE-BatchNorm

@@ -2163,3 +2163,40 @@ def test_sweep_gate_is_released_by_a_chain_start_or_by_its_fallback():
     torch.cuda.synchronize()
     assert gated_ms(3, 50_000_000, lambda: None) < 10.0
     assert not (int(err.item()) & 64)
+
+
+@pytest.mark.parametrize("B,d,L", [(64, 64, 2), (4096, 429, 3), (100, 30, 1), (2, 16, 2)])
+def test_cross_v2_layer_on_the_tile_gemm_vs_float64_formula(B, d, L):
+    """CrossNetV2.forward x <- x0 * (W_l x) + b_l + x (torch_rechub/basic/layers.py:440-444) as ONE launch per layer and
+    direction (rh_cross_v2_fwd: tile GEMM + Hadamard / bias / residual epilogue; rh_cross_v2_dgrad: g_y W + g): output and
+    every gradient against the formula in float64, and the same bits from the torch.library op."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.layers import CrossNetV2
+    import torch_rechub_amd.library  # noqa: F401
+    g = torch.Generator().manual_seed(B + d)
+    net = CrossNetV2(d, L).to(dev())
+    with torch.no_grad():
+        for l in range(L):
+            net.w[l].weight.copy_(torch.randn(d, d, generator=g) / d ** 0.5)
+            net.b[l].copy_(torch.randn(d, generator=g) * 0.1)
+    x = torch.randn(B, d, generator=g)
+    assert ops.cross_v2_layer_ok(x.to(dev()), net.w[0])
+    xa = x.to(dev()).requires_grad_(True)
+    out = net(xa)
+    up = torch.randn(B, d, generator=g)
+    (out * up.to(dev())).sum().backward()
+    xr = x.double().requires_grad_(True)
+    Ws = [net.w[l].weight.detach().cpu().double().requires_grad_(True) for l in range(L)]
+    bs = [net.b[l].detach().cpu().double().requires_grad_(True) for l in range(L)]
+    xl = xr
+    for l in range(L):
+        xl = xr * (xl @ Ws[l].t()) + bs[l] + xl
+    (xl * up.double()).sum().backward()
+    close(out, xl.detach().numpy(), rtol=1e-4, atol_scale=1e-5, what="cross_v2 out")
+    close(xa.grad, xr.grad.numpy(), rtol=2e-4, atol_scale=2e-5, what="cross_v2 g_x")
+    for l in range(L):
+        close(net.w[l].weight.grad, Ws[l].grad.numpy(), rtol=2e-4, atol_scale=2e-5, what=f"cross_v2 g_W[{l}]")
+        close(net.b[l].grad, bs[l].grad.numpy(), rtol=2e-4, atol_scale=2e-5, what=f"cross_v2 g_b[{l}]")
+    W = torch.stack([net.w[l].weight.detach() for l in range(L)])
+    bb = torch.stack([net.b[l].detach() for l in range(L)])
+    assert torch.equal(torch.ops.rechub_hip.cross_net_v2(x.to(dev()), W, bb), out.detach())

@@ -85,6 +85,8 @@ SIGNATURES = {
     "rh_linear_fwd_gate": [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                            c_ptr, c_ptr],
     "rh_linear_dgrad": [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr],
+    "rh_cross_v2_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_cross_v2_dgrad": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr],
     "rh_gemm_chain_stats_rows": [c_int],
     "rh_linear_bnact_fwd": [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr,
                             c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],

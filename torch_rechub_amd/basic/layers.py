@@ -461,8 +461,12 @@ class CrossNetV2(nn.Module):
     def forward(self, x):
         ops.require_hip(x)
         x0 = x
-        for i in range(self.num_layers):  # (d, d) GEMM on hipBLASLt, then ONE fused Hadamard + bias + residual pass
-            x = ops.cross_v2_epilogue(x0, self.w[i](x), self.b[i], x)
+        for i in range(self.num_layers):
+            if ops.cross_v2_layer_ok(x, self.w[i]):
+                # ONE launch: the (d, d) product on the f32-MFMA tile GEMM with Hadamard + bias + residual as its epilogue
+                x = ops.cross_v2_layer(x0, x, self.w[i].weight, self.b[i])
+            else:  # (d, d) GEMM on hipBLASLt, then the fused Hadamard + bias + residual pass
+                x = ops.cross_v2_epilogue(x0, self.w[i](x), self.b[i], x)
         return x
 
 

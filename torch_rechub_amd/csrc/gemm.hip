@@ -76,6 +76,13 @@ struct GemmArgs {
   int64_t ldh;
   float* bwd_partial;       // BNBWD: (ceil(M / BM), 2, N)
   long long* chain_gate;    // rh_linear_fwd_gate: the deferred sweep's gate words (csrc/optim.hip), or null
+  // CrossNetV2 (round 5): ep_out != null -> C = the raw product y, ep_out = ep_mul * y + bias + ep_add (x0 * (W x) + b + x,
+  // torch_rechub/basic/layers.py:440-444); ep_out == null, ep_add != null -> C = product + ep_add (the residual of the input
+  // gradient).  ep_* are (M, N) with leading dimension ld_ep.
+  const float* ep_mul;
+  const float* ep_add;
+  float* ep_out;
+  int64_t ld_ep;
 };
 
 constexpr int kProMaxSlabs = 32;  // PRO: slabs per thread and round of loads of the statistics prologue (common.h)
@@ -361,11 +368,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmArgs a
   const bool cok = col < a.N;
   const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
   const int rbase = m0 + wm * 32 + 4 * kk;
+  if (a.ep_add != nullptr) {
+    // CrossNetV2 epilogues: the (M, N) operands of the Hadamard / residual terms are read here, all 16 (+ 16) loads of a lane
+    // in flight together
+    float ea[16], em[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    acc[r] += bv;
-    const int row = rbase + (r & 3) + 8 * (r >> 2);
-    if (cok && row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[r];
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      const bool ok = cok && row < a.M;
+      ea[r] = ok ? a.ep_add[(int64_t)row * a.ld_ep + col] : 0.f;
+      em[r] = (ok && a.ep_out != nullptr) ? a.ep_mul[(int64_t)row * a.ld_ep + col] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      if (!(cok && row < a.M)) continue;
+      if (a.ep_out != nullptr) {
+        a.C[(int64_t)row * a.ldc + col] = acc[r];                                        // y = W x (the backward needs it)
+        a.ep_out[(int64_t)row * a.ld_ep + col] = fmaf(em[r], acc[r], bv) + ea[r];        // x0 * y + b + x (cross_v2_kernel)
+      } else {
+        a.C[(int64_t)row * a.ldc + col] = acc[r] + bv + ea[r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] += bv;
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      if (cok && row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[r];
+    }
   }
   if (STATS && a.bn_rng != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     // the BatchNorm + Dropout launch that consumes `stats` is a single launch of many blocks: it cannot advance its own
@@ -607,5 +638,34 @@ extern "C" int rh_linear_dgrad_bnbwd(const float* g, int64_t ldg, const float* w
   a.pro_p = p_drop; a.pro_rng = rng; a.pro_ctr = ctr; a.bwd_partial = bwd_partial;
   launch<false, false, false, true>(a, reinterpret_cast<hipStream_t>(stream));
   RH_LAUNCH_CHECK("rh_linear_dgrad_bnbwd");
+  return 0;
+}
+
+// One CrossNetV2 layer forward in ONE launch (round 5; reference CrossNetV2.forward, torch_rechub/basic/layers.py:440-444:
+// x <- x0 * (W_l x) + b_l + x): y (M, d) = x W^T on the f32-MFMA tile GEMM, and from the accumulators out = x0 * y + b + x.
+// Rounds 1-4 ran the product on the library and the Hadamard + bias + residual as a second pass over four (M, d) arrays
+// (rh_cross_v2_epilogue_fwd).  y is stored too: the backward's g_x0 = g * y needs it.
+extern "C" int rh_cross_v2_fwd(const float* x0, const float* x, const float* w, const float* b, int M, int d, float* y,
+                               float* out, void* stream) {
+  RH_REQUIRE(x0 && x && w && b && y && out, RH_E_BADARG, "rh_cross_v2_fwd: null pointer");
+  RH_REQUIRE(M >= 1 && d >= 1, RH_E_BADARG, "rh_cross_v2_fwd: bad shape M=%d d=%d", M, d);
+  GemmArgs a{};
+  a.A = x; a.lda = d; a.B = w; a.ldb = d; a.bias = b; a.C = y; a.ldc = d; a.M = M; a.N = d; a.K = d;
+  a.ep_mul = x0; a.ep_add = x; a.ep_out = out; a.ld_ep = d;
+  launch<true, false>(a, reinterpret_cast<hipStream_t>(stream));
+  RH_LAUNCH_CHECK("rh_cross_v2_fwd");
+  return 0;
+}
+
+// ... and the input gradient of the layer: gx (M, d) = g_y W + g, g_y = g * x0 the gradient of the product (formed by
+// rh_cross_v2_epilogue_bwd together with g_x0 = g * y), g the upstream gradient that also reaches x through the residual.
+extern "C" int rh_cross_v2_dgrad(const float* g_y, const float* w, const float* g, int M, int d, float* gx, void* stream) {
+  RH_REQUIRE(g_y && w && g && gx, RH_E_BADARG, "rh_cross_v2_dgrad: null pointer");
+  RH_REQUIRE(M >= 1 && d >= 1, RH_E_BADARG, "rh_cross_v2_dgrad: bad shape M=%d d=%d", M, d);
+  GemmArgs a{};
+  a.A = g_y; a.lda = d; a.B = w; a.ldb = d; a.C = gx; a.ldc = d; a.M = M; a.N = d; a.K = d;
+  a.ep_add = g; a.ld_ep = d;
+  launch<false, false>(a, reinterpret_cast<hipStream_t>(stream));
+  RH_LAUNCH_CHECK("rh_cross_v2_dgrad");
   return 0;
 }

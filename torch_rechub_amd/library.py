@@ -348,10 +348,16 @@ def _cross_v2_layers(x, W, b):
     x0 = x.contiguous()
     B, d = x0.shape
     xl, layers = x0, []
+    fused = x0.dtype == torch.float32 and W.dtype == torch.float32 and 1 <= B <= 16384 and d <= 1024
     for l in range(W.shape[0]):
-        y = torch.mm(xl, W[l].t()).contiguous()
         out = torch.empty_like(x0)
-        _lib.call("rh_cross_v2_epilogue_fwd", _p(x0), _p(y), _p(b[l].contiguous()), _p(xl), B, d, _p(out), _stream())
+        if fused:  # ONE launch per layer: tile GEMM with the Hadamard + bias + residual epilogue (csrc/gemm.hip, round 5)
+            y = torch.empty_like(x0)
+            _lib.call("rh_cross_v2_fwd", _p(x0), _p(xl), _p(W[l].contiguous()), _p(b[l].contiguous()), B, d, _p(y), _p(out),
+                      _stream())
+        else:
+            y = torch.mm(xl, W[l].t()).contiguous()
+            _lib.call("rh_cross_v2_epilogue_fwd", _p(x0), _p(y), _p(b[l].contiguous()), _p(xl), B, d, _p(out), _stream())
         layers.append((xl, y))
         xl = out
     return x0, layers, xl
@@ -382,7 +388,12 @@ def cross_net_v2_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor,
         g_x0_total += g_x0
         g_b[l] = g.sum(0)
         g_W[l] = torch.mm(g_y.t(), xl)
-        g = (g + torch.mm(g_y, W[l])).contiguous()  # residual + through W_l
+        if x0.dtype == torch.float32 and W.dtype == torch.float32 and 1 <= B <= 16384 and d <= 1024:
+            g_next = torch.empty_like(g)  # g_y W_l + g: the input-gradient GEMM with the residual as its epilogue
+            _lib.call("rh_cross_v2_dgrad", _p(g_y), _p(W[l].contiguous()), _p(g), B, d, _p(g_next), _stream())
+            g = g_next
+        else:
+            g = (g + torch.mm(g_y, W[l])).contiguous()  # residual + through W_l
     return g + g_x0_total, g_W, g_b
 
 

@@ -1923,6 +1923,56 @@ def cross_v2_epilogue(x0, y, b, x):
     return _CrossV2Epilogue.apply(x0, y, b, x)
 
 
+class _CrossV2LayerFn(torch.autograd.Function):
+    """out = x0 * (x W^T) + b + x: ONE CrossNetV2 layer (torch_rechub/basic/layers.py:440-444) as one launch each for the
+    forward (rh_cross_v2_fwd: tile GEMM whose epilogue is the Hadamard + bias + residual) and the input gradient
+    (rh_cross_v2_dgrad: g_y W + g), plus rh_cross_v2_epilogue_bwd (g_x0 = g * y, g_y = g * x0) and the split-batch weight
+    gradient.  Round 5; before: library GEMM + epilogue pass forward, epilogue pass + two library products + autograd's residual
+    add backward."""
+
+    @staticmethod
+    def forward(ctx, x0, x, weight, bias):
+        require_hip(x0, x, weight, bias)
+        x0, x = x0.contiguous(), x.contiguous()
+        B, d = x.shape
+        y = torch.empty_like(x)
+        out = torch.empty_like(x)
+        _lib.call("rh_cross_v2_fwd", _p(x0), _p(x), _p(weight), _p(bias), B, d, _p(y), _p(out), _stream())
+        ctx.save_for_backward(x0, x, y, weight)
+        ctx.params = (weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, x, y, weight = ctx.saved_tensors
+        B, d = x.shape
+        g = g.contiguous()
+        g_x0 = torch.empty_like(x0)
+        g_y = torch.empty_like(y)
+        _lib.call("rh_cross_v2_epilogue_bwd", _p(x0), _p(y), _p(g), B, d, _p(g_x0), _p(g_y), _stream())
+        g_x = None
+        if ctx.needs_input_grad[1]:
+            g_x = torch.empty_like(x)
+            _lib.call("rh_cross_v2_dgrad", _p(g_y), _p(weight), _p(g), B, d, _p(g_x), _stream())
+        g_w = None
+        if ctx.needs_input_grad[2]:
+            g_w, _ = linear_wgrad(g_y, x, want_bias=False, weight=ctx.params[0])
+        g_b = g.sum(0) if ctx.needs_input_grad[3] else None
+        return (g_x0 if ctx.needs_input_grad[0] else None), g_x, g_w, g_b
+
+
+def cross_v2_layer_ok(x, lin):
+    """Can one CrossNetV2 layer run on the tile GEMM (f32, square weight without bias up to the GEMM's widths)?"""
+    d = x.shape[1] if x.dim() == 2 else 0
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and 1 <= x.shape[0] <= 16384 and
+            type(lin) is torch.nn.Linear and lin.bias is None and tuple(lin.weight.shape) == (d, d) and d <= _GEMM_MAX_NK and
+            lin.weight.dtype == torch.float32 and lin.weight.is_contiguous() and linear_ok(x, lin.weight))
+
+
+def cross_v2_layer(x0, x, weight, bias):
+    return _CrossV2LayerFn.apply(x0, x, weight, bias)
+
+
 class _CrossMixEpilogue(torch.autograd.Function):
     """out = sum_e gate_e * x0 * (uv_e + bias) + xl: bias + Hadamard + gated expert mix + residual in one pass."""
 
