@@ -99,6 +99,7 @@ class DenseGradBucket(object):
         self.pending = []
         self.defer = False  # True: flush() only packs; reduce_deferred() starts the all-reduces (split-graph step)
         self._deferred_runs = []
+        self._pack_keep_dp = []  # sources of this step's slab-packing launches (flush with ops.deferred armed)
 
     def view(self, i):
         return self.flat[self.offsets[i]:self.offsets[i + 1]].view_as(self.params[i])
@@ -212,8 +213,7 @@ class DenseGradBucket(object):
             else:
                 it.src, it.nparts, it.stride, it.add = g.data_ptr(), 1, self.sizes[k], 0
             self.packed[k] = True
-        self._pack_keep = getattr(self, "_pack_keep_dp", []) + keep  # alive until enqueued (pooled by a capturing graph)
-        self._pack_keep_dp = self._pack_keep
+        self._pack_keep_dp.extend(keep)  # alive until the step's launches are enqueued (under capture: pooled by the graph)
         _lib.call("rh_pack_grads", ctypes.cast(items, ctypes.c_void_p), len(idx), ops._p(self.flat), ops._stream())
 
     def finish(self, assign_views=False):
