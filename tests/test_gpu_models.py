@@ -243,6 +243,45 @@ def test_device_loader_training_equals_host_loader_training_bitwise(use_graph, l
         _assert_bitwise_twins(ta, tb, ma, mb)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_mlp_chain_grouped_weight_gradients_equal_the_per_layer_launches_bitwise(use_graph, monkeypatch):
+    """ops._MlpChainFn.backward with CHAIN_WGRAD_GROUP: the chain's weight gradients as ONE rh_linear_wgrad_partial_group
+    launch behind its last input-gradient GEMM instead of one rh_linear_wgrad_partial launch per layer.  Same kernel body,
+    same split plan per problem, the same slabs summed by the same packing launch: the trainings must agree bit for bit
+    (collision-free batches, so no fp32 sum anywhere depends on an order)."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 12, 64
+    vocabs, sparse, dense, label = _loader_twin_data("collision_free", nb, B, seed=43)
+    ma, dfe, sfe = _deepfm(vocabs, 2)
+    mb, _, _ = _deepfm(vocabs, 2)
+    mb.load_state_dict(ma.state_dict())
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
+              lazy_small_rows=8, use_graph=use_graph)
+    calls = {"group": 0, "chain": 0}
+    real_group, real_chain = ops.linear_wgrad_partial_group, ops._MlpChainFn.backward
+
+    def spy_group(problems, Bq):
+        calls["group"] += 1
+        assert len(problems) == 2  # both Linear layers of the chain in one launch
+        return real_group(problems, Bq)
+
+    monkeypatch.setattr(ops, "linear_wgrad_partial_group", spy_group)
+    losses = []
+    for model, grouped in ((ma, False), (mb, True)):
+        monkeypatch.setattr(ops, "CHAIN_WGRAD_GROUP", grouped)
+        t = CTRTrainer(model, **kw)
+        dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        before = calls["group"]
+        losses.append((t.train_one_epoch(dl), t.train_one_epoch(dl)))
+        assert (calls["group"] > before) == grouped  # the grouped launch ran in exactly one of the two trainings
+        model._t = t
+    assert losses[0] == losses[1]
+    _assert_bitwise_twins(ma._t, mb._t, ma, mb)
+
+
 def noisy_twin_tolerance(a, b, travel, what, atol=1e-4, rtol=1e-4, outlier_frac=0.08):
     """Two HIP trainings of the same batches under float atomics in an unspecified order: Adam divides by sqrt(v), so an
     element whose gradient nearly cancels turns summation-order noise into steps of up to lr.  Measured (tools/noise_budget.py,

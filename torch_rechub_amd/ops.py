@@ -839,6 +839,25 @@ def bn_relu_dropout(h, bn, p_drop, stats=None, relu=True):
 _MAX_WGRAD_TILES = 4096
 
 
+def _offer_wgrad_slabs(weight, bias, partial, B):
+    """Register the per-split slabs rh_linear_wgrad_partial(_group) left in ``partial`` -- S x (N, K), then S x (N,) -- as
+    the gradient sources of ``weight`` / ``bias`` (None: no bias) with the armed ops.deferred."""
+    N, K = weight.shape
+    S = _lib.call("rh_linear_wgrad_splits", B, N, K)
+
+    def reduce_w():
+        return partial[:S * N * K].view(S, N, K).sum(0)
+
+    def reduce_b():
+        return partial[S * N * K:S * N * K + S * N].view(S, N).sum(0)
+
+    dW = deferred.offer(weight, partial.data_ptr(), S, N * K, N * K, reduce_w, partial)
+    db = None
+    if bias is not None:
+        db = deferred.offer(bias, partial.data_ptr() + 4 * S * N * K, S, N, N, reduce_b, partial)
+    return dW, db
+
+
 def linear_wgrad(g, x, want_bias=True, weight=None, bias=None):
     """(dW (N, K), db (N,) | None) = (g^T x, colsum(g)) for g (B, N), x (B, K): split-batch f32 MFMA kernel.
 
@@ -860,20 +879,8 @@ def linear_wgrad(g, x, want_bias=True, weight=None, bias=None):
     armed = deferred.armed
     if armed is not None and weight is not None and id(weight) in armed and (not want_bias or
                                                                               (bias is not None and id(bias) in armed)):
-        S = _lib.call("rh_linear_wgrad_splits", B, N, K)
         _lib.call("rh_linear_wgrad_partial", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(partial), _stream())
-
-        def reduce_w():
-            return partial[:S * N * K].view(S, N, K).sum(0)
-
-        def reduce_b():
-            return partial[S * N * K:S * N * K + S * N].view(S, N).sum(0)
-
-        dW = deferred.offer(weight, partial.data_ptr(), S, N * K, N * K, reduce_w, partial)
-        db = None
-        if want_bias:
-            db = deferred.offer(bias, partial.data_ptr() + 4 * S * N * K, S, N, N, reduce_b, partial)
-        return dW, db
+        return _offer_wgrad_slabs(weight, bias if want_bias else None, partial, B)
     dW = torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty((N,), dtype=torch.float32, device=dev) if want_bias else None
     _lib.call("rh_linear_wgrad", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(dW), _p(db), _p(partial),
@@ -1168,6 +1175,12 @@ class _HeadFn(torch.autograd.Function):
 # -> sigmoid of torch_rechub/basic/layers.py:276-292 + models/ranking/deepfm.py:39-43 as ONE autograd node over L + 1 forward
 # launches and 3 L + 1 backward launches.  A/B switch for benchmarks: RECHUB_AB=chain=0 (tests flip the attribute).
 FUSE_MLP_CHAIN = _lib.ab("chain")
+# The chain's L weight gradients as ONE grouped launch behind its last input-gradient GEMM (A/B: RECHUB_AB=chainwgroup=0).
+# Bit-equal to the per-layer launches (same body, same split plan).  Measured on the headline step, same box, 200 steps, two
+# rounds: 0.2422 / 0.2424 -> 0.2411 / 0.2411 ms (profiles/r05_ab_chain_wgroup_same_box.txt): one launch less on a chain that is
+# co-critical with the deferred sweep, so most of the 5 us it saves on the chain is not a shorter step.
+CHAIN_WGRAD_GROUP = _lib.ab("chainwgroup")
+_WGRAD_GROUP_MAX_B = 32768  # kLongRows of csrc/linear.hip: the grouped launch takes batch-sized reductions only
 chain_gate = None      # the gate words of the optimizer whose step-ahead graph is being captured (optim.TableAdam), or None
 chain_gate_used = []   # ... and a mark per rh_linear_fwd_gate launch captured for it
 _CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
@@ -1310,6 +1323,14 @@ class _MlpChainFn(torch.autograd.Function):
         grads[4 * L], grads[4 * L + 1] = g_w, g_b
         nchunks = nblk
         g_x = None
+        # The L weight gradients depend on nothing later in this backward and nothing later depends on them (their slabs are
+        # summed by the step's packing launch): with ops.deferred armed for every Linear of the chain they run as ONE
+        # rh_linear_wgrad_partial_group launch behind the last input-gradient GEMM instead of one launch per layer between
+        # the GEMMs -- same kernel body, same split plan per problem, hence the same slabs bit for bit.
+        group = (CHAIN_WGRAD_GROUP and 2 <= L <= 8 and armed is not None and B < _WGRAD_GROUP_MAX_B and
+                 all(id(params[4 * l]) in armed and (params[4 * l + 1] is None or id(params[4 * l + 1]) in armed)
+                     for l in range(L)))
+        problems = []
         for l in range(L - 1, -1, -1):
             W, b, gamma, beta = params[4 * l:4 * l + 4]
             N, Kin = W.shape
@@ -1331,7 +1352,20 @@ class _MlpChainFn(torch.autograd.Function):
             elif ctx.needs_input_grad[0]:
                 g_x = torch.empty((B, Kin), dtype=torch.float32, device=dev)
                 _lib.call("rh_linear_dgrad", _p(g_h), N, _p(W), Kin, B, N, Kin, _p(g_x), Kin, _stream())
-            grads[4 * l], grads[4 * l + 1] = linear_wgrad(g_h, inp, want_bias=b is not None, weight=W, bias=b)
+            if group:
+                problems.append((l, g_h, inp, W, b))
+            else:
+                grads[4 * l], grads[4 * l + 1] = linear_wgrad(g_h, inp, want_bias=b is not None, weight=W, bias=b)
+        if group:
+            problems.reverse()  # layer 0 first: the widest problem's workgroups are dispatched first
+            recs = []
+            for l, g_h, inp, W, b in problems:
+                N, Kin = W.shape
+                part = torch.empty(_lib.call("rh_linear_wgrad_workspace", B, N, Kin), dtype=torch.float32, device=dev)
+                recs.append((g_h, g_h.stride(0), inp, inp.stride(0), N, Kin, part))
+            linear_wgrad_partial_group(recs, B)
+            for (l, g_h, inp, W, b), rec in zip(problems, recs):
+                grads[4 * l], grads[4 * l + 1] = _offer_wgrad_slabs(W, b, rec[6], B)
         s0, s1 = ctx.shapes
         return (g_x, None if s0 is None else g_z.view(s0), None if s1 is None else g_z.view(s1), None) + tuple(grads)
 
