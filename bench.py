@@ -792,6 +792,10 @@ def _run_mode(args, wl, placement, use_graph, world, rank, device, profile, mode
                                        for c in tune["cands"]],
                         "ms_per_step_during_tuning": tune.get("ms")} if tune.get("chosen") else \
         {"chosen": {"form": getattr(trainer, "_form", None), "pinned": True}}
+    if getattr(trainer, "short_sweep_inline", False):
+        # row-sharded tables: the rank's shard is small enough for the window sweep to run in line (optim.TableAdam.
+        # prefer_inline_for_short_sweeps), chosen by the trainer before its first step -- nothing was pinned by the caller
+        res["step_form"]["chosen"].update(pinned=False, rule="short per-rank sweep: in line", lazy_k=int(getattr(opt, "lazy_k", 0)))
     # the north-star kernels over batch sizes (same tables, same stream, HIP events): their bandwidth regime starts
     # where the launch is no longer three dependent memory round trips long.  Last: it leaves junk gradient rows behind.
     if profile and wl.name == "deepfm" and trainer.dp is None and not args.no_kernel_sweep:

@@ -834,7 +834,8 @@ def nccl_world1():
 
 @pytest.mark.noise_tolerant
 @pytest.mark.parametrize("use_graph,tables", [(False, "replicate"), ("single", "replicate"), ("split", "replicate"),
-                                              (False, "shard"), ("single", "shard")])
+                                              (False, "shard"), ("single", "shard"), (False, "shard+deferred"),
+                                              ("single", "shard+deferred")])
 def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, monkeypatch, use_graph, tables):
     """RECHUB_FORCE_DP: dense all-reduce on the side stream + all-gather of (indices, gradient rows) + row scatter
     (eager, captured as one hipGraph with the RCCL launches inside, or as the two-graph split step) on a world of one
@@ -859,10 +860,17 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
     la = ta.train_one_epoch(mk())
     monkeypatch.setenv("RECHUB_FORCE_DP", "1")
     monkeypatch.setenv("RECHUB_DP_GRAPH", use_graph or "single")
+    # (a shard this small takes the in-line sweep by itself, optim.TableAdam.prefer_inline_for_short_sweeps;
+    # "+deferred" pins the deferred form, which full-size shards of fewer than four ranks keep)
+    tables, _, pin = tables.partition("+")
+    if pin:
+        monkeypatch.setenv("RECHUB_STEP_FORM", pin)
     tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
                     use_graph=bool(use_graph), tables=tables)
     assert tb.dp is not None and ops._sparse_exchange is not None
     assert all(sharding.is_sharded(m) for m in mb.embedding.embed_dict.values()) == (tables == "shard")
+    assert tb.short_sweep_inline == (tables == "shard" and not pin) and tb.optimizer.overlap_sweep != tb.short_sweep_inline
+    assert tb.optimizer.lazy_k == 4  # an explicit lazy_k is kept
     try:
         lb = tb.train_one_epoch(mk())
         if use_graph:
@@ -884,6 +892,7 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
                                                      ("single", "replicate", "duplicated_samples"),
                                                      ("split", "replicate", "duplicated_samples"),
                                                      (False, "shard", "duplicated_samples"),
+                                                     (False, "shard+deferred", "duplicated_samples"),
                                                      (False, "replicate", "collision_free"),
                                                      ("single", "replicate", "collision_free")])
 def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_world1, monkeypatch, use_graph, tables, layout):
@@ -911,9 +920,13 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
     la = ta.train_one_epoch(mk())
     monkeypatch.setenv("RECHUB_FORCE_DP", "1")
     monkeypatch.setenv("RECHUB_DP_GRAPH", use_graph or "single")
+    tables, _, pin = tables.partition("+")
+    if pin:
+        monkeypatch.setenv("RECHUB_STEP_FORM", pin)
     tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
                     use_graph=bool(use_graph), tables=tables)
     assert tb.dp is not None and ops._sparse_exchange is not None
+    assert tb.short_sweep_inline == (tables == "shard" and not pin)
     try:
         lb = tb.train_one_epoch(mk())
         if use_graph:

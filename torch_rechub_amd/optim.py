@@ -677,6 +677,30 @@ class TableAdam(torch.optim.Adam):
 
     SWEEP_BOUND_ROWS = 64_000_000  # lazy rows beyond which a step is bound by the window sweep, not by its chain (lazy_k, tuner)
 
+    # Row-sharded tables under data parallelism (the step does not self-tune there): a rank's shard sweeps rows / world rows
+    # per step.  Below ~200 M lazy elements the deferred sweep no longer pays for its segment boundary and cross-queue edge --
+    # the window sweep goes back in line (the merged end-of-step launch) and an automatic lazy_k drops to 64 (a shorter
+    # replay per refreshed row; the short sweep's traffic does not matter).  Measured per-rank step of the DeepFM headline on a
+    # one-rank group with every table at 1/2, 1/4, 1/8 of its rows (tools/r05_session{3,4}.sh, profiles/r05_dp_shard_form.txt):
+    #   1/2 (270 M elements): deferred K = 128 / 64 0.326 / 0.322 ms, in line K = 128 / 64 0.332 / 0.324  -> left deferred
+    #   1/4 (135 M):          deferred 0.325 / 0.315,                 in line 0.300 / 0.289
+    #   1/8 ( 68 M):          deferred 0.313,                          in line 0.282 / 0.269 (K = 32: 0.267, K = 16: 0.272)
+    SHORT_SWEEP_ELEMENTS = 200_000_000
+
+    def prefer_inline_for_short_sweeps(self, auto_k):
+        """Called by the trainers once, before the first step, for row-sharded tables (RECHUB_STEP_FORM pins the form
+        instead).  Returns True when the in-line form was chosen."""
+        if self.lazy_k <= 1 or not self._tables or self._host_step or self._sweep_pending or self._sweep_inflight:
+            return False
+        n = sum(int(p.numel()) for p in self._tables if self.table_k(p) != 1)
+        if n > self.SHORT_SWEEP_ELEMENTS:
+            return False
+        self.overlap_sweep = False
+        if auto_k and self.lazy_k > 64:
+            self.lazy_k = 64
+            self._lazy_groups = None
+        return True
+
     def lazy_rows(self):
         """Rows of the tables that are stepped lazily (window sweep + touched passes)."""
         return sum(int(p.shape[0]) for p in self._tables if self.table_k(p) != 1)

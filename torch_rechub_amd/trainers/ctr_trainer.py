@@ -88,6 +88,12 @@ class CTRTrainer(object):
         else:
             self.optimizer = optimizer_fn(self.model.parameters(), **optimizer_params)
         table_ids = {id(p) for p in tables}
+        self.short_sweep_inline = False
+        if (self.dp is not None and self.tables == "shard" and isinstance(self.optimizer, TableAdam) and
+                not os.environ.get("RECHUB_STEP_FORM")):
+            # a rank's shard of the tables may be small enough for the window sweep to go back in line (optim.py,
+            # SHORT_SWEEP_ELEMENTS: from four ranks up on the Criteo-shape tables; -11 % / -14 % per-rank step at 4 / 8 ranks)
+            self.short_sweep_inline = self.optimizer.prefer_inline_for_short_sweeps(auto_k=lazy_k is None)
         if self.dp is not None and (self.tables == "replicate" or shard_min_rows > 0) and getattr(self.optimizer, "lazy_k", 0) > 1:
             # the gradient-row exchange hands this rank the rows of every rank's batch: TableAdam._join_before_foreign_rows
             self.optimizer.foreign_rows = True
