@@ -73,7 +73,7 @@ pmc) for c in FETCH_SIZE WRITE_SIZE; do
   find "$OUT/pmc_sweep_$c" -name '*.csv' -size +5M -delete
  done;;
 dptrace) for pl in ${DP_PLACEMENTS:-shard replicate}; do
-  (cd /tmp && rm -rf /tmp/dp_prof_$pl && MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/dp_prof_$pl -o dp -- python $OLDPWD/bench.py --force-dp --tables $pl --trace-inner --steps 10 --warmup 5 --rows 4000000 > /dev/null 2> $OLDPWD/$OUT/dp_prof_$pl.err)
+  (cd /tmp && rm -rf /tmp/dp_prof_$pl && MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/dp_prof_$pl -o dp -- python $OLDPWD/bench.py --force-dp --tables $pl --trace-inner --steps 10 --warmup 5 --rows 4000000 ${DP_ARGS:-} > /dev/null 2> $OLDPWD/$OUT/dp_prof_$pl.err)
   python - $pl > "$OUT/dp_${pl}_step_kernels.txt" 2>&1 <<'PY'
 import csv,glob,os,sys
 m=sys.argv[1]
