@@ -515,3 +515,41 @@ def test_environment_switches_stay_few_and_documented():
     assert all(n in doc for n in names), sorted(n for n in names if n not in doc)
     twins = set(re.findall(r"_lib\.ab\(\"([a-z]+)\"", text)) | set(re.findall(r"[^_]ab\(\"([a-z]+)\"", text))
     assert twins and all(t + "=0" in doc for t in twins), sorted(t for t in twins if t + "=0" not in doc)
+
+
+def test_short_sweep_rule_of_the_row_sharded_step():
+    """optim.TableAdam.prefer_inline_for_short_sweeps (host logic only; the GPU tests run both forms): a rank whose lazily stepped
+    tables hold fewer than SHORT_SWEEP_ELEMENTS elements takes the in-line window sweep and, when lazy_k was not given, lazy_k 64;
+    a full-size table keeps the deferred sweep; nothing changes once a step has run or a sweep is pending."""
+    import types
+
+    from torch_rechub_amd.optim import TableAdam
+
+    def table(rows, d=16):
+        return types.SimpleNamespace(shape=(rows, d), numel=lambda: rows * d)
+
+    def opt(tables, lazy_k=128, **kw):
+        o = types.SimpleNamespace(lazy_k=lazy_k, _tables=tables, lazy_small_rows=4096, _dense_by_volume=set(), _host_step=0,
+                                  _sweep_pending=False, _sweep_inflight=False, overlap_sweep=True, _lazy_groups="built",
+                                  SHORT_SWEEP_ELEMENTS=TableAdam.SHORT_SWEEP_ELEMENTS)
+        o.table_k = lambda p: TableAdam.table_k(o, p)
+        o.__dict__.update(kw)
+        return o
+
+    criteo = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10, 5652,
+              2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+    for world, inline in ((1, False), (2, False), (4, True), (8, True)):
+        o = opt([table(-(-v // world)) for v in criteo])
+        assert TableAdam.prefer_inline_for_short_sweeps(o, auto_k=True) is inline, world
+        assert o.overlap_sweep is (not inline) and o.lazy_k == (64 if inline else 128)
+        assert (o._lazy_groups is None) == inline  # the window layout is rebuilt for the new lazy_k
+    o = opt([table(-(-v // 8)) for v in criteo], lazy_k=32)
+    assert TableAdam.prefer_inline_for_short_sweeps(o, auto_k=False) and o.lazy_k == 32 and not o.overlap_sweep  # explicit K kept
+    o = opt([table(-(-v // 8)) for v in criteo])
+    assert TableAdam.prefer_inline_for_short_sweeps(o, auto_k=False) and o.lazy_k == 128
+    for late in (dict(_host_step=3), dict(_sweep_pending=True), dict(_sweep_inflight=True), dict(lazy_k=0)):
+        o = opt([table(1000000)], **late)
+        assert TableAdam.prefer_inline_for_short_sweeps(o, auto_k=True) is False and o.overlap_sweep
+    # tables stepped densely (<= lazy_small_rows rows) do not count: their pass is not a window sweep
+    o = opt([table(4096, 64)] * 1000 + [table(13_000_000)])
+    assert TableAdam.prefer_inline_for_short_sweeps(o, auto_k=True) is False
