@@ -799,6 +799,38 @@ def test_reported_loss_includes_the_dense_regulariser_on_one_gpu(use_graph, monk
     assert at == nb
 
 
+def test_world_scaling_rides_on_the_backward_root():
+    """CTRTrainer._scale_for_world / _grad_root: with more than one rank the data loss counts 1/world (the ranks' gradients are
+    SUMMED by the exchange).  Without an embedding regulariser that factor is the ROOT of the backward -- the same gradients
+    as backward(loss / world), no launches in the forward; with one, the loss itself is scaled and the root stays 1 (the
+    regulariser's local table gradient keeps its full strength).  The world-2 tests train through both paths; this one pins the
+    factor itself, which Adam's scale invariance would hide there."""
+    from torch_rechub_amd.trainers import CTRTrainer
+    vocabs = [50, 60]
+    model, _, _ = _deepfm(vocabs, 4)
+    t = CTRTrainer(model, device="cuda:0", show_progress=False)
+    w = torch.nn.Parameter(torch.tensor([1.5, -2.0], device=dev()))
+    for world in (1, 2, 8, 3):
+        t.world = world
+        loss = (w * w).sum()
+        out = t._scale_for_world(loss)
+        assert out is loss
+        root = t._grad_root(out)
+        assert root.shape == loss.shape and root.item() == np.float32(1.0 / world)
+        w.grad = None
+        out.backward(root)
+        want = torch.autograd.grad(((w * w).sum() / world), w)[0]
+        assert torch.equal(w.grad, want)
+    t2 = CTRTrainer(_deepfm(vocabs, 4)[0], device="cuda:0", show_progress=False,
+                    regularization_params={"embedding_l1": 0.0, "embedding_l2": 1e-2, "dense_l1": 0.0, "dense_l2": 0.0})
+    t2.world = 4
+    loss = (w * w).sum()
+    out = t2._scale_for_world(loss)
+    assert out is not loss and t2._grad_root(out).item() == 1.0
+    reg = t2.reg_loss_fn.embedding_term(t2.model)
+    assert torch.allclose(out, loss / 4 + 0.75 * reg)
+
+
 def test_stock_optimizer_sees_dense_table_gradients():
     """optimizer_fn other than Adam: tables expose an ordinary dense .grad (persistent buffer) to torch.optim."""
     from torch_rechub_amd import ops
