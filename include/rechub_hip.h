@@ -60,6 +60,8 @@ const char* rh_last_error(void);
 #define RH_TUNE_SWEEP_GATE_NS 13 /* rh_adam_sweep_gate(fallback_ns = 0): hold-back behind the opening, ns (default 32000) */
 #define RH_TUNE_SWEEP_WIDE 14 /* deferred window sweep of the lazy tables: float4 per lane at embed_dim >= 8 (2 = default: two
                                  independent float4 chains per lane, round 5; 1 = one float4 per lane, the round-4 kernel) */
+#define RH_TUNE_WGRAD_RIDER_ORDER 15 /* rh_adam_lazy_step_ahead_wgrad: weight-gradient workgroups 2 = behind the optimizer's parts
+                                      * (default), 0 = in front of them, 1 = dealt alternately with them */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
 #define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build (default) */
 #define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront
@@ -620,6 +622,20 @@ int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_t* h_rows, 
                             const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
                             int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
                             int64_t* sparse_out, float* dense_out, float* label_out, int look_depth, void* stream);
+/* rh_adam_lazy_step_ahead whose launch ALSO carries the weight gradients of the step's nn.Linear layers (round 6; reference:
+ * the Linear backward inside loss.backward(), trainers/ctr_trainer.py:98, dW = g^T x of basic/layers.py:279,290): wn <= 8
+ * problems, arrays of wn host entries as rh_linear_wgrad_partial_group (problem i writes its split slabs to wpartial[i],
+ * rh_linear_wgrad_workspace floats, for rh_pack_grads).  Nothing between the last input-gradient GEMM of the backward and
+ * the packing launch behind the optimizer reads those slabs, so they leave the step's critical chain: their MFMA workgroups
+ * run beside the replay arithmetic of the optimizer's parts.  Same workgroup body and split plan as the grouped launch --
+ * the same slabs bit for bit. */
+int rh_adam_lazy_step_ahead_wgrad(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                  const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                  const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
+                                  int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
+                                  int64_t* sparse_out, float* dense_out, float* label_out, int look_depth, int wn,
+                                  const float* const* wg, const int64_t* wldg, const float* const* wx, const int64_t* wldx,
+                                  const int* wB, const int* wN, const int* wK, float* const* wpartial, void* stream);
 /* rh_adam_lazy_touched (refresh = 0, int64 indices) + rh_adam_lazy_sweep (RH_SWEEP_WINDOW) of the same step as ONE launch:
  * both parts claim a lazy row with atomicMax on its last-step word and the claimant applies the row's gradient. */
 int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,

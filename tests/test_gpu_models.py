@@ -261,14 +261,16 @@ def test_mlp_chain_grouped_weight_gradients_equal_the_per_layer_launches_bitwise
     kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
               lazy_small_rows=8, use_graph=use_graph)
     calls = {"group": 0, "chain": 0}
-    real_group, real_chain = ops.linear_wgrad_partial_group, ops._MlpChainFn.backward
+    real_args = ops.wgrad_group_args
 
     def spy_group(problems, Bq):
+        # (the argument block of EVERY grouped launch: rh_linear_wgrad_partial_group, or -- under hipGraph, step-ahead form --
+        # the optimizer's end-of-step launch that carries the group, rh_adam_lazy_step_ahead_wgrad)
         calls["group"] += 1
         assert len(problems) == 2  # both Linear layers of the chain in one launch
-        return real_group(problems, Bq)
+        return real_args(problems, Bq)
 
-    monkeypatch.setattr(ops, "linear_wgrad_partial_group", spy_group)
+    monkeypatch.setattr(ops, "wgrad_group_args", spy_group)
     losses = []
     for model, grouped in ((ma, False), (mb, True)):
         monkeypatch.setattr(ops, "CHAIN_WGRAD_GROUP", grouped)
@@ -277,6 +279,53 @@ def test_mlp_chain_grouped_weight_gradients_equal_the_per_layer_launches_bitwise
         before = calls["group"]
         losses.append((t.train_one_epoch(dl), t.train_one_epoch(dl)))
         assert (calls["group"] > before) == grouped  # the grouped launch ran in exactly one of the two trainings
+        model._t = t
+    assert losses[0] == losses[1]
+    _assert_bitwise_twins(ma._t, mb._t, ma, mb)
+
+
+def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their_own_launch_bitwise(monkeypatch):
+    """Round 6: while TableAdam captures a step-ahead graph, ops._MlpChainFn.backward hands its grouped weight gradients to the
+    optimizer (ops.wgrad_rider) and rh_adam_lazy_step_ahead_wgrad carries them as the first workgroups of the end-of-step
+    launch.  Same workgroup body, same split plan, the same slabs summed by the same packing launch behind it: the trainings
+    with and without the rider must agree bit for bit, and the rider launch must actually have been the one that ran."""
+    from torch_rechub_amd import _lib, ops, optim
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 12, 64
+    vocabs, sparse, dense, label = _loader_twin_data("collision_free", nb, B, seed=47)
+    ma, dfe, sfe = _deepfm(vocabs, 2)
+    mb, _, _ = _deepfm(vocabs, 2)
+    mb.load_state_dict(ma.state_dict())
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
+              lazy_small_rows=8, use_graph=True)
+    seen = {"rider": 0, "group": 0, "plain": 0}
+    real_call = _lib.call
+
+    def spy(name, *args):
+        if name == "rh_adam_lazy_step_ahead_wgrad":
+            seen["rider"] += 1
+        elif name == "rh_linear_wgrad_partial_group":
+            seen["group"] += 1
+        elif name == "rh_adam_lazy_step_ahead":
+            seen["plain"] += 1
+        return real_call(name, *args)
+
+    monkeypatch.setattr(_lib, "call", spy)
+    losses = []
+    for model, rider in ((ma, False), (mb, True)):
+        monkeypatch.setattr(optim, "WGRAD_RIDER", rider)
+        for k in seen:
+            seen[k] = 0
+        t = CTRTrainer(model, **kw)
+        dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        losses.append((t.train_one_epoch(dl), t.train_one_epoch(dl)))
+        if rider:  # every captured step-ahead graph ends with the launch that carries the group
+            assert seen["rider"] >= 1 and seen["plain"] == 0, seen
+        else:
+            assert seen["rider"] == 0 and seen["plain"] >= 1 and seen["group"] >= 1, seen
+        assert ops.wgrad_rider is None and t.optimizer._rider is None  # nothing left armed behind the capture
         model._t = t
     assert losses[0] == losses[1]
     _assert_bitwise_twins(ma._t, mb._t, ma, mb)

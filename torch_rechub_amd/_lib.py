@@ -148,6 +148,9 @@ SIGNATURES = {
     "rh_adam_sweep_gate_open": [c_ptr, c_ptr],
     "rh_adam_lazy_step_ahead": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                 c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr],
+    "rh_adam_lazy_step_ahead_wgrad": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr,
+                                      c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int,
+                                      c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_adam_lazy_sweep": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr],
     "rh_l2norm_fwd": [c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr, c_ptr],
     "rh_l2norm_bwd": [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr],

@@ -10,7 +10,7 @@ pids=()
 for src in api.cpp embed.hip cross.hip optim.hip data.hip match.hip fm.hip seqpool.hip mlp.hip din.hip dinmlp.hip crossmix.hip moe.hip linear.hip gemm.hip shard.hip augru.hip; do
   [ -f "$src" ] || continue
   obj="_build/${src%.*}.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ $INC/rechub_hip.h -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ wgrad_body.h -nt "$obj" ] || [ $INC/rechub_hip.h -nt "$obj" ]; then
     ( $HIPCC $FLAGS -x hip -c "$src" -o "$obj" ) &
     pids+=($!)
   fi

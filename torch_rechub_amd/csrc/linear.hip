@@ -17,203 +17,11 @@
 //    backward kernels in the reference).  Roofline: HBM (h read once per direction).
 // 3. bce: mean binary cross entropy and its backward, log clamped at -100 like torch.nn.BCELoss.
 #include "common.h"
+#include "wgrad_body.h"
 
 namespace {
 
-typedef float v16f __attribute__((ext_vector_type(16)));
-
-constexpr int kTile = 64;               // output tile edge per block (2 x 2 MFMA tiles of 32 x 32 per wave)
-constexpr int kWaves = RH_BLOCK / RH_WAVE;
-constexpr int kTileElems = kTile * kTile;
-constexpr int kPartStride = kTileElems + kTile;  // tile + its db slice
-constexpr int kUnroll = 4;              // row pairs in flight per wave
-
-struct WgradArgs {
-  const float* g;  // (B, N), row stride ldg
-  int64_t ldg;
-  const float* x;  // (B, K), row stride ldx
-  int64_t ldx;
-  int B, N, K;
-  int S, rows_per_split;
-  float* partial;      // split s: dW part at partial + s * N * K, db part at partial + S * N * K + s * N
-  float* dW;           // (N, K) contiguous
-  float* db;           // (N,) or null
-  int direct;          // 1: S == 1 and the block writes dW / db itself
-};
-
-// LONG: the build for long reductions (see the two kernels below): simple prefetch loop and ONE LDS tile; otherwise the
-// round-1 form (ping-pong register sets, one LDS tile per wavefront).  Same sums in the same order either way.
-template <bool LONG>
-__device__ __forceinline__ void linear_wgrad_body(const WgradArgs& a, float* red, const int bx, const int by, const int s) {
-  RH_CHAIN_PRIO();
-  const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
-  const int half = lane >> 5, c = lane & 31;
-  // (Measured and dropped: a 1-D launch that puts the tiles of one split on ONE XCD, so that its L2 serves the rows they
-  // share -- 945 us against 884 for DIN's four long launches; with x-fastest tiles each XCD streams its own column range.)
-  const int k0 = bx * kTile, n0 = by * kTile;
-  const int b_lo = s * a.rows_per_split;
-  const int b_hi = min(a.B, b_lo + a.rows_per_split);
-
-  // Columns past N / K are clamped to column 0: their products land in tile rows / columns that are never stored, so
-  // the inner loop needs no column masks (and stays free of exec-masked loads).
-  const int na0 = n0 + c, na1 = n0 + 32 + c, kb0 = k0 + c, kb1 = k0 + 32 + c;
-  const float* ga0 = a.g + (na0 < a.N ? na0 : 0) + (int64_t)half * a.ldg;
-  const float* ga1 = a.g + (na1 < a.N ? na1 : 0) + (int64_t)half * a.ldg;
-  const float* xb0 = a.x + (kb0 < a.K ? kb0 : 0) + (int64_t)half * a.ldx;
-  const float* xb1 = a.x + (kb1 < a.K ? kb1 : 0) + (int64_t)half * a.ldx;
-
-  v16f acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
-  float bs0 = 0.f, bs1 = 0.f;
-  float fa0[kUnroll], fa1[kUnroll], fb0[kUnroll], fb1[kUnroll];
-  float qa0[kUnroll], qa1[kUnroll], qb0[kUnroll], qb1[kUnroll];
-  // wave w takes row pairs w, w + 4, ...; one iteration = kUnroll pairs = 16 dword loads, fetched one iteration ahead
-  auto fetch = [&](int p, float* A0, float* A1, float* B0, float* B1) {
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int64_t r = p + 2 * kWaves * u;
-      A0[u] = gload<float>(ga0 + r * a.ldg);
-      A1[u] = gload<float>(ga1 + r * a.ldg);
-      B0[u] = gload<float>(xb0 + r * a.ldx);
-      B1[u] = gload<float>(xb1 + r * a.ldx);
-    }
-  };
-  auto issue = [&](const float* A0, const float* A1, const float* B0, const float* B1) {
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B0[u], acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B1[u], acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B0[u], acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B1[u], acc11, 0, 0, 0);
-      bs0 += A0[u];
-      bs1 += A1[u];
-    }
-  };
-  constexpr int kStep = 2 * kWaves * kUnroll;
-  int p = b_lo + 2 * wave;
-  const int last_full = b_hi - (2 * kWaves * (kUnroll - 1) + 2);  // p <= last_full: every row of the iteration exists
-  if (p <= last_full) {
-    fetch(p, fa0, fa1, fb0, fb1);
-    if (LONG) {
-      for (; p + kStep <= last_full; p += kStep) {
-        fetch(p + kStep, qa0, qa1, qb0, qb1);
-        issue(fa0, fa1, fb0, fb1);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          fa0[u] = qa0[u];
-          fa1[u] = qa1[u];
-          fb0[u] = qb0[u];
-          fb1[u] = qb1[u];
-        }
-      }
-      issue(fa0, fa1, fb0, fb1);
-      p += kStep;
-    } else {
-      while (true) {  // ping-pong between the two register sets; the branch conditions are wave-uniform
-        if (p + kStep > last_full) {
-          issue(fa0, fa1, fb0, fb1);
-          p += kStep;
-          break;
-        }
-        fetch(p + kStep, qa0, qa1, qb0, qb1);
-        issue(fa0, fa1, fb0, fb1);
-        p += kStep;
-        if (p + kStep > last_full) {
-          issue(qa0, qa1, qb0, qb1);
-          p += kStep;
-          break;
-        }
-        fetch(p + kStep, fa0, fa1, fb0, fb1);
-        issue(qa0, qa1, qb0, qb1);
-        p += kStep;
-      }
-    }
-  }
-  // ragged end of the last split: fewer than kStep rows, guarded per row
-  for (; p < b_hi; p += 2 * kWaves) {
-    const bool ok = p + half < b_hi;
-    const int64_t r = ok ? p : b_lo - half;  // (the fragment pointers already carry + half rows)
-    const float m = ok ? 1.f : 0.f;
-    const float t0 = gload<float>(ga0 + r * a.ldg) * m, t1 = gload<float>(ga1 + r * a.ldg) * m;
-    const float t2 = gload<float>(xb0 + r * a.ldx) * m, t3 = gload<float>(xb1 + r * a.ldx) * m;
-    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t2, acc00, 0, 0, 0);
-    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t3, acc01, 0, 0, 0);
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t2, acc10, 0, 0, 0);
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t3, acc11, 0, 0, 0);
-    bs0 += t0;
-    bs1 += t1;
-  }
-  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  // LONG: the four wavefronts add their tiles into ONE LDS tile, one after the other in wavefront order (deterministic, and the
-  // same sum ((w0 + w1) + w2) + w3 as four separate tiles summed afterwards).  Four tiles were 66.5 KB per workgroup = two
-  // workgroups per CU = two wavefronts per SIMD, too few to hide the operand loads of a long reduction (DIN: 409 600 rows,
-  // ~70 TF); one tile is 16.6 KB.
-  bs0 += __shfl_xor(bs0, 32);
-  bs1 += __shfl_xor(bs1, 32);
-  if (!LONG) {
-    float* mine = red + wave * kPartStride;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      mine[row * kTile + c] = acc00[r];
-      mine[row * kTile + 32 + c] = acc01[r];
-      mine[(32 + row) * kTile + c] = acc10[r];
-      mine[(32 + row) * kTile + 32 + c] = acc11[r];
-    }
-    if (half == 0) {
-      mine[kTileElems + c] = bs0;
-      mine[kTileElems + 32 + c] = bs1;
-    }
-    __syncthreads();
-  }
-  for (int w = 0; LONG && w < kWaves; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        float* q = red + row * kTile + c;
-        if (w == 0) {
-          q[0] = acc00[r];
-          q[32] = acc01[r];
-          q[32 * kTile] = acc10[r];
-          q[32 * kTile + 32] = acc11[r];
-        } else {
-          q[0] += acc00[r];
-          q[32] += acc01[r];
-          q[32 * kTile] += acc10[r];
-          q[32 * kTile + 32] += acc11[r];
-        }
-      }
-      if (half == 0) {
-        if (w == 0) {
-          red[kTileElems + c] = bs0;
-          red[kTileElems + 32 + c] = bs1;
-        } else {
-          red[kTileElems + c] += bs0;
-          red[kTileElems + 32 + c] += bs1;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // Partial results of split s in the layout of the outputs themselves -- (N, K) and (N,) slabs, one per split -- so
-  // that summing the splits is a plain slab sum for whoever does it (wgrad_reduce_kernel, or rh_pack_grads fused with
-  // the packing of the step's dense gradients).
-  float* outW = a.direct ? a.dW : a.partial + (int64_t)s * a.N * a.K;
-  float* outB = a.direct ? a.db : a.partial + (int64_t)a.S * a.N * a.K + (int64_t)s * a.N;
-  for (int e = threadIdx.x; e < kPartStride; e += RH_BLOCK) {
-    float v = red[e];
-    if (!LONG) {
-#pragma unroll
-      for (int w = 1; w < kWaves; ++w) v += red[w * kPartStride + e];
-    }
-    if (e < kTileElems) {
-      const int n = n0 + e / kTile, k = k0 + e % kTile;
-      if (n < a.N && k < a.K) outW[(int64_t)n * a.K + k] = v;
-    } else if (outB && bx == 0 && n0 + e - kTileElems < a.N) {
-      outB[n0 + e - kTileElems] = v;
-    }
-  }
-}
+using namespace rh_wgrad;
 
 // Two builds of the same body: the default (the compiler takes 78 VGPRs + 128 AGPRs: two wavefronts per SIMD, what a
 // B = 4096 launch of ~500 workgroups fills anyway) and one held to 128 registers = four wavefronts per SIMD for the long
@@ -223,27 +31,9 @@ __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_kernel(const WgradArgs 
   linear_wgrad_body<false>(a, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Several independent weight-gradient problems as ONE launch (round 4): the backward of CrossNetMix leaves two per layer
-// (g_UTb = g_Y^T wp, g_VgT = g_PG^T x_l), none of which anything else in the backward waits for -- eight launches of
-// 16.5 us each were a sixth of the DCN-v2 step.  Workgroup b belongs to problem i with prefix[i] <= b < prefix[i + 1]; inside
-// a problem the workgroups are numbered tile-column fastest, then tile row, then split, as the 3-D grid of the single launch.
-constexpr int kWgradGroup = 8;
-struct WgradGroupArgs {
-  WgradArgs p[kWgradGroup];
-  int prefix[kWgradGroup + 1];
-  int tiles_k[kWgradGroup], tiles_n[kWgradGroup];
-  int n;
-};
-
 __global__ __launch_bounds__(RH_BLOCK) void linear_wgrad_group_kernel(const WgradGroupArgs ga) {
   extern __shared__ float red[];
-  const int b = blockIdx.x;
-  int i = 0;
-#pragma unroll
-  for (int q = 1; q < kWgradGroup; ++q) i += (q < ga.n && b >= ga.prefix[q]) ? 1 : 0;
-  const int local = b - ga.prefix[i];
-  const int tk = ga.tiles_k[i], tn = ga.tiles_n[i];
-  linear_wgrad_body<false>(ga.p[i], red, local % tk, (local / tk) % tn, local / (tk * tn));
+  linear_wgrad_group_body<false>(ga, red, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void linear_wgrad_long_kernel(
@@ -256,13 +46,7 @@ __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void linear_wgrad_group_long_kernel(
     const WgradGroupArgs ga) {
   extern __shared__ float red[];
-  const int b = blockIdx.x;
-  int i = 0;
-#pragma unroll
-  for (int q = 1; q < kWgradGroup; ++q) i += (q < ga.n && b >= ga.prefix[q]) ? 1 : 0;
-  const int local = b - ga.prefix[i];
-  const int tk = ga.tiles_k[i], tn = ga.tiles_n[i];
-  linear_wgrad_body<true>(ga.p[i], red, local % tk, (local / tk) % tn, local / (tk * tn));
+  linear_wgrad_group_body<true>(ga, red, (int)blockIdx.x);
 }
 
 // Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
@@ -911,21 +695,20 @@ static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, 
   return 0;
 }
 
-// n <= 8 problems of rh_linear_wgrad_partial as one launch: arrays of n entries each (host memory); problem i writes its
-// slabs to partial[i] (rh_linear_wgrad_workspace(B[i], N[i], K[i]) floats, S = rh_linear_wgrad_splits(...) as the single call).
-extern "C" int rh_linear_wgrad_partial_group(int n, const float* const* g, const int64_t* ldg, const float* const* x,
-                                             const int64_t* ldx, const int* B, const int* N, const int* K,
-                                             float* const* partial, void* stream) {
+// (declared in wgrad_body.h: the argument block of a grouped launch, for rh_linear_wgrad_partial_group below and for
+// rh_adam_lazy_step_ahead_wgrad of csrc/optim.hip)
+int rh_wgrad_group_fill(int n, const float* const* g, const int64_t* ldg, const float* const* x, const int64_t* ldx, const int* B,
+                        const int* N, const int* K, float* const* partial, rh_wgrad::WgradGroupArgs* out, const char* who) {
   RH_REQUIRE(n >= 1 && n <= kWgradGroup && g && ldg && x && ldx && B && N && K && partial, RH_E_BADARG,
-             "rh_linear_wgrad_partial_group: 1 <= n <= %d problems", kWgradGroup);
-  WgradGroupArgs ga{};
+             "%s: 1 <= n <= %d problems", who, kWgradGroup);
+  WgradGroupArgs& ga = *out;
+  ga = WgradGroupArgs{};
   ga.n = n;
   ga.prefix[0] = 0;
   for (int i = 0; i < n; ++i) {
     RH_REQUIRE(g[i] && x[i] && partial[i] && B[i] >= 1 && N[i] >= 1 && K[i] >= 1 && ldg[i] >= N[i] && ldx[i] >= K[i], RH_E_BADARG,
-               "rh_linear_wgrad_partial_group: bad problem %d", i);
-    RH_REQUIRE(B[i] < kLongRows, RH_E_UNSUPPORTED, "rh_linear_wgrad_partial_group: B = %d (long reductions take the single call)",
-               B[i]);
+               "%s: bad problem %d", who, i);
+    RH_REQUIRE(B[i] < kLongRows, RH_E_UNSUPPORTED, "%s: B = %d (long reductions take the single call)", who, B[i]);
     WgradArgs a{g[i], ldg[i], x[i], ldx[i], B[i], N[i], K[i], 1, B[i], partial[i], nullptr, nullptr, 0};
     int tn, tk;
     wgrad_plan(B[i], N[i], K[i], &tn, &tk, &a.S, &a.rows_per_split);
@@ -935,6 +718,17 @@ extern "C" int rh_linear_wgrad_partial_group(int n, const float* const* g, const
     ga.prefix[i + 1] = ga.prefix[i] + tk * tn * a.S;
   }
   for (int i = n; i < kWgradGroup; ++i) ga.prefix[i + 1] = ga.prefix[n];
+  return 0;
+}
+
+// n <= 8 problems of rh_linear_wgrad_partial as one launch: arrays of n entries each (host memory); problem i writes its
+// slabs to partial[i] (rh_linear_wgrad_workspace(B[i], N[i], K[i]) floats, S = rh_linear_wgrad_splits(...) as the single call).
+extern "C" int rh_linear_wgrad_partial_group(int n, const float* const* g, const int64_t* ldg, const float* const* x,
+                                             const int64_t* ldx, const int* B, const int* N, const int* K,
+                                             float* const* partial, void* stream) {
+  WgradGroupArgs ga;
+  const int rc = rh_wgrad_group_fill(n, g, ldg, x, ldx, B, N, K, partial, &ga, "rh_linear_wgrad_partial_group");
+  if (rc != 0) return rc;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_group_kernel),

@@ -9,6 +9,7 @@
 // (7 streams x 4 B; 15.1 GB per step at 33.76 M rows x 16).  The gradient buffer is re-zeroed in
 // the same pass (stores only where it was non-zero), so no separate zero_grad / memset pass exists.
 #include "common.h"
+#include "wgrad_body.h"
 
 namespace {
 
@@ -796,12 +797,11 @@ struct StepAheadParts {
   int spbA;
   int nC, chunksC;  // part C: chunksC x F workgroups of `look` samples
   int nD;           // part D
+  int w_order;      // adam_lazy_step_ahead_wgrad_kernel: how part W is dealt among the others (RH_TUNE_WGRAD_RIDER_ORDER)
 };
 
 template <int LPR>
-__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const LazySweepArgs a, const StepAheadParts parts) {
-  RH_CHAIN_PRIO();
-  int bx = (int)blockIdx.x;
+__device__ __forceinline__ void step_ahead_body(const LazySweepArgs& a, const StepAheadParts& parts, int bx, const int nblocks) {
   if (bx < parts.nB) {
     LazyTouchedArgs ta = a.touch;
     ta.spb = parts.spbB;
@@ -843,9 +843,61 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const La
     return;
   }
   bx -= parts.nD;
-  lazy_sweep_body<LPR, true>(a, bx, (int)gridDim.x - parts.nB - parts.nA - parts.nC - parts.nD);
+  lazy_sweep_body<LPR, true>(a, bx, nblocks - parts.nB - parts.nA - parts.nC - parts.nD);
 }
 
+template <int LPR>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_step_ahead_kernel(const LazySweepArgs a, const StepAheadParts parts) {
+  RH_CHAIN_PRIO();
+  step_ahead_body<LPR>(a, parts, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ... with part W in front (round 6): the grouped weight gradients of the step's MLP chain (dW_l = g_l^T a_{l-1}, reference:
+// the nn.Linear backward inside loss.backward(), trainers/ctr_trainer.py:98) as the FIRST nW workgroups of this launch.
+// Nothing on the step's critical chain waits for them -- their slabs are summed by the packing launch BEHIND this one -- so
+// they no longer occupy ~32 us of the chain between the last input-gradient GEMM and the gather's backward: their MFMA work
+// runs beside the replay arithmetic (VALU) and the dependent row traffic of parts B / A.  Same workgroup body, same split
+// plan per problem (rh_wgrad_group_fill) as rh_linear_wgrad_partial_group: the same slabs bit for bit.  Held to 128 registers
+// (what both the 108-register parts above and the long-reduction build of the weight gradient fit into).
+template <int LPR>
+__global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void adam_lazy_step_ahead_wgrad_kernel(
+    const LazySweepArgs a, const StepAheadParts parts, const rh_wgrad::WgradGroupArgs ga) {
+  RH_CHAIN_PRIO();
+  extern __shared__ float wred[];  // rh_wgrad::kPartStride floats
+  const int nW = ga.prefix[rh_wgrad::kWgradGroup];
+  const int nrest = (int)gridDim.x - nW;
+  // Workgroup order (beside the optimizer's resident sweep a SIMD has room for two wavefronts of this launch).  Measured, same
+  // box, ms per step (profiles/r06_ab_wgrad_rider.txt): no rider 0.2418; W in front of the other parts (w_order 0) 0.2315; dealt
+  // alternately with them (1: pair p = (W[p], rest[p]), the order inside a pair flipping every 256 workgroups) 0.2378; W
+  // BEHIND them (2, the default) 0.2268 -- the refresh part's workgroups run longest (a replay of up to lazy_k steps per row)
+  // and want to be placed first; the short MFMA workgroups then fill the launch's tail.
+  int bx = (int)blockIdx.x;
+  bool is_w;
+  int idx;
+  if (parts.w_order == 1) {
+    const int m = nW < nrest ? nW : nrest;
+    if (bx < 2 * m) {
+      is_w = (((bx & 1) ^ ((bx >> 8) & 1)) == 0);
+      idx = bx >> 1;
+    } else {
+      is_w = nW > nrest;
+      idx = bx - m;
+    }
+  } else if (parts.w_order == 2) {
+    is_w = bx >= nrest;
+    idx = is_w ? bx - nrest : bx;
+  } else {
+    is_w = bx < nW;
+    idx = is_w ? bx : bx - nW;
+  }
+  if (is_w) {
+    rh_wgrad::linear_wgrad_group_body<true>(ga, wred, idx);
+    return;
+  }
+  step_ahead_body<LPR>(a, parts, idx, nrest);
+}
+
+int g_rider_order = 2;  // RH_TUNE_WGRAD_RIDER_ORDER: workgroup order of adam_lazy_step_ahead_wgrad_kernel (see there)
 int g_sweep_wide = 2;  // RH_TUNE_SWEEP_WIDE: float4 per lane of the deferred lazy-table sweep at embed_dim >= 8 (2 = default; 1 = round-4 kernel)
 
 // the deferred window sweep of the lazy tables, VPL float4 per lane (lazy_sweep_wide_body)
@@ -1169,6 +1221,10 @@ extern "C" int rh_optim_set_tuning(int key, int value) {
     g_sweep_wide = value;
     return 0;
   }
+  if (key == RH_TUNE_WGRAD_RIDER_ORDER) {
+    g_rider_order = value;
+    return 0;
+  }
   return RH_E_BADARG;
 }
 
@@ -1414,12 +1470,46 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
 // adam_lazy_step_ahead_kernel).  B is the size of BOTH batches; pos must already be advanced to batch t + 1; idesc describes
 // index columns inside sparse_out (as rh_adam_lazy_refresh_assemble).  look_depth >= 0: batches looked ahead for the coming
 // deferred sweep's window.
+static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                           const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
+                           int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
+                           int64_t* sparse_out, float* dense_out, float* label_out, int look_depth,
+                           const rh_wgrad::WgradGroupArgs* ga, void* stream);
+
 extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                                        const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                                        const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm,
                                        const int64_t* pos, int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND,
                                        const float* label, int64_t* sparse_out, float* dense_out, float* label_out,
                                        int look_depth, void* stream) {
+  return step_ahead_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, err_flag, perm, pos, N,
+                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, nullptr, stream);
+}
+
+// rh_adam_lazy_step_ahead whose launch also carries n <= 8 weight-gradient problems (arrays as rh_linear_wgrad_partial_group:
+// problem i writes its split slabs to wpartial[i]) -- see adam_lazy_step_ahead_wgrad_kernel.
+extern "C" int rh_adam_lazy_step_ahead_wgrad(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                             const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                             const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm,
+                                             const int64_t* pos, int64_t N, const int64_t* sparse, int Fd, const float* dense,
+                                             int ND, const float* label, int64_t* sparse_out, float* dense_out, float* label_out,
+                                             int look_depth, int wn, const float* const* wg, const int64_t* wldg,
+                                             const float* const* wx, const int64_t* wldx, const int* wB, const int* wN,
+                                             const int* wK, float* const* wpartial, void* stream) {
+  rh_wgrad::WgradGroupArgs ga;
+  const int rc = rh_wgrad_group_fill(wn, wg, wldg, wx, wldx, wB, wN, wK, wpartial, &ga, "rh_adam_lazy_step_ahead_wgrad");
+  if (rc != 0) return rc;
+  return step_ahead_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, err_flag, perm, pos, N,
+                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, &ga, stream);
+}
+
+static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                           const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
+                           int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
+                           int64_t* sparse_out, float* dense_out, float* label_out, int look_depth,
+                           const rh_wgrad::WgradGroupArgs* ga, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc && perm && pos && sparse && sparse_out,
              RH_E_BADARG, "rh_adam_lazy_step_ahead: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1 && N >= B && Fd >= 1 && ND >= 0 && look_depth >= 0 &&
@@ -1461,12 +1551,28 @@ extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_
   parts.chunksC = (look_depth * B + look - 1) / look;
   parts.nC = parts.chunksC * F;
   parts.nD = parts.chunksB;
+  parts.w_order = g_rider_order;
   int64_t sweep_grid = a.total_vblocks;
   const int64_t cap = g_sweep_grid > 0 ? g_sweep_grid : 256 * 32;
   if (sweep_grid > cap) sweep_grid = cap;
   if (sweep_grid < 1) sweep_grid = 1;
-  const dim3 grid((unsigned)(parts.nB + parts.nA + parts.nC + parts.nD + sweep_grid));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (ga != nullptr) {
+    const dim3 gridw((unsigned)(ga->prefix[rh_wgrad::kWgradGroup] + parts.nB + parts.nA + parts.nC + parts.nD + sweep_grid));
+    const size_t lds = (size_t)rh_wgrad::kPartStride * sizeof(float);
+    switch (D / 4) {
+      case 1: hipLaunchKernelGGL((adam_lazy_step_ahead_wgrad_kernel<1>), gridw, dim3(RH_BLOCK), lds, s, a, parts, *ga); break;
+      case 2: hipLaunchKernelGGL((adam_lazy_step_ahead_wgrad_kernel<2>), gridw, dim3(RH_BLOCK), lds, s, a, parts, *ga); break;
+      case 4: hipLaunchKernelGGL((adam_lazy_step_ahead_wgrad_kernel<4>), gridw, dim3(RH_BLOCK), lds, s, a, parts, *ga); break;
+      case 8: hipLaunchKernelGGL((adam_lazy_step_ahead_wgrad_kernel<8>), gridw, dim3(RH_BLOCK), lds, s, a, parts, *ga); break;
+      case 16: hipLaunchKernelGGL((adam_lazy_step_ahead_wgrad_kernel<16>), gridw, dim3(RH_BLOCK), lds, s, a, parts, *ga); break;
+      case 32: hipLaunchKernelGGL((adam_lazy_step_ahead_wgrad_kernel<32>), gridw, dim3(RH_BLOCK), lds, s, a, parts, *ga); break;
+      default: rh_set_error("rh_adam_lazy_step_ahead_wgrad: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
+    }
+    RH_LAUNCH_CHECK("rh_adam_lazy_step_ahead_wgrad");
+    return 0;
+  }
+  const dim3 grid((unsigned)(parts.nB + parts.nA + parts.nC + parts.nD + sweep_grid));
   switch (D / 4) {
     case 1: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<1>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;
     case 2: hipLaunchKernelGGL((adam_lazy_step_ahead_kernel<2>), grid, dim3(RH_BLOCK), 0, s, a, parts); break;

@@ -1183,6 +1183,11 @@ CHAIN_WGRAD_GROUP = _lib.ab("chainwgroup")
 _WGRAD_GROUP_MAX_B = 32768  # kLongRows of csrc/linear.hip: the grouped launch takes batch-sized reductions only
 chain_gate = None      # the gate words of the optimizer whose step-ahead graph is being captured (optim.TableAdam), or None
 chain_gate_used = []   # ... and a mark per rh_linear_fwd_gate launch captured for it
+# Round 6: while optim.TableAdam captures a step-ahead graph, the chain's grouped weight gradients are not launched where the
+# backward produces them but handed to the optimizer, whose end-of-step launch carries them as its first workgroups
+# (rh_adam_lazy_step_ahead_wgrad): nothing on the step's critical chain reads their slabs.  wgrad_rider(problems, B) -> True
+# when the optimizer took them (it launches them itself if its step then ends differently: TableAdam._flush_rider).
+wgrad_rider = None
 _CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
 
 
@@ -1363,7 +1368,9 @@ class _MlpChainFn(torch.autograd.Function):
                 N, Kin = W.shape
                 part = torch.empty(_lib.call("rh_linear_wgrad_workspace", B, N, Kin), dtype=torch.float32, device=dev)
                 recs.append((g_h, g_h.stride(0), inp, inp.stride(0), N, Kin, part))
-            linear_wgrad_partial_group(recs, B)
+            rider = wgrad_rider
+            if not (rider is not None and rider(recs, B)):
+                linear_wgrad_partial_group(recs, B)
             for (l, g_h, inp, W, b), rec in zip(problems, recs):
                 grads[4 * l], grads[4 * l + 1] = _offer_wgrad_slabs(W, b, rec[6], B)
         s0, s1 = ctx.shapes
@@ -2164,8 +2171,9 @@ class _CrossMoeFn(torch.autograd.Function):
 WGRAD_GROUP = _lib.ab("wgroup")  # False (RECHUB_AB=wgroup=0, tests): one rh_linear_wgrad_partial launch per problem
 
 
-def linear_wgrad_partial_group(problems, B):
-    """ONE launch for <= 8 independent weight-gradient problems (g (B, N) ld, x (B, K) ld, N, K, partial workspace)."""
+def wgrad_group_args(problems, B):
+    """The nine array arguments of a grouped weight-gradient launch (n, g, ldg, x, ldx, B, N, K, partial) + what must stay
+    alive until the call returns.  problems = [(g (B, N), ldg, x (B, K), ldx, N, K, partial workspace)]."""
     import ctypes
     n = len(problems)
     g = (ctypes.c_void_p * n)(*[p_[0].data_ptr() for p_ in problems])
@@ -2177,8 +2185,14 @@ def linear_wgrad_partial_group(problems, B):
     Ks = (ctypes.c_int * n)(*[int(p_[5]) for p_ in problems])
     part = (ctypes.c_void_p * n)(*[p_[6].data_ptr() for p_ in problems])
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-    _lib.call("rh_linear_wgrad_partial_group", n, cast(g), cast(ldg), cast(x), cast(ldx), cast(Bs), cast(Ns), cast(Ks),
-              cast(part), _stream())
+    return (n, cast(g), cast(ldg), cast(x), cast(ldx), cast(Bs), cast(Ns), cast(Ks), cast(part)), (g, ldg, x, ldx, Bs, Ns, Ks, part)
+
+
+def linear_wgrad_partial_group(problems, B):
+    """ONE launch for <= 8 independent weight-gradient problems (g (B, N) ld, x (B, K) ld, N, K, partial workspace)."""
+    args, keep = wgrad_group_args(problems, B)
+    _lib.call("rh_linear_wgrad_partial_group", *args, _stream())
+    del keep
 
 
 def cross_moe(x, u_list, v_list, c_list, bias_list, gating_weights):

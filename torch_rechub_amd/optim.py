@@ -26,6 +26,7 @@ ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
 CHAIN_GATE = _lib.ab("chaingate")  # False (RECHUB_AB=chaingate=0): the sweep is released RH_TUNE_SWEEP_GATE_NS behind the opening (round 4)
+WGRAD_RIDER = _lib.ab("wgradrider")  # False (RECHUB_AB=wgradrider=0): the chain's grouped weight gradients stay a launch of the backward
 LATE_PACK = _lib.ab("latepack")  # False (RECHUB_AB=latepack=0): the gate is opened by a one-lane launch of its own
 GATE_FALLBACK_NS = 50000  # step-ahead form with a chain-start count in the graph: release of a sweep no chain start follows (ns)
 LOOK_DEPTH = 2  # step-ahead form: batches beyond the next one whose lookups in the coming sweep's window are refreshed early
@@ -34,6 +35,7 @@ LOOK_DEPTH = 2  # step-ahead form: batches beyond the next one whose lookups in 
 class TableAdam(torch.optim.Adam):
 
     RING = 1024  # per-step (A, E) history for the lazy replay; lazy_k must be < RING
+    _rider = None  # weight-gradient group the coming end-of-step launch carries (_ride_wgrad)
 
     def __init__(self, params, table_params=(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_k=0,
                  lazy_small_rows=None, lazy_dense_ratio=None, lazy_k_auto=False, **kw):
@@ -134,6 +136,7 @@ class TableAdam(torch.optim.Adam):
                 self._sweep_events = None   # relaxed join: the ends of the sweeps launched by the last two heads
                 self._look_token = None     # relaxed join: (graph, loader generation, step) the last head looked ahead for
                 self._step_ahead = None     # step-ahead form: what _merged_step launches while the graph `seg` is captured
+                self._rider = None          # ... and the weight-gradient group that launch carries (_ride_wgrad)
                 # step-ahead form: the sweep's release is a device word the LAST launch of the step's graph counts up
                 # (rh_adam_sweep_gate_open): [openings, wall clock of the last one]
                 self._gate = torch.zeros(16, dtype=torch.int64, device=dev)  # RH_GATE_WORDS (include/rechub_hip.h)
@@ -346,6 +349,7 @@ class TableAdam(torch.optim.Adam):
             return False
         if ops.chain_gate is self._gate:
             ops.chain_gate = None  # (a capture that was abandoned between its head and its last launch)
+        self._drop_rider()
         recs = self._last_recs
         if len(recs) != 1 or (self._gathers_per_step or 0) != 1 or self._gathers != 0:
             return False
@@ -470,6 +474,8 @@ class TableAdam(torch.optim.Adam):
                 # dependency instead of round 4's wall-clock hold-back behind the opening; ops._MlpChainFn, csrc/gemm.hip)
                 ops.chain_gate = self._gate if CHAIN_GATE else None
                 del ops.chain_gate_used[:]
+                # ... and the chain's grouped weight gradients ride in this graph's last table launch (round 6)
+                ops.wgrad_rider = self._ride_wgrad if WGRAD_RIDER else None
             else:
                 seg.at_start(head_relaxed if RELAXED_JOIN else head)
             self._join_seg = seg
@@ -626,6 +632,28 @@ class TableAdam(torch.optim.Adam):
         self._gate_by_pack = True
         return self._gate
 
+    def _ride_wgrad(self, problems, B):
+        """ops.wgrad_rider while this optimizer captures a step-ahead graph: take the MLP chain's grouped weight gradients
+        into the end-of-step launch (_merged_step).  False = not this step (the backward launches them itself)."""
+        ah = self._step_ahead
+        if ah is None or self._rider is not None or graphs.active() is not ah["seg"] or \
+                not torch.cuda.is_current_stream_capturing() or not 1 <= len(problems) <= 8:
+            return False
+        self._rider = (list(problems), int(B))
+        return True
+
+    def _flush_rider(self):
+        """Weight gradients taken by _ride_wgrad that no end-of-step launch carried (the step ended in another form): their own
+        grouped launch, now -- the packing launch that sums their slabs comes after step()."""
+        rider, self._rider = self._rider, None
+        if rider is not None:
+            ops.linear_wgrad_partial_group(*rider)
+
+    def _drop_rider(self):
+        self._rider = None  # (of a capture that was abandoned: its tensors belong to a dead graph)
+        if ops.wgrad_rider == self._ride_wgrad:
+            ops.wgrad_rider = None
+
     def _merge_ahead_ok(self, rec, grp):
         """Will _merged_step of the step being captured see exactly this gather over exactly this table group?"""
         groups = self._lazy_setup()
@@ -649,12 +677,22 @@ class TableAdam(torch.optim.Adam):
                 raise RuntimeError("TableAdam: the captured step does not end with the gather its head announced "
                                    "(step-ahead form; RECHUB_AB=ahead=0 captures the eager-head form)")
             a = ah["a"]
-            _lib.call("rh_adam_lazy_step_ahead", ops._p(grp["ldesc"]), len(grp["members"]),
-                      ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
-                      ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(ah["ft"]), ops._p(rec["idesc"]), rec["B"],
-                      rec["F"], ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"],
-                      ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]),
-                      ops._p(a["dense_out"]), ops._p(a["label_out"]), LOOK_DEPTH, stream)
+            cargs = (ops._p(grp["ldesc"]), len(grp["members"]),
+                     ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                     ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(ah["ft"]), ops._p(rec["idesc"]), rec["B"],
+                     rec["F"], ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"],
+                     ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]),
+                     ops._p(a["dense_out"]), ops._p(a["label_out"]), LOOK_DEPTH)
+            rider, self._rider = self._rider, None
+            if ops.wgrad_rider == self._ride_wgrad:
+                ops.wgrad_rider = None
+            if rider is not None:
+                # the chain's weight gradients as the first workgroups of this launch (ops._MlpChainFn.backward handed them over)
+                wargs, keep = ops.wgrad_group_args(*rider)
+                _lib.call("rh_adam_lazy_step_ahead_wgrad", *cargs, *wargs, stream)
+                del keep
+            else:
+                _lib.call("rh_adam_lazy_step_ahead", *cargs, stream)
             if not self._gate_by_pack:  # (else the packing launch behind this one opens it: gate_for_late_pack)
                 _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
             self._gate_by_pack = False
@@ -933,6 +971,7 @@ class TableAdam(torch.optim.Adam):
             if not torch.cuda.is_current_stream_capturing():
                 self.sync_hyper()
             self.step_tables()
+            self._flush_rider()
         dense_groups = [] if self._bucket is not None else [g for g in self.param_groups if not g.get("rh_tables")]
         if dense_groups:
             all_groups = self.param_groups
