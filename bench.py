@@ -1225,6 +1225,10 @@ def main():
                 # batch touched are replayed by rh_adam_lazy_touched instead): an upper bound on the work, hence on frac.
                 # One replay iteration = 16 packed f32 ops (4 cycles / wavefront) + 4 sqrt + 4 rcp (8 cycles each,
                 # measured) + 2 VALU ops = 136 cycles per 256 element-steps on each of 1024 SIMDs at 2.4 GHz.
+                # A ceiling of THIS kernel's instruction mix (the arithmetic torch.optim.Adam prescribes per element and
+                # step, as the ISA issues it) -- not of the chip.  (Round 6 measured a 14-packed-op form -- the step scale
+                # inside the denominator's fma -- at the same step time: the replay is bound by its dependent chain
+                # sqrt -> fma -> rcp -> fma at two wavefronts per SIMD, not by the packed-op count; reverted.)
                 valu_peak = 1024 * 2.4e9 / 136 * 256
                 es = total_elems / (k["avg_ms"] * 1e-3)
                 frac = es / valu_peak
@@ -1236,7 +1240,8 @@ def main():
                 roofline.update({"bound": "valu", "achieved": round(es / 1e9, 1), "peak": round(valu_peak / 1e9, 1),
                                  "unit": "G element-steps/s", "frac": round(frac, 4),
                                  "element_steps_per_launch": total_elems,
-                                 "peak_model": "one replay iteration = 16 v_pk_*_f32 (4 cycles) + 4 v_sqrt_f32 + 4 v_rcp_f32 "
+                                 "peak_model": "ceiling of the kernel's OWN instruction mix, not of the chip: one replay "
+                                               "iteration = 16 v_pk_*_f32 (4 cycles) + 4 v_sqrt_f32 + 4 v_rcp_f32 "
                                                "(8 cycles each, measured) + 2 VALU ops = 136 cycles per 256 element-steps, "
                                                "x 1024 SIMDs x 2.4 GHz (DESIGN 3.3); element-steps per launch = every table "
                                                "element once (an upper bound: the batch's rows are replayed by the touched "

@@ -1021,6 +1021,70 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
         assert torch.equal(sd_a[k], sd_b[k]), k
 
 
+def test_twelve_data_parallel_trainers_in_one_process_keep_their_stream_roles(nccl_world1, monkeypatch):
+    """Regression test of round 5's hipStreamEndCapture segfault (tools/bitwise_probe.py dp with
+    RECHUB_STEP_FORM=deferred reproduced it at round-6 HEAD before the fix).  The sequence that died -- a plain trainer and five
+    data-parallel trainers (eager / single-graph / split-graph over replicated tables, eager / single-graph over row shards, the
+    row-sharded step pinned to the deferred sweep), TWICE, in one process -- plus two more: twelve data-parallel trainers, seven
+    of them captured.  Cause: torch.cuda.Stream() hands out 32 pooled hipStreams round robin, and the origin of the tenth
+    trainer's capture was the pooled stream the first trainer had issued its asynchronous RCCL all-reduces on.  Since round 6
+    every stream of the path has ONE role for the life of the process (graphs.role_stream): the run must come through, bit-equal
+    to plain training on order-free batches, and draw at most one pooled stream per role however many trainers it builds."""
+    from torch_rechub_amd import graphs, ops, sharding
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    drawn = []
+    real_stream = torch.cuda.Stream
+
+    def counting_stream(*a, **kw):
+        if "stream_id" not in kw and "stream_ptr" not in kw:  # a draw from the pool (not the wrapper current_stream() builds)
+            drawn.append(1)
+        return real_stream(*a, **kw)
+
+    monkeypatch.setattr(torch.cuda, "Stream", counting_stream)
+    monkeypatch.setenv("RECHUB_STEP_FORM", "deferred")
+    nb, B = 6, 64
+    built = 0
+    cases = ((False, "replicate"), ("single", "replicate"), ("split", "replicate"), (False, "shard"), ("single", "shard"))
+    for rnd, layout in enumerate(("collision_free", "duplicated_samples", "duplicated_samples")):
+        vocabs, sparse, dense, label = _loader_twin_data(layout, nb, B, seed=61 + rnd)
+        params = {"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64}
+
+        def mk():
+            m, dfe, sfe = _deepfm(vocabs, 3)
+            return m, [f.name for f in sfe], [f.name for f in dfe]
+
+        ma, names, dnames = mk()
+        sd0 = {k: v.clone() for k, v in ma.state_dict().items()}
+        loader = lambda: DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        monkeypatch.setenv("RECHUB_FORCE_DP", "0")
+        ta = CTRTrainer(ma, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4)
+        la = ta.train_one_epoch(loader())
+        sa = {k: v.detach().clone() for k, v in ma.state_dict().items()}
+        for use_graph, tables in (cases if rnd < 2 else cases[1::3]):
+            mb, _, _ = mk()
+            mb.load_state_dict(sd0)
+            monkeypatch.setenv("RECHUB_FORCE_DP", "1")
+            monkeypatch.setenv("RECHUB_DP_GRAPH", use_graph or "single")
+            tb = CTRTrainer(mb, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4,
+                            use_graph=bool(use_graph), tables=tables)
+            try:
+                lb = tb.train_one_epoch(loader())
+                sb = sharding.full_state_dict(mb) if tables == "shard" else mb.state_dict()
+                sb = {k: v.detach().clone() for k, v in sb.items()}
+            finally:
+                tb.dp.close()
+            built += 1
+            if not (tables == "shard" and layout == "collision_free"):  # (the row-sharded lookup sums in another order there)
+                assert la == lb
+                for k in sa:
+                    assert torch.equal(sa[k], sb[k]), (rnd, use_graph, tables, k)
+    assert built == 12
+    roles = {r for r, _ in graphs._ROLE_STREAMS}
+    assert {"capture", "dense_allreduce", "warmup"} <= roles
+    assert len(drawn) <= len(graphs._ROLE_STREAMS) <= 8, (len(drawn), sorted(graphs._ROLE_STREAMS))
+
+
 def test_dssm_towers_side_by_side_are_the_sequential_towers(monkeypatch):
     """DSSM.towers with ``model.tower_branches = True`` (item tower's MLP on a second stream, forward and backward) == the two tower
     calls one after the other, bit for bit: same kernels on the same inputs, only their streams differ."""

@@ -79,6 +79,12 @@ def dp_pairs(cases=None, layouts=("collision_free", "duplicated_samples")):
                 sb = {k: v.detach().clone() for k, v in sb.items()}
             finally:
                 tb.dp.close()
+            skew = os.environ.get("PROBE_SKEW")  # "j:n": draw n extra pool streams after the j-th data-parallel trainer
+            if skew:
+                j, n = (int(v) for v in skew.split(":"))
+                dp_pairs.count = getattr(dp_pairs, "count", 0) + 1
+                if dp_pairs.count == j:
+                    dp_pairs.keep = [torch.cuda.Stream() for _ in range(n)]
             print(f"[dp {layout} graph={use_graph} tables={tables}] loss plain {la!r} dp {lb!r}")
             report(f"dp one rank, {layout}, graph={use_graph}, tables={tables}", sa, sb)
             if os.environ.get("PROBE_GC") == "1":  # destroy this trainer's graphs NOW, with an idle device

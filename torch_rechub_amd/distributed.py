@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from . import ops
+from . import graphs, ops
 
 
 def table_parameters(model):
@@ -93,8 +93,9 @@ class DenseGradBucket(object):
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(self.offsets[-1], dtype=torch.float32, device=dev)
         self.use_cuda = dev.type == "cuda"
-        self.side = torch.cuda.Stream(device=dev) if (self.use_cuda and dist.is_available() and dist.is_initialized()) \
-            else None
+        # (ONE stream per role and process, not a pooled stream per bucket: graphs.role_stream says why)
+        self.side = graphs.role_stream("dense_allreduce", dev) if (self.use_cuda and dist.is_available() and
+                                                                    dist.is_initialized()) else None
         self.packed = [False] * len(self.params)
         self.pending = []
         self.defer = False  # True: flush() only packs; reduce_deferred() starts the all-reduces (split-graph step)

@@ -14,6 +14,31 @@ import gc
 import torch
 
 _active = None
+_ROLE_STREAMS = {}
+
+
+def role_stream(role, device=None):
+    """THE stream of ``role`` ("capture", "sweep", "dense_allreduce", "warmup", "branch", "copy") on ``device`` -- created
+    once, kept for the life of the process.
+
+    ``torch.cuda.Stream()`` does not create a stream: it hands out the next of 32 pooled hipStreams per device, round robin.
+    A process that builds many trainers (a capture stream per capture, a side stream for the optimizer's sweep, one for the
+    dense all-reduce, one for the warm-up ...) wraps around the pool and gets the SAME hipStream back under another role.
+    Round 5's ``tools/bitwise_probe.py dp`` died that way, deterministically, inside ``hipStreamEndCapture`` (an unbounded
+    recursion ``hip::Stream::EndCapture`` -> ``EndCapture`` -> ..., rocgdb backtrace in profiles/r06_endcapture_backtrace.txt):
+    the ORIGIN of the tenth data-parallel trainer's capture was the pooled stream on which the first trainer had issued its
+    asynchronous RCCL all-reduces 32 ``torch.cuda.Stream()`` calls earlier (tools/probe/stream_trace.py); one extra pool
+    stream drawn anywhere in between -- any change of that distance -- and the same sequence runs through
+    (``PROBE_SKEW`` of the probe).  With one stream per role no hipStream ever changes its role, and a
+    long-lived process uses a handful of streams however many trainers it builds."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (str(role), dev.index)
+    s = _ROLE_STREAMS.get(key)
+    if s is None:
+        s = _ROLE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def active():
@@ -48,7 +73,7 @@ class SegmentedGraph(object):
             raise RuntimeError("a segmented capture is already running")
         torch.cuda.synchronize()
         gc.collect()
-        self._stream = torch.cuda.Stream()
+        self._stream = role_stream("capture")  # (one origin stream for every capture of the process: see role_stream)
         self._stream.wait_stream(torch.cuda.current_stream())
         _active = self
         try:

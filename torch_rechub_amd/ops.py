@@ -56,7 +56,8 @@ def run_beside(fn_main, fn_side, side_inputs=()):
     key = cur.device.index
     side = _BRANCH_STREAMS.get(key)
     if side is None:
-        side = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=cur.device)
+        from . import graphs
+        side = _BRANCH_STREAMS[key] = graphs.role_stream("branch", cur.device)
     side.wait_stream(cur)
     for t in side_inputs:
         t.record_stream(side)

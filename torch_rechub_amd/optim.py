@@ -600,7 +600,7 @@ class TableAdam(torch.optim.Adam):
 
     def _make_side_stream(self):
         """The sweep's stream (a plain stream: CU-masked and priority streams were measured in round 3 and bought nothing)."""
-        return torch.cuda.Stream(device=self._tables[0].device)
+        return graphs.role_stream("sweep", self._tables[0].device)  # one per process: graphs.role_stream says why
 
     def _join_sweep(self):
         if self._sweep_inflight:

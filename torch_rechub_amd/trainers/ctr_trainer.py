@@ -465,7 +465,7 @@ class CTRTrainer(object):
             if isinstance(self.optimizer, TableAdam):
                 self.optimizer.sync_hyper()
             total = torch.zeros((), dtype=torch.float32, device=self.device)
-            side = torch.cuda.Stream(device=self.device)
+            side = graphs.role_stream("warmup", self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(self.GRAPH_WARMUP):  # allocator, descriptor caches, lazily created optimizer state

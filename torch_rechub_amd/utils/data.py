@@ -210,7 +210,8 @@ class DeviceDataLoader(object):
         sparse = torch.empty((n_rows, F), dtype=torch.int64, device=dev)
         dense = torch.empty((n_rows, ND), dtype=torch.float32, device=dev) if ND else None
         label = torch.empty((n_rows,), dtype=torch.float32, device=dev)
-        copy_stream = torch.cuda.Stream(device=dev)
+        from .. import graphs
+        copy_stream = graphs.role_stream("copy", dev)
         stage = [None, None]  # pinned (sparse, dense, label) staging blocks, used alternately
         done = [None, None]
         columns = sparse_names + dense_names + [label_name]
