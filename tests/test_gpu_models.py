@@ -1021,6 +1021,91 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
         assert torch.equal(sd_a[k], sd_b[k]), k
 
 
+def test_data_parallel_step_keeps_both_uses_of_a_linear_shared_across_two_embedding_lookups(nccl_world1, monkeypatch):
+    """Round-5 advisor finding (distributed.DenseGradBucket.flush): the data-parallel step packs dense gradients from their
+    partial slabs and starts the all-reduce from the pre-embedding-backward hook, in the MIDDLE of the backward.  A slab is
+    registered at the FIRST use of a parameter -- for a tower shared by two lookups (item tower backward, item embedding
+    backward + hook, user tower backward) the bucket took the first use for the gradient and the second contribution was
+    silently lost.  Since round 6 the uses of every armed parameter are counted in the autograd graph (ops.DeferredGrads.arm
+    with the root) and a slab is packed only when all of them have reported.  On a one-rank RCCL group the all-reduce is the
+    identity, so the data-parallel training must reproduce the plain one; the hook must have fired between the two uses."""
+    from torch import nn
+
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.basic.features import SparseFeature
+    from torch_rechub_amd.basic.layers import MLP, EmbeddingLayer
+    from torch_rechub_amd.trainers import CTRTrainer
+
+    class SharedTower(nn.Module):
+        def __init__(self, ufe, ife):
+            super().__init__()
+            self.ufe, self.ife = ufe, ife
+            self.embedding = EmbeddingLayer(ufe + ife)
+            self.tower = MLP(32, output_layer=False, dims=[32, 16], dropout=0.0, activation="relu")
+
+        def forward(self, x):
+            # item side first, THEN the user lookup: autograd runs the user tower's backward, the user lookup's backward (the
+            # bucket's hook fires in front of it) and only then the item tower's backward -- the tower's second use
+            hi = self.tower(self.embedding(x, self.ife, squeeze_dim=True))
+            hu = self.tower(self.embedding(x, self.ufe, squeeze_dim=True))
+            return torch.sigmoid((hu * hi).sum(1))
+
+    nb, B = 6, 64
+    vocabs = [300, 1000, 5000, 20000]
+    sparse = _collision_free_columns(vocabs, [1] * 4, nb, B, seed=71)
+    label = (torch.rand(nb * B, generator=torch.Generator().manual_seed(72)) < 0.3).float()
+    names = [f"C{i}" for i in range(4)]
+    batches = [({n: sparse[b * B:(b + 1) * B, j].to(dev()) for j, n in enumerate(names)}, label[b * B:(b + 1) * B].to(dev()))
+               for b in range(nb)]
+
+    def mk():
+        torch.manual_seed(5)
+        fe = [SparseFeature(n, v, 16) for n, v in zip(names, vocabs)]
+        return SharedTower(fe[:2], fe[2:])
+
+    hooks = []
+    real_offer = ops.deferred.offer
+
+    def spy_offer(param, *a, **kw):
+        hooks.append(("offer", id(param)))
+        return real_offer(param, *a, **kw)
+
+    monkeypatch.setattr(ops.deferred, "offer", spy_offer)
+    from torch_rechub_amd.distributed import DenseGradBucket
+    real_flush = DenseGradBucket.flush
+
+    def spy_flush(self):
+        hooks.append(("flush", 0))
+        return real_flush(self)
+
+    monkeypatch.setattr(DenseGradBucket, "flush", spy_flush)  # (before the trainers register it as the embedding backward's hook)
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("RECHUB_FORCE_DP", force)
+        m = mk()
+        t = CTRTrainer(m, optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
+                       use_graph=False)
+        assert (t.dp is not None) == (force == "1")
+        del hooks[:]
+        try:
+            for x, y in batches:
+                t.train_step(x, y)
+            t.flush()
+        finally:
+            if t.dp is not None:
+                t.dp.close()
+        if force == "1":  # the mid-backward flush really fell between the two uses of the tower's first weight
+            w0 = id(m.tower.mlp[0].weight)
+            seq = [h for h in hooks if h == ("flush", 0) or h == ("offer", w0)]
+            pat = [("offer", w0), ("flush", 0), ("offer", w0)]
+            assert any(seq[j:j + 3] == pat for j in range(len(seq) - 2)), seq[:12]
+        out.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    for k in out[0]:
+        if k.endswith("num_batches_tracked"):
+            continue
+        torch.testing.assert_close(out[1][k], out[0][k], rtol=1e-5, atol=1e-7, msg=lambda s, k=k: f"{k}: {s}")
+
+
 def test_twelve_data_parallel_trainers_in_one_process_keep_their_stream_roles(nccl_world1, monkeypatch):
     """Regression test of round 5's hipStreamEndCapture segfault (tools/bitwise_probe.py dp with
     RECHUB_STEP_FORM=deferred reproduced it at round-6 HEAD before the fix).  The sequence that died -- a plain trainer and five

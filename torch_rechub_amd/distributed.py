@@ -121,12 +121,17 @@ class DenseGradBucket(object):
         def missing(k):
             p = self.params[k]
             return p.grad is None and (slabs is None or id(p) not in slabs)
+
+        def ready(k):
+            # a slab is the parameter's gradient only once EVERY use of the parameter in this backward has reported
+            # (ops.DeferredGrads.final: a Linear shared across two embedding lookups registers its first slab early)
+            return want_missing or slabs is None or ops.deferred.final(self.params[k])
         runs, i, n = [], 0, len(self.params)
         while i < n:
-            ok = (not self.packed[i]) and (missing(i) == want_missing)
+            ok = (not self.packed[i]) and (missing(i) == want_missing) and ready(i)
             if ok:
                 j = i
-                while j < n and (not self.packed[j]) and (missing(j) == want_missing):
+                while j < n and (not self.packed[j]) and (missing(j) == want_missing) and ready(j):
                     j += 1
                 runs.append((i, j))
                 i = j
@@ -219,6 +224,7 @@ class DenseGradBucket(object):
 
     def finish(self, assign_views=False):
         """Pack / reduce what is left (parameters without a gradient contribute zeros, like DDP) and join."""
+        ops.deferred.backward_done()  # (called behind loss.backward(): every gradient that exists is final now)
         self.flush()
         slabs = ops.deferred.items if (ops.deferred.armed is not None and self.use_cuda) else None
         missing = self._runs(want_missing=True, slabs=slabs)

@@ -1000,16 +1000,57 @@ class DeferredGrads(object):
         self.armed = None  # {id(param): param} of the parameters whose gradients may be deferred
         self.items = {}    # id(param) -> dict(param, slab, nparts, stride, numel, reduce_now)
 
-    def arm(self, params):
+    def arm(self, params, root=None):
+        """``root``: the tensor ``backward()`` is about to be called on.  Given (the data-parallel step: its bucket packs slabs
+        and starts their all-reduce IN THE MIDDLE of the backward, DenseGradBucket.flush from the pre-embedding-backward hook),
+        the uses of every armed parameter in the autograd graph are counted, and ``final(p)`` says whether all of them have
+        reported -- a slab registered by the first of two uses (a Linear shared by two towers, with an embedding backward in
+        between) is not the parameter's gradient yet (round-5 advisor finding: the second contribution was lost)."""
         self.armed = {id(p): p for p in params}
         self.items = {}
+        self.uses = None
+        if root is not None and root.grad_fn is not None:
+            self.uses = self._count_uses(root.grad_fn, self.armed)
+
+    @staticmethod
+    def _count_uses(root_fn, want):
+        """{id(param): edges into its AccumulateGrad node} over the graph below ``root_fn`` (one edge per use of the leaf)."""
+        counts, seen, stack = {}, set(), [root_fn]
+        while stack:
+            fn = stack.pop()
+            if fn in seen:
+                continue
+            seen.add(fn)
+            for nxt, _ in fn.next_functions:
+                if nxt is None:
+                    continue
+                v = getattr(nxt, "variable", None)  # AccumulateGrad
+                if v is not None:
+                    if id(v) in want:
+                        counts[id(v)] = counts.get(id(v), 0) + 1
+                else:
+                    stack.append(nxt)
+        return counts
+
+    uses = None
+
+    def final(self, param):
+        """Have all uses of ``param`` in this backward produced their gradient?  (True when uses are not tracked: the
+        single-GPU step packs once, after the backward.)"""
+        return self.uses is None or self.uses.get(id(param), 0) <= 0
+
+    def backward_done(self):
+        self.uses = None  # the backward has returned: whatever exists now is final
 
     def disarm(self):
         items, self.items, self.armed = self.items, {}, None
+        self.uses = None
         return items
 
     def offer(self, param, slab_ptr, nparts, stride, numel, reduce_now, keep):
         """Called from a backward: returns the gradient to hand to autograd (None = deferred)."""
+        if self.uses is not None and param is not None and id(param) in self.uses:
+            self.uses[id(param)] -= 1
         if self.armed is None or param is None or id(param) not in self.armed:
             return reduce_now()
         first = self.items.pop(id(param), None)

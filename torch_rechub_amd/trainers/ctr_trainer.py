@@ -222,7 +222,8 @@ class CTRTrainer(object):
         # the start of the embedding backward -- the all-reduce of the MLP's gradients starts on it -- one for the rest)
         defer_dp = packed and self.dp is not None and self.bucket.use_cuda
         if defer or defer_dp:
-            ops.deferred.arm(self.bucket.params)
+            # (data parallel: the bucket packs slabs in the middle of the backward -- count the uses of every parameter first)
+            ops.deferred.arm(self.bucket.params, root=loss if defer_dp else None)
         try:
             loss.backward(self._grad_root(loss))
             if defer_dp:
@@ -280,9 +281,10 @@ class CTRTrainer(object):
         self._zero_grad()
         defer_dp = self.optimizer._bucket is not None and self.bucket.use_cuda
         if defer_dp:
-            ops.deferred.arm(self.bucket.params)
+            ops.deferred.arm(self.bucket.params, root=loss)
         try:
             loss.backward(self._grad_root(loss))
+            ops.deferred.backward_done()
             if not self._bucket_attached:
                 self._bucket_attached = True
                 if self.bucket.all_present() and self.bucket.params:
