@@ -880,6 +880,48 @@ def test_world_scaling_rides_on_the_backward_root():
     assert torch.allclose(out, loss / 4 + 0.75 * reg)
 
 
+def test_world_scaling_reaches_the_fused_head_and_loss_kernels_through_one_persistent_root_tensor():
+    """Round-5 advisor finding: the 1/world factor lives in the cached root tensor only, and the fused head + BCE kernels read
+    it BY POINTER (rh_head_bwd_bn*: g_loss) -- the path the test above does not take.  A fused DeepFM step with world forced to
+    2 must leave exactly half of the world-1 dense gradients (a power of two: exact in fp32), and a change of the scale must
+    refill the SAME tensor (a captured step keeps its pointer), never allocate another."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.trainers import CTRTrainer
+    vocabs, sparse, dense, label = _loader_twin_data("collision_free", 1, 64, seed=77)
+    grads, roots = [], []
+    for world in (1, 2):
+        model, dfe, sfe = _deepfm(vocabs, 9)
+        names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+        (x, y), = _host_column_batches(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), 64)
+        t = CTRTrainer(model, optimizer_params={"lr": 1e-2, "weight_decay": 0.0}, device="cuda:0", show_progress=False)
+        t.world = world
+        seen = []
+        real = ops._lib.call
+
+        def spy(name, *a, _seen=seen, _real=real):
+            _seen.append(name)
+            return _real(name, *a)
+
+        ops._lib.call = spy
+        try:
+            t.train_step(x, y)
+        finally:
+            ops._lib.call = real
+        assert any(n.startswith("rh_head_bwd_bn") for n in seen)  # the fused head backward formed dL/dy from y, t and the root
+        tables = {id(p) for p in model.embedding.parameters()}
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if id(p) not in tables and p.grad is not None})
+        roots.append(t)
+    assert grads[0] and grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[1][k], 0.5 * grads[0][k]), k
+    t = roots[1]
+    ptr = t._one.data_ptr()
+    assert t._one.item() == 0.5
+    t.world = 4
+    t._scale_for_world(torch.zeros((), device=dev(), requires_grad=True))
+    assert t._grad_root(torch.zeros((), device=dev())).data_ptr() == ptr and t._one.item() == 0.25
+
+
 def test_stock_optimizer_sees_dense_table_gradients():
     """optimizer_fn other than Adam: tables expose an ordinary dense .grad (persistent buffer) to torch.optim."""
     from torch_rechub_amd import ops

@@ -15,6 +15,7 @@ import torch
 
 _active = None
 _ROLE_STREAMS = {}
+capture_end_hooks = []  # callables run when a SegmentedGraph.capture ends, completed OR abandoned (ops resets its capture-scoped state)
 
 
 def role_stream(role, device=None):
@@ -85,6 +86,8 @@ class SegmentedGraph(object):
                     self.segments[-1][0].capture_end()
         finally:
             _active = None
+            for hook in capture_end_hooks:
+                hook()
         torch.cuda.current_stream().wait_stream(self._stream)
         return out
 

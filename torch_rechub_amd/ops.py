@@ -1230,6 +1230,22 @@ chain_gate_used = []   # ... and a mark per rh_linear_fwd_gate launch captured f
 # (rh_adam_lazy_step_ahead_wgrad): nothing on the step's critical chain reads their slabs.  wgrad_rider(problems, B) -> True
 # when the optimizer took them (it launches them itself if its step then ends differently: TableAdam._flush_rider).
 wgrad_rider = None
+
+
+def _reset_capture_state():
+    """chain_gate / chain_gate_used / wgrad_rider belong to ONE capture (optim.TableAdam arms them at the head of a step-ahead
+    capture and disarms them at its last launch).  A capture that is abandoned in between must not leave them armed for
+    whatever is captured next -- another trainer's MLP chain would bake rh_linear_fwd_gate with THIS optimizer's gate words
+    into its graph, or hand its weight gradients to a launch that never comes (round-5 advisor finding)."""
+    global chain_gate, wgrad_rider
+    chain_gate = None
+    wgrad_rider = None
+    del chain_gate_used[:]
+
+
+from . import graphs as _graphs  # noqa: E402  (graphs imports torch only)
+
+_graphs.capture_end_hooks.append(_reset_capture_state)
 _CHAIN_MAX_B = 4096  # rh_head_bwd_bn hands over rh_head_nblocks(B) <= 128 partial rows up to here
 
 

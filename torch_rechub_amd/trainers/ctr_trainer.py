@@ -261,12 +261,22 @@ class CTRTrainer(object):
         one rank (and no embedding regulariser) the root is 1/world: the loss scaling of _scale_for_world."""
         scale = float(getattr(self, "_root_scale", 1.0))
         one = getattr(self, "_one", None)
-        if one is None or one.device != loss.device or one.shape != loss.shape or getattr(self, "_one_scale", 1.0) != scale:
-            if torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            if capturing:
                 # (not cached yet: never the case after the eager warm-up steps in front of a capture)
                 return None if scale == 1.0 else torch.full_like(loss, scale)
             one = torch.full_like(loss, scale)
             self._one, self._one_scale = one, scale
+        elif getattr(self, "_one_scale", 1.0) != scale:
+            # ONE persistent root tensor per trainer: the fused head / BCE kernels of a captured step read it BY POINTER, so
+            # it is refilled in place, never replaced (round-5 advisor finding) -- and a captured step baked the other
+            # scale's whole forward (the embedding regulariser's terms), so it cannot be replayed after such a change
+            if capturing or getattr(self, "_graph", None) is not None:
+                raise RuntimeError("the loss scale of the data-parallel step changed (embedding regulariser switched on or "
+                                   "off) under a captured hipGraph step; build a new trainer")
+            one.fill_(scale)
+            self._one_scale = scale
         return one
 
     # -- data-parallel step in three phases: [A: batch, forward, backward, pack] -> [X: RCCL collectives] ->
