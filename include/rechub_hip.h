@@ -365,7 +365,8 @@ int rh_linear_dgrad(const float* g, int64_t ldg, const float* w, int64_t ldw, in
  * bias + residual as its epilogue (round 5; rounds 1-4: library GEMM + rh_cross_v2_epilogue_fwd as a second pass).
  * rh_cross_v2_fwd: x0, x (M, d), w (d, d) row-major as nn.Linear.weight, b (d,) -> y (M, d) = x w^T (kept for the backward) and
  * out (M, d) = x0 * y + b + x.  rh_cross_v2_dgrad: gx (M, d) = g_y w + g with g_y = g * x0 (rh_cross_v2_epilogue_bwd forms g_y
- * and g_x0 = g * y): the layer's gradient with respect to x, residual path included. */
+ * and g_x0 = g * y): the layer's gradient with respect to x, residual path included.  Every operand contiguous (row stride d);
+ * 1 <= M <= 16384, 1 <= d <= 1024, else RH_E_UNSUPPORTED. */
 int rh_cross_v2_fwd(const float* x0, const float* x, const float* w, const float* b, int M, int d, float* y, float* out,
                     void* stream);
 int rh_cross_v2_dgrad(const float* g_y, const float* w, const float* g, int M, int d, float* gx, void* stream);

@@ -641,6 +641,8 @@ extern "C" int rh_linear_dgrad_bnbwd(const float* g, int64_t ldg, const float* w
   return 0;
 }
 
+constexpr int kCrossV2MaxM = 16384, kCrossV2MaxD = 1024;  // = ops.CROSS_V2_MAX_B / CROSS_V2_MAX_D
+
 // One CrossNetV2 layer forward in ONE launch (round 5; reference CrossNetV2.forward, torch_rechub/basic/layers.py:440-444:
 // x <- x0 * (W_l x) + b_l + x): y (M, d) = x W^T on the f32-MFMA tile GEMM, and from the accumulators out = x0 * y + b + x.
 // Rounds 1-4 ran the product on the library and the Hadamard + bias + residual as a second pass over four (M, d) arrays
@@ -648,7 +650,9 @@ extern "C" int rh_linear_dgrad_bnbwd(const float* g, int64_t ldg, const float* w
 extern "C" int rh_cross_v2_fwd(const float* x0, const float* x, const float* w, const float* b, int M, int d, float* y,
                                float* out, void* stream) {
   RH_REQUIRE(x0 && x && w && b && y && out, RH_E_BADARG, "rh_cross_v2_fwd: null pointer");
-  RH_REQUIRE(M >= 1 && d >= 1, RH_E_BADARG, "rh_cross_v2_fwd: bad shape M=%d d=%d", M, d);
+  // (all operands contiguous: row stride d; the limits of the tile GEMM at batch size, ops.CROSS_V2_MAX_B / _MAX_D)
+  RH_REQUIRE(M >= 1 && M <= kCrossV2MaxM && d >= 1 && d <= kCrossV2MaxD, RH_E_UNSUPPORTED,
+             "rh_cross_v2_fwd: bad shape M=%d d=%d (1 <= M <= %d, 1 <= d <= %d)", M, d, kCrossV2MaxM, kCrossV2MaxD);
   GemmArgs a{};
   a.A = x; a.lda = d; a.B = w; a.ldb = d; a.bias = b; a.C = y; a.ldc = d; a.M = M; a.N = d; a.K = d;
   a.ep_mul = x0; a.ep_add = x; a.ep_out = out; a.ld_ep = d;
@@ -661,7 +665,8 @@ extern "C" int rh_cross_v2_fwd(const float* x0, const float* x, const float* w, 
 // rh_cross_v2_epilogue_bwd together with g_x0 = g * y), g the upstream gradient that also reaches x through the residual.
 extern "C" int rh_cross_v2_dgrad(const float* g_y, const float* w, const float* g, int M, int d, float* gx, void* stream) {
   RH_REQUIRE(g_y && w && g && gx, RH_E_BADARG, "rh_cross_v2_dgrad: null pointer");
-  RH_REQUIRE(M >= 1 && d >= 1, RH_E_BADARG, "rh_cross_v2_dgrad: bad shape M=%d d=%d", M, d);
+  RH_REQUIRE(M >= 1 && M <= kCrossV2MaxM && d >= 1 && d <= kCrossV2MaxD, RH_E_UNSUPPORTED,
+             "rh_cross_v2_dgrad: bad shape M=%d d=%d (1 <= M <= %d, 1 <= d <= %d)", M, d, kCrossV2MaxM, kCrossV2MaxD);
   GemmArgs a{};
   a.A = g_y; a.lda = d; a.B = w; a.ldb = d; a.C = gx; a.ldc = d; a.M = M; a.N = d; a.K = d;
   a.ep_add = g; a.ld_ep = d;

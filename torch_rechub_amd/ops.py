@@ -2060,12 +2060,21 @@ class _CrossV2LayerFn(torch.autograd.Function):
         return (g_x0 if ctx.needs_input_grad[0] else None), g_x, g_w, g_b
 
 
+CROSS_V2_MAX_B, CROSS_V2_MAX_D = 16384, 1024  # limits of rh_cross_v2_fwd / rh_cross_v2_dgrad (enforced there: csrc/gemm.hip)
+
+
+def cross_v2_shape_ok(x, weight):
+    """THE predicate of the fused CrossNetV2 layer (ops.cross_v2_layer_ok and torch.ops.rechub_hip.cross_net_v2 share it):
+    contiguous f32 x (B, d) and W (d, d) within the entry points' limits."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and
+            1 <= x.shape[0] <= CROSS_V2_MAX_B and 1 <= x.shape[1] <= CROSS_V2_MAX_D and
+            tuple(weight.shape[-2:]) == (x.shape[1], x.shape[1]))
+
+
 def cross_v2_layer_ok(x, lin):
     """Can one CrossNetV2 layer run on the tile GEMM (f32, square weight without bias up to the GEMM's widths)?"""
-    d = x.shape[1] if x.dim() == 2 else 0
-    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and 1 <= x.shape[0] <= 16384 and
-            type(lin) is torch.nn.Linear and lin.bias is None and tuple(lin.weight.shape) == (d, d) and d <= _GEMM_MAX_NK and
-            lin.weight.dtype == torch.float32 and lin.weight.is_contiguous() and linear_ok(x, lin.weight))
+    return (type(lin) is torch.nn.Linear and lin.bias is None and x.dim() == 2 and cross_v2_shape_ok(x, lin.weight) and
+            x.shape[1] <= _GEMM_MAX_NK and lin.weight.is_contiguous() and linear_ok(x, lin.weight))
 
 
 def cross_v2_layer(x0, x, weight, bias):
