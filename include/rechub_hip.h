@@ -69,7 +69,9 @@ const char* rh_last_error(void);
 #define RH_TUNE_BWD_SPLIT 4     /* retired (accepted, ignored) */
 #define RH_TUNE_BWD_SLABS 5     /* retired (accepted, ignored) */
 #define RH_TUNE_FWD_PATH 7      /* rh_embed_fwd: 0 auto (by batch size), 1 lane-split kernel only, 2 field-uniform kernel only */
-#define RH_TUNE_BWD_PATH 6      /* rh_embed_bwd experiments: 0 auto, 1 global atomics for every table, 3 no sink */
+#define RH_TUNE_BWD_PATH 6      /* rh_embed_bwd experiments: 0 auto, 1 global atomics for every table, 3 no sink, 4 chunk-fastest
+                                 * block order; TIMING ONLY (wrong sums on colliding rows, tools/bwd_ceiling_probe.py): 5 the
+                                 * row-wide requests as plain stores, 6 one plain 16-byte store per lane */
 int rh_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------

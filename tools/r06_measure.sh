@@ -15,6 +15,7 @@
 #   ab         same-box A/B lines: AB_CASES="name|ENV=..;ENV2=..|bench args" ...
 #   hist       step period distribution without a profiler (tools/period_hist.py)
 #   crash      tools/bitwise_probe.py dp under faulthandler and under rocgdb (backtrace of the capture segfault)
+#   ceiling    tools/bwd_ceiling_probe.py (timing) + its two PMC passes
 #   cmd        run CMD verbatim
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -88,6 +89,11 @@ PY
 hist) timeout 300 python tools/period_hist.py ${HIST_ARGS:-} > "$OUT/period_hist${HISTTAG:-}.txt" 2>&1; tail -12 "$OUT/period_hist${HISTTAG:-}.txt";;
 crash) timeout 400 python -X faulthandler tools/bitwise_probe.py dp > "$OUT/crash_probe.txt" 2> "$OUT/crash_probe.err"; echo "rc=$?"; tail -5 "$OUT/crash_probe.txt"; tail -40 "$OUT/crash_probe.err"
   if [ -x /opt/rocm/bin/rocgdb ]; then timeout 600 /opt/rocm/bin/rocgdb -batch -ex "set pagination off" -ex "handle SIGSEGV stop" -ex run -ex "bt 40" -ex "info threads" --args python tools/bitwise_probe.py dp > "$OUT/crash_gdb.txt" 2>&1; echo "gdb rc=$?"; grep -n "SIGSEGV" -A 60 "$OUT/crash_gdb.txt" | head -120; fi;;
+ceiling) timeout 600 python tools/bwd_ceiling_probe.py ${CEIL_ARGS:-} > "$OUT/bwd_ceiling.txt" 2>&1; echo "rc=$?"; cat "$OUT/bwd_ceiling.txt"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rm -rf /tmp/ceil_$c && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/ceil_$c -o c -- python "$OLDPWD/tools/bwd_ceiling_probe.py" --pmc --batches 65536 > /dev/null 2> "$OLDPWD/$OUT/ceil_$c.err"); echo "pmc $c rc=$?"
+  done
+  python tools/bwd_ceiling_pmc.py /tmp/ceil_FETCH_SIZE /tmp/ceil_WRITE_SIZE 8 > "$OUT/bwd_ceiling_pmc.txt" 2>&1; cat "$OUT/bwd_ceiling_pmc.txt";;
 cmd) bash -c "${CMD}" > "$OUT/cmd${CMDTAG:-}.log" 2>&1; echo "rc=$?"; tail -${CMDTAIL:-40} "$OUT/cmd${CMDTAG:-}.log";;
 *) echo "unknown stage $s";;
 esac; done

@@ -522,6 +522,12 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
           const int j = u * LPP + slot;
           *reinterpret_cast<float4*>(park + j * (4 * LPR) + q * 4) = gr;
           if (q == 0) park_row[j] = live ? (int)row[u] : -1;
+        } else if (a.path == 6) {
+          // TIMING ONLY (tools/bwd_ceiling_probe.py; wrong sums when two lookups meet on a row): the cheapest scatter there
+          // is -- one plain 16-byte store per lane, a whole 64-byte row per LPR lanes, no re-layout, no read-modify-write.
+          // The ceiling of ANY scheme that writes each lookup's row once (sorted / segmented reductions included: with
+          // uniform indices over 10 M-row tables a batch holds next to no duplicate to merge).
+          if (live) gstore<float4>(gtab + row[u] * D + q * 4, gr);
         } else if (a.wide_atomics) {
           // Re-lay the wavefront's 256 gradient floats (64/LPR rows x 4*LPR dwords) so that one atomic
           // instruction carries WHOLE rows: 4 requests of 64 contiguous dwords instead of 4 requests that each
@@ -543,7 +549,10 @@ __global__ __launch_bounds__(RH_BLOCK) void embed_bwd_kernel(const EmbedBwdArgs 
             const int head = rsl * LPR;
             const int64_t r = ((int64_t)__shfl(row_hi, head, RH_WAVE) << 32) | (uint32_t)__shfl(row_lo, head, RH_WAVE);
             const int flag = __shfl((int)live, head, RH_WAVE);
-            if (flag) gatomic_add_f32(gtab + r * DD + dw, val);
+            if (flag) {
+              if (a.path == 5) gstore<float>(gtab + r * DD + dw, val);  // TIMING ONLY: the same requests as plain stores
+              else gatomic_add_f32(gtab + r * DD + dw, val);
+            }
           }
         } else if (live) {
           gatomic_add_f4(gtab + row[u] * D + q * 4, gr);
