@@ -95,8 +95,17 @@ def _worker(rank, port, outdir, train, arg, backend="gloo"):
         torch.cuda.set_device(rank if backend == "nccl" else 0)
         sd, losses = train(lambda s: slice(s * 2 * B + rank * B, s * 2 * B + (rank + 1) * B), 2, arg)
         torch.save({"sd": sd, "losses": losses}, os.path.join(outdir, f"rank{rank}.pt"))
+        torch.cuda.synchronize()
+        dist.barrier()  # neither rank tears its transport down while the other may still be inside a collective
     finally:
         dist.destroy_process_group()
+    # The result is on disk; leave without the interpreter's finalisation.  One run in five of round 6's full suite lost rank 0
+    # to "terminate called without an active exception" (SIGABRT, a joinable C++ thread destroyed at exit) about where this
+    # function returns; the training itself had completed.
+    import sys
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def _two_ranks(tmp_path, train, arg, backend="gloo"):
