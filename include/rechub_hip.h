@@ -596,6 +596,10 @@ int rh_adam_sweep_stagger(void* stream);
 #define RH_ERR_GATE_TIMEOUT 64
 int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int64_t fallback_ns, int32_t* err_flag, void* stream);
 int rh_adam_sweep_gate_open(int64_t* gate, void* stream);
+/* Releases a deferred sweep that rh_adam_sweep_gate holds back for the NEXT step's chain start when the host knows that no
+ * further step follows the ones it has enqueued (end of an epoch, a synchronisation): counts one chain start in gate[2], so the
+ * sweep starts at once instead of after its fallback (round 6; enqueue on the stream the step's graph was launched on). */
+int rh_adam_sweep_release(int64_t* gate, void* stream);
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);

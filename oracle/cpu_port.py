@@ -218,7 +218,8 @@ def time_cpu_end_to_end(vocabs, n_dense, batch_size, rows=200_000, budget_s=12.0
                 loader_ms_per_step=1e3 * loader_s / steps, cores=torch.get_num_threads(), rows=rows)
 
 
-def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=200_000, seed=2022, threads=None):
+def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=200_000, seed=2022, threads=None,
+                  model_step_leg=True):
     """Both legs of SURVEY 8(d)'s CPU baseline on ONE model / optimizer (the 8.4 GB of p / g / m / v are built once):
     (i) the reference's ``train_one_epoch`` loop END TO END over a DataGenerator-style loader (dict of numpy columns),
     (ii) model-step-only on pre-collated batches.  Every step is timed on its own; the MEDIAN is reported.
@@ -226,7 +227,9 @@ def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=2
     ``full``: the protocol as written (3 warm-up + 10 timed steps per leg; ~90 s at the Criteo shape on 128 threads);
     ``"auto"``: the full protocol unless the first step shows it would take longer than ~8x ``budget_s``.
     Otherwise the run is bounded to about ``budget_s`` seconds of steps: 1 warm-up step (it allocates the dense
-    gradients and the Adam state) and as many timed steps per leg as fit, at least 3 -- the record says which."""
+    gradients and the Adam state) and as many timed steps per leg as fit, at least 3 -- the record says which.
+    ``model_step_leg=False`` (bench.py's default run since round 6: ONE 3 + 10 leg, ~45 s instead of ~100 s of a 2-minute
+    run): leg (ii) is skipped and the model step is taken as end-to-end minus loader, per step."""
     if threads:
         torch.set_num_threads(threads)
     rng = np.random.default_rng(seed)
@@ -282,11 +285,13 @@ def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=2
         xb.update({n: torch.rand(batch_size, generator=g) for n in dense_names})
         return xb, (torch.rand(batch_size, generator=g) < 0.25).long()
 
-    batches = [batch() for _ in range(4)]
-    for i in range(n_warm if full else 0):  # the model and the optimizer state are warm from leg (i) already
+    batches = [batch() for _ in range(4)] if model_step_leg else []
+    for i in range(n_warm if (full and model_step_leg) else 0):  # the model and the optimizer state are warm from leg (i) already
         train_step(model, opt, crit, *batches[i % 4])
     step_ms, t_leg = [], time.perf_counter()
-    while len(step_ms) < n_timed:
+    if not model_step_leg:
+        step_ms = [a - b for a, b in zip(e2e_ms, loader_ms)]
+    while model_step_leg and len(step_ms) < n_timed:
         t0 = time.perf_counter()
         train_step(model, opt, crit, *batches[len(step_ms) % 4])
         step_ms.append(1e3 * (time.perf_counter() - t0))
@@ -320,5 +325,5 @@ def time_cpu_legs(vocabs, n_dense, batch_size, budget_s=24.0, full=False, rows=2
                   samples_per_s=batch_size / ((float(np.median(df_ms)) + step_med) * 1e-3),
                   note="loader timed alone (1 warm-up + 3 batches), model-step median of this run added")
     return dict(end_to_end=e2e, end_to_end_dataframe=df_leg,
-                model_step=leg(step_ms, n_warm + len(e2e_ms) + (n_warm if full else 0)),
+                model_step=leg(step_ms, n_warm + len(e2e_ms) + (n_warm if full else 0)) if model_step_leg else None,
                 cores=torch.get_num_threads(), rows=rows, build_s=build_s, full_protocol=bool(full))

@@ -564,6 +564,11 @@ static __device__ __forceinline__ void gate_open(long long* gate) {
 }
 
 __global__ void stream_gate_open_kernel(long long* gate) { gate_open(gate); }
+// rh_adam_sweep_release: counts a chain start that is not one -- the host knows that no further step follows the ones it has
+// enqueued (end of an epoch, a synchronisation), so the last deferred sweep need not sit out its fallback
+__global__ void stream_gate_release_kernel(long long* gate) {
+  __hip_atomic_fetch_add(gate + 2, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // REFRESH: the pre-gather pass -- the rows carry no gradient yet (their gradient rows are zero), so they are neither
 // read nor re-zeroed and the closing step is the zero-gradient form too (a quarter less traffic per row)
@@ -1352,6 +1357,14 @@ extern "C" int rh_adam_sweep_gate_open(int64_t* gate, void* stream) {
   hipLaunchKernelGGL(stream_gate_open_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<long long*>(gate));
   RH_LAUNCH_CHECK("rh_adam_sweep_gate_open");
+  return 0;
+}
+
+extern "C" int rh_adam_sweep_release(int64_t* gate, void* stream) {
+  RH_REQUIRE(gate != nullptr, RH_E_BADARG, "rh_adam_sweep_release: null gate");
+  hipLaunchKernelGGL(stream_gate_release_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<long long*>(gate));
+  RH_LAUNCH_CHECK("rh_adam_sweep_release");
   return 0;
 }
 

@@ -530,10 +530,20 @@ class TableAdam(torch.optim.Adam):
             torch.cuda.current_stream().wait_stream(self._side)
         self._sweep_inflight = False
 
+    def release_gate(self):
+        """No further step follows the ones enqueued so far (the caller is about to synchronise, or the epoch is over): the
+        last step-ahead sweep, which rh_adam_sweep_gate holds back for the NEXT step's chain start, may go at once instead of
+        after GATE_FALLBACK_NS.  Harmless when nothing is held back (a chain start counted where none was needed: every
+        later gate takes its base count at its own opening)."""
+        if getattr(self, "gate_by_chain", False) and getattr(self, "_gate", None) is not None and \
+                not torch.cuda.is_current_stream_capturing():
+            _lib.call("rh_adam_sweep_release", ops._p(self._gate), ops._stream())
+
     def settle_sweep(self):
         """Bring the deferred-sweep state to rest (nothing in flight, nothing pending) without a full flush: what a
         switch between the forms of the captured step starts from."""
         if self.lazy_k > 1 and self._tables and self.overlap_sweep:
+            self.release_gate()
             self._join_sweep()
             self._finish_sweep()
 
@@ -844,6 +854,7 @@ class TableAdam(torch.optim.Adam):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("TableAdam.flush() inside a hipGraph capture")
             self.rollback_abandoned_prepare()  # a forward that never reached its optimizer step advanced the counter
+            self.release_gate()
             self._join_sweep()
             self._sweep_pending = False  # subsumed: the flush visits every row
             t = int(self._t_step.item())
