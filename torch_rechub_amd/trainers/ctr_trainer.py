@@ -285,7 +285,9 @@ class CTRTrainer(object):
     def _phase_a(self, x_dict, y):
         self.dp.deferred_mode, self.dp.deferred = True, []
         self.bucket.defer = True
-        loss = self._forward_loss(x_dict, y)
+        # (defer_scalars as in train_step: the loss value is read after the backward, which follows at once -- the chain's head
+        # backward carries the step's scalar launch; not with an active regulariser, which reads the loss in the forward)
+        loss = self._forward_loss(x_dict, y, defer_scalars=not self.reg_loss_fn.active())
         report = loss.detach()
         loss = self._scale_for_world(loss)
         self._zero_grad()
