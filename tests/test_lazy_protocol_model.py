@@ -94,9 +94,17 @@ def simulate(rows, K, B, steps, depth, look, seed):
 
 @pytest.mark.parametrize("rows,K,B", [(4096, 64, 256), (1000, 8, 300), (50000, 128, 2048)])
 def test_step_ahead_protocol_is_safe_and_exact(rows, K, B):
-    """Default form: a sweep may run under the next TWO replays (joined before the third), lookahead over two batches."""
-    conflicts, violations = simulate(rows, K, B, steps=3 * K + 5, depth=2, look=2, seed=1)
+    """Default form: a sweep may run under the next LOOK_DEPTH replays (joined before the one after), lookahead over LOOK_DEPTH
+    batches -- the constant the product uses (optim.LOOK_DEPTH: the depth of its sweep-event ring, the `look_depth` argument of
+    rh_adam_lazy_step_ahead*), not a copy of it."""
+    import torch_rechub_amd.optim as optim
+    d = optim.LOOK_DEPTH
+    assert K >= d + 2  # the product's own guard for this form (TableAdam._merge_ahead_ok)
+    conflicts, violations = simulate(rows, K, B, steps=3 * K + 5, depth=d, look=d, seed=1)
     assert conflicts == 0 and violations == []
+    # one batch of lookahead less than the product's constant is a race (the negative control below, at the product's depth)
+    conflicts, _ = simulate(rows, K, B, steps=3 * K + 5, depth=d, look=d - 1, seed=1)
+    assert conflicts > 0
 
 
 def test_relaxed_join_protocol_is_safe_and_exact():
