@@ -595,6 +595,12 @@ int rh_adam_sweep_stagger(void* stream);
 #define RH_GATE_WORDS 16
 #define RH_ERR_GATE_TIMEOUT 64
 int rh_adam_sweep_gate(const int64_t* gate, int64_t expected, int64_t fallback_ns, int32_t* err_flag, void* stream);
+/* rh_adam_sweep_gate that first stores done_value into *done_host -- the DEVICE address (rh_host_device_pointer) of a word of
+ * pinned, mapped host memory: by stream order "everything enqueued on `stream` before this launch has completed", i.e. the
+ * caller's count of finished deferred sweeps, readable by the host without an event record between the sweeps (round 6). */
+int rh_adam_sweep_gate_done(const int64_t* gate, int64_t expected, int64_t fallback_ns, int32_t* err_flag, int64_t* done_host,
+                            int64_t done_value, void* stream);
+int rh_host_device_pointer(void* host, void** device);
 int rh_adam_sweep_gate_open(int64_t* gate, void* stream);
 /* Releases a deferred sweep that rh_adam_sweep_gate holds back for the NEXT step's chain start when the host knows that no
  * further step follows the ones it has enqueued (end of an epoch, a synchronisation): counts one chain start in gate[2], so the

@@ -145,6 +145,8 @@ SIGNATURES = {
                                       c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr],
     "rh_adam_sweep_stagger": [c_ptr],
     "rh_adam_sweep_gate": [c_ptr, c_i64, c_i64, c_ptr, c_ptr],
+    "rh_adam_sweep_gate_done": [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr],
+    "rh_host_device_pointer": [c_ptr, c_ptr],
     "rh_adam_sweep_gate_open": [c_ptr, c_ptr],
     "rh_adam_sweep_release": [c_ptr, c_ptr],
     "rh_adam_lazy_step_ahead": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,

@@ -26,6 +26,7 @@ ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
 CHAIN_GATE = _lib.ab("chaingate")  # False (RECHUB_AB=chaingate=0): the sweep is released RH_TUNE_SWEEP_GATE_NS behind the opening (round 4)
+HOST_DONE = _lib.ab("hostdone")  # False (RECHUB_AB=hostdone=0): an event record behind every deferred sweep instead of the gates' host-mapped count
 WGRAD_RIDER = _lib.ab("wgradrider")  # False (RECHUB_AB=wgradrider=0): the chain's grouped weight gradients stay a launch of the backward
 LATE_PACK = _lib.ab("latepack")  # False (RECHUB_AB=latepack=0): the gate is opened by a one-lane launch of its own
 GATE_FALLBACK_NS = 50000  # step-ahead form with a chain-start count in the graph: release of a sweep no chain start follows (ns)
@@ -437,9 +438,18 @@ class TableAdam(torch.optim.Adam):
                     self._sweep_events = [torch.cuda.Event() for _ in range(LOOK_DEPTH + 1)]
                     self._head_event = self._head_event or torch.cuda.Event()
                 if self._look_token == (id(seg), loader.generation, self._host_step):
-                    ev = self._sweep_events[(self._host_step + 1) % (LOOK_DEPTH + 1)]
-                    if not ev.query():  # (normally long done: every packet between two graphs costs the chain ~7 us of idle queue)
-                        main.wait_event(ev)
+                    done = self._done_word()
+                    if done is not None:
+                        # round 6: the sweeps' progress is a word of host-mapped memory the gate launches write (the gate of
+                        # sweep s starts when sweep s - 1 has finished and says so) -- no event record between two kernels of
+                        # the sweep's stream (7.5 us of idle queue per step on the step's longer path), no wait packet in front
+                        # of the graph.  The host simply does not enqueue this replay before the sweep launched LOOK_DEPTH + 1
+                        # tails ago has finished: it stays at most ~2 steps ahead of the device (it needs ~60 us per step).
+                        self._wait_sweeps_done(done[0], self._host_step - LOOK_DEPTH, main)
+                    else:
+                        ev = self._sweep_events[(self._host_step + 1) % (LOOK_DEPTH + 1)]
+                        if not ev.query():  # (every packet between two graphs costs the chain ~7 us of idle queue)
+                            main.wait_event(ev)
                 else:
                     main.wait_stream(self._side_stream())
                     _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 0, ops._stream())
@@ -457,11 +467,18 @@ class TableAdam(torch.optim.Adam):
                     # next replay's chain start (its first own GEMM has placed its workgroups: rh_linear_fwd_gate) -- into that
                     # GEMM, not beside a launch of the chain; without a chain start GATE_FALLBACK_NS behind the opening (round 4:
                     # a wall-clock hold-back of RH_TUNE_SWEEP_GATE_NS, which remains the release for graphs without an own GEMM)
-                    _lib.call("rh_adam_sweep_gate", ops._p(self._gate), self._gate_seen,
-                              GATE_FALLBACK_NS if self.gate_by_chain else 0,
-                              ops._p(ops.err_flag(self._tables[0].device)), ops._stream())
-                    self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
-                    self._sweep_events[h % (LOOK_DEPTH + 1)].record()
+                    done = self._done_word()
+                    if done is not None:  # (this gate starts when everything before it on this stream -- sweep h - 1 -- is done)
+                        _lib.call("rh_adam_sweep_gate_done", ops._p(self._gate), self._gate_seen,
+                                  GATE_FALLBACK_NS if self.gate_by_chain else 0,
+                                  ops._p(ops.err_flag(self._tables[0].device)), done[1], h - 1, ops._stream())
+                        self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
+                    else:
+                        _lib.call("rh_adam_sweep_gate", ops._p(self._gate), self._gate_seen,
+                                  GATE_FALLBACK_NS if self.gate_by_chain else 0,
+                                  ops._p(ops.err_flag(self._tables[0].device)), ops._stream())
+                        self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
+                        self._sweep_events[h % (LOOK_DEPTH + 1)].record()
                 self._look_token = (id(seg), loader.generation, h)
                 self._sweep_pending, self._sweep_inflight = False, True
 
@@ -641,6 +658,34 @@ class TableAdam(torch.optim.Adam):
             return None
         self._gate_by_pack = True
         return self._gate
+
+    _sweep_done = None  # (pinned host int64 word, its device address) | False: no host-mapped memory (events instead)
+
+    def _done_word(self):
+        """The host-mapped word in which the sweep gates of the step-ahead form count the finished sweeps, or None."""
+        if self._sweep_done is None:
+            self._sweep_done = False
+            if HOST_DONE:
+                try:
+                    host = torch.zeros(1, dtype=torch.int64).pin_memory()
+                    dev = ctypes.c_void_p()
+                    _lib.call("rh_host_device_pointer", ctypes.c_void_p(host.data_ptr()), ctypes.byref(dev))
+                    self._sweep_done = (host, dev)
+                except RuntimeError:
+                    self._sweep_done = False
+        return self._sweep_done or None
+
+    @staticmethod
+    def _wait_sweeps_done(host_word, need, main, timeout_s=0.05):
+        """Host-side wait until the device has counted ``need`` finished sweeps (normally true on the first look)."""
+        if need <= 0 or int(host_word[0]) >= need:
+            return
+        import time
+        t_end = time.perf_counter() + timeout_s
+        while int(host_word[0]) < need:
+            if time.perf_counter() > t_end:  # (a stalled device: fall back to the stream dependency and go on)
+                main.wait_stream(graphs.role_stream("sweep", main.device))
+                return
 
     def _ride_wgrad(self, problems, B):
         """ops.wgrad_rider while this optimizer captures a step-ahead graph: take the MLP chain's grouped weight gradients
