@@ -284,7 +284,19 @@ def test_mlp_chain_grouped_weight_gradients_equal_the_per_layer_launches_bitwise
     _assert_bitwise_twins(ma._t, mb._t, ma, mb)
 
 
-def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their_own_launch_bitwise(monkeypatch):
+def _dcnv2(vocabs, seed):
+    """DCN-v2 (CrossNetMix + parallel DNN: an MLP WITHOUT output layer, i.e. not the fused chain -- its weight gradients come
+    from one ops.linear_wgrad call per layer)."""
+    from torch_rechub_amd.basic.features import DenseFeature, SparseFeature
+    from torch_rechub_amd.models.ranking import DCNv2
+    torch.manual_seed(seed)
+    dense = [DenseFeature(f"I{i}") for i in range(4)]
+    sparse = [SparseFeature(f"C{i}", v, 16) for i, v in enumerate(vocabs)]
+    return DCNv2(dense + sparse, 2, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}, low_rank=8, num_experts=3), dense, sparse
+
+
+@pytest.mark.parametrize("kind", ["deepfm", "dcnv2"])
+def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their_own_launch_bitwise(kind, monkeypatch):
     """Round 6: while TableAdam captures a step-ahead graph, ops._MlpChainFn.backward hands its grouped weight gradients to the
     optimizer (ops.wgrad_rider) and rh_adam_lazy_step_ahead_wgrad carries them as the first workgroups of the end-of-step
     launch.  Same workgroup body, same split plan, the same slabs summed by the same packing launch behind it: the trainings
@@ -294,13 +306,16 @@ def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their
     from torch_rechub_amd.utils.data import DeviceDataLoader
     nb, B = 12, 64
     vocabs, sparse, dense, label = _loader_twin_data("collision_free", nb, B, seed=47)
-    ma, dfe, sfe = _deepfm(vocabs, 2)
-    mb, _, _ = _deepfm(vocabs, 2)
+    # deepfm: the fused chain's grouped problems; dcnv2: two single-problem hand-overs from ops.linear_wgrad (round 6: the
+    # per-layer launches of a non-chain MLP ride too, collected into one group of <= 8 problems)
+    mk = _deepfm if kind == "deepfm" else _dcnv2
+    ma, dfe, sfe = mk(vocabs, 2)
+    mb, _, _ = mk(vocabs, 2)
     mb.load_state_dict(ma.state_dict())
     names, dnames = [f.name for f in sfe], [f.name for f in dfe]
     kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
               lazy_small_rows=8, use_graph=True)
-    seen = {"rider": 0, "group": 0, "plain": 0}
+    seen = {"rider": 0, "group": 0, "plain": 0, "single": 0}
     real_call = _lib.call
 
     def spy(name, *args):
@@ -308,6 +323,8 @@ def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their
             seen["rider"] += 1
         elif name == "rh_linear_wgrad_partial_group":
             seen["group"] += 1
+        elif name == "rh_linear_wgrad_partial":
+            seen["single"] += 1
         elif name == "rh_adam_lazy_step_ahead":
             seen["plain"] += 1
         return real_call(name, *args)
@@ -324,7 +341,7 @@ def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their
         if rider:  # every captured step-ahead graph ends with the launch that carries the group
             assert seen["rider"] >= 1 and seen["plain"] == 0, seen
         else:
-            assert seen["rider"] == 0 and seen["plain"] >= 1 and seen["group"] >= 1, seen
+            assert seen["rider"] == 0 and seen["plain"] >= 1 and seen["group" if kind == "deepfm" else "single"] >= 1, seen
         assert ops.wgrad_rider is None and t.optimizer._rider is None  # nothing left armed behind the capture
         model._t = t
     assert losses[0] == losses[1]

@@ -880,7 +880,11 @@ def linear_wgrad(g, x, want_bias=True, weight=None, bias=None):
     armed = deferred.armed
     if armed is not None and weight is not None and id(weight) in armed and (not want_bias or
                                                                               (bias is not None and id(bias) in armed)):
-        _lib.call("rh_linear_wgrad_partial", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(partial), _stream())
+        # (step-ahead graph being captured: the slabs feed nothing but the packing launch at the end of the step, so the launch
+        # rides in the optimizer's end-of-step launch with the other weight gradients of the step -- wgrad_rider below)
+        rider = wgrad_rider
+        if not (rider is not None and B < _WGRAD_GROUP_MAX_B and rider([(g, g.stride(0), x, x.stride(0), N, K, partial)], B)):
+            _lib.call("rh_linear_wgrad_partial", _p(g), g.stride(0), _p(x), x.stride(0), B, N, K, _p(partial), _stream())
         return _offer_wgrad_slabs(weight, bias if want_bias else None, partial, B)
     dW = torch.empty((N, K), dtype=torch.float32, device=dev)
     db = torch.empty((N,), dtype=torch.float32, device=dev) if want_bias else None

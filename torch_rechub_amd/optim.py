@@ -691,10 +691,14 @@ class TableAdam(torch.optim.Adam):
         """ops.wgrad_rider while this optimizer captures a step-ahead graph: take the MLP chain's grouped weight gradients
         into the end-of-step launch (_merged_step).  False = not this step (the backward launches them itself)."""
         ah = self._step_ahead
-        if ah is None or self._rider is not None or graphs.active() is not ah["seg"] or \
-                not torch.cuda.is_current_stream_capturing() or not 1 <= len(problems) <= 8:
+        if ah is None or graphs.active() is not ah["seg"] or not torch.cuda.is_current_stream_capturing() or not problems:
             return False
-        self._rider = (list(problems), int(B))
+        have = self._rider
+        if have is not None and (have[1] != int(B) or len(have[0]) + len(problems) > 8):
+            return False  # (one launch carries at most eight problems of one batch size: the rest launch themselves)
+        if len(problems) > 8:
+            return False
+        self._rider = ((have[0] if have is not None else []) + list(problems), int(B))
         return True
 
     def _flush_rider(self):
