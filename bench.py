@@ -254,6 +254,8 @@ class Workload(object):
                 from torch_rechub_amd.models.ranking import DIN
                 m = DIN(self.feats, self.hist, self.tgt, mlp_params={"dims": [256, 128], "dropout": 0.2},
                         attention_mlp_params={"dims": [256, 128]})
+                if os.environ.get("PROBE_DIN_BRANCHES") == "0":  # (A/B of the side-by-side activation units)
+                    m.attention_branches = False
             else:
                 from torch_rechub_amd.models.matching import DSSM
                 tower = {"dims": [256, 128, 64], "activation": "prelu"}
