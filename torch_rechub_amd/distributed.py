@@ -201,6 +201,7 @@ class DenseGradBucket(object):
         import ctypes
 
         from . import _lib
+        ops.flush_wgrad_rider()
         idx = [k for i, j in runs for k in range(i, j)]
         items = (_lib.PackItem * len(idx))()
         keep = []
@@ -246,6 +247,7 @@ class DenseGradBucket(object):
         import ctypes
 
         from . import _lib
+        ops.flush_wgrad_rider()  # (a packing launch in FRONT of optimizer.step(): slabs still riding are launched now)
         n = len(self.params)
         items = (_lib.PackItem * n)()
         keep = []

@@ -847,9 +847,11 @@ def _offer_wgrad_slabs(weight, bias, partial, B):
     S = _lib.call("rh_linear_wgrad_splits", B, N, K)
 
     def reduce_w():
+        flush_wgrad_rider()  # (the slabs may still be waiting for the optimizer's end-of-step launch)
         return partial[:S * N * K].view(S, N, K).sum(0)
 
     def reduce_b():
+        flush_wgrad_rider()
         return partial[S * N * K:S * N * K + S * N].view(S, N).sum(0)
 
     dW = deferred.offer(weight, partial.data_ptr(), S, N * K, N * K, reduce_w, partial)
@@ -1234,6 +1236,16 @@ chain_gate_used = []   # ... and a mark per rh_linear_fwd_gate launch captured f
 # (rh_adam_lazy_step_ahead_wgrad): nothing on the step's critical chain reads their slabs.  wgrad_rider(problems, B) -> True
 # when the optimizer took them (it launches them itself if its step then ends differently: TableAdam._flush_rider).
 wgrad_rider = None
+wgrad_rider_flush = None  # the rider's owner launches what it holds NOW (whoever reads weight-gradient slabs calls flush_wgrad_rider)
+
+
+def flush_wgrad_rider():
+    """Weight gradients handed to the optimizer's end-of-step launch that has not run yet are launched on their own, now: called
+    by everything that reads their slabs (the packing launches, an immediate reduction) -- a step whose packing launch comes
+    BEFORE optimizer.step() (no dense-parameter Adam riding in it) must not read slabs that are still to be written."""
+    f = wgrad_rider_flush
+    if f is not None:
+        f()
 
 
 def _reset_capture_state():
@@ -1241,9 +1253,10 @@ def _reset_capture_state():
     capture and disarms them at its last launch).  A capture that is abandoned in between must not leave them armed for
     whatever is captured next -- another trainer's MLP chain would bake rh_linear_fwd_gate with THIS optimizer's gate words
     into its graph, or hand its weight gradients to a launch that never comes (round-5 advisor finding)."""
-    global chain_gate, wgrad_rider
+    global chain_gate, wgrad_rider, wgrad_rider_flush
     chain_gate = None
     wgrad_rider = None
+    wgrad_rider_flush = None
     del chain_gate_used[:]
 
 

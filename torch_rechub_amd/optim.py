@@ -493,6 +493,7 @@ class TableAdam(torch.optim.Adam):
                 del ops.chain_gate_used[:]
                 # ... and the chain's grouped weight gradients ride in this graph's last table launch (round 6)
                 ops.wgrad_rider = self._ride_wgrad if WGRAD_RIDER else None
+                ops.wgrad_rider_flush = self._flush_rider if WGRAD_RIDER else None
             else:
                 seg.at_start(head_relaxed if RELAXED_JOIN else head)
             self._join_seg = seg
@@ -711,7 +712,7 @@ class TableAdam(torch.optim.Adam):
     def _drop_rider(self):
         self._rider = None  # (of a capture that was abandoned: its tensors belong to a dead graph)
         if ops.wgrad_rider == self._ride_wgrad:
-            ops.wgrad_rider = None
+            ops.wgrad_rider = ops.wgrad_rider_flush = None
 
     def _merge_ahead_ok(self, rec, grp):
         """Will _merged_step of the step being captured see exactly this gather over exactly this table group?"""
@@ -744,7 +745,7 @@ class TableAdam(torch.optim.Adam):
                      ops._p(a["dense_out"]), ops._p(a["label_out"]), LOOK_DEPTH)
             rider, self._rider = self._rider, None
             if ops.wgrad_rider == self._ride_wgrad:
-                ops.wgrad_rider = None
+                ops.wgrad_rider = ops.wgrad_rider_flush = None
             if rider is not None:
                 # the chain's weight gradients as the first workgroups of this launch (ops._MlpChainFn.backward handed them over)
                 wargs, keep = ops.wgrad_group_args(*rider)
