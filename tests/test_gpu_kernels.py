@@ -209,6 +209,17 @@ def test_embed_bwd(B, vocabs, D, shared, pads, spb, fwd_path):
         _lib.call("rh_set_tuning", 7, 0)
 
 
+@pytest.mark.parametrize("B,vocabs,shared,pads", [
+    (20000, CRITEO_LIKE, None, None),
+    (9001, [3, 50, 700, 3, 9000, 31, 12], {3: 0}, [None, 0, None, None, 5, None, None]),
+    (8200, [40], None, None),
+    (8193, [7, 31], None, None),  # every field on the small-table path
+])
+def test_embed_bwd_large_batch(B, vocabs, shared, pads):
+    """B > 8192: the launch without the chain's priority (and the batch sizes of the roofline sweep)."""
+    _embed_bwd_case(B, vocabs, 16, shared, pads, 0)
+
+
 def _embed_bwd_case(B, vocabs, D, shared, pads, spb):
     from torch_rechub_amd import ops
     ND = 2
