@@ -250,6 +250,8 @@ class Workload(object):
             elif self.name == "dcnv2":
                 from torch_rechub_amd.models.ranking import DCNv2
                 m = DCNv2(self.dense_feas + self.sparse_feas, 3, mlp)
+                if os.environ.get("PROBE_DCN_BRANCHES") == "0":  # (A/B of the cross stack beside the MLP)
+                    m.parallel_branches = False
             elif self.name == "din":
                 from torch_rechub_amd.models.ranking import DIN
                 m = DIN(self.feats, self.hist, self.tgt, mlp_params={"dims": [256, 128], "dropout": 0.2},

@@ -208,7 +208,9 @@ int rh_cross_mix_epilogue_bwd_b(const float* x0, const float* uv, const float* g
  *                      of device pointers (L, L, L, E entries).
  *   rh_cross_moe_mid_fwd / _bwd: the pass between the two products; the backward takes g_wp (B, KP), writes g_PG (B, KP)
  *                      and rh_cross_moe_mid_blocks(B, E, r) partial rows (E r r) of g_C.
- *   rh_cross_moe_res_bwd: g_Y = g * x0, acc = (first ? 0 : acc) + g * Y  (acc: running gradient of x0; g, x0 with row strides).
+ *   rh_cross_moe_res_bwd: g_Y = g * x0, acc = ((mode & 1) ? 0 : acc) + g * Y + ((mode & 2) ? g : 0)  (acc: running gradient of
+ *                      x0; g, x0 with row strides; bit 0 = first layer of the backward, bit 1 = last: acc also takes the residual
+ *                      path's gradient, the caller's closing product accumulates into it).
  *   rh_cross_moe_unpack: sums the weight-gradient slabs of the two products (rh_linear_wgrad_partial: slabV_l = S1_l slabs
  *                      (KP, d) of g_PG^T x_l, slabU_l = S2_l slabs (d, KP) of g_Y^T wp) and the g_C partials into g_U, g_V
  *                      (E, d, r), g_bias (d,), g_C (E, r, r) per layer and g_Wg (d,) per expert (summed over the layers).
@@ -224,7 +226,7 @@ int rh_cross_moe_mid_fwd(const float* PG, const float* C, int B, int E, int r, f
                          void* stream);
 int rh_cross_moe_mid_bwd(const float* g_wp, const float* v1, const float* v2, const float* gate, const float* C, int B, int E,
                          int r, float* g_PG, float* gC_partial, void* stream);
-int rh_cross_moe_res_bwd(const float* g, int64_t ldg, const float* x0, int64_t ldx0, const float* Y, int B, int d, int first,
+int rh_cross_moe_res_bwd(const float* g, int64_t ldg, const float* x0, int64_t ldx0, const float* Y, int B, int d, int mode,
                          float* g_Y, float* acc, void* stream);
 int rh_cross_moe_unpack(const float* const* slabV, const int* S1, const float* const* slabU, const int* S2,
                         const float* const* gC, const int* NB, int L, int E, int d, int r, float* const* g_U,

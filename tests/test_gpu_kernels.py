@@ -1672,8 +1672,10 @@ def test_cross_net_mix_two_product_form_vs_reference_formula(B, d, L, E, r, stri
     else:
         xd = x.to(dev()).requires_grad_()
     out = mix(xd)
-    out.backward(gy.to(dev()))
+    gyd = gy.to(dev())
+    out.backward(gyd)
     torch.cuda.synchronize()
+    assert torch.equal(gyd.cpu(), gy)  # (the backward accumulates in place in ITS OWN buffers only, never in the incoming gradient)
     close(out, want.detach().numpy(), rtol=2e-5, atol_scale=2e-6, what="crossmix out")
     close(xd.grad, xr.grad.numpy(), rtol=1e-4, atol_scale=1e-5, what="crossmix g_x")
     ours = (mix.u_list, mix.v_list, mix.c_list, mix.bias, [m.weight for m in mix.gating])

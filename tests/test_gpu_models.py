@@ -298,6 +298,44 @@ def _dcnv2(vocabs, seed):
     return DCNv2(dense + sparse, 2, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"}, low_rank=8, num_experts=3), dense, sparse
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_dcnv2_cross_stack_beside_the_mlp_on_two_streams_equals_the_sequence_bitwise(use_graph, monkeypatch):
+    """Round 6: DCNv2 ("parallel") runs its cross stack and its MLP side by side on two HIP streams, forward and backward
+    (ops.run_beside; as two branches of the step's hipGraph when captured).  Same kernels, same arithmetic: training with
+    ``parallel_branches = False`` (the reference's order, dcn_v2.py:52-56) must agree bit for bit, and the side-by-side form
+    must actually have forked."""
+    from torch_rechub_amd import ops
+    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 10, 64
+    vocabs, sparse, dense, label = _loader_twin_data("collision_free", nb, B, seed=53)
+    ma, dfe, sfe = _dcnv2(vocabs, 4)
+    mb, _, _ = _dcnv2(vocabs, 4)
+    mb.load_state_dict(ma.state_dict())
+    ma.parallel_branches = False
+    names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+    kw = dict(optimizer_params={"lr": 1e-2, "weight_decay": 1e-4}, device="cuda:0", show_progress=False, lazy_k=4,
+              lazy_small_rows=8, use_graph=use_graph)
+    forks = {"n": 0}
+    real = ops.run_beside
+
+    def spy(*a, **k):
+        forks["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "run_beside", spy)
+    losses = []
+    for model in (ma, mb):
+        before = forks["n"]
+        t = CTRTrainer(model, **kw)
+        dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+        losses.append((t.train_one_epoch(dl), t.train_one_epoch(dl)))
+        assert (forks["n"] > before) == (model is mb)
+        model._t = t
+    assert losses[0] == losses[1]
+    _assert_bitwise_twins(ma._t, mb._t, ma, mb)
+
+
 @pytest.mark.parametrize("kind", ["deepfm", "dcnv2"])
 def test_mlp_chain_weight_gradients_riding_in_the_end_of_step_launch_equal_their_own_launch_bitwise(kind, monkeypatch):
     """Round 6: while TableAdam captures a step-ahead graph, ops._MlpChainFn.backward hands its grouped weight gradients to the

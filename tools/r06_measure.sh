@@ -75,7 +75,7 @@ models) for m in $MODELS; do model_table $m > "$OUT/${m}_step_kernels.txt" 2>&1;
 modelbench) for m in $MODELS; do timeout 300 python bench.py --model $m --steps 100 --warmup 10 --no-cpu-baseline --brief > "$OUT/bench_$m.json" 2> "$OUT/bench_$m.err"; echo "$m rc=$?"; brief "$OUT/bench_$m.json"; done;;
 ab) IFS=' ' read -r -a cases <<< "${AB_CASES:-base||}"
   for rep in $(seq 1 ${AB_REPEAT:-2}); do for c in "${cases[@]}"; do
-    name=${c%%|*}; rest=${c#*|}; envs=${rest%%|*}; args=${rest#*|}
+    name=${c%%|*}; rest=${c#*|}; envs=${rest%%|*}; args=${rest#*|}; args=${args//;/ }  # (bench args: ';' for ' ')
     ( IFS=';'; for e in $envs; do [ -n "$e" ] && export "$e"; done; unset IFS
       timeout 300 python bench.py --steps ${AB_STEPS:-200} --warmup 10 --no-cpu-baseline --brief --no-kernel-sweep --no-step-accounting --no-pmc --no-twin-check $args > "$OUT/ab_${name}_$rep.json" 2> "$OUT/ab_${name}_$rep.err" )
     python - "$OUT/ab_${name}_$rep.json" "$name" "$rep" <<'PY' | tee -a "$OUT/ab_table.txt"

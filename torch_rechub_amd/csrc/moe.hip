@@ -233,10 +233,14 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_mid_bwd_kernel(const MoeMidArgs 
 }
 
 // residual backward of x_{l+1} = x0 * Y + x_l:  g_Y = g * x0,  acc (+)= g * Y   (acc: the running gradient of x0)
+// mode bit 0: first layer of the backward (acc is written, not accumulated); bit 1: last one -- acc also takes g itself (the
+// residual path's gradient), so that the caller's closing product accumulates into acc and IS the gradient of x (= x0 = x_0):
+// no copy of g for an out-of-place addmm and no final add (round 6: three launches of the DCN-v2 step less)
 __global__ __launch_bounds__(RH_BLOCK) void moe_res_bwd_kernel(const float* __restrict__ g, int64_t ldg,
                                                                const float* __restrict__ x0, int64_t ldx0,
-                                                               const float* __restrict__ Y, int B, int d, int first,
+                                                               const float* __restrict__ Y, int B, int d, int mode,
                                                                float* __restrict__ g_Y, float* __restrict__ acc) {
+  const bool first = (mode & 1) != 0, fold = (mode & 2) != 0;
   RH_CHAIN_PRIO();
   const int64_t n = (int64_t)B * d;
   for (int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * RH_BLOCK) {
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(RH_BLOCK) void moe_res_bwd_kernel(const float* __re
     const float gi = g[b * ldg + j];
     g_Y[i] = gi * x0[b * ldx0 + j];
     const float t = gi * Y[i];
-    acc[i] = first ? t : acc[i] + t;
+    const float a = first ? t : acc[i] + t;
+    acc[i] = fold ? a + gi : a;
   }
 }
 
@@ -440,14 +445,15 @@ extern "C" int rh_cross_moe_mid_bwd(const float* g_wp, const float* v1, const fl
 }
 
 extern "C" int rh_cross_moe_res_bwd(const float* g, int64_t ldg, const float* x0, int64_t ldx0, const float* Y, int B, int d,
-                                    int first, float* g_Y, float* acc, void* stream) {
+                                    int mode, float* g_Y, float* acc, void* stream) {
   RH_REQUIRE(g && x0 && Y && g_Y && acc, RH_E_BADARG, "rh_cross_moe_res_bwd: null pointer");
   RH_REQUIRE(B >= 0 && d >= 1 && ldg >= d && ldx0 >= d, RH_E_BADARG, "rh_cross_moe_res_bwd: bad shape");
+  RH_REQUIRE(mode >= 0 && mode <= 3, RH_E_BADARG, "rh_cross_moe_res_bwd: mode %d (bit 0 first, bit 1 last)", mode);
   if (B == 0) return 0;
   int64_t grid = ((int64_t)B * d + RH_BLOCK - 1) / RH_BLOCK;
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(moe_res_bwd_kernel, dim3((unsigned)grid), dim3(RH_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), g,
-                     ldg, x0, ldx0, Y, B, d, first, g_Y, acc);
+                     ldg, x0, ldx0, Y, B, d, mode, g_Y, acc);
   RH_LAUNCH_CHECK("rh_cross_moe_res_bwd");
   return 0;
 }

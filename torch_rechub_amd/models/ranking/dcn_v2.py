@@ -37,11 +37,19 @@ class DCNv2(nn.Module):
 
     def forward(self, x):
         h = self.embedding(x, self.features, squeeze_dim=True)
-        z = self.crossnet(h)
-        if self.model_structure == "stacked":
-            z = self.stacked_dnn(z)
-        elif self.model_structure == "parallel":
-            z = torch.cat((z, self.parallel_dnn(h)), dim=1)
+        if self.model_structure == "parallel" and getattr(self, "parallel_branches", True) and h.is_cuda:
+            # (round 6: the cross stack and the MLP read the same embeddings and meet at the concatenation -- two independent
+            # chains of small launches (B x 400-wide products fill a fraction of the 256 CUs): side by side on two streams,
+            # forward and backward (ops.run_beside); the reference runs one after the other, dcn_v2.py:52-56.  Same kernels,
+            # same arithmetic.  ``model.parallel_branches = False`` restores the sequence)
+            z, deep = ops.run_beside(lambda: self.crossnet(h), lambda: self.parallel_dnn(h), side_inputs=(h,))
+            z = torch.cat((z, deep), dim=1)
+        else:
+            z = self.crossnet(h)
+            if self.model_structure == "stacked":
+                z = self.stacked_dnn(z)
+            elif self.model_structure == "parallel":
+                z = torch.cat((z, self.parallel_dnn(h)), dim=1)
         fc = self.linear.fc
         if ops.head_ok(z, fc, ()):
             return ops.head_sigmoid(z, fc.weight, fc.bias)

@@ -2213,11 +2213,13 @@ class _CrossMoeFn(torch.autograd.Function):
         # are collected and run as grouped launches of <= 8 problems after the loop (round 4: 2 L launches of ~16.5 us -> 1)
         group = WGRAD_GROUP and B < 32768
         problems = []
+        own_G = False
         for l in reversed(range(L)):
             xl, v1, v2, gate, wp, Y = saved[6 * l:6 * l + 6]
             g_Y = torch.empty((B, d), dtype=torch.float32, device=dev)
-            _lib.call("rh_cross_moe_res_bwd", _p(G), G.stride(0), _p(x), x.stride(0), _p(Y), B, d, 1 if l == L - 1 else 0,
-                      _p(g_Y), _p(acc), _stream())
+            # (l == 0: acc also takes G, the closing product below accumulates into it -- that IS the gradient of x)
+            _lib.call("rh_cross_moe_res_bwd", _p(G), G.stride(0), _p(x), x.stride(0), _p(Y), B, d,
+                      (1 if l == L - 1 else 0) | (2 if l == 0 else 0), _p(g_Y), _p(acc), _stream())
             pu = torch.empty((ws2,), dtype=torch.float32, device=dev)  # g_UTb (d, KP) = g_Y^T wp
             if group:
                 problems.append((g_Y, d, wp, KP, d, KP, pu))
@@ -2233,12 +2235,18 @@ class _CrossMoeFn(torch.autograd.Function):
                 problems.append((g_PG, KP, xl, xl.stride(0), KP, d, pv))
             else:
                 _lib.call("rh_linear_wgrad_partial", _p(g_PG), KP, _p(xl), xl.stride(0), B, KP, d, _p(pv), _stream())
-            G = torch.addmm(G, g_PG, VgT[l])  # gradient of x_l: residual + through the first product
+            # gradient of x_l: residual + through the first product.  Only the first of the backward copies (the incoming
+            # gradient is not ours to overwrite); the others accumulate in place, the last one into acc
+            if l == 0:
+                g_x = acc.addmm_(g_PG, VgT[l])  # x is both x_0 (Hadamard factor of every layer) and the first x_l
+            elif own_G:
+                G.addmm_(g_PG, VgT[l])
+            else:
+                G, own_G = torch.addmm(G, g_PG, VgT[l]), True
             slabV.append(pv), slabU.append(pu), gC.append(pc)
         for i in range(0, len(problems), 8):
             linear_wgrad_partial_group(problems[i:i + 8], B)
         slabV.reverse(), slabU.reverse(), gC.reverse()
-        g_x = G + acc  # x is both x_0 (Hadamard factor of every layer) and the first x_l
         g_U = [torch.empty(ctx.shapes[l], dtype=torch.float32, device=dev) for l in range(L)]
         g_V = [torch.empty(ctx.shapes[L + l], dtype=torch.float32, device=dev) for l in range(L)]
         g_C = [torch.empty(ctx.shapes[2 * L + l], dtype=torch.float32, device=dev) for l in range(L)]
