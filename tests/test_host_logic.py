@@ -495,7 +495,7 @@ def test_step_form_candidates_carry_form_grid_and_hold_back():
     assert all(len(c) == 3 for c in cands)
     assert {c[0] for c in cands} == {"deferred", "inline"}
     assert [c for c in cands if c[0] == "inline"] == [("inline", 0, 0)]
-    assert all(c[1] in (256, 512) and 20000 <= c[2] <= 60000 for c in cands if c[0] == "deferred")
+    assert all(c[1] in (256, 512) and 20000 <= c[2] <= 200000 for c in cands if c[0] == "deferred")
     assert len({c[:2] for c in cands}) < len(cands)  # at least one (form, grid) comes with two hold-backs
 
 

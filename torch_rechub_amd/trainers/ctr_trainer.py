@@ -343,7 +343,11 @@ class CTRTrainer(object):
     # whether they spread evenly over the SIMDs; 22 us was a 305 us step where 28 us was a 245 us one, tools/period_hist.py)
     # (the opening is counted by the packing launch, ~5 us before the graph ends: 32 / 40 us here = 28 / 36 us behind a separate
     # opening launch, where the landscape was measured)
-    TUNE_CANDIDATES = (("deferred", 512, 32000), ("deferred", 512, 40000), ("deferred", 256, 32000), ("inline", 0, 0))
+    # (round 6, steps WITHOUT a chain start to release the sweep -- DCN-v2, DSSM: a hold-back of 150 us moves the sweep off the
+    # step's first library GEMMs, which run at the sweep's own wave priority and take 4 x their time beside it: DCN-v2
+    # 0.6346 -> 0.6162 ms on one box, 280 us 0.6199, 400 us 0.6820)
+    TUNE_CANDIDATES = (("deferred", 512, 32000), ("deferred", 512, 40000), ("deferred", 256, 32000), ("deferred", 256, 150000),
+                       ("inline", 0, 0))
     TUNE_SETTLE, TUNE_STEPS = 6, 16
 
     def tune_budget_steps(self):
