@@ -259,6 +259,12 @@ int rh_bn_stats_fwd(const float* h, int B, int C, const float* gamma, const floa
                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int training,
                     float* partial, float* stat, void* stream);
 int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta, void* stream);
+/* ... and, in the same launch, the other per-block partials of the statistics pass: extra (rows, C) -> extra_out (C) (the
+ * attention head's weight gradient; null = none) and nscal <= 8 scalar rows scal (nscal, rows) -> scal_out (nscal) (Dice's alpha,
+ * the head's bias; 0 = none).  Replaces torch_rechub/basic/activation.py:15-25's autograd sums over the (B L)-row tensors.
+ * Fixed summation order. */
+int rh_bn_finalize_bwd_tail(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta, const float* extra,
+                            float* extra_out, const float* scal, int nscal, float* scal_out, void* stream);
 int rh_bn_dice_stats_blocks(int64_t N);
 int rh_bn_dice_bwd_stats(const float* h, const float* g, const float* alpha, float eps, int64_t N, int C,
                          const float* stat, const float* gamma, float* col_partial, float* alpha_partial, void* stream);

@@ -1147,6 +1147,47 @@ def test_bn_dice_head_vs_modules(N, C, bias):
               what="eval")
 
 
+@pytest.mark.parametrize("rows,C,nscal,extra", [(2048, 256, 1, False), (1600, 128, 2, True), (300, 36, 2, True), (1, 5, 0, False),
+                                                (513, 7, 8, True)])
+def test_bn_finalize_bwd_tail_sums_every_partial_of_the_statistics_pass_in_one_launch(rows, C, nscal, extra):
+    """rh_bn_finalize_bwd_tail: column sums of the (rows, 2, C) partials (= rh_bn_finalize_bwd) plus, in the same launch, the
+    column sums of a (rows, C) array and nscal scalar rows -- against float64 sums; both instantiations (rows > 512 / <= 512)."""
+    from torch_rechub_amd import _lib, ops
+    g = torch.Generator().manual_seed(rows + C)
+    part = torch.randn(rows, 2, C, generator=g)
+    ex = torch.randn(rows, C, generator=g)
+    sc = torch.randn(max(nscal, 1), rows, generator=g)
+    d = lambda t: t.to(dev()).contiguous()
+    part_d, ex_d, sc_d = d(part), d(ex), d(sc)
+    stat = torch.zeros(6, C, device=dev())
+    dgamma, dbeta = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    ex_out = torch.full((C,), float("nan"), device=dev())
+    sc_out = torch.full((max(nscal, 1),), float("nan"), device=dev())
+    _lib.call("rh_bn_finalize_bwd_tail", ops._p(part_d), rows, C, ops._p(stat), ops._p(dgamma), ops._p(dbeta),
+              ops._p(ex_d if extra else None), ops._p(ex_out if extra else None), ops._p(sc_d if nscal else None), nscal,
+              ops._p(sc_out if nscal else None), ops._stream())
+    torch.cuda.synchronize()
+    want = part.double().sum(0)
+    close(dbeta, want[0].numpy(), rtol=1e-5, atol_scale=1e-6, what="dbeta")
+    close(dgamma, want[1].numpy(), rtol=1e-5, atol_scale=1e-6, what="dgamma")
+    close(stat[2], want[0].numpy(), rtol=1e-5, atol_scale=1e-6, what="stat row 2")
+    close(stat[3], want[1].numpy(), rtol=1e-5, atol_scale=1e-6, what="stat row 3")
+    if extra:
+        close(ex_out, ex.double().sum(0).numpy(), rtol=1e-5, atol_scale=1e-6, what="extra column sums")
+    else:
+        assert bool(torch.isnan(ex_out).all())
+    if nscal:
+        close(sc_out, sc[:nscal].double().sum(1).numpy(), rtol=1e-5, atol_scale=1e-6, what="scalar rows")
+    # the plain entry point is the same launch without the tail
+    dg2, db2 = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    _lib.call("rh_bn_finalize_bwd", ops._p(part_d), rows, C, ops._p(stat), ops._p(dg2), ops._p(db2), ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+    with pytest.raises(RuntimeError):
+        _lib.call("rh_bn_finalize_bwd_tail", ops._p(part_d), rows, C, ops._p(stat), ops._p(dgamma), ops._p(dbeta), ops._p(ex_d),
+                  ops._p(None), ops._p(None), 0, ops._p(None), ops._stream())
+
+
 # -- row-sharded tables (csrc/shard.hip) and the rectangular in-batch sampler -----------------------------------------
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])

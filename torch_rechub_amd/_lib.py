@@ -59,6 +59,7 @@ SIGNATURES = {
     "rh_dice_bwd": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr],
     "rh_bn_stats_fwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_ptr, c_ptr, c_ptr],
     "rh_bn_finalize_bwd": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "rh_bn_finalize_bwd_tail": [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr],
     "rh_bn_dice_stats_blocks": [c_i64],
     "rh_bn_dice_bwd_stats": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_bn_dice_bwd_apply": [c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr],

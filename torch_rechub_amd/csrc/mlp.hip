@@ -46,6 +46,13 @@ struct BnArgs {
                        // 2: PReLU with ONE slope (nn.PReLU(), the two-tower MLPs): y = bn > 0 ? bn : slope * bn
   const float* slope;  // relu == 2
   float* slope_partial;  // relu == 2, backward: per-block sums of dy * min(bn, 0) (one per workgroup of bn_partial_kernel<1>)
+  // rh_bn_finalize_bwd_tail (round 6): further per-block partials of the same statistics pass, summed by the SAME launch
+  const float* extra;     // (nchunks, C) -> extra_out (C): a third column sum (the head's weight gradient), or null
+  float* extra_out;
+  const float* scal;      // (nscal, nchunks) -> scal_out (nscal): scalar sums (Dice alpha, head bias), one more workgroup each
+  float* scal_out;
+  int nscal;
+  int col_blocks;         // workgroups [0, col_blocks) take columns, [col_blocks, col_blocks + nscal) one scalar row each
 };
 
 // activation after the normalisation and its derivative factor (relu: 0 none, 1 ReLU, 2 PReLU)
@@ -216,7 +223,10 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
   }
   if (MODE == 0) {
     float mean, var;
-    chan_combine<GROUPS, kFinCols, 16>(a, c, cl, grp, cok, red, mean, var);
+    // (4-column form = the long lists of B * L-row layers, 2048 chunks = 32 per thread: all of them loaded up front -- past
+    // MAXIT the passes are load -> add chains, ~2.5 us per link beside a bandwidth-bound kernel of the other attention unit:
+    // 84 us measured in the DIN step for this launch with MAXIT = 16; same summation order)
+    chan_combine<GROUPS, kFinCols, (FINCOLS <= 4 ? 32 : 16)>(a, c, cl, grp, cok, red, mean, var);
     if (grp != 0 || !cok) return;
     const float n = (float)a.B;
     const float rstd = rsqrtf(var + a.eps);
@@ -234,28 +244,82 @@ __global__ __launch_bounds__(RH_BLOCK) void bn_finalize_kernel(const BnArgs a) {
     }
     return;
   }
-  float s1 = 0.f, s2 = 0.f;
+  if (a.nscal > 0 && (int)blockIdx.x >= a.col_blocks) {
+    // one scalar row: thread-strided sums (8 loads in flight), then the 256 lane sums in lane order -- fixed order
+    const float* row = a.scal + (int64_t)((int)blockIdx.x - a.col_blocks) * a.nchunks;
+    float v = 0.f;
+    int k = threadIdx.x;
+    for (; k + 7 * RH_BLOCK < a.nchunks; k += 8 * RH_BLOCK) {
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = row[k + i * RH_BLOCK];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v += t[i];
+    }
+    for (; k < a.nchunks; k += RH_BLOCK) v += row[k];
+    float* rs = red;  // (2 * GROUPS * (kFinCols + 1) >= 256 floats for both instantiations)
+    rs[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < RH_WAVE) {
+      float w = rs[threadIdx.x];
+      for (int q = 1; q < RH_BLOCK / RH_WAVE; ++q) w += rs[q * RH_WAVE + threadIdx.x];
+      for (int off = RH_WAVE / 2; off > 0; off >>= 1) w += __shfl_down(w, off, RH_WAVE);
+      if (threadIdx.x == 0) a.scal_out[(int)blockIdx.x - a.col_blocks] = w;
+    }
+    return;
+  }
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const bool has3 = a.extra != nullptr;
   if (cok) {
-    // chunk partials are summed in a fixed order (group-strided, then across groups): deterministic
-    for (int k = grp; k < a.nchunks; k += GROUPS) {
+    // batches of 8 chunks: 16 independent loads in flight, then the adds in chunk order (the order of the plain loop)
+    int k = grp;
+    for (; k + 7 * GROUPS < a.nchunks; k += 8 * GROUPS) {
+      float t1[8], t2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        t1[i] = a.partial[((int64_t)(k + i * GROUPS) * 2 + 0) * a.C + c];
+        t2[i] = a.partial[((int64_t)(k + i * GROUPS) * 2 + 1) * a.C + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s1 += t1[i], s2 += t2[i];
+      if (has3) {
+        float t3[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t3[i] = a.extra[(int64_t)(k + i * GROUPS) * a.C + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s3 += t3[i];
+      }
+    }
+    for (; k < a.nchunks; k += GROUPS) {
       s1 += a.partial[((int64_t)k * 2 + 0) * a.C + c];
       s2 += a.partial[((int64_t)k * 2 + 1) * a.C + c];
+      if (has3) s3 += a.extra[(int64_t)k * a.C + c];
     }
   }
   red[grp * (kFinCols + 1) + cl] = s1;
   red[(GROUPS + grp) * (kFinCols + 1) + cl] = s2;
   __syncthreads();
-  if (grp != 0 || !cok) return;
-  s1 = red[cl];
-  s2 = red[GROUPS * (kFinCols + 1) + cl];
-  for (int g2 = 1; g2 < GROUPS; ++g2) {
-    s1 += red[g2 * (kFinCols + 1) + cl];
-    s2 += red[(GROUPS + g2) * (kFinCols + 1) + cl];
+  if (grp == 0 && cok) {
+    s1 = red[cl];
+    s2 = red[GROUPS * (kFinCols + 1) + cl];
+    for (int g2 = 1; g2 < GROUPS; ++g2) {
+      s1 += red[g2 * (kFinCols + 1) + cl];
+      s2 += red[(GROUPS + g2) * (kFinCols + 1) + cl];
+    }
+    a.stat[2 * a.C + c] = s1;  // sum g1        = dbeta
+    a.stat[3 * a.C + c] = s2;  // sum g1 * xhat = dgamma
+    a.dbeta[c] = s1;
+    a.dgamma[c] = s2;
   }
-  a.stat[2 * a.C + c] = s1;  // sum g1        = dbeta
-  a.stat[3 * a.C + c] = s2;  // sum g1 * xhat = dgamma
-  a.dbeta[c] = s1;
-  a.dgamma[c] = s2;
+  if (!has3) return;  // (workgroup-uniform)
+  __syncthreads();
+  red[grp * (kFinCols + 1) + cl] = s3;
+  __syncthreads();
+  if (grp == 0 && cok) {
+    s3 = red[cl];
+    for (int g2 = 1; g2 < GROUPS; ++g2) s3 += red[g2 * (kFinCols + 1) + cl];
+    a.extra_out[c] = s3;
+  }
 }
 
 // eval mode of rh_bn_stats_fwd: the folded affine from the running statistics
@@ -588,19 +652,41 @@ extern "C" int rh_bn_stats_from_partial(const float* partial, int rows_per_chunk
 }
 
 // Column sums of (rows, 2, C) partials -> stat rows 2, 3 (sum g, sum g * xhat) and dbeta / dgamma.
-extern "C" int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta,
-                                  void* stream) {
-  RH_REQUIRE(partial && stat && dgamma && dbeta && rows >= 1 && C >= 1, RH_E_BADARG, "rh_bn_finalize_bwd: bad arguments");
+// _tail: the same launch also sums the other per-block partials of the statistics pass that wrote `partial` -- a third column
+// sum extra (rows, C) -> extra_out (C) (null: none) and nscal scalar rows scal (nscal, rows) -> scal_out (nscal) (0: none) --
+// instead of one framework reduction launch each behind it (DIN backward: 3 + 1 launches per attention unit, 5 - 100 us each
+// beside the other unit's bandwidth-bound passes).  Fixed summation order.
+static int finalize_bwd(const char* who, float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta,
+                        const float* extra, float* extra_out, const float* scal, int nscal, float* scal_out, void* stream) {
+  RH_REQUIRE(partial && stat && dgamma && dbeta && rows >= 1 && C >= 1, RH_E_BADARG, "%s: bad arguments", who);
+  RH_REQUIRE((extra == nullptr) == (extra_out == nullptr), RH_E_BADARG, "%s: extra and extra_out go together", who);
+  RH_REQUIRE(nscal >= 0 && nscal <= 8 && (nscal == 0 || (scal && scal_out)), RH_E_BADARG, "%s: %d scalar rows (0..8)", who, nscal);
   BnArgs a{};
   a.partial = partial; a.stat = stat; a.dgamma = dgamma; a.dbeta = dbeta; a.C = C; a.nchunks = rows; a.B = 1;
-  if (rows > 512)
-    hipLaunchKernelGGL((bn_finalize_kernel<1, 4>), dim3((unsigned)((C + 3) / 4)), dim3(RH_BLOCK), 0,
+  a.extra = extra; a.extra_out = extra_out; a.scal = scal; a.scal_out = scal_out; a.nscal = nscal;
+  if (rows > 512) {
+    a.col_blocks = (C + 3) / 4;
+    hipLaunchKernelGGL((bn_finalize_kernel<1, 4>), dim3((unsigned)(a.col_blocks + nscal)), dim3(RH_BLOCK), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)((C + kFinCols - 1) / kFinCols)), dim3(RH_BLOCK), 0,
+  } else {
+    a.col_blocks = (C + kFinCols - 1) / kFinCols;
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3((unsigned)(a.col_blocks + nscal)), dim3(RH_BLOCK), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
-  RH_LAUNCH_CHECK("rh_bn_finalize_bwd");
+  }
+  RH_LAUNCH_CHECK(who);
   return 0;
+}
+
+extern "C" int rh_bn_finalize_bwd(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta,
+                                  void* stream) {
+  return finalize_bwd("rh_bn_finalize_bwd", partial, rows, C, stat, dgamma, dbeta, nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int rh_bn_finalize_bwd_tail(float* partial, int rows, int C, float* stat, float* dgamma, float* dbeta,
+                                       const float* extra, float* extra_out, const float* scal, int nscal, float* scal_out,
+                                       void* stream) {
+  return finalize_bwd("rh_bn_finalize_bwd_tail", partial, rows, C, stat, dgamma, dbeta, extra, extra_out, scal, nscal, scal_out,
+                      stream);
 }
 
 // The backward with the column sums (sum g1, sum g1 * xhat) ALREADY formed by the producer of dy (csrc/linear.hip: the

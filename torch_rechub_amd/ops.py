@@ -1768,10 +1768,13 @@ class _BnDiceFn(torch.autograd.Function):
         _lib.call("rh_bn_dice_bwd_stats", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(col_partial),
                   _p(alpha_partial), _stream())
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        _lib.call("rh_bn_finalize_bwd", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _stream())
+        d_alpha = torch.empty((1,), dtype=torch.float32, device=dev)
+        # (the finalize launch also sums Dice's alpha partials: no framework reduction launch behind the apply pass)
+        _lib.call("rh_bn_finalize_bwd_tail", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _p(None), _p(None),
+                  _p(alpha_partial), 1, _p(d_alpha), _stream())
         dh = torch.empty_like(h)
         _lib.call("rh_bn_dice_bwd_apply", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(dh), _stream())
-        return dh, dgamma, dbeta, None, None, None, None, None, alpha_partial.sum().reshape(1), None, None, None
+        return dh, dgamma, dbeta, None, None, None, None, None, d_alpha, None, None, None
 
 
 def bn_dice_ok(h, bn, dice_mod):
@@ -1839,12 +1842,16 @@ class _BnDiceHeadFn(torch.autograd.Function):
         _lib.call("rh_bn_dice_head_bwd_stats", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(head_w),
                   _p(col_partial), _p(scalar_partial), _p(head_partial), _stream())
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        _lib.call("rh_bn_finalize_bwd", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _stream())
+        scalars = torch.empty((2,), dtype=torch.float32, device=dev)
+        d_head_w = torch.empty((1, C), dtype=torch.float32, device=dev)
+        # (the finalize launch also sums the head's weight-gradient partials and the two scalar rows -- Dice's alpha, the head's
+        # bias: three framework reduction launches + a fill per attention unit less on the backward's critical path)
+        _lib.call("rh_bn_finalize_bwd_tail", _p(col_partial), nb, C, _p(stat), _p(dgamma), _p(dbeta), _p(head_partial),
+                  _p(d_head_w), _p(scalar_partial), 2, _p(scalars), _stream())
         dh = torch.empty_like(h)
         _lib.call("rh_bn_dice_head_bwd_apply", _p(h), _p(g), _p(alpha), ctx.eps, N, C, _p(stat), _p(gamma), _p(head_w),
                   _p(dh), _stream())
-        scalars = scalar_partial.sum(1)
-        return (dh, dgamma, dbeta, None, None, None, None, None, scalars[0:1], None, head_partial.sum(0, keepdim=True),
+        return (dh, dgamma, dbeta, None, None, None, None, None, scalars[0:1], None, d_head_w,
                 scalars[1:2] if ctx.has_bias else None, None, None)
 
 
