@@ -262,6 +262,8 @@ class Workload(object):
                 from torch_rechub_amd.models.matching import DSSM
                 tower = {"dims": [256, 128, 64], "activation": "prelu"}
                 m = DSSM(self.user, self.item, user_params=dict(tower), item_params=dict(tower), temperature=0.02)
+                if os.environ.get("PROBE_DSSM_BRANCHES") == "0":  # (A/B of the two towers side by side)
+                    m.tower_branches = False
         # (a.lazy_k is the headline's value; other batch sizes of the sweep follow the trainer's own rule unless --lazy-k was given)
         # (None: the trainer's own rule -- 128, or 64 for steps of more than 8192 samples and for sweep-bound table sets)
         k = a.lazy_k if a.lazy_k_explicit else None

@@ -40,10 +40,10 @@ class DSSM(nn.Module):
         """(user_tower(x), item_tower(x)) with the two MLPs side by side (extension; the reference runs them one after the
         other, trainers/match_trainer.py:112-113).  Both gathers stay on the calling stream -- they refresh optimizer state
         in order -- then the item tower's MLP + normalisation run on a second stream beside the user tower's: each of their
-        ~12 launches per direction fills a fraction of the chip.  Opt-in (``model.tower_branches = True``): at configs[4] the step is
-        bounded by the deferred window sweep, not by the chain (0.823 ms either way); with the chain as the bound (sweep at
-        1024 workgroups) the branches take 1.04 -> 0.92 ms."""
-        if self.mode is not None or not getattr(self, "tower_branches", False):
+        ~12 launches per direction fills a fraction of the chip.  On by default since round 6 (``model.tower_branches = False``
+        restores the sequence): in round 5 the configs[4] step was bounded by the deferred window sweep (0.823 ms either way);
+        with the round-6 sweep the chain is the longer path and the branches take it 0.776 -> 0.746 ms (same box)."""
+        if self.mode is not None or not getattr(self, "tower_branches", True):
             return self.user_tower(x), self.item_tower(x)
         hu = self.embedding(x, self.user_features, squeeze_dim=True)
         hi = self.embedding(x, self.item_features, squeeze_dim=True)
