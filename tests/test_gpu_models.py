@@ -1108,6 +1108,18 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
                     use_graph=bool(use_graph), tables=tables)
     assert tb.dp is not None and ops._sparse_exchange is not None
     assert tb.short_sweep_inline == (tables == "shard" and not pin)
+    from torch_rechub_amd import _lib
+    heads = {"fused": 0, "gather": 0}
+    real_call = _lib.call
+
+    def spy(name, *args):
+        if name == "rh_adam_lazy_refresh_assemble":
+            heads["fused"] += 1
+        elif name == "rh_batch_gather":
+            heads["gather"] += 1
+        return real_call(name, *args)
+
+    monkeypatch.setattr(_lib, "call", spy)
     try:
         lb = tb.train_one_epoch(mk())
         if use_graph:
@@ -1115,6 +1127,10 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
         sd_b = sharding.full_state_dict(mb) if tables == "shard" else mb.state_dict()
     finally:
         tb.dp.close()
+        monkeypatch.setattr(_lib, "call", real_call)
+    # round 6: with replicated tables the CAPTURED data-parallel step takes the one-kernel head (batch assembly inside the refresh
+    # of the local batch's rows; strict form under the segmented capture); row-sharded tables keep the two launches
+    assert (heads["fused"] > 0) == (tables == "replicate" and bool(use_graph)), heads
     assert la == lb
     sd_a = ma.state_dict()
     for k in sd_a:

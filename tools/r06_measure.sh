@@ -3,7 +3,7 @@
 # summaries that are cited are copied into profiles/ by hand).
 #   integ      mounted-reference integration tests on the GPU (tools/mount_reference.sh first, in the build container)
 #   tests      the driver's command: pytest tests -m gpu -x -q
-#   testsel    pytest -m gpu on TEST_SEL (a -k expression or file list)
+#   testsel    pytest -m gpu on TEST_SEL (file list), TEST_K = a -k expression (may hold spaces)
 #   bench      the driver's bench command (incl. CPU baseline, dense twin check)
 #   bench300   300 steps, no CPU baseline (steady state)
 #   timeline   one traced step of the default workload (tools/timeline.py)
@@ -56,7 +56,7 @@ PY
 for s in $STAGES; do echo "=== stage $s $(date +%T)"; case $s in
 integ) RECHUB_REFERENCE=$PWD/_refmount timeout 900 python -m pytest -m gpu tests/test_integration_patch.py -v > "$OUT/integration_gpu.log" 2>&1; echo "rc=$?"; tail -15 "$OUT/integration_gpu.log";;
 tests) timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; echo "rc=$?"; tail -5 "$OUT/pytest_gpu.log";;
-testsel) timeout 1200 python -m pytest -m gpu -x -q ${TEST_SEL:-tests} > "$OUT/pytest_sel${SELTAG:-}.log" 2>&1; echo "rc=$?"; tail -15 "$OUT/pytest_sel${SELTAG:-}.log";;
+testsel) timeout 1200 python -m pytest -m gpu -x -q ${TEST_SEL:-tests} ${TEST_K:+-k "$TEST_K"} > "$OUT/pytest_sel${SELTAG:-}.log" 2>&1; echo "rc=$?"; tail -15 "$OUT/pytest_sel${SELTAG:-}.log";;
 bench) ( time timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" ) 2>&1 | grep real
   brief "$OUT/bench_default.json"; tail -5 "$OUT/bench_default.err";;
 bench300) timeout 400 python bench.py --steps 300 --warmup 10 --no-cpu-baseline --brief ${BENCH300_ARGS:-} > "$OUT/bench_300.json" 2> "$OUT/bench_300.err"; echo "rc=$?"; brief "$OUT/bench_300.json";;

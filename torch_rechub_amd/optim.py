@@ -341,11 +341,14 @@ class TableAdam(torch.optim.Adam):
             and len(a["weights"]) == len(b["weights"]) and all(x is y for x, y in zip(a["weights"], b["weights"])) \
             and list(a["pads"]) == list(b["pads"])
 
-    def assemble_with_refresh(self, loader, B=None):
+    def assemble_with_refresh(self, loader, B=None, strict=False):
         """Called by the trainers INSTEAD of the loader's batch assembly when the coming step is known to gather ONE index
         batch that lives in the loader's static buffer (the previous step's record): the assembly and the pre-gather refresh
         of that batch run as ONE launch (rh_adam_lazy_refresh_assemble), the refresh reading its indices from the dataset.
-        Returns False (nothing launched: the caller assembles the ordinary way) whenever that is not the situation."""
+        Returns False (nothing launched: the caller assembles the ordinary way) whenever that is not the situation.
+        ``strict``: only the strict eager head (round 6, replicated tables under data parallelism: the sweep is joined in front
+        of the touched pass over the gathered rows in every step, so neither the relaxed join's preview nor the step-ahead
+        launch -- both protect the LOCAL batch's rows only -- has anything to win or the right to run)."""
         if self.lazy_k <= 1 or not self._tables or not ASSEMBLE_WITH_REFRESH or not self._k_decided:
             return False
         if ops.chain_gate is self._gate:
@@ -482,7 +485,9 @@ class TableAdam(torch.optim.Adam):
                 self._look_token = (id(seg), loader.generation, h)
                 self._sweep_pending, self._sweep_inflight = False, True
 
-            if RELAXED_JOIN and STEP_AHEAD and self._merge_ahead_ok(rec, grp):
+            if strict:
+                seg.at_start(head)
+            elif RELAXED_JOIN and STEP_AHEAD and self._merge_ahead_ok(rec, grp):
                 seg.at_start(head_ahead)
                 seg.after(tail_ahead)
                 self._advance_seg = seg  # (step_tables: tail_ahead counts the replayed steps)

@@ -17,12 +17,14 @@ import torch
 import torch.distributed as dist
 import tqdm
 
-from .. import graphs, ops, sharding
+from .. import _lib, graphs, ops, sharding
 from ..basic.callback import EarlyStopper
 from ..basic.loss_func import RegularizationLoss
 from ..distributed import DataParallelContext, DenseGradBucket, table_parameters
 from ..optim import TableAdam
 from ..utils.data import DeviceDataLoader
+
+DP_FUSED_HEAD = _lib.ab("dphead")  # False (RECHUB_AB=dphead=0): batch assembly and refresh as two launches under data parallelism
 
 
 class CTRTrainer(object):
@@ -142,7 +144,10 @@ class CTRTrainer(object):
     def _load(self, loader, B=None):
         """Next batch of a DeviceDataLoader; its position counter is advanced by this step's scalar launch."""
         opt = self.optimizer
-        fused = isinstance(opt, TableAdam) and self.dp is None and opt.assemble_with_refresh(loader, B)
+        # (data parallel, replicated tables: the one-kernel head in its strict form; row-sharded tables localise the gathered
+        # global indices first and keep the two launches)
+        dp_ok = self.dp is None or (DP_FUSED_HEAD and not self.dp.sharded)
+        fused = isinstance(opt, TableAdam) and dp_ok and opt.assemble_with_refresh(loader, B, strict=self.dp is not None)
         x, y = loader.load_next(B, advance=False, assemble=not fused)
         self._counters.append(loader.counter(loader.batch_size if B is None else B))
         return x, y
