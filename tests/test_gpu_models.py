@@ -1075,7 +1075,9 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
                                                      (False, "shard", "duplicated_samples"),
                                                      (False, "shard+deferred", "duplicated_samples"),
                                                      (False, "replicate", "collision_free"),
-                                                     ("single", "replicate", "collision_free")])
+                                                     ("single", "replicate", "collision_free"),
+                                                     ("single", "replicate/front", "collision_free"),
+                                                     ("single", "replicate/two", "duplicated_samples")])
 def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_world1, monkeypatch, use_graph, tables, layout):
     """The test above on order-free batches -- every sample twice over collision-free rows (_duplicate_samples: every float
     atomic adds identical addends), or collision-free rows outright: the data-parallel step -- loss / world, dense gradients
@@ -1084,9 +1086,17 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
     indices -- must leave the SAME bits as the single-GPU fused step (measured so in round 5: tools/bitwise_probe.py,
     profiles/r05_bitwise_probe_dp.txt; the row-sharded lookup sums its dense gradients in another order and is bit-equal on
     duplicated samples only).  Reference: nn.DataParallel computes the global-batch update (trainers/ctr_trainer.py:53-55)."""
-    from torch_rechub_amd import ops, sharding
-    from torch_rechub_amd.trainers import CTRTrainer
+    from torch_rechub_amd import ops, optim, sharding
+    from torch_rechub_amd.trainers import CTRTrainer, ctr_trainer
     from torch_rechub_amd.utils.data import DeviceDataLoader
+    # head of the captured step with replicated tables (round 6): "behind" (default) = batch assembly + refresh as ONE kernel, the
+    # last launch of the previous replay's graph, the sweep behind a gate the next chain start releases; "front" = that kernel
+    # eager in front of every replay on the sweep's queue (RECHUB_AB=dpbehind=0); "two" = rh_batch_gather + the refresh as a
+    # captured head segment (RECHUB_AB=dphead=0, rounds 3-5)
+    tables, _, head_form = tables.partition("/")
+    head_form = head_form or "behind"
+    monkeypatch.setattr(optim, "DP_HEAD_BEHIND", head_form == "behind")
+    monkeypatch.setattr(ctr_trainer, "DP_FUSED_HEAD", head_form != "two")
     nb, B = 12, 64
     vocabs, sparse, dense, label = _loader_twin_data(layout, nb, B, seed=51)
     ma, dfe, sfe = _deepfm(vocabs, 3)
@@ -1109,7 +1119,7 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
     assert tb.dp is not None and ops._sparse_exchange is not None
     assert tb.short_sweep_inline == (tables == "shard" and not pin)
     from torch_rechub_amd import _lib
-    heads = {"fused": 0, "gather": 0}
+    heads = {"fused": 0, "gather": 0, "gated": 0}
     real_call = _lib.call
 
     def spy(name, *args):
@@ -1117,6 +1127,8 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
             heads["fused"] += 1
         elif name == "rh_batch_gather":
             heads["gather"] += 1
+        elif name == "rh_adam_sweep_gate":
+            heads["gated"] += 1
         return real_call(name, *args)
 
     monkeypatch.setattr(_lib, "call", spy)
@@ -1130,7 +1142,9 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
         monkeypatch.setattr(_lib, "call", real_call)
     # round 6: with replicated tables the CAPTURED data-parallel step takes the one-kernel head (batch assembly inside the refresh
     # of the local batch's rows; strict form under the segmented capture); row-sharded tables keep the two launches
-    assert (heads["fused"] > 0) == (tables == "replicate" and bool(use_graph)), heads
+    assert (heads["fused"] > 0) == (tables == "replicate" and bool(use_graph) and head_form != "two"), heads
+    # ("behind": one gated sweep per replay of the single-graph step; the split step captures plain graphs -- no eager sweep)
+    assert (heads["gated"] > 0) == (tables == "replicate" and use_graph == "single" and head_form == "behind"), heads
     assert la == lb
     sd_a = ma.state_dict()
     for k in sd_a:

@@ -24,6 +24,7 @@ SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  #
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
+DP_HEAD_BEHIND = _lib.ab("dpbehind")  # False (RECHUB_AB=dpbehind=0): the data-parallel strict head stays an eager launch in front of the graph
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
 CHAIN_GATE = _lib.ab("chaingate")  # False (RECHUB_AB=chaingate=0): the sweep is released RH_TUNE_SWEEP_GATE_NS behind the opening (round 4)
 HOST_DONE = _lib.ab("hostdone")  # False (RECHUB_AB=hostdone=0): an event record behind every deferred sweep instead of the gates' host-mapped count
@@ -37,6 +38,7 @@ class TableAdam(torch.optim.Adam):
 
     RING = 1024  # per-step (A, E) history for the lazy replay; lazy_k must be < RING
     _rider = None  # weight-gradient group the coming end-of-step launch carries (_ride_wgrad)
+    _dp_tail_head = None  # strict head at the END of the step's graph (replicated tables under data parallelism): what _lazy_step launches
 
     def __init__(self, params, table_params=(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, lazy_k=0,
                  lazy_small_rows=None, lazy_dense_ratio=None, lazy_k_auto=False, **kw):
@@ -322,7 +324,10 @@ class TableAdam(torch.optim.Adam):
                 return  # the sweep of this step ran (and was joined) already
             if self._head_forks and capturing:
                 self._head_forks = False
-                return  # the eager head of every replay launches this step's sweep (assemble_with_refresh)
+                # the eager head of every replay launches this step's sweep (assemble_with_refresh): it IS in flight from here
+                # on in every replay -- what _join_before_foreign_rows (replicated tables under data parallelism) must see
+                self._sweep_inflight = True
+                return
             if self._sweep_pending and self._gathers >= (self._gathers_per_step or 1):
                 if not capturing:
                     self._fork_sweep()
@@ -354,6 +359,7 @@ class TableAdam(torch.optim.Adam):
         if ops.chain_gate is self._gate:
             ops.chain_gate = None  # (a capture that was abandoned between its head and its last launch)
         self._drop_rider()
+        self._dp_tail_head = None
         recs = self._last_recs
         if len(recs) != 1 or (self._gathers_per_step or 0) != 1 or self._gathers != 0:
             return False
@@ -485,7 +491,43 @@ class TableAdam(torch.optim.Adam):
                 self._look_token = (id(seg), loader.generation, h)
                 self._sweep_pending, self._sweep_inflight = False, True
 
-            if strict:
+            def head_behind(cargs=cargs, keep=keep, seg=seg, loader=loader):
+                # Strict head whose kernel is the LAST launch of the previous replay's graph (_lazy_step captured it behind the
+                # touched pass): this batch is assembled and its rows are refreshed already, on the chain's own queue -- no
+                # cross-queue hop in front of the chain, the sweep goes to its queue at once.  Replicated tables under data
+                # parallelism only: there every step joins its sweep in front of the touched pass (foreign rows), so the
+                # refresh behind that pass follows the sweep AND the chain by stream order, which is all the strict head asks.
+                # Whenever the previous replay was not this graph's, the loader moved or a step went in between: prepare here.
+                main = torch.cuda.current_stream()
+                if self._look_token != (id(seg), loader.generation, self._host_step):
+                    main.wait_stream(self._side_stream())
+                    _lib.call("rh_adam_lazy_refresh_assemble", *cargs, 0, ops._stream())
+                self._gate_seen += 1  # the last launch of this replay's graph opens the gate of this step's sweep
+                self._sweep_pending, self._sweep_inflight = False, True
+
+            def tail_behind(seg=seg, loader=loader):
+                # after the step's graph: the sweep of the step just completed goes to its queue behind a gate -- opened by the
+                # graph's last launch and released by the NEXT replay's chain start (its first own GEMM has placed its
+                # workgroups), as in the step-ahead form: dispatched a few microseconds into the chain instead, the sweep's
+                # workgroups spread unevenly and the statistics-prologue GEMM beside them took 93 us for 27 (traced)
+                self._host_step += 1
+                h = self._host_step
+                with torch.cuda.stream(self._side_stream()):
+                    _lib.call("rh_adam_sweep_gate", ops._p(self._gate), self._gate_seen,
+                              GATE_FALLBACK_NS if self.gate_by_chain else 0, ops._p(ops.err_flag(self._tables[0].device)),
+                              ops._stream())
+                    self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=h)
+                self._look_token = (id(seg), loader.generation, h)
+                self._sweep_pending, self._sweep_inflight = False, True
+
+            if strict and DP_HEAD_BEHIND and self.foreign_rows:
+                seg.at_start(head_behind)
+                seg.after(tail_behind)
+                self._advance_seg = seg  # (step_tables: tail_behind counts the replayed steps)
+                self._dp_tail_head = dict(seg=seg, cargs=cargs, keep=keep)
+                ops.chain_gate = self._gate if CHAIN_GATE else None  # (the first own GEMM captured into this graph counts the chain start)
+                del ops.chain_gate_used[:]
+            elif strict:
                 seg.at_start(head)
             elif RELAXED_JOIN and STEP_AHEAD and self._merge_ahead_ok(rec, grp):
                 seg.at_start(head_ahead)
@@ -876,15 +918,23 @@ class TableAdam(torch.optim.Adam):
         groups = self._lazy_setup()
         if self._merged_step(groups, stream):
             del self._touch_log[:]
-            return
-        for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
-            self._touch(rec, groups, stream)
-        del self._touch_log[:]
-        if self.overlap_sweep:
-            self._sweep(SWEEP_DENSE_TABLES, stream)  # small tables take their gradient now; the rest is deferred
-            self._sweep_pending = True
         else:
-            self._sweep(SWEEP_WINDOW, stream)
+            for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
+                self._touch(rec, groups, stream)
+            del self._touch_log[:]
+            if self.overlap_sweep:
+                self._sweep(SWEEP_DENSE_TABLES, stream)  # small tables take their gradient now; the rest is deferred
+                self._sweep_pending = True
+            else:
+                self._sweep(SWEEP_WINDOW, stream)
+        th, self._dp_tail_head = self._dp_tail_head, None
+        if th is not None and graphs.active() is th["seg"] and torch.cuda.is_current_stream_capturing():
+            # (head_behind: the NEXT batch's assembly + refresh as the last launch of this step's graph; the loader's position
+            # has been advanced by this step's scalar launch)
+            _lib.call("rh_adam_lazy_refresh_assemble", *th["cargs"], 0, stream)
+            _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
+            self.gate_by_chain = bool(ops.chain_gate_used)
+            ops.chain_gate = None
 
     def _finish_sweep(self):
         """A sweep that was not forked (no training-mode gather since the last step, or a plain hipGraph capture)
