@@ -96,6 +96,13 @@ class CTRTrainer(object):
             # a rank's shard of the tables may be small enough for the window sweep to go back in line (optim.py,
             # SHORT_SWEEP_ELEMENTS: from four ranks up on the Criteo-shape tables; -11 % / -14 % per-rank step at 4 / 8 ranks)
             self.short_sweep_inline = self.optimizer.prefer_inline_for_short_sweeps(auto_k=lazy_k is None)
+        if self.dp is not None and self.tables == "shard" and isinstance(self.optimizer, TableAdam):
+            # Row-sharded step: its head (batch assembly, index all-gather, localisation, refresh of the shard's rows) stays on the
+            # chain's queue and only the sweep crosses to its own -- the sharded chain (lookup exchange + reduce-scatter on top of
+            # the N = 1 chain) is the longer of the two paths, so the cross-queue edge belongs on the sweep's side: one rank
+            # 0.3394 / 0.3407 / 0.3393 -> 0.3191 / 0.3196 / 0.3203 ms same box (round 6; the N = 1 DSSM / DCN-v2 steps, whose
+            # sweep or library GEMMs are the bound, lose 2 % / 8 % by the same switch and keep the head on the sweep's queue)
+            self.optimizer.head_on_side = False
         if self.dp is not None and (self.tables == "replicate" or shard_min_rows > 0) and getattr(self.optimizer, "lazy_k", 0) > 1:
             # the gradient-row exchange hands this rank the rows of every rank's batch: TableAdam._join_before_foreign_rows
             self.optimizer.foreign_rows = True
