@@ -1077,7 +1077,9 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training(nccl_world1, 
                                                      (False, "replicate", "collision_free"),
                                                      ("single", "replicate", "collision_free"),
                                                      ("single", "replicate/front", "collision_free"),
-                                                     ("single", "replicate/two", "duplicated_samples")])
+                                                     ("single", "replicate/two", "duplicated_samples"),
+                                                     ("single", "shard+deferred", "duplicated_samples"),
+                                                     ("single", "shard+deferred/cut", "duplicated_samples")])
 def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_world1, monkeypatch, use_graph, tables, layout):
     """The test above on order-free batches -- every sample twice over collision-free rows (_duplicate_samples: every float
     atomic adds identical addends), or collision-free rows outright: the data-parallel step -- loss / world, dense gradients
@@ -1097,6 +1099,9 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
     head_form = head_form or "behind"
     monkeypatch.setattr(optim, "DP_HEAD_BEHIND", head_form == "behind")
     monkeypatch.setattr(ctr_trainer, "DP_FUSED_HEAD", head_form != "two")
+    # row-sharded tables, deferred sweep: the head stays on the chain's queue and the sweep is launched behind the graph, held by a
+    # gate ("cut": forked at a segment boundary behind the head, RECHUB_AB=gatedfork=0)
+    monkeypatch.setattr(optim, "GATED_FORK", head_form != "cut")
     nb, B = 12, 64
     vocabs, sparse, dense, label = _loader_twin_data(layout, nb, B, seed=51)
     ma, dfe, sfe = _deepfm(vocabs, 3)
@@ -1144,7 +1149,8 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
     # of the local batch's rows; strict form under the segmented capture); row-sharded tables keep the two launches
     assert (heads["fused"] > 0) == (tables == "replicate" and bool(use_graph) and head_form != "two"), heads
     # ("behind": one gated sweep per replay of the single-graph step; the split step captures plain graphs -- no eager sweep)
-    assert (heads["gated"] > 0) == (tables == "replicate" and use_graph == "single" and head_form == "behind"), heads
+    assert (heads["gated"] > 0) == (use_graph == "single" and ((tables == "replicate" and head_form == "behind") or
+                                                              (tables == "shard" and pin == "deferred" and head_form != "cut"))), heads
     assert la == lb
     sd_a = ma.state_dict()
     for k in sd_a:

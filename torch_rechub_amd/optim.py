@@ -24,6 +24,7 @@ SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  #
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
+GATED_FORK = _lib.ab("gatedfork")  # False (RECHUB_AB=gatedfork=0): a head on the chain's queue forks its sweep at a segment boundary
 DP_HEAD_BEHIND = _lib.ab("dpbehind")  # False (RECHUB_AB=dpbehind=0): the data-parallel strict head stays an eager launch in front of the graph
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
 CHAIN_GATE = _lib.ab("chaingate")  # False (RECHUB_AB=chaingate=0): the sweep is released RH_TUNE_SWEEP_GATE_NS behind the opening (round 4)
@@ -648,7 +649,39 @@ class TableAdam(torch.optim.Adam):
         else:
             if self.head_on_side and self._join_seg is seg and self._head_begin in seg.before:
                 seg.before[seg.before.index(self._head_begin)] = self._join_sweep  # the head stays on the main stream
-            seg.cut(self._fork_sweep)
+            if GATED_FORK and self.gated_fork and not self.head_on_side and not self.foreign_rows and \
+                    len(seg.segments) == 1 and (self._gathers_per_step or 1) == 1:
+                # Head on the chain's queue, one gather per step, no join inside the step (the trainers set ``gated_fork`` for
+                # row-sharded tables under data parallelism: a join at a LATER segment boundary -- foreign rows, a refresh-ahead
+                # mismatch -- would run before the sweep launched behind the graph and find nothing to wait for): NO segment
+                # boundary for the fork (15 us of idle queue in front of the chain, profiles/r06_dp_one_rank_shard_step.txt).
+                # The graph counts an opening behind the head's refresh instead, and the sweep is launched AFTER the whole
+                # graph has been enqueued, behind a gate that waits for that opening and then for the chain start -- the
+                # step's first own GEMM has placed its workgroups -- like the step-ahead form's (stream_gate_kernel; a gate
+                # nobody opens gives up after its timeout).  Same order on the device: refresh -> sweep -> (join in front
+                # of the next replay).
+                _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), ops._stream())
+                ops.chain_gate = self._gate if CHAIN_GATE else None
+                del ops.chain_gate_used[:]
+                self._gated_fork_seg = seg
+                if self._fork_sweep_gated not in seg.after_fns:
+                    seg.after(self._fork_sweep_gated)  # (registered before step_tables' host-step advance: runs first)
+            else:
+                seg.cut(self._fork_sweep)
+
+    _gated_fork_seg = None
+    gated_fork = False  # set by the trainers (row-sharded tables under data parallelism)
+
+    def _fork_sweep_gated(self):
+        """after() of a graph captured by the gated fork above: this replay's opening is enqueued -- its sweep may wait for it."""
+        self._gate_seen += 1
+        if self._host_step > 0:
+            with torch.cuda.stream(self._side_stream()):
+                _lib.call("rh_adam_sweep_gate", ops._p(self._gate), self._gate_seen,
+                          GATE_FALLBACK_NS if self.gate_by_chain else 0, ops._p(ops.err_flag(self._tables[0].device)),
+                          ops._stream())
+                self._sweep(SWEEP_LAZY_TABLES, ops._stream(), t_value=self._host_step)
+        self._sweep_pending, self._sweep_inflight = False, True
 
     def _fork_sweep_behind_head(self):
         """After the head segment was enqueued on the side stream: mark the end of the refresh there (the chain waits for
@@ -927,6 +960,11 @@ class TableAdam(torch.optim.Adam):
                 self._sweep_pending = True
             else:
                 self._sweep(SWEEP_WINDOW, stream)
+        if self._gated_fork_seg is not None:
+            if graphs.active() is self._gated_fork_seg:
+                self.gate_by_chain = bool(ops.chain_gate_used)  # (else: the gate's wall-clock hold-back behind the opening)
+                ops.chain_gate = None
+            self._gated_fork_seg = None
         th, self._dp_tail_head = self._dp_tail_head, None
         if th is not None and graphs.active() is th["seg"] and torch.cuda.is_current_stream_capturing():
             # (head_behind: the NEXT batch's assembly + refresh as the last launch of this step's graph; the loader's position

@@ -103,6 +103,9 @@ class CTRTrainer(object):
             # 0.3394 / 0.3407 / 0.3393 -> 0.3191 / 0.3196 / 0.3203 ms same box (round 6; the N = 1 DSSM / DCN-v2 steps, whose
             # sweep or library GEMMs are the bound, lose 2 % / 8 % by the same switch and keep the head on the sweep's queue)
             self.optimizer.head_on_side = False
+            # ... and forks its sweep behind a gate instead of at a segment boundary (optim.TableAdam._cut_fork) when every table
+            # is sharded (no replicated small table whose gathered rows would ask for a join inside the step)
+            self.optimizer.gated_fork = shard_min_rows <= 0
         if self.dp is not None and (self.tables == "replicate" or shard_min_rows > 0) and getattr(self.optimizer, "lazy_k", 0) > 1:
             # the gradient-row exchange hands this rank the rows of every rank's batch: TableAdam._join_before_foreign_rows
             self.optimizer.foreign_rows = True
