@@ -643,6 +643,17 @@ int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_t* h_rows, 
                             const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
                             int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
                             int64_t* sparse_out, float* dense_out, float* label_out, int look_depth, void* stream);
+/* rh_adam_lazy_step_ahead whose touched-rows part walks touched_B rows of ANOTHER int64 index matrix (touched_idesc: F column
+ * pointers, then F strides) instead of the batch before the one it assembles: the GATHERED lookups of every rank's batch under
+ * data parallelism with replicated tables (round 6; reference: nn.DataParallel applies the global batch's update on every
+ * replica, trainers/ctr_trainer.py:53-55, optimizer.step() :99).  The refresh / assembly / look-ahead parts work on the LOCAL
+ * batch as before; a row both index sets hold is claimed by one of the two passes, as in rh_adam_lazy_step_ahead. */
+int rh_adam_lazy_step_ahead_touched(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                    const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                    const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm,
+                                    const int64_t* pos, int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND,
+                                    const float* label, int64_t* sparse_out, float* dense_out, float* label_out, int look_depth,
+                                    const int64_t* touched_idesc, int touched_B, void* stream);
 /* rh_adam_lazy_step_ahead whose launch ALSO carries the weight gradients of the step's nn.Linear layers (round 6; reference:
  * the Linear backward inside loss.backward(), trainers/ctr_trainer.py:98, dW = g^T x of basic/layers.py:279,290): wn <= 8
  * problems, arrays of wn host entries as rh_linear_wgrad_partial_group (problem i writes its split slabs to wpartial[i],

@@ -1157,6 +1157,75 @@ def test_data_parallel_machinery_on_one_rank_equals_plain_training_bitwise(nccl_
         assert torch.equal(sd_a[k], sd_b[k]), k
 
 
+def test_replicated_step_with_a_second_ranks_rows_is_the_same_in_every_form_of_its_head_and_tail(nccl_world1, monkeypatch):
+    """Round 6: the captured data-parallel step with replicated tables ends with ONE launch -- the touched-rows step over the
+    GATHERED index matrix, the dense tables' step, the next LOCAL batch's assembly and the refresh of its rows
+    (rh_adam_lazy_step_ahead_touched) -- where it ran two (rh_adam_lazy_step_mode, rh_adam_lazy_refresh_assemble), and begins
+    without a head of its own.  On a one-rank group the gathered matrix IS the local batch; here the all-gather is replaced by
+    one that appends a second rank's contribution -- a fixed set of FOREIGN lookups (rows this rank's refresh never stamps) with
+    fixed gradient rows -- so that the touched part walks 2 B rows of another matrix than the one the refresh assembles, the
+    sweep is joined in front of it (TableAdam._join_before_foreign_rows) and rows of both sets meet in the claims.  Every form
+    of the step (merged tail / two launches behind the graph / eager one-kernel head / the two-launch head of rounds 3-5)
+    must leave the same bits; lazy tables (K = 4) so that replay, window sweep and flush are on the path."""
+    from torch_rechub_amd import _lib, distributed, optim
+    from torch_rechub_amd.trainers import CTRTrainer, ctr_trainer
+    from torch_rechub_amd.utils.data import DeviceDataLoader
+    nb, B = 12, 64
+    vocabs, sparse, dense, label = _loader_twin_data("collision_free", nb, B, seed=57)
+    g = torch.Generator().manual_seed(9)
+    foreign_idx = torch.stack([torch.randperm(v, generator=g)[:B] for v in vocabs], 1).to(dev())  # collision-free per column
+    foreign_rows = (torch.randn(B, len(vocabs), 16, generator=g) * 1e-2).to(dev())
+
+    def two_rank_gather(t, group=None, out=None):
+        other = foreign_idx if t.dtype == torch.int64 else foreign_rows
+        assert t.shape == other.shape, (t.shape, other.shape)
+        if out is None or out.shape[0] != 2 * t.shape[0]:
+            out = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:t.shape[0]].copy_(t)
+        out[t.shape[0]:].copy_(other)
+        return out
+
+    monkeypatch.setattr(distributed, "_EMULATE_WORLD", 2)
+    monkeypatch.setattr(distributed, "all_gather_cat", two_rank_gather)
+    monkeypatch.setenv("RECHUB_FORCE_DP", "1")
+    monkeypatch.setenv("RECHUB_DP_GRAPH", "single")
+    params = {"lr": 1e-2, "weight_decay": 1e-4, "lazy_small_rows": 64}
+    seen = {}
+    real_call = _lib.call
+
+    def spy(name, *args):
+        seen[name] = seen.get(name, 0) + 1
+        return real_call(name, *args)
+
+    monkeypatch.setattr(_lib, "call", spy)
+    twins = []
+    for form in ("merged", "behind", "front", "two"):
+        monkeypatch.setattr(optim, "DP_MERGED_TAIL", form == "merged")
+        monkeypatch.setattr(optim, "DP_HEAD_BEHIND", form in ("merged", "behind"))
+        monkeypatch.setattr(ctr_trainer, "DP_FUSED_HEAD", form != "two")
+        model, dfe, sfe = _deepfm(vocabs, 3)
+        if twins:
+            model.load_state_dict(twins[0][3])
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        names, dnames = [f.name for f in sfe], [f.name for f in dfe]
+        seen.clear()
+        t = CTRTrainer(model, optimizer_params=dict(params), device="cuda:0", show_progress=False, lazy_k=4, use_graph=True,
+                       tables="replicate")
+        assert t.dp is not None and t.optimizer.foreign_rows
+        try:
+            dl = DeviceDataLoader(sparse.to(dev()), names, dense.to(dev()), dnames, label.to(dev()), B, shuffle=False)
+            losses = (t.train_one_epoch(dl), t.train_one_epoch(dl))
+            assert t._graph is not None and t.dp_graph == "single"
+        finally:
+            t.dp.close()
+        assert (seen.get("rh_adam_lazy_step_ahead_touched", 0) > 0) == (form == "merged"), (form, seen)
+        assert (seen.get("rh_adam_sweep_gate", 0) > 0) == (form in ("merged", "behind")), (form, seen)
+        twins.append((t, model, losses, init))
+    for t, model, losses, _ in twins[1:]:
+        assert losses == twins[0][2]
+        _assert_bitwise_twins(twins[0][0], t, twins[0][1], model)
+
+
 def test_data_parallel_step_keeps_both_uses_of_a_linear_shared_across_two_embedding_lookups(nccl_world1, monkeypatch):
     """Round-5 advisor finding (distributed.DenseGradBucket.flush): the data-parallel step packs dense gradients from their
     partial slabs and starts the all-reduce from the pre-embedding-backward hook, in the MIDDLE of the backward.  A slab is

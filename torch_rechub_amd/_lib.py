@@ -152,6 +152,9 @@ SIGNATURES = {
     "rh_adam_sweep_release": [c_ptr, c_ptr],
     "rh_adam_lazy_step_ahead": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                 c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr],
+    "rh_adam_lazy_step_ahead_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr,
+                                        c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr,
+                                        c_int, c_ptr],
     "rh_adam_lazy_step_ahead_wgrad": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr,
                                       c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int,
                                       c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],

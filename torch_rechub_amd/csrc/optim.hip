@@ -808,6 +808,10 @@ struct StepAheadParts {
   int nC, chunksC;  // part C: chunksC x F workgroups of `look` samples
   int nD;           // part D
   int w_order;      // adam_lazy_step_ahead_wgrad_kernel: how part W is dealt among the others (RH_TUNE_WGRAD_RIDER_ORDER)
+  // rh_adam_lazy_step_ahead_touched (round 6, data parallel): part A walks BA rows of another index matrix -- the GATHERED
+  // lookups of every rank's batch, columns idescA -- instead of the batch at dataset positions pos - B .. (BA = 0)
+  const int64_t* idescA;
+  int BA;
 };
 
 template <int LPR>
@@ -823,6 +827,13 @@ __device__ __forceinline__ void step_ahead_body(const LazySweepArgs& a, const St
   if (bx < parts.nA) {
     LazyTouchedArgs ta = a.touch;
     ta.spb = parts.spbA;
+    if (parts.BA > 0) {  // (launch-uniform) the touched rows come from an index matrix of their own: the plain touched pass
+      ta.idesc = parts.idescA;
+      ta.B = parts.BA;
+      ta.off = 0;
+      lazy_touched_body<LPR, int64_t, false, false, false, true>(ta, bx % parts.chunksA, bx / parts.chunksA);
+      return;
+    }
     ta.off = -(int64_t)ta.B;
     lazy_touched_body<LPR, int64_t, false, true, false, true>(ta, bx % parts.chunksA, bx / parts.chunksA);
     return;
@@ -1519,7 +1530,7 @@ static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, c
                            const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
                            int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
                            int64_t* sparse_out, float* dense_out, float* label_out, int look_depth,
-                           const rh_wgrad::WgradGroupArgs* ga, void* stream);
+                           const rh_wgrad::WgradGroupArgs* ga, const int64_t* touched_idesc, int touched_B, void* stream);
 
 extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                                        const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
@@ -1528,7 +1539,23 @@ extern "C" int rh_adam_lazy_step_ahead(const int64_t* ldesc, int T, const int64_
                                        const float* label, int64_t* sparse_out, float* dense_out, float* label_out,
                                        int look_depth, void* stream) {
   return step_ahead_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, err_flag, perm, pos, N,
-                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, nullptr, stream);
+                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, nullptr, nullptr, 0, stream);
+}
+
+// rh_adam_lazy_step_ahead whose touched-rows part walks touched_B rows of ANOTHER index matrix (touched_idesc: F column
+// pointers + F strides, int64 indices) -- the gathered lookups of every rank's batch under data parallelism with replicated
+// tables -- instead of the batch before the one it assembles.  Everything else as rh_adam_lazy_step_ahead.
+extern "C" int rh_adam_lazy_step_ahead_touched(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                               const double* hyper, const float* ring, int ring_size,
+                                               const int64_t* field_table, const int64_t* idesc, int B, int F, int32_t* err_flag,
+                                               const int64_t* perm, const int64_t* pos, int64_t N, const int64_t* sparse, int Fd,
+                                               const float* dense, int ND, const float* label, int64_t* sparse_out,
+                                               float* dense_out, float* label_out, int look_depth,
+                                               const int64_t* touched_idesc, int touched_B, void* stream) {
+  RH_REQUIRE(touched_idesc != nullptr && touched_B >= 1, RH_E_BADARG, "rh_adam_lazy_step_ahead_touched: no touched index matrix");
+  return step_ahead_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, err_flag, perm, pos, N,
+                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, nullptr, touched_idesc,
+                         touched_B, stream);
 }
 
 // rh_adam_lazy_step_ahead whose launch also carries n <= 8 weight-gradient problems (arrays as rh_linear_wgrad_partial_group:
@@ -1545,7 +1572,7 @@ extern "C" int rh_adam_lazy_step_ahead_wgrad(const int64_t* ldesc, int T, const 
   const int rc = rh_wgrad_group_fill(wn, wg, wldg, wx, wldx, wB, wN, wK, wpartial, &ga, "rh_adam_lazy_step_ahead_wgrad");
   if (rc != 0) return rc;
   return step_ahead_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, err_flag, perm, pos, N,
-                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, &ga, stream);
+                         sparse, Fd, dense, ND, label, sparse_out, dense_out, label_out, look_depth, &ga, nullptr, 0, stream);
 }
 
 static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
@@ -1553,7 +1580,7 @@ static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, c
                            const int64_t* idesc, int B, int F, int32_t* err_flag, const int64_t* perm, const int64_t* pos,
                            int64_t N, const int64_t* sparse, int Fd, const float* dense, int ND, const float* label,
                            int64_t* sparse_out, float* dense_out, float* label_out, int look_depth,
-                           const rh_wgrad::WgradGroupArgs* ga, void* stream) {
+                           const rh_wgrad::WgradGroupArgs* ga, const int64_t* touched_idesc, int touched_B, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc && perm && pos && sparse && sparse_out,
              RH_E_BADARG, "rh_adam_lazy_step_ahead: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1 && N >= B && Fd >= 1 && ND >= 0 && look_depth >= 0 &&
@@ -1590,7 +1617,9 @@ static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, c
   parts.chunksB = (B + parts.spbB - 1) / parts.spbB;
   parts.nB = parts.chunksB * F;
   parts.spbA = 256;
-  parts.chunksA = (B + parts.spbA - 1) / parts.spbA;
+  parts.idescA = touched_idesc;
+  parts.BA = touched_idesc != nullptr ? touched_B : 0;
+  parts.chunksA = ((parts.BA > 0 ? parts.BA : B) + parts.spbA - 1) / parts.spbA;
   parts.nA = parts.chunksA * F;
   parts.chunksC = (look_depth * B + look - 1) / look;
   parts.nC = parts.chunksC * F;

@@ -24,6 +24,7 @@ SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  #
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
+DP_MERGED_TAIL = _lib.ab("dptail")  # False (RECHUB_AB=dptail=0): head_behind's touched pass and next refresh as two launches
 GATED_FORK = _lib.ab("gatedfork")  # False (RECHUB_AB=gatedfork=0): a head on the chain's queue forks its sweep at a segment boundary
 DP_HEAD_BEHIND = _lib.ab("dpbehind")  # False (RECHUB_AB=dpbehind=0): the data-parallel strict head stays an eager launch in front of the graph
 STEP_AHEAD = _lib.ab("ahead")  # False (RECHUB_AB=ahead=0): the head stays an eager launch in front of every replay
@@ -525,7 +526,7 @@ class TableAdam(torch.optim.Adam):
                 seg.at_start(head_behind)
                 seg.after(tail_behind)
                 self._advance_seg = seg  # (step_tables: tail_behind counts the replayed steps)
-                self._dp_tail_head = dict(seg=seg, cargs=cargs, keep=keep)
+                self._dp_tail_head = dict(seg=seg, cargs=cargs, keep=keep, rec=rec, grp=grp, ft=ft, a=a)
                 ops.chain_gate = self._gate if CHAIN_GATE else None  # (the first own GEMM captured into this graph counts the chain start)
                 del ops.chain_gate_used[:]
             elif strict:
@@ -949,6 +950,9 @@ class TableAdam(torch.optim.Adam):
             self._decide_dense_by_volume()
         self._join_before_foreign_rows()
         groups = self._lazy_setup()
+        if self._dp_merged_tail(groups, stream):
+            del self._touch_log[:]
+            return
         if self._merged_step(groups, stream):
             del self._touch_log[:]
         else:
@@ -973,6 +977,32 @@ class TableAdam(torch.optim.Adam):
             _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
             self.gate_by_chain = bool(ops.chain_gate_used)
             ops.chain_gate = None
+
+    def _dp_merged_tail(self, groups, stream):
+        """Replicated tables under data parallelism, head_behind form: the touched-rows step over the GATHERED index matrix, the
+        dense tables' step, the next local batch's assembly and the refresh of its rows as ONE launch
+        (rh_adam_lazy_step_ahead_touched, look-ahead depth 0: the sweep is joined in every step) instead of two; then the
+        opening of this step's sweep gate.  False whenever the step is not that shape (the two launches follow)."""
+        th = self._dp_tail_head
+        if th is None or not DP_MERGED_TAIL or not self._merge_ok(groups) or graphs.active() is not th["seg"] or \
+                not torch.cuda.is_current_stream_capturing() or groups[0] is not th["grp"]:
+            return False
+        rec, grp, a, lrec = self._touch_log[0], th["grp"], th["a"], th["rec"]
+        if rec["F"] != lrec["F"] or rec["D"] != lrec["D"] or not lrec["idx_is_i64"]:
+            return False
+        self._dp_tail_head = None
+        _lib.call("rh_adam_lazy_step_ahead_touched", ops._p(grp["ldesc"]), len(grp["members"]),
+                  ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
+                  ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(th["ft"]), ops._p(lrec["idesc"]), lrec["B"],
+                  lrec["F"], ops._p(ops.err_flag(self._tables[0].device)), ops._p(a["perm"]), ops._p(a["pos"]), a["N"],
+                  ops._p(a["sparse"]), a["F"], ops._p(a["dense"]), a["ND"], ops._p(a["label"]), ops._p(a["sparse_out"]),
+                  ops._p(a["dense_out"]), ops._p(a["label_out"]), 0, ops._p(rec["idesc"]), rec["B"], stream)
+        _lib.call("rh_adam_sweep_gate_open", ops._p(self._gate), stream)
+        self.gate_by_chain = bool(ops.chain_gate_used)
+        ops.chain_gate = None
+        self._gated_fork_seg = None
+        self._sweep_pending = True
+        return True
 
     def _finish_sweep(self):
         """A sweep that was not forked (no training-mode gather since the last step, or a plain hipGraph capture)
