@@ -679,6 +679,12 @@ int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t* h_rows, c
                            const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                            const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
                            void* stream);
+/* ... for int32 or int64 index columns (idx_is_i64 as rh_adam_lazy_touched): the row-sharded step's localised indices are int32
+ * (round 6: its touched-rows step and the dense tables' step as one launch). */
+int rh_adam_lazy_step_mode_idx(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                               const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                               const int64_t* idesc, int idx_is_i64, int B, int F, int samples_per_block, int32_t* err_flag,
+                               int sweep_mode, void* stream);
 int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                        const double* hyper, const float* ring, int ring_size, int mode, int64_t t_value, void* stream);
 

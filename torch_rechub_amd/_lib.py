@@ -140,6 +140,8 @@ SIGNATURES = {
                           c_ptr],
     "rh_adam_lazy_step_mode": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                                c_ptr, c_int, c_ptr],
+    "rh_adam_lazy_step_mode_idx": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
+                                   c_ptr, c_int, c_ptr],
     "rh_adam_lazy_touched": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int,
                              c_ptr, c_ptr],
     "rh_adam_lazy_refresh_assemble": [c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr,

@@ -249,6 +249,7 @@ struct LazySweepArgs {
   // the window sweep.  Both claim a lazy row with atomicMax on its last-step word, and whoever claims it replays it AND
   // applies its gradient row (the sweep then reads the gradient of every window row)
   int touch_blocks, touch_chunks, touch_period;
+  int touch_i32;  // merged launch: the batch's index columns are int32 (row-sharded tables: localised indices)
   LazyTouchedArgs touch;
 };
 
@@ -268,7 +269,10 @@ static __device__ __forceinline__ void lazy_sweep_body(const LazySweepArgs& a, c
     const int bx = bx_, P = a.touch_period;
     const int slot_ = bx / P;
     if (bx % P == 0 && slot_ < a.touch_blocks) {
-      lazy_touched_body<LPR, int64_t, false>(a.touch, slot_ % a.touch_chunks, slot_ / a.touch_chunks);
+      if (a.touch_i32)  // (launch-uniform)
+        lazy_touched_body<LPR, int, false>(a.touch, slot_ % a.touch_chunks, slot_ / a.touch_chunks);
+      else
+        lazy_touched_body<LPR, int64_t, false>(a.touch, slot_ % a.touch_chunks, slot_ / a.touch_chunks);
       return;
     }
     bid = bx - (slot_ + 1 < a.touch_blocks ? slot_ + 1 : a.touch_blocks);
@@ -1297,7 +1301,7 @@ extern "C" int rh_adam_lazy_sweep(const int64_t* ldesc, int T, const int64_t* h_
   RH_REQUIRE(T >= 1 && T <= kMaxTensors, RH_E_UNSUPPORTED, "rh_adam_lazy_sweep: T=%d (max %d)", T, kMaxTensors);
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_sweep: ring_size must be a power of two <= %d", kMaxRing);
-  LazySweepArgs a;
+  LazySweepArgs a{};
   a.ldesc = ldesc;
   a.hyper = hyper;
   a.ring = ring;
@@ -1489,7 +1493,7 @@ extern "C" int rh_adam_lazy_refresh_assemble(const int64_t* ldesc, int T, const 
 static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
                           const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
                           const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag, int sweep_mode,
-                          void* stream) {
+                          int idx_is_i64, void* stream) {
   RH_REQUIRE(ldesc && h_rows && h_window && hyper && ring && field_table && idesc, RH_E_BADARG,
              "rh_adam_lazy_step: null pointer");
   RH_REQUIRE(T >= 1 && T <= kMaxTensors && F >= 1 && F <= 65535 && B >= 1, RH_E_BADARG, "rh_adam_lazy_step: bad shape");
@@ -1497,7 +1501,7 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
              "rh_adam_lazy_step: ring_size must be a power of two <= %d", kMaxRing);
   const int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
   LazyTouchedArgs ta{ldesc, field_table, idesc, hyper, ring, ring_size - 1, T, B, F, spb, err_flag};
-  LazySweepArgs a;
+  LazySweepArgs a{};
   a.ldesc = ldesc;
   a.hyper = hyper;
   a.ring = ring;
@@ -1505,6 +1509,7 @@ static int lazy_step_impl(const int64_t* ldesc, int T, const int64_t* h_rows, co
   a.T = T;
   a.flush = 0;
   a.t_value = -1;
+  a.touch_i32 = idx_is_i64 ? 0 : 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = RH_E_UNSUPPORTED;
   switch (D / 4) {
@@ -1589,7 +1594,7 @@ static int step_ahead_impl(const int64_t* ldesc, int T, const int64_t* h_rows, c
   RH_REQUIRE(label == nullptr || label_out != nullptr, RH_E_BADARG, "rh_adam_lazy_step_ahead: label_out null");
   RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
              "rh_adam_lazy_step_ahead: ring_size must be a power of two <= %d", kMaxRing);
-  LazySweepArgs a;
+  LazySweepArgs a{};
   a.ldesc = ldesc;
   a.hyper = hyper;
   a.ring = ring;
@@ -1690,7 +1695,7 @@ extern "C" int rh_adam_lazy_step(const int64_t* ldesc, int T, const int64_t* h_r
                                  const int64_t* idesc, int B, int F, int samples_per_block, int32_t* err_flag,
                                  void* stream) {
   return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, RH_SWEEP_WINDOW, stream);
+                        err_flag, RH_SWEEP_WINDOW, 1, stream);
 }
 
 // rh_adam_lazy_step with the sweep part restricted as rh_adam_lazy_sweep's `mode`: RH_SWEEP_DENSE_TABLES = the touched-rows
@@ -1703,5 +1708,17 @@ extern "C" int rh_adam_lazy_step_mode(const int64_t* ldesc, int T, const int64_t
   RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
              "rh_adam_lazy_step_mode: sweep_mode %d", sweep_mode);
   return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
-                        err_flag, sweep_mode, stream);
+                        err_flag, sweep_mode, 1, stream);
+}
+
+// rh_adam_lazy_step_mode for int32 OR int64 index columns (idx_is_i64 as rh_adam_lazy_touched): the row-sharded step's
+// localised indices are int32 -- its touched-rows step and the dense tables' step were two launches (round 6: one).
+extern "C" int rh_adam_lazy_step_mode_idx(const int64_t* ldesc, int T, const int64_t* h_rows, const int64_t* h_window, int D,
+                                          const double* hyper, const float* ring, int ring_size, const int64_t* field_table,
+                                          const int64_t* idesc, int idx_is_i64, int B, int F, int samples_per_block,
+                                          int32_t* err_flag, int sweep_mode, void* stream) {
+  RH_REQUIRE(sweep_mode == RH_SWEEP_WINDOW || sweep_mode == RH_SWEEP_DENSE_TABLES, RH_E_BADARG,
+             "rh_adam_lazy_step_mode_idx: sweep_mode %d", sweep_mode);
+  return lazy_step_impl(ldesc, T, h_rows, h_window, D, hyper, ring, ring_size, field_table, idesc, B, F, samples_per_block,
+                        err_flag, sweep_mode, idx_is_i64, stream);
 }

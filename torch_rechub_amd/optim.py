@@ -24,6 +24,7 @@ SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  #
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
+MERGE_I32 = _lib.ab("mergei32")  # False (RECHUB_AB=mergei32=0): int32 index batches keep the touched pass and the dense tables' step apart
 DP_MERGED_TAIL = _lib.ab("dptail")  # False (RECHUB_AB=dptail=0): head_behind's touched pass and next refresh as two launches
 GATED_FORK = _lib.ab("gatedfork")  # False (RECHUB_AB=gatedfork=0): a head on the chain's queue forks its sweep at a segment boundary
 DP_HEAD_BEHIND = _lib.ab("dpbehind")  # False (RECHUB_AB=dpbehind=0): the data-parallel strict head stays an eager launch in front of the graph
@@ -729,7 +730,9 @@ class TableAdam(torch.optim.Adam):
         if len(self._touch_log) != 1 or len(groups) != 1:
             return False
         rec, grp = self._touch_log[0], groups[0]
-        return not (grp["D"] != rec["D"] or not rec["idx_is_i64"] or rec["B"] < 1 or
+        # (int32 index columns -- the row-sharded step's localised indices -- take the merged launch too since round 6,
+        # rh_adam_lazy_step_mode_idx; the step-ahead launches read int64 indices from the dataset and check for themselves)
+        return not (grp["D"] != rec["D"] or not (rec["idx_is_i64"] or MERGE_I32) or rec["B"] < 1 or
                     not any(id(w) in grp["local"] for w in rec["weights"]))
 
     def gate_for_late_pack(self):
@@ -845,11 +848,11 @@ class TableAdam(torch.optim.Adam):
             return True
         # deferred sweep: only the dense (K = 1) tables ride along here, the lazy tables' window goes to the side stream
         mode = SWEEP_DENSE_TABLES if self.overlap_sweep else SWEEP_WINDOW
-        _lib.call("rh_adam_lazy_step_mode", ops._p(grp["ldesc"]), len(grp["members"]),
+        _lib.call("rh_adam_lazy_step_mode_idx", ops._p(grp["ldesc"]), len(grp["members"]),
                   ctypes.cast(grp["h_rows"], ctypes.c_void_p), ctypes.cast(grp["h_win"], ctypes.c_void_p), grp["D"],
                   ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, ops._p(self._field_table(rec, grp)),
-                  ops._p(rec["idesc"]), rec["B"], rec["F"], 64, ops._p(ops.err_flag(self._tables[0].device)), mode,
-                  stream)
+                  ops._p(rec["idesc"]), int(bool(rec["idx_is_i64"])), rec["B"], rec["F"], 64,
+                  ops._p(ops.err_flag(self._tables[0].device)), mode, stream)
         if self.overlap_sweep:
             self._sweep_pending = True
         return True
@@ -988,7 +991,7 @@ class TableAdam(torch.optim.Adam):
                 not torch.cuda.is_current_stream_capturing() or groups[0] is not th["grp"]:
             return False
         rec, grp, a, lrec = self._touch_log[0], th["grp"], th["a"], th["rec"]
-        if rec["F"] != lrec["F"] or rec["D"] != lrec["D"] or not lrec["idx_is_i64"]:
+        if rec["F"] != lrec["F"] or rec["D"] != lrec["D"] or not lrec["idx_is_i64"] or not rec["idx_is_i64"]:
             return False
         self._dp_tail_head = None
         _lib.call("rh_adam_lazy_step_ahead_touched", ops._p(grp["ldesc"]), len(grp["members"]),
