@@ -749,6 +749,9 @@ int rh_augru_bwd(const float* xw, const float* attn, const float* U, const float
  *           nn.DataParallel (trainers/ctr_trainer.py:53-55), which broadcasts every table every step. */
 int rh_shard_localize(const void* idx, int idx_is_i64, int64_t n_rows, int F, const int64_t* desc, int world, int rank,
                       int32_t* local, int32_t* err_flag, void* stream);
+/* The (n_rows, F) int64 index matrix (row stride ld) as contiguous int32 for the wire of the index all-gather, saturating (ids
+ * beyond int32 stay out of range, below -1 -> -1); written into the caller's slice of the gather buffer (in-place collective). */
+int rh_shard_narrow(const int64_t* idx, int64_t ld, int64_t n_rows, int F, int32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1189,6 +1189,27 @@ def test_bn_finalize_bwd_tail_sums_every_partial_of_the_statistics_pass_in_one_l
 
 
 # -- row-sharded tables (csrc/shard.hip) and the rectangular in-batch sampler -----------------------------------------
+def test_shard_narrow_is_the_saturating_int32_cast_written_into_a_slice():
+    """rh_shard_narrow == idx.clamp(-1, 2**31 - 1).to(int32) (sharding._localize, the wire format of the index all-gather), for
+    a strided (N, F) view, ids beyond int32 and below -1, written into a slice of a larger buffer (bit-exact: integers)."""
+    from torch_rechub_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, F = 1000, 7
+    base = torch.randint(-5, 2**33, (N, F + 3), generator=g, dtype=torch.int64)
+    base[0, 0], base[1, 1], base[2, 2], base[3, 3] = 2**31 - 1, 2**31, -1, -(2**40)
+    idx = base.to(dev())[:, :F]  # rows contiguous, row stride F + 3
+    buf = torch.full((3 * N, F), 77, dtype=torch.int32, device=dev())
+    out = ops.shard_narrow(idx, buf[N:2 * N])
+    torch.cuda.synchronize()
+    assert out.data_ptr() == buf[N:2 * N].data_ptr()
+    want = base[:, :F].clamp(min=-1, max=2**31 - 1).to(torch.int32)
+    assert torch.equal(buf[N:2 * N].cpu(), want)
+    assert bool((buf[:N] == 77).all()) and bool((buf[2 * N:] == 77).all())
+    with pytest.raises(ValueError):
+        ops.shard_narrow(idx.t(), buf[:F])
+
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
 def test_shard_localize_is_the_oracles(world, idx_dtype):

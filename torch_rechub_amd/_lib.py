@@ -175,6 +175,7 @@ SIGNATURES = {
     "rh_augru_fwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "rh_augru_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "rh_shard_localize": [c_ptr, c_int, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "rh_shard_narrow": [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr],
 }
 _RESTYPES = {"rh_last_error": ctypes.c_char_p, "rh_linear_wgrad_workspace": ctypes.c_int64}
 # functions whose int return value is a result, not a status

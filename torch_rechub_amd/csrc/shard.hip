@@ -40,7 +40,33 @@ __global__ __launch_bounds__(RH_BLOCK) void shard_localize_kernel(const IdxT* __
   local[i] = (int32_t)out;
 }
 
+// int64 ids -> int32 for the wire, saturating: an id beyond int32 stays out of every table's range (RH_FLAG_INDEX_OOB at the
+// localisation), it does not wrap onto a valid row; -1 and below -> -1.  Row r of the (rows, F) matrix is row stride `ld`.
+__global__ __launch_bounds__(RH_BLOCK) void shard_narrow_kernel(const int64_t* __restrict__ idx, int64_t ld, int64_t n, int F,
+                                                                int32_t* __restrict__ out) {
+  RH_CHAIN_PRIO();
+  const int64_t i = (int64_t)blockIdx.x * RH_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int64_t g = idx[(i / F) * ld + (i % F)];
+  out[i] = (int32_t)(g < -1 ? -1 : (g > 2147483647ll ? 2147483647ll : g));
+}
+
 }  // namespace
+
+// The (rows, F) int64 index matrix (row stride ld) as the contiguous int32 matrix that travels in the index all-gather of the
+// row-sharded lookup -- written straight into this rank's slice of the gather buffer, so that the collective runs in place
+// (round 6: `idx.clamp(-1, 2^31 - 1).to(int32)` + the copy into the buffer were three launches of the sharded step's head).
+extern "C" int rh_shard_narrow(const int64_t* idx, int64_t ld, int64_t n_rows, int F, int32_t* out, void* stream) {
+  RH_REQUIRE(n_rows >= 0 && F >= 1 && ld >= F, RH_E_BADARG, "rh_shard_narrow: bad shape (%lld, %d) ld %lld", (long long)n_rows, F,
+             (long long)ld);
+  if (n_rows == 0) return 0;
+  RH_REQUIRE(idx && out, RH_E_BADARG, "rh_shard_narrow: null pointer");
+  const int64_t n = n_rows * F;
+  hipLaunchKernelGGL(shard_narrow_kernel, dim3((unsigned)((n + RH_BLOCK - 1) / RH_BLOCK)), dim3(RH_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), idx, ld, n, F, out);
+  RH_LAUNCH_CHECK("rh_shard_narrow");
+  return 0;
+}
 
 extern "C" int rh_shard_localize(const void* idx, int idx_is_i64, int64_t n_rows, int F, const int64_t* desc,
                                  int world, int rank, int32_t* local, int32_t* err_flag, void* stream) {

@@ -2440,6 +2440,17 @@ def inbatch_sample(batch_size, k, device, seed=None, cols=None, row0=0):
     return out
 
 
+def shard_narrow(idx, out):
+    """``out`` (N, F) int32, contiguous <- the int64 index matrix ``idx`` (N, F) (rows contiguous, any row stride), saturating
+    (``rh_shard_narrow``: what ``idx.clamp(-1, 2**31 - 1).to(torch.int32)`` computes, written where the caller says)."""
+    require_hip(idx, out)
+    if idx.dim() != 2 or idx.dtype != torch.int64 or idx.stride(1) != 1 or out.shape != idx.shape or \
+            out.dtype != torch.int32 or not out.is_contiguous():
+        raise ValueError("shard_narrow: idx (N, F) int64 with contiguous rows, out (N, F) contiguous int32")
+    _lib.call("rh_shard_narrow", _p(idx), idx.stride(0), int(idx.shape[0]), int(idx.shape[1]), _p(out), _stream())
+    return out
+
+
 def shard_localize(idx, desc, world, rank, out=None):
     """int32 (N, F): the index matrix ``idx`` (N, F) of a global batch rewritten for this rank's table shards
     (``rh_shard_localize``; desc = device int64 [vocab | pad | sink] per field, see sharding.RowShard)."""

@@ -294,7 +294,14 @@ def _localize(embs, idx, group, static=False):
             idx.dtype, str(idx.device), sh0.rank)
     idx_all, loc, rows = _buffers.get(site, make) if static else make()
     # saturating: an id beyond int32 must stay out of range (-> RH_FLAG_INDEX_OOB), not wrap onto a valid row
-    send = idx.clamp(min=-1, max=2**31 - 1).to(torch.int32) if narrow else idx
+    if narrow and idx.is_cuda and idx.stride(1) == 1:
+        # (round 6) narrowed straight into this rank's slice of the gather buffer: the collective then runs IN PLACE -- one
+        # launch where clamp, cast and the copy into the buffer were three in the sharded step's head
+        world = dist.get_world_size(group)
+        r = dist.get_rank(group) if world > 1 else 0
+        send = ops.shard_narrow(idx, idx_all[r * idx.shape[0]:(r + 1) * idx.shape[0]])
+    else:
+        send = idx.clamp(min=-1, max=2**31 - 1).to(torch.int32) if narrow else idx
     all_gather_cat(send, group, out=idx_all)
     return ops.shard_localize(idx_all, desc, sh0.world, sh0.rank, out=loc), rows
 
