@@ -617,6 +617,13 @@ int rh_adam_sweep_release(int64_t* gate, void* stream);
 int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* field_table, const int64_t* idesc,
                          int idx_is_i64, int B, int F, int D, const double* hyper, const float* ring,
                          int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
+/* n <= 4 rh_adam_lazy_touched passes over ONE table group as one launch (round 6): the refreshes in front of the first gather of a
+ * step with several gathers (two-tower / sequence models: user, item, history lookups; reference: one nn.Embedding call each,
+ * basic/layers.py:83-99), or the touched-rows steps at its end.  field_table / idesc: HOST arrays of n device pointers;
+ * idx_is_i64, B, F: host arrays of n entries. */
+int rh_adam_lazy_touched_group(const int64_t* ldesc, int T, int n, const int64_t* const* field_table, const int64_t* const* idesc,
+                               const int* idx_is_i64, const int* B, const int* F, int D, const double* hyper, const float* ring,
+                               int ring_size, int samples_per_block, int refresh, int32_t* err_flag, void* stream);
 /* rh_adam_lazy_touched, refresh argument: 0 = the touched-rows step (rows take their gradient); 1 = pre-gather refresh of
  * every row of the batch (no gradient traffic). */
 /* rh_batch_gather + rh_adam_lazy_touched (refresh = 1, int64 indices) as ONE launch (round 4): the batch is assembled into the

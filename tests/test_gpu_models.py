@@ -724,8 +724,21 @@ def test_graph_mode_flush_leaves_no_row_behind_match_trainer(monkeypatch):
     mb.load_state_dict(ma.state_dict())
     epochs = int(os.environ.get("RECHUB_SOAK_EPOCHS", 2))  # soak runs: thousands of replayed steps, same bits demanded
     results = []
+    from torch_rechub_amd import _lib
+    grouped = {"n": 0, "passes": 0}
+    real_call = _lib.call
+
+    def spy(name, *args):
+        if name == "rh_adam_lazy_touched_group":  # round 6: the step's three gathers' touched-rows passes as ONE launch
+            grouped["n"] += 1
+            grouped["passes"] += int(args[2])
+        return real_call(name, *args)
+
+    monkeypatch.setattr(_lib, "call", spy)
     for m, extra in ((ma, dict(table_update="lazy", lazy_k=4, lazy_small_rows=8)), (mb, dict(table_update="dense"))):
         ops._sample_rng.clear()  # both twins draw the same negatives: same seed, call counter from 0
+        if extra["table_update"] == "dense":
+            assert grouped["n"] >= 2 and grouped["passes"] == 3 * grouped["n"], grouped  # (refreshes + end-of-step passes)
         t = MatchTrainer(m, **extra, **kw)
         dl = DeviceDataLoader(sparse.to(dev()), ["user_id", "item_id", ("hist_item_id", L)], None, [], label.to(dev()), B,
                               shuffle=False)

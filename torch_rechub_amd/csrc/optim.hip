@@ -755,6 +755,38 @@ __global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_kernel(const LazyT
   lazy_touched_body<LPR, IdxT, REFRESH>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// Up to kTouchGroup touched-rows passes (one per gather of a step with several: two-tower / sequence models) as ONE launch
+// (round 6): the refreshes in front of a step's first gather -- and the touched-rows steps at its end -- are independent passes
+// over different index batches of the same table group; as dependent launches the short ones (16 k lookups) cost a launch each
+// in front of the step's chain (DSSM: 14 + 51 + 16 us -> the longest).  Workgroups [prefix[i], prefix[i + 1]) run pass i.
+constexpr int kTouchGroup = 4;
+struct LazyTouchedGroupArgs {
+  LazyTouchedArgs rec[kTouchGroup];
+  int prefix[kTouchGroup + 1];
+  int chunks[kTouchGroup];
+  int i64[kTouchGroup];
+  int n;
+};
+
+template <int LPR, bool REFRESH>
+__global__ __launch_bounds__(RH_BLOCK) void adam_lazy_touched_group_kernel(const LazyTouchedGroupArgs g) {
+  RH_CHAIN_PRIO();
+  const int bx = (int)blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kTouchGroup; ++k) i += (k < g.n && bx >= g.prefix[k]) ? 1 : 0;
+  const int local = bx - g.prefix[i];
+  // (workgroup-uniform branches; a by-value copy keeps the pass's arguments in scalar registers)
+#pragma unroll
+  for (int k = 0; k < kTouchGroup; ++k) {
+    if (k == i) {
+      if (g.i64[k]) lazy_touched_body<LPR, int64_t, REFRESH>(g.rec[k], local % g.chunks[k], local / g.chunks[k]);
+      else lazy_touched_body<LPR, int, REFRESH>(g.rec[k], local % g.chunks[k], local / g.chunks[k]);
+      return;
+    }
+  }
+}
+
 // Batch assembly + pre-gather refresh as ONE launch (round 4; reference: TorchDataset.__getitem__ + default_collate,
 // torch_rechub/utils/data.py:14-25,61-83, then the rows optimizer.step() would have left in the tables, trainers/ctr_trainer.py:99).
 // Row blockIdx.y < F of the grid: the refresh of field f for its 64-sample chunk, the indices read from the dataset through
@@ -1447,6 +1479,53 @@ extern "C" int rh_adam_lazy_touched(const int64_t* ldesc, int T, const int64_t* 
   }
 #undef RH_LT
   RH_LAUNCH_CHECK("rh_adam_lazy_touched");
+  return 0;
+}
+
+// n <= 4 rh_adam_lazy_touched passes over ONE table group (ldesc, T, D, hyper, ring) as one launch: arrays of n host entries
+// (field_table / idesc: device pointers; idx_is_i64, B, F per pass).  refresh as rh_adam_lazy_touched, for all passes.
+extern "C" int rh_adam_lazy_touched_group(const int64_t* ldesc, int T, int n, const int64_t* const* field_table,
+                                          const int64_t* const* idesc, const int* idx_is_i64, const int* B, const int* F, int D,
+                                          const double* hyper, const float* ring, int ring_size, int samples_per_block,
+                                          int refresh, int32_t* err_flag, void* stream) {
+  RH_REQUIRE(ldesc && field_table && idesc && idx_is_i64 && B && F && hyper && ring, RH_E_BADARG,
+             "rh_adam_lazy_touched_group: null pointer");
+  RH_REQUIRE(T >= 1 && n >= 1 && n <= kTouchGroup, RH_E_BADARG, "rh_adam_lazy_touched_group: %d passes (1..%d)", n, kTouchGroup);
+  RH_REQUIRE(ring_size > 0 && (ring_size & (ring_size - 1)) == 0 && ring_size <= kMaxRing, RH_E_BADARG,
+             "rh_adam_lazy_touched_group: ring_size must be a power of two <= %d", kMaxRing);
+  const int spb = samples_per_block <= 0 ? 256 : ((samples_per_block + 63) / 64) * 64;
+  LazyTouchedGroupArgs g{};
+  g.n = n;
+  g.prefix[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    RH_REQUIRE(field_table[i] && idesc[i] && F[i] >= 1 && F[i] <= 65535 && B[i] >= 0, RH_E_BADARG,
+               "rh_adam_lazy_touched_group: bad pass %d", i);
+    g.rec[i] = LazyTouchedArgs{ldesc, field_table[i], idesc[i], hyper, ring, ring_size - 1, T, B[i], F[i], spb, err_flag};
+    g.chunks[i] = (B[i] + spb - 1) / spb;
+    if (g.chunks[i] < 1) g.chunks[i] = 1;  // (an empty pass: its workgroups find no sample)
+    g.i64[i] = idx_is_i64[i] ? 1 : 0;
+    const int64_t blocks = B[i] > 0 ? (int64_t)g.chunks[i] * F[i] : 0;
+    RH_REQUIRE((int64_t)g.prefix[i] + blocks < (1ll << 30), RH_E_UNSUPPORTED, "rh_adam_lazy_touched_group: grid too large");
+    g.prefix[i + 1] = g.prefix[i] + (int)blocks;
+  }
+  for (int i = n; i < kTouchGroup; ++i) g.prefix[i + 1] = g.prefix[n], g.chunks[i] = 1;
+  if (g.prefix[n] == 0) return 0;
+  const dim3 grid((unsigned)g.prefix[n]);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define RH_LTG(LPR)                                                                                          \
+  if (refresh) hipLaunchKernelGGL((adam_lazy_touched_group_kernel<LPR, true>), grid, dim3(RH_BLOCK), 0, s, g); \
+  else hipLaunchKernelGGL((adam_lazy_touched_group_kernel<LPR, false>), grid, dim3(RH_BLOCK), 0, s, g);
+  switch (D / 4) {
+    case 1: RH_LTG(1) break;
+    case 2: RH_LTG(2) break;
+    case 4: RH_LTG(4) break;
+    case 8: RH_LTG(8) break;
+    case 16: RH_LTG(16) break;
+    case 32: RH_LTG(32) break;
+    default: rh_set_error("rh_adam_lazy_touched_group: embed_dim %d unsupported", D); return RH_E_UNSUPPORTED;
+  }
+#undef RH_LTG
+  RH_LAUNCH_CHECK("rh_adam_lazy_touched_group");
   return 0;
 }
 

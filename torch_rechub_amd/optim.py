@@ -24,6 +24,7 @@ SWEEP_WINDOW, SWEEP_FLUSH, SWEEP_LAZY_TABLES, SWEEP_DENSE_TABLES = 0, 1, 2, 3  #
 EAGER_HEAD = _lib.ab("eagerhead")  # False (RECHUB_AB=eagerhead=0): the one-kernel head stays a captured graph segment
 ASSEMBLE_WITH_REFRESH = _lib.ab("assemble")  # False (RECHUB_AB=assemble=0): rh_batch_gather and the refresh as two launches
 RELAXED_JOIN = _lib.ab("lookahead")  # False (RECHUB_AB=lookahead=0): the eager head on the sweep's queue, strict join (below)
+TOUCH_GROUP = _lib.ab("touchgroup")  # False (RECHUB_AB=touchgroup=0): one touched-rows launch per gather of a step with several
 MERGE_I32 = _lib.ab("mergei32")  # False (RECHUB_AB=mergei32=0): int32 index batches keep the touched pass and the dense tables' step apart
 DP_MERGED_TAIL = _lib.ab("dptail")  # False (RECHUB_AB=dptail=0): head_behind's touched pass and next refresh as two launches
 GATED_FORK = _lib.ab("gatedfork")  # False (RECHUB_AB=gatedfork=0): a head on the chain's queue forks its sweep at a segment boundary
@@ -276,6 +277,33 @@ class TableAdam(torch.optim.Adam):
                       ops._p(rec["idesc"]), rec["idx_is_i64"], rec["B"], rec["F"], rec["D"], ops._p(self._t_hyper),
                       ops._p(self._t_ring), self.RING, 64, int(refresh),
                       ops._p(ops.err_flag(self._tables[0].device)), stream)
+
+    def _touch_many(self, recs, groups, stream, refresh=False):
+        """``_touch`` for several gathers of one step: ONE launch (rh_adam_lazy_touched_group) when they all belong to the same
+        table group, one launch each otherwise."""
+        recs = list(recs)
+        if TOUCH_GROUP and 2 <= len(recs) <= 4 and len(groups) >= 1:
+            owner = []
+            for rec in recs:
+                mine = [g for g in groups if g["D"] == rec["D"] and any(id(w) in g["local"] for w in rec["weights"])]
+                owner.append(mine[0] if len(mine) == 1 else None)
+            grp = owner[0]
+            if grp is not None and all(o is grp for o in owner):
+                n = len(recs)
+                fts = [self._field_table(rec, grp) for rec in recs]
+                ft = (ctypes.c_void_p * n)(*[t.data_ptr() for t in fts])
+                idesc = (ctypes.c_void_p * n)(*[rec["idesc"].data_ptr() for rec in recs])
+                i64 = (ctypes.c_int * n)(*[int(bool(rec["idx_is_i64"])) for rec in recs])
+                Bs = (ctypes.c_int * n)(*[int(rec["B"]) for rec in recs])
+                Fs = (ctypes.c_int * n)(*[int(rec["F"]) for rec in recs])
+                cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+                _lib.call("rh_adam_lazy_touched_group", ops._p(grp["ldesc"]), len(grp["members"]), n, cast(ft), cast(idesc),
+                          cast(i64), cast(Bs), cast(Fs), grp["D"], ops._p(self._t_hyper), ops._p(self._t_ring), self.RING, 64,
+                          int(refresh), ops._p(ops.err_flag(self._tables[0].device)), stream)
+                del fts
+                return
+        for rec in recs:
+            self._touch(rec, groups, stream, refresh=refresh)
 
     def on_gather(self, rec):
         """Pre-gather event: replay the rows of this index batch up to the last completed step (their gradient rows are
@@ -581,8 +609,7 @@ class TableAdam(torch.optim.Adam):
             if len(recs) < 2 or (self._gathers_per_step or 0) != len(recs) or not same(rec, recs[0]):
                 return False
             groups = self._lazy_setup()
-            for r in recs:
-                self._touch(dict(r, training=True), groups, ops._stream(), refresh=True)
+            self._touch_many([dict(r, training=True) for r in recs], groups, ops._stream(), refresh=True)
             self._ahead = len(recs)
             self._gathers = 1
             self._cut_fork(seg, head_only=True)  # every replay: the side-stream launch, after the refreshes above
@@ -959,8 +986,8 @@ class TableAdam(torch.optim.Adam):
         if self._merged_step(groups, stream):
             del self._touch_log[:]
         else:
-            for rec in self._touch_log:  # rows of the batch are at step t-1 (refreshed before the forward): one step each
-                self._touch(rec, groups, stream)
+            # rows of the batches are at step t-1 (refreshed before the forward): one step each
+            self._touch_many(self._touch_log, groups, stream)
             del self._touch_log[:]
             if self.overlap_sweep:
                 self._sweep(SWEEP_DENSE_TABLES, stream)  # small tables take their gradient now; the rest is deferred
