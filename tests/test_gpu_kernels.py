@@ -1064,6 +1064,75 @@ def test_batchnorm_only_mode_vs_torch(B, C):
         close(ops.bn_relu_dropout(h0, bn_mine, 0.0, relu=False), bn_ref(h0).cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="eval")
 
 
+def test_dice_mlp_over_many_rows_takes_the_tile_gemm_with_the_statistics_epilogue(monkeypatch):
+    """Round 6: the forward of a Linear over (B L) rows in front of BatchNorm1d -> Dice (DIN's attention MLP,
+    models/ranking/din.py:75-85 over basic/layers.py:279-288) runs on the tile GEMM, whose epilogue hands the BatchNorm its
+    per-slab (sum, M2) -- no statistics pass over the (B L, C) tensor (ops.linear_chunk_stats -> bn_dice / bn_dice_head with
+    chunk_stats).  Against the float64 modules and against its own twin (library GEMM + statistics pass, RECHUB_AB=tallgemm=0):
+    output, input gradient, every parameter gradient, running statistics, num_batches_tracked counted once."""
+    from torch_rechub_amd import _lib, ops
+    from torch_rechub_amd.basic.activation import Dice
+    from torch_rechub_amd.basic.layers import MLP
+    torch.manual_seed(5)
+    N, K = 70016, 48
+    x0 = (torch.randn(N, K) * 0.7).to(dev())
+    gy = torch.randn(N, 1).to(dev())
+    ref = MLP(K, output_layer=True, dims=[64, 32], activation="dice").to(dev())
+    with torch.no_grad():
+        for m in ref.mlp:
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_()
+    seen = {"stats": 0, "plain": 0, "from_partial": 0}
+    real_call = _lib.call
+
+    def spy(name, *args):
+        if name == "rh_linear_fwd":
+            seen["stats" if args[10].value else "plain"] += 1  # (argument 10: the statistics array)
+        elif name == "rh_bn_stats_from_partial":
+            seen["from_partial"] += 1
+        return real_call(name, *args)
+
+    monkeypatch.setattr(_lib, "call", spy)
+    outs = []
+    for tall in (True, False):
+        monkeypatch.setattr(ops, "TALL_GEMM_FWD", tall)
+        m = MLP(K, output_layer=True, dims=[64, 32], activation="dice").to(dev())
+        m.load_state_dict(ref.state_dict())
+        m.train()
+        for k in seen:
+            seen[k] = 0
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        assert (seen["stats"] == 2 and seen["from_partial"] == 2) if tall else (seen["stats"] == 0 and seen["from_partial"] == 0), seen
+        bns = [q for q in m.mlp if isinstance(q, torch.nn.BatchNorm1d)]
+        assert all(int(b.num_batches_tracked) == 1 for b in bns)
+        outs.append((y.detach(), x.grad.detach(), {n: p.grad.detach() for n, p in m.named_parameters()},
+                     [b.running_var.detach().clone() for b in bns]))
+    # float64 modules (torch BatchNorm1d in float64, the reference's Dice formula)
+    r64 = MLP(K, output_layer=True, dims=[64, 32], activation="dice").double().to(dev())
+    r64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    r64.train()
+    for q in r64.mlp:
+        assert not isinstance(q, Dice) or q.alpha.dtype == torch.float64
+    x64 = x0.double().requires_grad_(True)
+    h = x64
+    for q in r64.mlp:  # (module by module: the float64 input takes torch's own kernels, not the HIP path)
+        h = _dice_ref(h, q.alpha) if isinstance(q, Dice) else q(h)
+    h.backward(gy.double())
+    for what, (y, gx, gp, rv) in zip(("tile GEMM + epilogue statistics", "library GEMM + statistics pass"), outs):
+        close(y, h.detach().cpu().numpy(), rtol=3e-4, atol_scale=1e-5, what=f"{what}: out")
+        close(gx, x64.grad.cpu().numpy(), rtol=2e-3, atol_scale=5e-5, what=f"{what}: dx")
+        for n, p in r64.named_parameters():
+            if n in ("mlp.0.bias", "mlp.4.bias"):
+                continue  # (the bias of a Linear in front of a BatchNorm has a zero gradient: what is left is cancellation noise)
+            close(gp[n], p.grad.cpu().numpy(), rtol=2e-3, atol_scale=5e-5, what=f"{what}: d {n}")
+    for a, b in zip(outs[0][3], outs[1][3]):
+        close(a, b.cpu().numpy(), rtol=2e-5, what="running_var: epilogue statistics vs statistics pass")
+
+
 @pytest.mark.parametrize("N,C", [(25600, 256), (1000, 128), (77, 36), (300, 200), (409600, 64)])
 def test_bn_dice_folded_vs_modules(N, C):
     """Linear's BatchNorm1d -> Dice with the normalisation folded into the Dice passes == the two modules one after the

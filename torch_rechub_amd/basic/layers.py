@@ -371,10 +371,16 @@ class MLP(nn.Module):
                   not (torch.is_grad_enabled() and not mods[i + 1].training)):
                 # Linear -> BatchNorm1d -> Dice (DIN's ActivationUnit): the normalisation is folded into the Dice passes
                 head = self.head_after(mods, i + 3, mods[i].out_features, mods[i + 1], mods[i + 2])
+                lin, bn = mods[i], mods[i + 1]
+                if type(lin) is nn.Linear and bn.training and ops.linear_ok(x, lin.weight):
+                    # ((B L)-row inputs: the tile GEMM's epilogue emits the BatchNorm's per-slab statistics, round 6)
+                    h, cst, crows = ops.linear_chunk_stats(x, lin.weight, lin.bias)
+                else:
+                    h, cst, crows = self._linear(lin, x), None, 0
                 if head is not None:
                     # ... -> Linear(C, 1) at the end of the stack: the Dice output is never written (ops.bn_dice_head)
-                    return ops.bn_dice_head(self._linear(mods[i], x), mods[i + 1], mods[i + 2].alpha, mods[i + 2].epsilon, head)
-                x = ops.bn_dice(self._linear(mods[i], x), mods[i + 1], mods[i + 2].alpha, mods[i + 2].epsilon)
+                    return ops.bn_dice_head(h, bn, mods[i + 2].alpha, mods[i + 2].epsilon, head, chunk_stats=cst, chunk_rows=crows)
+                x = ops.bn_dice(h, bn, mods[i + 2].alpha, mods[i + 2].epsilon, chunk_stats=cst, chunk_rows=crows)
                 i += 3
             elif (i + 3 < len(mods) and isinstance(mods[i], nn.Linear) and type(mods[i + 1]) is nn.BatchNorm1d and
                   self._bn_ok(mods[i + 1], x) and isinstance(mods[i + 3], nn.Dropout) and

@@ -166,8 +166,19 @@ static __device__ __forceinline__ void chan_combine(const BnArgs& a, int c, int 
   }
 #pragma unroll
   for (int i = 0; i < MAXIT; ++i) s += ps[i];
-  if (cok)
-    for (int k = grp + MAXIT * GROUPS; k < a.nchunks; k += GROUPS) s += a.partial[((int64_t)k * 2 + 0) * a.C + c];
+  if (cok) {
+    // (lists longer than MAXIT * GROUPS -- the 6400 slabs of a tile GEMM over 409 600 rows: batches of 8 independent loads, the
+    // adds in chunk order; as a load -> add chain this tail cost ~2.5 us per chunk beside a bandwidth-bound neighbour)
+    int k = grp + MAXIT * GROUPS;
+    for (; k + 7 * GROUPS < a.nchunks; k += 8 * GROUPS) {
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = a.partial[((int64_t)(k + i * GROUPS) * 2 + 0) * a.C + c];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += t[i];
+    }
+    for (; k < a.nchunks; k += GROUPS) s += a.partial[((int64_t)k * 2 + 0) * a.C + c];
+  }
   red[grp * (COLS + 1) + cl] = s;
   __syncthreads();
   s = red[cl];
@@ -188,7 +199,22 @@ static __device__ __forceinline__ void chan_combine(const BnArgs& a, int c, int 
     }
   }
   if (cok) {
-    for (int k = grp + MAXIT * GROUPS; k < a.nchunks; k += GROUPS) {
+    int k = grp + MAXIT * GROUPS;
+    for (; k + 7 * GROUPS < a.nchunks; k += 8 * GROUPS) {
+      float t0[8], t1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        t0[i] = a.partial[((int64_t)(k + i * GROUPS) * 2 + 0) * a.C + c];
+        t1[i] = a.partial[((int64_t)(k + i * GROUPS) * 2 + 1) * a.C + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = k + i * GROUPS;
+        const float d = t0[i] * (kk == last ? inv_tail : inv_full) - mean;
+        m2 += fmaf((kk == last ? tail : full) * d, d, t1[i]);
+      }
+    }
+    for (; k < a.nchunks; k += GROUPS) {
       const float d = a.partial[((int64_t)k * 2 + 0) * a.C + c] * (k == last ? inv_tail : inv_full) - mean;
       m2 += fmaf((k == last ? tail : full) * d, d, a.partial[((int64_t)k * 2 + 1) * a.C + c]);
     }

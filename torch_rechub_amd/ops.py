@@ -914,6 +914,20 @@ def _own_gemm(M, N, K):
     return 0 < M <= _GEMM_MAX_M and N <= _GEMM_MAX_NK and K <= _GEMM_MAX_NK
 
 
+# Round 6: the FORWARD of an nn.Linear over (B L) rows (DIN's attention MLP: 409 600 x 256 -> 128) on the tile kernel too -- on
+# those shapes it is faster than the library GEMM it replaced (configs[3] 5.02-5.17 -> 4.91-4.92 ms per step, same box; the input
+# gradient is not: 5.18-5.44 with both), and its epilogue hands the BatchNorm that follows the per-slab statistics of the output
+# (no statistics pass over the (B L, C) tensor).  RECHUB_AB=tallgemm=0: the library GEMM + the statistics pass.
+TALL_GEMM_FWD = _lib.ab("tallgemm")
+_TALL_MIN_M = 65536
+_STATS_ONLY = object()  # _LinearFn: per-slab statistics of the output WITHOUT the BatchNorm bookkeeping of rh_linear_fwd
+
+
+def _tall_fwd(M, N, K):
+    # (the measured territory: the attention MLP's widths; wide layers stay with the library's larger tiles)
+    return TALL_GEMM_FWD and M >= _TALL_MIN_M and N <= 256 and K <= 512
+
+
 class _LinearFn(torch.autograd.Function):
     """nn.Linear: forward and input gradient on the f32-MFMA tile kernel at CTR batch sizes (library GEMM otherwise),
     weight + bias gradient on the split-batch MFMA kernel.  With ``want_stats`` the forward also returns the per-slab
@@ -928,21 +942,26 @@ class _LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         stats = ctr = None
-        if _own_gemm(M, N, K) and weight.is_contiguous() and x.stride(1) == 1:
+        stats_only = bn_batches is _STATS_ONLY
+        if (_own_gemm(M, N, K) or _tall_fwd(M, N, K)) and weight.is_contiguous() and x.stride(1) == 1:
             y = torch.empty((M, N), dtype=torch.float32, device=x.device)
             rng = None
             if want_stats:
                 rows = _lib.call("rh_gemm_stats_rows", M, N)
                 stats = torch.empty((-(-M // rows), 2, N), dtype=torch.float32, device=x.device)
-                ctr = torch.empty(1, dtype=torch.int64, device=x.device)
-                rng = _dropout_rng(x.device)
+                if not stats_only:
+                    ctr = torch.empty(1, dtype=torch.int64, device=x.device)
+                    rng = _dropout_rng(x.device)
             _lib.call("rh_linear_fwd", _p(x), x.stride(0), _p(weight), K, _p(bias), M, N, K, _p(y), N, _p(stats), _p(rng),
-                      _p(ctr), _p(bn_batches if want_stats else None), _stream())
+                      _p(ctr), _p(bn_batches if want_stats and not stats_only else None), _stream())
         else:
             y = torch.nn.functional.linear(x, weight, bias)
         if want_stats:
             if stats is None:
                 return y, None, None
+            if stats_only:
+                ctx.mark_non_differentiable(stats)
+                return y, stats, None
             ctx.mark_non_differentiable(stats, ctr)
             return y, stats, ctr
         return y
@@ -965,9 +984,23 @@ class _LinearFn(torch.autograd.Function):
         return gx, dW, db, None
 
 
+def linear_chunk_stats(x, weight, bias=None):
+    """(h, chunk_stats, chunk_rows) for a Linear in front of a training-mode BatchNorm1d whose statistics the consumer finalises
+    itself (``bn_dice`` / ``bn_dice_head`` with ``chunk_stats``: rh_bn_stats_from_partial does the BatchNorm bookkeeping): on
+    (B L)-row inputs the tile GEMM's epilogue emits the per-slab (sum, M2) of h; otherwise (h, None, 0)."""
+    if linear_ok(x, weight) and x.dim() == 2 and _tall_fwd(x.shape[0], weight.shape[0], weight.shape[1]) and \
+            weight.is_contiguous() and x.stride(1) == 1:
+        h, st, _ = _LinearFn.apply(x, weight, bias, _STATS_ONLY)
+        if st is not None:
+            return h, st, _lib.call("rh_gemm_stats_rows", int(x.shape[0]), int(weight.shape[0]))
+        return h, None, 0
+    return linear(x, weight, bias), None, 0
+
+
 def linear(x, weight, bias=None):
     """F.linear for 2-D fp32 HIP activations; see _LinearFn."""
-    if linear_ok(x, weight) and (_own_gemm(x.shape[0], weight.shape[0], weight.shape[1]) or (
+    if linear_ok(x, weight) and (_own_gemm(x.shape[0], weight.shape[0], weight.shape[1]) or _tall_fwd(
+            x.shape[0], weight.shape[0], weight.shape[1]) or (
             torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)))):
         return _LinearFn.apply(x, weight, bias, None)
     return torch.nn.functional.linear(x, weight, bias)
