@@ -58,8 +58,9 @@ def all_gather_cat(t, group=None, out=None):
     if _EMULATE_WORLD > 1 and world == 1:
         if out is None or out.shape[0] != _EMULATE_WORLD * t.shape[0]:
             out = torch.empty((_EMULATE_WORLD * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        for r in range(_EMULATE_WORLD):
-            out[r * t.shape[0]:(r + 1) * t.shape[0]].copy_(t)
+        # ONE broadcast copy (a real all-gather is one collective launch, not N copies: seven extra 5 us launches per gather
+        # made the emulated 8-rank step look 65 us longer than its kernels)
+        out.view((_EMULATE_WORLD,) + tuple(t.shape)).copy_(t.unsqueeze(0).expand((_EMULATE_WORLD,) + tuple(t.shape)))
         return out
     if out is None:
         out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
