@@ -828,7 +828,10 @@ def test_cross_mix_and_v2_epilogues_vs_reference_formula(B, d, E):
 # ----------------------------------------------------------------------------------------------------------
 # csrc/linear.hip: split-batch MFMA weight gradient, fused output head, BCE
 @pytest.mark.parametrize("B,N,K,pad", [(4096, 256, 429, 0), (4096, 128, 256, 0), (100, 1, 7, 0), (37, 70, 130, 3),
-                                       (1, 5, 3, 0), (8191, 64, 64, 0), (50000, 36, 64, 0)])
+                                       (1, 5, 3, 0), (8191, 64, 64, 0), (50000, 36, 64, 0),
+                                       # long reductions of 2 .. 8 tiles: ONE workgroup per row split computes the whole slab
+                                       # (linear_wgrad_rows_kernel, round 6); 20 tiles: back to one workgroup per tile
+                                       (40000, 128, 256, 0), (33001, 130, 70, 3), (70001, 256, 64, 0), (40000, 200, 300, 0)])
 def test_linear_wgrad_vs_float64(B, N, K, pad):
     """dW = g^T x, db = colsum(g): f32 MFMA == k-ordered fmaf chain, so only the summation order differs from float64."""
     from torch_rechub_amd import ops

@@ -49,6 +49,100 @@ __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
   linear_wgrad_group_body<true>(ga, red, (int)blockIdx.x);
 }
 
+// Long reductions whose whole output is at most kRowsMaxTiles tiles (round 6; DIN's attention MLP: 409 600 rows, (128, 256) and
+// (256, 64)): ONE workgroup per row split computes the WHOLE (N, K) slab -- wavefront w owns tile (w / tiles_k, w % tiles_k) and
+// walks every row pair of the split by itself.  In the tile-per-workgroup form above every 64-column slice of g is read once per
+// K tile and every slice of x once per N tile, by workgroups that the dispatcher deals to eight different XCDs: rocprofv3
+// FETCH_SIZE 1 678 MB for the (128, 256) gradient whose operands are 629 MB, 839 for the (256, 64) one (524).  Here the slices a
+// workgroup's wavefronts share come out of its own CU's vector cache / the XCD's L2.  No LDS, no cross-wavefront reduction (each
+// output element has one owner); per element the sum runs over the split's rows in order -- another order than the form above
+// (four wavefronts' interleaved rows added up afterwards), the same for every launch of this form.
+constexpr int kRowsMaxTiles = 8;
+__global__ __launch_bounds__(RH_WAVE * kRowsMaxTiles) void linear_wgrad_rows_kernel(const WgradArgs a, const int tiles_k) {
+  RH_CHAIN_PRIO();
+  const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
+  const int half = lane >> 5, c = lane & 31;
+  const int s = (int)blockIdx.x;
+  const int n0 = (wave / tiles_k) * kTile, k0 = (wave % tiles_k) * kTile;
+  const int b_lo = s * a.rows_per_split;
+  const int b_hi = min(a.B, b_lo + a.rows_per_split);
+  const int na0 = n0 + c, na1 = n0 + 32 + c, kb0 = k0 + c, kb1 = k0 + 32 + c;
+  const float* ga0 = a.g + (na0 < a.N ? na0 : 0) + (int64_t)half * a.ldg;
+  const float* ga1 = a.g + (na1 < a.N ? na1 : 0) + (int64_t)half * a.ldg;
+  const float* xb0 = a.x + (kb0 < a.K ? kb0 : 0) + (int64_t)half * a.ldx;
+  const float* xb1 = a.x + (kb1 < a.K ? kb1 : 0) + (int64_t)half * a.ldx;
+  v16f acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
+  float bs0 = 0.f, bs1 = 0.f;
+  constexpr int U = 8;  // row pairs in flight: 32 dword loads, one iteration ahead
+  float fa0[U], fa1[U], fb0[U], fb1[U], qa0[U], qa1[U], qb0[U], qb1[U];
+  auto fetch = [&](int p, float* A0, float* A1, float* B0, float* B1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = p + 2 * u;
+      A0[u] = gload<float>(ga0 + r * a.ldg);
+      A1[u] = gload<float>(ga1 + r * a.ldg);
+      B0[u] = gload<float>(xb0 + r * a.ldx);
+      B1[u] = gload<float>(xb1 + r * a.ldx);
+    }
+  };
+  auto issue = [&](const float* A0, const float* A1, const float* B0, const float* B1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B0[u], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B1[u], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B0[u], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B1[u], acc11, 0, 0, 0);
+      bs0 += A0[u];
+      bs1 += A1[u];
+    }
+  };
+  constexpr int kStep = 2 * U;
+  int p = b_lo;
+  const int last_full = b_hi - kStep;  // p <= last_full: rows p .. p + kStep - 1 exist
+  if (p <= last_full) {
+    fetch(p, fa0, fa1, fb0, fb1);
+    for (; p + kStep <= last_full; p += kStep) {
+      fetch(p + kStep, qa0, qa1, qb0, qb1);
+      issue(fa0, fa1, fb0, fb1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) fa0[u] = qa0[u], fa1[u] = qa1[u], fb0[u] = qb0[u], fb1[u] = qb1[u];
+    }
+    issue(fa0, fa1, fb0, fb1);
+    p += kStep;
+  }
+  for (; p < b_hi; p += 2) {  // ragged end, guarded per row
+    const bool ok = p + half < b_hi;
+    const int64_t r = ok ? p : b_lo - half;
+    const float m = ok ? 1.f : 0.f;
+    const float t0 = gload<float>(ga0 + r * a.ldg) * m, t1 = gload<float>(ga1 + r * a.ldg) * m;
+    const float t2 = gload<float>(xb0 + r * a.ldx) * m, t3 = gload<float>(xb1 + r * a.ldx) * m;
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t2, acc00, 0, 0, 0);
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t3, acc01, 0, 0, 0);
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t2, acc10, 0, 0, 0);
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t3, acc11, 0, 0, 0);
+    bs0 += t0;
+    bs1 += t1;
+  }
+  bs0 += __shfl_xor(bs0, 32);
+  bs1 += __shfl_xor(bs1, 32);
+  float* outW = a.direct ? a.dW : a.partial + (int64_t)s * a.N * a.K;
+  float* outB = a.direct ? a.db : a.partial + (int64_t)a.S * a.N * a.K + (int64_t)s * a.N;
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int nA = n0 + row, nB = n0 + 32 + row, kA = k0 + c, kB = k0 + 32 + c;
+    if (nA < a.N && kA < a.K) outW[(int64_t)nA * a.K + kA] = acc00[r];
+    if (nA < a.N && kB < a.K) outW[(int64_t)nA * a.K + kB] = acc01[r];
+    if (nB < a.N && kA < a.K) outW[(int64_t)nB * a.K + kA] = acc10[r];
+    if (nB < a.N && kB < a.K) outW[(int64_t)nB * a.K + kB] = acc11[r];
+  }
+  if (outB != nullptr && k0 == 0 && half == 0) {
+    if (na0 < a.N) outB[na0] = bs0;
+    if (na1 < a.N) outB[na1] = bs1;
+  }
+}
+
 // Second launch of the split weight gradient: sums the S partial tiles in split order (deterministic).  An in-kernel
 // "last block reduces" election needs a device-scope fence per block, which on this 8-XCD part writes back and
 // invalidates the XCD's whole L2 (measured: ~140 us for 500 blocks) -- a 3 us launch is the cheaper barrier.
@@ -84,11 +178,29 @@ constexpr int kLongRows = 32768;
 // (optim.py) took the sweep off the step's critical cycle: 0.2622 -> 0.2580 ms per step (same box, two rounds); while the
 // sweep's path was the longer one the two builds tied.
 int g_short_form = 1;
+// RH_TUNE_WGRAD_ROWS_FORM: long reductions of at most kRowsMaxTiles tiles as ONE workgroup per row split (linear_wgrad_rows_kernel);
+// value = the workgroups aimed for (default 512: two 512-thread workgroups per CU), 0 = the tile-per-workgroup form.
+int g_rows_form = 512;
+
+static bool wgrad_rows_form(int B, int N, int K) {
+  const int tiles = ((N + kTile - 1) / kTile) * ((K + kTile - 1) / kTile);
+  return g_rows_form > 0 && g_long_blocks > 0 && B >= kLongRows && tiles >= 2 && tiles <= kRowsMaxTiles;
+}
 
 void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rps) {
   *tiles_n = (N + kTile - 1) / kTile;
   *tiles_k = (K + kTile - 1) / kTile;
   const int tiles = *tiles_n * *tiles_k;
+  if (wgrad_rows_form(B, N, K)) {
+    int s = g_rows_form;
+    const int max_s = (B + 255) / 256;
+    if (s > max_s) s = max_s;
+    int r = (B + s - 1) / s;
+    r = (r + 15) / 16 * 16;
+    *rps = r;
+    *S = (B + r - 1) / r;
+    return;
+  }
   int s = (B >= kLongRows ? abs(g_long_blocks) : 512) / tiles;
   const int max_s = (B + 63) / 64;
   if (s > max_s) s = max_s;
@@ -684,7 +796,9 @@ static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, 
     attr_set = true;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (long_form)
+  if (wgrad_rows_form(B, N, K))
+    hipLaunchKernelGGL(linear_wgrad_rows_kernel, dim3(a.S), dim3(RH_WAVE * tn * tk), 0, st, a, tk);
+  else if (long_form)
     hipLaunchKernelGGL(linear_wgrad_long_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
   else
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
@@ -753,6 +867,10 @@ extern "C" int rh_linear_set_tuning(int key, int value) {
   }
   if (key == RH_TUNE_WGRAD_SHORT_FORM) {
     g_short_form = value;
+    return 0;
+  }
+  if (key == RH_TUNE_WGRAD_ROWS_FORM) {
+    g_rows_form = value;
     return 0;
   }
   return RH_E_BADARG;
