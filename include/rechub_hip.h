@@ -64,8 +64,9 @@ const char* rh_last_error(void);
                                       * (default), 0 = in front of them, 1 = dealt alternately with them */
 #define RH_TUNE_WGRAD_BLOCKS 9 /* workgroups rh_linear_wgrad aims for when the reduction is >= 32768 rows (default 1024) */
 #define RH_TUNE_WGRAD_ROWS_FORM 16 /* rh_linear_wgrad, reductions >= 32768 rows whose output is 2 .. 8 tiles of 64 x 64: value > 0 = ONE
-                                      workgroup per row split computes the whole (N, K) slab, `value` workgroups aimed for (default 512);
-                                      0 = one workgroup per tile and split (rounds 1-5) */
+                                      workgroup per row split computes the whole (N, K) slab, `value` workgroups aimed for (default 512), two
+                                      tiles per wavefront where the tile counts pair up; value < 0 = -value workgroups, one tile per
+                                      wavefront; 0 = one workgroup per tile and split (rounds 1-5) */
 #define RH_TUNE_WGRAD_SHORT_FORM 11 /* rh_linear_wgrad at B < 32768: 0 = 206-register build, 1 = the 128-register build (default) */
 #define RH_TUNE_DICE_VEC 10    /* bit mask of lanes-per-row (16 | 32 | 64) for which the Dice passes use the rows-per-wavefront
                                   kernel (C = 64 / 128 / 256); default 16 | 32 */

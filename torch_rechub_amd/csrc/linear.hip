@@ -58,88 +58,108 @@ __global__ __launch_bounds__(RH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 // output element has one owner); per element the sum runs over the split's rows in order -- another order than the form above
 // (four wavefronts' interleaved rows added up afterwards), the same for every launch of this form.
 constexpr int kRowsMaxTiles = 8;
-__global__ __launch_bounds__(RH_WAVE * kRowsMaxTiles) void linear_wgrad_rows_kernel(const WgradArgs a, const int tiles_k) {
+// TN x TK: 64 x 64 tiles per WAVEFRONT (1 x 1, 1 x 2 or 2 x 1).  Both forms of the weight gradient load one dword per MFMA
+// operand and are bound by the CU's vector-cache bandwidth (55 % of the f32 MFMA peak alone); two tiles per wavefront reuse the
+// shared operand from registers: 6 loads per 8 MFMAs instead of 4 per 4.
+template <int TN, int TK>
+__global__ __launch_bounds__(RH_WAVE * kRowsMaxTiles) void linear_wgrad_rows_kernel(const WgradArgs a, const int groups_k) {
   RH_CHAIN_PRIO();
+  constexpr int NA = 2 * TN, NB = 2 * TK;  // 32-column operand slices per wavefront
   const int lane = threadIdx.x % RH_WAVE, wave = threadIdx.x / RH_WAVE;
   const int half = lane >> 5, c = lane & 31;
   const int s = (int)blockIdx.x;
-  const int n0 = (wave / tiles_k) * kTile, k0 = (wave % tiles_k) * kTile;
+  const int n0 = (wave / groups_k) * (kTile * TN), k0 = (wave % groups_k) * (kTile * TK);
   const int b_lo = s * a.rows_per_split;
   const int b_hi = min(a.B, b_lo + a.rows_per_split);
-  const int na0 = n0 + c, na1 = n0 + 32 + c, kb0 = k0 + c, kb1 = k0 + 32 + c;
-  const float* ga0 = a.g + (na0 < a.N ? na0 : 0) + (int64_t)half * a.ldg;
-  const float* ga1 = a.g + (na1 < a.N ? na1 : 0) + (int64_t)half * a.ldg;
-  const float* xb0 = a.x + (kb0 < a.K ? kb0 : 0) + (int64_t)half * a.ldx;
-  const float* xb1 = a.x + (kb1 < a.K ? kb1 : 0) + (int64_t)half * a.ldx;
-  v16f acc00 = {}, acc01 = {}, acc10 = {}, acc11 = {};
-  float bs0 = 0.f, bs1 = 0.f;
-  constexpr int U = 8;  // row pairs in flight: 32 dword loads, one iteration ahead
-  float fa0[U], fa1[U], fb0[U], fb1[U], qa0[U], qa1[U], qb0[U], qb1[U];
-  auto fetch = [&](int p, float* A0, float* A1, float* B0, float* B1) {
+  // Columns past N / K are clamped to column 0: their products land in rows / columns that are never stored
+  const float* ga[NA];
+  const float* xb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) ga[i] = a.g + (n0 + 32 * i + c < a.N ? n0 + 32 * i + c : 0) + (int64_t)half * a.ldg;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) xb[j] = a.x + (k0 + 32 * j + c < a.K ? k0 + 32 * j + c : 0) + (int64_t)half * a.ldx;
+  v16f acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = v16f{};
+  float bs[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) bs[i] = 0.f;
+  constexpr int U = (TN * TK == 1) ? 8 : 4;  // row pairs in flight, fetched one iteration ahead
+  float fa[U][NA], fb[U][NB], qa[U][NA], qb[U][NB];
+  auto fetch = [&](int p, float (*A)[NA], float (*B)[NB]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t r = p + 2 * u;
-      A0[u] = gload<float>(ga0 + r * a.ldg);
-      A1[u] = gload<float>(ga1 + r * a.ldg);
-      B0[u] = gload<float>(xb0 + r * a.ldx);
-      B1[u] = gload<float>(xb1 + r * a.ldx);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) A[u][i] = gload<float>(ga[i] + r * a.ldg);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) B[u][j] = gload<float>(xb[j] + r * a.ldx);
     }
   };
-  auto issue = [&](const float* A0, const float* A1, const float* B0, const float* B1) {
+  auto issue = [&](float (*A)[NA], float (*B)[NB]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B0[u], acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B1[u], acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B0[u], acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B1[u], acc11, 0, 0, 0);
-      bs0 += A0[u];
-      bs1 += A1[u];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][i], B[u][j], acc[i][j], 0, 0, 0);
+        bs[i] += A[u][i];
+      }
     }
   };
   constexpr int kStep = 2 * U;
   int p = b_lo;
   const int last_full = b_hi - kStep;  // p <= last_full: rows p .. p + kStep - 1 exist
   if (p <= last_full) {
-    fetch(p, fa0, fa1, fb0, fb1);
+    fetch(p, fa, fb);
     for (; p + kStep <= last_full; p += kStep) {
-      fetch(p + kStep, qa0, qa1, qb0, qb1);
-      issue(fa0, fa1, fb0, fb1);
+      fetch(p + kStep, qa, qb);
+      issue(fa, fb);
 #pragma unroll
-      for (int u = 0; u < U; ++u) fa0[u] = qa0[u], fa1[u] = qa1[u], fb0[u] = qb0[u], fb1[u] = qb1[u];
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) fa[u][i] = qa[u][i];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fb[u][j] = qb[u][j];
+      }
     }
-    issue(fa0, fa1, fb0, fb1);
+    issue(fa, fb);
     p += kStep;
   }
   for (; p < b_hi; p += 2) {  // ragged end, guarded per row
     const bool ok = p + half < b_hi;
     const int64_t r = ok ? p : b_lo - half;
     const float m = ok ? 1.f : 0.f;
-    const float t0 = gload<float>(ga0 + r * a.ldg) * m, t1 = gload<float>(ga1 + r * a.ldg) * m;
-    const float t2 = gload<float>(xb0 + r * a.ldx) * m, t3 = gload<float>(xb1 + r * a.ldx) * m;
-    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t2, acc00, 0, 0, 0);
-    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(t0, t3, acc01, 0, 0, 0);
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t2, acc10, 0, 0, 0);
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(t1, t3, acc11, 0, 0, 0);
-    bs0 += t0;
-    bs1 += t1;
+    float ta[NA], tb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ta[i] = gload<float>(ga[i] + r * a.ldg) * m;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) tb[j] = gload<float>(xb[j] + r * a.ldx) * m;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[i], tb[j], acc[i][j], 0, 0, 0);
+      bs[i] += ta[i];
+    }
   }
-  bs0 += __shfl_xor(bs0, 32);
-  bs1 += __shfl_xor(bs1, 32);
   float* outW = a.direct ? a.dW : a.partial + (int64_t)s * a.N * a.K;
   float* outB = a.direct ? a.db : a.partial + (int64_t)a.S * a.N * a.K + (int64_t)s * a.N;
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const int nA = n0 + row, nB = n0 + 32 + row, kA = k0 + c, kB = k0 + 32 + c;
-    if (nA < a.N && kA < a.K) outW[(int64_t)nA * a.K + kA] = acc00[r];
-    if (nA < a.N && kB < a.K) outW[(int64_t)nA * a.K + kB] = acc01[r];
-    if (nB < a.N && kA < a.K) outW[(int64_t)nB * a.K + kA] = acc10[r];
-    if (nB < a.N && kB < a.K) outW[(int64_t)nB * a.K + kB] = acc11[r];
-  }
-  if (outB != nullptr && k0 == 0 && half == 0) {
-    if (na0 < a.N) outB[na0] = bs0;
-    if (na1 < a.N) outB[na1] = bs1;
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int k = k0 + 32 * j + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < a.N && k < a.K) outW[(int64_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
+    const float b2 = bs[i] + __shfl_xor(bs[i], 32);
+    if (outB != nullptr && k0 == 0 && half == 0 && n0 + 32 * i + c < a.N) outB[n0 + 32 * i + c] = b2;
   }
 }
 
@@ -181,6 +201,7 @@ int g_short_form = 1;
 // RH_TUNE_WGRAD_ROWS_FORM: long reductions of at most kRowsMaxTiles tiles as ONE workgroup per row split (linear_wgrad_rows_kernel);
 // value = the workgroups aimed for (default 512: two 512-thread workgroups per CU), 0 = the tile-per-workgroup form.
 int g_rows_form = 512;
+int g_rows_pair = 1;  // (RH_TUNE_WGRAD_ROWS_FORM given negative: -value workgroups, one tile per wavefront)
 
 static bool wgrad_rows_form(int B, int N, int K) {
   const int tiles = ((N + kTile - 1) / kTile) * ((K + kTile - 1) / kTile);
@@ -192,7 +213,13 @@ void wgrad_plan(int B, int N, int K, int* tiles_n, int* tiles_k, int* S, int* rp
   *tiles_k = (K + kTile - 1) / kTile;
   const int tiles = *tiles_n * *tiles_k;
   if (wgrad_rows_form(B, N, K)) {
-    int s = g_rows_form;
+    // g_rows_form workgroups of 8 wavefronts = 4 x g_rows_form wavefronts (8 per CU at the default, two per SIMD: what the
+    // paired-tile builds' ~220 registers allow); a slab of fewer wavefronts is split further to keep that many in flight
+    // ((256, 64) as two wavefronts of 128 x 64: 1024 splits -- with 512 its launch took 228 us alone for 160)
+    const bool pair = g_rows_pair && (*tiles_k % 2 == 0 || *tiles_n % 2 == 0);
+    const int waves = pair ? tiles / 2 : tiles;
+    int s = g_rows_form * kRowsMaxTiles / (2 * waves);
+    if (s < g_rows_form) s = g_rows_form;
     const int max_s = (B + 255) / 256;
     if (s > max_s) s = max_s;
     int r = (B + s - 1) / s;
@@ -796,9 +823,15 @@ static int wgrad_impl(const float* g, int64_t ldg, const float* x, int64_t ldx, 
     attr_set = true;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (wgrad_rows_form(B, N, K))
-    hipLaunchKernelGGL(linear_wgrad_rows_kernel, dim3(a.S), dim3(RH_WAVE * tn * tk), 0, st, a, tk);
-  else if (long_form)
+  if (wgrad_rows_form(B, N, K)) {
+    // two tiles per wavefront along K when the K tiles pair up, else along N (RH_TUNE_WGRAD_ROWS_FORM < 0: one per wavefront)
+    if (g_rows_pair && tk % 2 == 0)
+      hipLaunchKernelGGL((linear_wgrad_rows_kernel<1, 2>), dim3(a.S), dim3(RH_WAVE * tn * (tk / 2)), 0, st, a, tk / 2);
+    else if (g_rows_pair && tn % 2 == 0)
+      hipLaunchKernelGGL((linear_wgrad_rows_kernel<2, 1>), dim3(a.S), dim3(RH_WAVE * (tn / 2) * tk), 0, st, a, tk);
+    else
+      hipLaunchKernelGGL((linear_wgrad_rows_kernel<1, 1>), dim3(a.S), dim3(RH_WAVE * tn * tk), 0, st, a, tk);
+  } else if (long_form)
     hipLaunchKernelGGL(linear_wgrad_long_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
   else
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(tk, tn, a.S), dim3(RH_BLOCK), lds, st, a);
@@ -870,7 +903,8 @@ extern "C" int rh_linear_set_tuning(int key, int value) {
     return 0;
   }
   if (key == RH_TUNE_WGRAD_ROWS_FORM) {
-    g_rows_form = value;
+    g_rows_form = value < 0 ? -value : value;
+    g_rows_pair = value < 0 ? 0 : 1;
     return 0;
   }
   return RH_E_BADARG;
