@@ -1033,8 +1033,11 @@ def dp_one_rank(args):
         cmd = [sys.executable, here, "--force-dp", "--tables", placement, "--steps", "100", "--warmup", str(args.warmup),
                "--no-cpu-baseline", "--brief", "--no-kernel-sweep", "--model", args.model, "--batch", str(args.batch),
                "--rows", str(min(args.rows or 8_000_000, 8_000_000)), "--dist", args.dist, "--graph", args.graph]
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 200), RANK="0", WORLD_SIZE="1",
-                   LOCAL_RANK="0")
+        # (a child of a torchrun-launched rank must not inherit the launcher's rendezvous: with TORCHELASTIC_USE_AGENT_STORE it
+        # would wait for an agent store at ITS master port until the time-out -- 2 x 240 s of a `torchrun --nproc-per-node 1` run)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k not in (
+            "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 200), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         try:
             p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
             line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
