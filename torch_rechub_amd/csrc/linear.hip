@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RH_WAVE * kRowsMaxTiles) void linear_wgrad_rows_ker
   float bs[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) bs[i] = 0.f;
-  constexpr int U = (TN * TK == 1) ? 8 : 4;  // row pairs in flight, fetched one iteration ahead
+  constexpr int U = (TN * TK == 1) ? 8 : (TK == 2 ? 6 : 4);  // row pairs in flight, fetched one iteration ahead
   float fa[U][NA], fb[U][NB], qa[U][NA], qb[U][NB];
   auto fetch = [&](int p, float (*A)[NA], float (*B)[NB]) {
 #pragma unroll
