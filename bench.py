@@ -258,10 +258,6 @@ class Workload(object):
                         attention_mlp_params={"dims": [256, 128]})
                 if os.environ.get("PROBE_DIN_BRANCHES") == "0":  # (A/B of the side-by-side activation units)
                     m.attention_branches = False
-                if os.environ.get("PROBE_TALL_GEMM"):  # (experiment: the own tile GEMM also for the (B L)-row products: "1" forward + input gradient, "fwd")
-                    from torch_rechub_amd import ops as _ops
-                    _ops._GEMM_MAX_M = 1 << 20
-                    _ops._GEMM_DGRAD = os.environ["PROBE_TALL_GEMM"] != "fwd"
             else:
                 from torch_rechub_amd.models.matching import DSSM
                 tower = {"dims": [256, 128, 64], "activation": "prelu"}
